@@ -1,0 +1,213 @@
+/*
+ * mi_face.h — C ABI of the MI355X-native BlazeFace / face-mesh / iris inference path.
+ *
+ * Drop-in boundary for okieraised/rs-face-detection-tflite's three `infer` entry points and for the engine surface
+ * they call into (the `tflite` crate).  Every entry point cites the reference interface it replaces; paths are
+ * relative to /root/reference/src/face_detection_lite/.  Plain pointers and sizes only: no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns MI_OK (0) or a negative MI_E* code; the message is in mi_last_error() (thread-local).
+ *     Nothing panics/aborts across the ABI (the reference panics at the unwrap/assert sites listed in SURVEY.md §5;
+ *     here those become MI_EINVAL / MI_ERANGE returns).
+ *   - `mem` says where the caller's tensor buffers live: MI_MEM_HOST (pageable/pinned host memory; the library
+ *     stages through its own device buffers) or MI_MEM_DEVICE (HIP device pointers on the handle's GPU).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).  With MI_MEM_DEVICE and a caller
+ *     stream the call is asynchronous with respect to the host; with MI_MEM_HOST it returns after results landed.
+ *   - handles are bound to one GPU (`device` = HIP ordinal).  One handle may be used from one thread at a time
+ *     (the reference's `infer(&self)` rebuilds an interpreter per call; here the interpreter state — activation
+ *     arena, captured hipGraphs — lives in the handle). Use one handle per worker thread/stream.
+ *   - all outputs are caller-allocated with explicit capacities.
+ */
+#ifndef MI_FACE_H_
+#define MI_FACE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument / shape mismatch                                   */
+#define MI_EIO (-2)      /* cannot read model file                                          */
+#define MI_EMODEL (-3)   /* malformed or unsupported .tflite graph                          */
+#define MI_EDEVICE (-4)  /* HIP runtime error, no GPU, or kernels missing for this GPU      */
+#define MI_ERANGE (-5)   /* numeric guard of the reference tripped (e.g. letterbox scale)   */
+#define MI_ENOMEM (-6)
+
+#define MI_MEM_HOST 0
+#define MI_MEM_DEVICE 1
+
+const char *mi_last_error(void);
+/* Number of HIP devices visible to the library (0 when none: every create/load then fails with MI_EDEVICE). */
+int mi_device_count(void);
+const char *mi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Value types crossing the boundary (types.rs)
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/* Detection { data: Array2<f32>[8,2], score: f32 } — types.rs:189-206.
+ * data = (xmin,ymin), (xmax,ymax), then 6 keypoints in FaceIndex order (face_detection.rs:91-98), normalised [0,1]. */
+typedef struct mi_detection {
+    float data[16];
+    float score;
+} mi_detection;
+
+/* Rect — types.rs:24-36 (rotation in radians, clockwise; normalized = relative to image size). */
+typedef struct mi_rect {
+    double x_center, y_center, width, height, rotation;
+    int normalized;
+} mi_rect;
+
+/* Landmark { x, y, z: f64 } — types.rs:176-187. */
+typedef struct mi_landmark {
+    double x, y, z;
+} mi_landmark;
+
+/* FaceDetectionModel — face_detection.rs:117-123. */
+enum { MI_FD_FRONT_CAMERA = 0, MI_FD_BACK_CAMERA = 1, MI_FD_SHORT = 2, MI_FD_FULL = 3, MI_FD_FULL_SPARSE = 4 };
+
+#define MI_NUM_FACE_LANDMARKS 468 /* face_landmark.rs:29 */
+#define MI_NUM_EYE_LANDMARKS 71   /* iris_landmark.rs:41 */
+#define MI_NUM_IRIS_LANDMARKS 5   /* iris_landmark.rs:42 */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * L0 — engine surface: replaces the `tflite` crate as used at face_detection.rs:188,207-257,
+ * face_landmark.rs:216,233-290, iris_landmark.rs:150,161-228.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_model mi_model;
+
+/* FlatBufferModel::build_from_file + InterpreterBuilder::build + allocate_tensors (face_detection.rs:188,207-210).
+ * Parses the TFL3 flatbuffer, lowers the graph to fused HIP kernels and uploads weights (f16 constants widened to
+ * f32 once, instead of the reference's per-call DEQUANTIZE). */
+int mi_model_load_file(const char *path, int device, mi_model **out);
+int mi_model_load_bytes(const uint8_t *tflite, size_t nbytes, int device, mi_model **out);
+void mi_model_free(mi_model *m);
+
+/* get_input_details()[0].dims (face_detection.rs:213-217): dims = {1,H,W,C}. */
+int mi_model_input_dims(const mi_model *m, int dims[4]);
+/* outputs().len() / tensor_info(outputs()[i]).dims (face_detection.rs:238-249). Returns rank via *rank. */
+int mi_model_num_outputs(const mi_model *m);
+int mi_model_output_dims(const mi_model *m, int index, int dims[4], int *rank);
+size_t mi_model_output_elems(const mi_model *m, int index); /* floats per frame */
+
+/* tensor_data_mut(input).copy_from_slice + invoke + tensor_data(outputs[i]) (face_detection.rs:229-257), batched:
+ * in  = f32 NHWC [batch,H,W,C];  outs[i] = f32 [batch, output_elems(i)] in the graph's output order. */
+int mi_model_run(mi_model *m, const float *in, int batch, float *const *outs, int mem, void *stream);
+
+/* Copy one intermediate activation (by .tflite tensor index) of the last chunk run, if it was materialised
+ * (fused-away tensors return MI_EINVAL).  Debug/test aid; dst is host memory. Returns floats written via *n. */
+int mi_model_debug_tensor(mi_model *m, int tensor_index, int frame, float *dst, size_t cap, size_t *n);
+/* Human-readable launch plan (one line per kernel launch). Returns bytes needed (incl. NUL). */
+size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
+/* Tuning knobs: "chunk" (frames per pass through the net, 0 = whole batch), "graph" (0/1 hipGraph replay),
+ * "fuse" (0 = op-by-op kernels, 1 = epilogue fusion, 2 = BlazeBlock fusion). Takes effect on the next run. */
+int mi_model_set_option(mi_model *m, const char *key, int value);
+/* Host-only: parse + lower a .tflite blob WITHOUT touching a GPU and write the launch plan text (same format as
+ * mi_model_describe). Returns bytes needed (incl. NUL), 0 on error (see mi_last_error). Used by CPU-side tests. */
+size_t mi_plan_describe(const uint8_t *tflite, size_t nbytes, int fuse_level, char *buf, size_t cap);
+/* Algorithmic traffic of the launch plan per frame (bytes read+written by the kernels as launched, weights
+ * included once) and MACs per frame; used by bench.py for the roofline figure. */
+int mi_model_plan_stats(const mi_model *m, double *bytes_per_frame, double *macs_per_frame, int *launches);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * L1 — FaceDetection (face_detection.rs:146-362)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_fd mi_fd;
+
+/* FaceDetection::new(model_type, model_path) — face_detection.rs:153-195. model_dir is a DIRECTORY (NULL = "./models");
+ * the file name is chosen by `kind` (face_detection.rs:125-129,163-185). Generates the SSD anchors (366-413). */
+int mi_fd_create(int kind, const char *model_dir, int device, mi_fd **out);
+/* Same, from bytes already in memory (e.g. after an RCCL broadcast of the frozen .tflite over xGMI). */
+int mi_fd_create_from_bytes(int kind, const uint8_t *tflite, size_t nbytes, int device, mi_fd **out);
+void mi_fd_free(mi_fd *h);
+mi_model *mi_fd_model(mi_fd *h); /* borrowed */
+int mi_fd_input_size(const mi_fd *h, int *width, int *height);
+int mi_fd_num_anchors(const mi_fd *h);
+int mi_fd_anchors(const mi_fd *h, float *out_xy, int cap); /* ssd_generate_anchors, [n][2] */
+
+/* Batched FaceDetection::infer from the tensor stage on (face_detection.rs:222-265): network, decode_boxes,
+ * get_sigmoid_score, convert_to_detections, weighted NMS (0.3 / 0.5), detection_letterbox_removal.
+ *   in       f32 [batch,H,W,3] in [-1,1] (what image_to_tensor produced)
+ *   padding  NULL (no letterbox) or f64 [batch][4] = (left, top, right, bottom) per frame (ImageTensor.padding)
+ *   out      [batch][cap_per_frame] detections, descending head-score order; counts[b] = number found in frame b
+ *            (may exceed cap_per_frame: only the first cap_per_frame are stored).  out/counts follow `mem`. */
+int mi_fd_infer_tensor(mi_fd *h, const float *in, int batch, const double *padding, mi_detection *out,
+                       int cap_per_frame, int *counts, int mem, void *stream);
+/* Post-network stage only, on raw outputs (regressors [batch,N,16], classificators [batch,N]). */
+int mi_fd_postprocess(mi_fd *h, const float *raw_boxes, const float *raw_scores, int batch, const double *padding,
+                      mi_detection *out, int cap_per_frame, int *counts, int mem, void *stream);
+/* FaceDetection::infer(&Mat, Option<Rect>) — face_detection.rs:205-267. rgb = 8UC3 RGB rows of `stride` bytes
+ * (utils.rs:8-21); roi NULL = whole image. Host pointers. *count = detections found (stored: min(count, cap)). */
+int mi_fd_infer_image(mi_fd *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
+                      mi_detection *out, int cap, int *count);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * L1 — FaceLandmark (face_landmark.rs:200-306)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_fl mi_fl;
+
+/* FaceLandmark::new(model_path) — face_landmark.rs:208-222. model_path is a FILE path (NULL =
+ * "./models/face_landmark.tflite"). Fails with MI_EMODEL when the mesh output is narrower than 1404 (244-247). */
+int mi_fl_create(const char *model_path, int device, mi_fl **out);
+int mi_fl_create_from_bytes(const uint8_t *tflite, size_t nbytes, int device, mi_fl **out);
+void mi_fl_free(mi_fl *h);
+mi_model *mi_fl_model(mi_fl *h);
+
+/* Batched FaceLandmark::infer from the tensor stage on (face_landmark.rs:252-305): network, face-flag test
+ * (sigmoid(flag) <= 0.5 => no landmarks, 292-296), project_landmarks (transform.rs:351-432).
+ *   in           f32 [batch,192,192,3] in [0,1]
+ *   rois         NULL or [batch] ROI each crop was taken from (Option<Rect>); image_sizes int [batch][2] = (w,h) of the
+ *                source image of each ROI (needed when a ROI is not normalised); may be NULL when rois is NULL
+ *   landmarks    f32 [batch][468][3] projected landmarks (x,y,z as the reference's f32 values before widening)
+ *   present      [batch] 1 when the face flag passed (reference returns an empty Vec otherwise), else 0
+ *   raw_flags    optional [batch] raw flag logits (may be NULL) */
+int mi_fl_infer_tensor(mi_fl *h, const float *in, int batch, const mi_rect *rois, const int *image_sizes,
+                       float *landmarks, int *present, float *raw_flags, int mem, void *stream);
+/* FaceLandmark::infer(&Mat, Option<Rect>) — face_landmark.rs:232-306. out = 468 landmarks; *count = 0 or 468. */
+int mi_fl_infer_image(mi_fl *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
+                      mi_landmark *out, int cap, int *count);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * L1 — IrisLandmark (iris_landmark.rs:130-248)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_iris mi_iris;
+
+/* IrisLandmark::new(model_path) — iris_landmark.rs:142-156 (FILE path; NULL = "./models/iris_landmark.tflite").
+ * Fails with MI_EMODEL unless the outputs are 213 and 15 wide (172-184). */
+int mi_iris_create(const char *model_path, int device, mi_iris **out);
+int mi_iris_create_from_bytes(const uint8_t *tflite, size_t nbytes, int device, mi_iris **out);
+void mi_iris_free(mi_iris *h);
+mi_model *mi_iris_model(mi_iris *h);
+
+/* Batched IrisLandmark::infer from the tensor stage on (iris_landmark.rs:190-246).
+ *   in            f32 [batch,64,64,3] in [0,1] (already flipped for right eyes, as image_to_tensor does)
+ *   rois/image_sizes as for mi_fl_infer_tensor; padding NULL or f64 [batch][4]; is_right_eye NULL or int [batch]
+ *   contour       f32 [batch][71][3], iris f32 [batch][5][3] */
+int mi_iris_infer_tensor(mi_iris *h, const float *in, int batch, const mi_rect *rois, const int *image_sizes,
+                         const double *padding, const int *is_right_eye, float *contour, float *iris, int mem,
+                         void *stream);
+/* IrisLandmark::infer(&Mat, Option<Rect>, Option<bool>) — iris_landmark.rs:158-248 -> IrisResults {contour, iris}. */
+int mi_iris_infer_image(mi_iris *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
+                        int is_right_eye, mi_landmark *contour71, mi_landmark *iris5);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Host-side helpers the reference exports next to the three structs
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* face_detection_to_roi(face_detection, image_size, None) — face_landmark.rs:180-198 (SquareLong, scale 1.5). */
+int mi_face_detection_to_roi(const mi_detection *det, int image_w, int image_h, mi_rect *out);
+/* iris_roi_from_face_landmarks(face_landmarks, image_size) — iris_landmark.rs:268-292 (scale 2.3). */
+int mi_iris_roi_from_face_landmarks(const mi_landmark *landmarks468, int image_w, int image_h, mi_rect *left_eye,
+                                    mi_rect *right_eye);
+/* transform::image_to_tensor — transform.rs:188-309, on the GPU (rotated-ROI warp, letterbox, resize, flip,
+ * normalise).  out = f32 [out_h][out_w][3] (follows `mem`); padding_out[4] = (left, top, right, bottom). */
+int mi_image_to_tensor(int device, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
+                       int out_w, int out_h, int keep_aspect_ratio, double range_min, double range_max,
+                       int flip_horizontal, float *out, double padding_out[4], int mem, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_FACE_H_ */

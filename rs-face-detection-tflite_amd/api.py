@@ -1,0 +1,519 @@
+"""Host-side mirror of the reference crate's public API over the C ABI (include/mi_face.h) via ctypes.
+
+The reference is a Rust crate (`FaceDetection::{new,infer}`, `FaceLandmark::{new,infer}`, `IrisLandmark::{new,infer}`,
+/root/reference/src/face_detection_lite/{face_detection,face_landmark,iris_landmark}.rs); there is no Rust toolchain in
+this image, so the host side above the C ABI is mirrored here with the same names, argument meaning and error behaviour
+(errors that the reference returns as `anyhow::Error` — or panics on — become `MiError`).  A Rust `extern "C"` shim with
+identical signatures is listed in INTEGRATION.md.
+
+No numerical work happens in this module: every result comes from the HIP kernels behind libmiface.so.  If that library
+is missing, importing this module raises (there is no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiface.so")
+REPO_ROOT = os.path.dirname(_HERE)
+DEFAULT_MODEL_DIR = os.path.join(REPO_ROOT, "models")
+
+MI_MEM_HOST, MI_MEM_DEVICE = 0, 1
+NUM_FACE_LANDMARKS, NUM_EYE_LANDMARKS, NUM_IRIS_LANDMARKS = 468, 71, 5
+
+EXPORTS = [
+    "mi_last_error", "mi_device_count", "mi_version",
+    "mi_model_load_file", "mi_model_load_bytes", "mi_model_free", "mi_model_input_dims", "mi_model_num_outputs",
+    "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
+    "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats",
+    "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
+    "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image",
+    "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
+    "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
+    "mi_iris_infer_image",
+    "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_image_to_tensor",
+]
+
+
+class MiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mi_face error %d: %s" % (code, msg))
+        self.code = code
+
+
+class CDetection(C.Structure):
+    _fields_ = [("data", C.c_float * 16), ("score", C.c_float)]
+
+
+class Rect(C.Structure):
+    """types.rs:24-36."""
+    _fields_ = [("x_center", C.c_double), ("y_center", C.c_double), ("width", C.c_double), ("height", C.c_double),
+                ("rotation", C.c_double), ("normalized", C.c_int)]
+
+    def __repr__(self):
+        return "Rect(x_center=%r, y_center=%r, width=%r, height=%r, rotation=%r, normalized=%r)" % (
+            self.x_center, self.y_center, self.width, self.height, self.rotation, bool(self.normalized))
+
+
+class CLandmark(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class FaceDetectionModel(enum.IntEnum):
+    """face_detection.rs:117-123."""
+    FrontCamera = 0
+    BackCamera = 1
+    Short = 2
+    Full = 3
+    FullSparse = 4
+
+
+@dataclass
+class Detection:
+    """types.rs:189-246: data [8,2] f32 (bbox corners then 6 keypoints), score f32."""
+    data: np.ndarray
+    score: float
+
+    def bbox(self):
+        return tuple(float(v) for v in (self.data[0, 0], self.data[0, 1], self.data[1, 0], self.data[1, 1]))
+
+    def keypoint(self, k):
+        return float(self.data[k + 2, 0]), float(self.data[k + 2, 1])
+
+
+@dataclass
+class Landmark:
+    x: float
+    y: float
+    z: float
+
+
+@dataclass
+class IrisResults:
+    """iris_landmark.rs:115-129."""
+    contour: list
+    iris: list
+
+    def eyeball_contour(self):
+        return self.contour[:15]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmiface.so (built in-tree by build.sh / __graft_entry__.build()). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run rs-face-detection-tflite_amd/build.sh (hipcc, gfx950). "
+                          "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, fp, ip, dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.mi_last_error.restype = C.c_char_p
+    L.mi_version.restype = C.c_char_p
+    L.mi_model_load_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.mi_model_load_bytes.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.mi_model_free.argtypes = [vp]
+    L.mi_model_free.restype = None
+    L.mi_model_input_dims.argtypes = [vp, ip]
+    L.mi_model_num_outputs.argtypes = [vp]
+    L.mi_model_output_dims.argtypes = [vp, C.c_int, ip, ip]
+    L.mi_model_output_elems.argtypes = [vp, C.c_int]
+    L.mi_model_output_elems.restype = C.c_size_t
+    L.mi_model_run.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.c_int, vp]
+    L.mi_model_debug_tensor.argtypes = [vp, C.c_int, C.c_int, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mi_model_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.mi_model_describe.restype = C.c_size_t
+    L.mi_model_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.mi_plan_describe.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
+    L.mi_plan_describe.restype = C.c_size_t
+    L.mi_model_plan_stats.argtypes = [vp, dp, dp, ip]
+    L.mi_fd_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.mi_fd_create_from_bytes.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.mi_fd_free.argtypes = [vp]
+    L.mi_fd_free.restype = None
+    L.mi_fd_model.argtypes = [vp]
+    L.mi_fd_model.restype = vp
+    L.mi_fd_input_size.argtypes = [vp, ip, ip]
+    L.mi_fd_num_anchors.argtypes = [vp]
+    L.mi_fd_anchors.argtypes = [vp, fp, C.c_int]
+    L.mi_fd_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]
+    L.mi_fd_postprocess.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]
+    L.mi_fd_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(CDetection), C.c_int, ip]
+    L.mi_fl_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.mi_fl_create_from_bytes.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.mi_fl_free.argtypes = [vp]
+    L.mi_fl_free.restype = None
+    L.mi_fl_model.argtypes = [vp]
+    L.mi_fl_model.restype = vp
+    L.mi_fl_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.mi_fl_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(CLandmark), C.c_int, ip]
+    L.mi_iris_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.mi_iris_create_from_bytes.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.mi_iris_free.argtypes = [vp]
+    L.mi_iris_free.restype = None
+    L.mi_iris_model.argtypes = [vp]
+    L.mi_iris_model.restype = vp
+    L.mi_iris_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.mi_iris_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.POINTER(CLandmark),
+                                      C.POINTER(CLandmark)]
+    L.mi_face_detection_to_roi.argtypes = [C.POINTER(CDetection), C.c_int, C.c_int, C.POINTER(Rect)]
+    L.mi_iris_roi_from_face_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(Rect)]
+    L.mi_image_to_tensor.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.c_int, C.c_int,
+                                     C.c_double, C.c_double, C.c_int, vp, dp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise MiError(rc, lib().mi_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().mi_device_count()
+
+
+def plan_describe(tflite_bytes: bytes, fuse_level=2) -> str:
+    """Host-only lowering of a .tflite blob (no GPU needed)."""
+    L = lib()
+    n = L.mi_plan_describe(tflite_bytes, len(tflite_bytes), fuse_level, None, 0)
+    if n == 0:
+        raise MiError(-3, L.mi_last_error().decode())
+    buf = C.create_string_buffer(n)
+    L.mi_plan_describe(tflite_bytes, len(tflite_bytes), fuse_level, buf, n)
+    return buf.value.decode()
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    """(pointer, mem) of a numpy array (host) or torch CUDA tensor (device)."""
+    if _is_torch(x):
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(x.data_ptr()), (MI_MEM_DEVICE if x.is_cuda else MI_MEM_HOST)
+    return C.c_void_p(x.ctypes.data), MI_MEM_HOST
+
+
+class Model:
+    """L0 engine handle (replaces the `tflite` crate's FlatBufferModel + Interpreter)."""
+
+    def __init__(self, path=None, device=0, handle=None, owner=None):
+        self.L = lib()
+        self._owner = owner
+        if handle is not None:
+            self.h = C.c_void_p(handle)
+        else:
+            self.h = C.c_void_p()
+            _check(self.L.mi_model_load_file(os.fsencode(path), device, C.byref(self.h)))
+        d = (C.c_int * 4)()
+        _check(self.L.mi_model_input_dims(self.h, d))
+        self.input_dims = list(d)
+        self.num_outputs = self.L.mi_model_num_outputs(self.h)
+        self.output_dims, self.output_elems = [], []
+        for i in range(self.num_outputs):
+            r = C.c_int()
+            _check(self.L.mi_model_output_dims(self.h, i, d, C.byref(r)))
+            self.output_dims.append(list(d)[:r.value])
+            self.output_elems.append(self.L.mi_model_output_elems(self.h, i))
+
+    def close(self):
+        if self._owner is None and getattr(self, "h", None):
+            self.L.mi_model_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _check(self.L.mi_model_set_option(self.h, key.encode(), int(value)))
+
+    def describe(self):
+        n = self.L.mi_model_describe(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        self.L.mi_model_describe(self.h, buf, n)
+        return buf.value.decode()
+
+    def plan_stats(self):
+        b, m, n = C.c_double(), C.c_double(), C.c_int()
+        _check(self.L.mi_model_plan_stats(self.h, C.byref(b), C.byref(m), C.byref(n)))
+        return b.value, m.value, n.value
+
+    def run(self, x, outs=None, stream=None):
+        """x: numpy [B,H,W,C] f32 (host) or torch CUDA tensor. Returns list of outputs in the same memory space."""
+        p, mem = _ptr(x)
+        B = int(x.shape[0])
+        if outs is None:
+            if mem == MI_MEM_DEVICE:
+                import torch
+                outs = [torch.empty([B] + d[1:], dtype=torch.float32, device=x.device) for d in self.output_dims]
+            else:
+                x = np.ascontiguousarray(x, np.float32)
+                p = C.c_void_p(x.ctypes.data)
+                outs = [np.empty([B] + d[1:], np.float32) for d in self.output_dims]
+        ptrs = (C.c_void_p * self.num_outputs)(*[_ptr(o)[0] for o in outs])
+        _check(self.L.mi_model_run(self.h, p, B, ptrs, mem, C.c_void_p(stream or 0)))
+        return outs
+
+    def debug_tensor(self, index, frame=0, cap=1 << 24):
+        dst = np.empty(cap, np.float32)
+        n = C.c_size_t()
+        _check(self.L.mi_model_debug_tensor(self.h, index, frame, dst.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n)))
+        return dst[:n.value].copy()
+
+
+def _image_args(image):
+    image = np.ascontiguousarray(image, np.uint8)
+    if image.ndim != 3 or image.shape[2] != 3:
+        raise ValueError("image must be uint8 [H,W,3] RGB")
+    h, w = image.shape[:2]
+    return image, w, h, image.strides[0]
+
+
+class FaceDetection:
+    """BlazeFace detector — mirrors face_detection.rs:146-267."""
+
+    def __init__(self, model_type=FaceDetectionModel.FrontCamera, model_path=None, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        # model_path is a DIRECTORY (face_detection.rs:157-161); default "./models" resolved against the repo here
+        d = model_path if model_path is not None else DEFAULT_MODEL_DIR
+        _check(self.L.mi_fd_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
+        w, h = C.c_int(), C.c_int()
+        self.L.mi_fd_input_size(self.h, C.byref(w), C.byref(h))
+        self.input_size = (w.value, h.value)
+        self.num_anchors = self.L.mi_fd_num_anchors(self.h)
+        self.model = Model(handle=self.L.mi_fd_model(self.h), owner=self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_fd_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def anchors(self):
+        a = np.zeros((self.num_anchors, 2), np.float32)
+        self.L.mi_fd_anchors(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), self.num_anchors)
+        return a
+
+    def infer(self, image, roi=None, cap=256):
+        """FaceDetection::infer(&Mat, Option<Rect>) -> Vec<Detection> (face_detection.rs:205-267)."""
+        image, w, h, stride = _image_args(image)
+        out = (CDetection * cap)()
+        n = C.c_int()
+        _check(self.L.mi_fd_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
+                                        C.byref(roi) if roi is not None else None, out, cap, C.byref(n)))
+        return [Detection(np.frombuffer(out[i].data, np.float32, 16).reshape(8, 2).copy(), float(out[i].score))
+                for i in range(min(n.value, cap))]
+
+    def infer_tensor(self, x, padding=None, cap=64, out=None, counts=None, stream=None):
+        """Batched tensor-stage entry (configs 2/4). x: [B,H,W,3] f32 numpy or torch CUDA tensor in [-1,1].
+        Returns (detections [B,cap,17] f32, counts [B] i32) in the same memory space as x."""
+        p, mem = _ptr(x)
+        B = int(x.shape[0])
+        if mem == MI_MEM_DEVICE:
+            import torch
+            if out is None:
+                out = torch.zeros((B, cap, 17), dtype=torch.float32, device=x.device)
+            if counts is None:
+                counts = torch.zeros((B,), dtype=torch.int32, device=x.device)
+            pp = C.c_void_p(padding.data_ptr()) if padding is not None else None
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            p = C.c_void_p(x.ctypes.data)
+            out = np.zeros((B, cap, 17), np.float32) if out is None else out
+            counts = np.zeros((B,), np.int32) if counts is None else counts
+            if padding is not None:
+                padding = np.ascontiguousarray(padding, np.float64).reshape(B, 4)
+            pp = C.c_void_p(padding.ctypes.data) if padding is not None else None
+        _check(self.L.mi_fd_infer_tensor(self.h, p, B, pp, _ptr(out)[0], cap, _ptr(counts)[0], mem, C.c_void_p(stream or 0)))
+        return out, counts
+
+    def postprocess(self, raw_boxes, raw_scores, padding=None, cap=64):
+        """Post-network stage only (decode + sigmoid + weighted NMS + letterbox removal) on host arrays."""
+        rb = np.ascontiguousarray(raw_boxes, np.float32).reshape(-1, self.num_anchors, 16)
+        rs = np.ascontiguousarray(raw_scores, np.float32).reshape(-1, self.num_anchors)
+        B = rb.shape[0]
+        out = np.zeros((B, cap, 17), np.float32)
+        counts = np.zeros((B,), np.int32)
+        pp = None
+        if padding is not None:
+            padding = np.ascontiguousarray(padding, np.float64).reshape(B, 4)
+            pp = C.c_void_p(padding.ctypes.data)
+        _check(self.L.mi_fd_postprocess(self.h, C.c_void_p(rb.ctypes.data), C.c_void_p(rs.ctypes.data), B, pp,
+                                        C.c_void_p(out.ctypes.data), cap, C.c_void_p(counts.ctypes.data), MI_MEM_HOST, None))
+        return out, counts
+
+
+class FaceLandmark:
+    """468-point face mesh — mirrors face_landmark.rs:200-306."""
+
+    def __init__(self, model_path=None, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        p = model_path if model_path is not None else os.path.join(DEFAULT_MODEL_DIR, "face_landmark.tflite")
+        _check(self.L.mi_fl_create(os.fsencode(p), device, C.byref(self.h)))
+        self.model = Model(handle=self.L.mi_fl_model(self.h), owner=self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_fl_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def infer(self, image, roi=None):
+        """FaceLandmark::infer(&Mat, Option<Rect>) -> Vec<Landmark> (empty when the face flag fails)."""
+        image, w, h, stride = _image_args(image)
+        out = (CLandmark * NUM_FACE_LANDMARKS)()
+        n = C.c_int()
+        _check(self.L.mi_fl_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
+                                        C.byref(roi) if roi is not None else None, out, NUM_FACE_LANDMARKS, C.byref(n)))
+        return [Landmark(out[i].x, out[i].y, out[i].z) for i in range(n.value)]
+
+    def infer_tensor(self, x, rois=None, image_sizes=None, stream=None):
+        """x [B,192,192,3] in [0,1]. rois: list of Rect (host path) . Returns (landmarks [B,468,3], present [B], flags [B])."""
+        p, mem = _ptr(x)
+        B = int(x.shape[0])
+        if mem == MI_MEM_DEVICE:
+            import torch
+            lm = torch.zeros((B, NUM_FACE_LANDMARKS, 3), dtype=torch.float32, device=x.device)
+            present = torch.zeros((B,), dtype=torch.int32, device=x.device)
+            flags = torch.zeros((B,), dtype=torch.float32, device=x.device)
+            rp = C.c_void_p(rois.data_ptr()) if rois is not None else None
+            sp = C.c_void_p(image_sizes.data_ptr()) if image_sizes is not None else None
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            p = C.c_void_p(x.ctypes.data)
+            lm = np.zeros((B, NUM_FACE_LANDMARKS, 3), np.float32)
+            present = np.zeros((B,), np.int32)
+            flags = np.zeros((B,), np.float32)
+            rp = sp = None
+            if rois is not None:
+                arr = (Rect * B)(*rois)
+                rp = C.cast(arr, C.c_void_p)
+                image_sizes = np.ascontiguousarray(image_sizes, np.int32).reshape(B, 2)
+                sp = C.c_void_p(image_sizes.ctypes.data)
+        _check(self.L.mi_fl_infer_tensor(self.h, p, B, rp, sp, _ptr(lm)[0], _ptr(present)[0], _ptr(flags)[0], mem,
+                                         C.c_void_p(stream or 0)))
+        return lm, present, flags
+
+
+class IrisLandmark:
+    """Iris / eye-contour model — mirrors iris_landmark.rs:130-248."""
+
+    def __init__(self, model_path=None, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        p = model_path if model_path is not None else os.path.join(DEFAULT_MODEL_DIR, "iris_landmark.tflite")
+        _check(self.L.mi_iris_create(os.fsencode(p), device, C.byref(self.h)))
+        self.model = Model(handle=self.L.mi_iris_model(self.h), owner=self)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_iris_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def infer(self, image, roi=None, is_right_eye=None):
+        """IrisLandmark::infer(&Mat, Option<Rect>, Option<bool>) -> IrisResults."""
+        image, w, h, stride = _image_args(image)
+        c = (CLandmark * NUM_EYE_LANDMARKS)()
+        i5 = (CLandmark * NUM_IRIS_LANDMARKS)()
+        _check(self.L.mi_iris_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
+                                          C.byref(roi) if roi is not None else None, int(bool(is_right_eye)), c, i5))
+        return IrisResults([Landmark(v.x, v.y, v.z) for v in c], [Landmark(v.x, v.y, v.z) for v in i5])
+
+    def infer_tensor(self, x, rois=None, image_sizes=None, padding=None, is_right_eye=None, stream=None):
+        p, mem = _ptr(x)
+        B = int(x.shape[0])
+        if mem == MI_MEM_DEVICE:
+            import torch
+            contour = torch.zeros((B, NUM_EYE_LANDMARKS, 3), dtype=torch.float32, device=x.device)
+            iris = torch.zeros((B, NUM_IRIS_LANDMARKS, 3), dtype=torch.float32, device=x.device)
+            g = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            rp, sp, pp, fp_ = g(rois), g(image_sizes), g(padding), g(is_right_eye)
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            p = C.c_void_p(x.ctypes.data)
+            contour = np.zeros((B, NUM_EYE_LANDMARKS, 3), np.float32)
+            iris = np.zeros((B, NUM_IRIS_LANDMARKS, 3), np.float32)
+            rp = sp = pp = fp_ = None
+            keep = []
+            if rois is not None:
+                arr = (Rect * B)(*rois)
+                keep.append(arr)
+                rp = C.cast(arr, C.c_void_p)
+                image_sizes = np.ascontiguousarray(image_sizes, np.int32).reshape(B, 2)
+                sp = C.c_void_p(image_sizes.ctypes.data)
+            if padding is not None:
+                padding = np.ascontiguousarray(padding, np.float64).reshape(B, 4)
+                pp = C.c_void_p(padding.ctypes.data)
+            if is_right_eye is not None:
+                is_right_eye = np.ascontiguousarray(is_right_eye, np.int32).reshape(B)
+                fp_ = C.c_void_p(is_right_eye.ctypes.data)
+        _check(self.L.mi_iris_infer_tensor(self.h, p, B, rp, sp, pp, fp_, _ptr(contour)[0], _ptr(iris)[0], mem,
+                                           C.c_void_p(stream or 0)))
+        return contour, iris
+
+
+def face_detection_to_roi(face_detection: Detection, image_size, size_mode=None) -> Rect:
+    """face_landmark.rs:180-198 (size_mode None = SquareLong, the only mode the reference's callers use)."""
+    if size_mode not in (None, 1):
+        raise ValueError("only SizeMode::SquareLong is exposed through the C ABI")
+    d = CDetection()
+    d.data[:] = [float(v) for v in np.asarray(face_detection.data, np.float32).reshape(16)]
+    d.score = float(face_detection.score)
+    r = Rect()
+    _check(lib().mi_face_detection_to_roi(C.byref(d), int(image_size[0]), int(image_size[1]), C.byref(r)))
+    return r
+
+
+def iris_roi_from_face_landmarks(face_landmarks, image_size):
+    """iris_landmark.rs:268-292 -> (left_eye_roi, right_eye_roi)."""
+    if len(face_landmarks) < NUM_FACE_LANDMARKS:
+        raise ValueError("expected 468 face landmarks")
+    arr = (CLandmark * NUM_FACE_LANDMARKS)(*[CLandmark(l.x, l.y, l.z) for l in face_landmarks[:NUM_FACE_LANDMARKS]])
+    a, b = Rect(), Rect()
+    _check(lib().mi_iris_roi_from_face_landmarks(arr, int(image_size[0]), int(image_size[1]), C.byref(a), C.byref(b)))
+    return a, b
+
+
+def image_to_tensor(image, roi=None, output_size=None, keep_aspect_ratio=False, output_range=(0., 1.), flip_horizontal=False,
+                    device=0):
+    """transform::image_to_tensor (transform.rs:188-309) on the GPU -> (tensor [h,w,3] f32 numpy, padding)."""
+    image, w, h, stride = _image_args(image)
+    ow, oh = output_size
+    out = np.zeros((oh, ow, 3), np.float32)
+    pad = (C.c_double * 4)()
+    _check(lib().mi_image_to_tensor(device, C.c_void_p(image.ctypes.data), w, h, stride, C.byref(roi) if roi is not None else None,
+                                    ow, oh, int(keep_aspect_ratio), output_range[0], output_range[1], int(flip_horizontal),
+                                    C.c_void_p(out.ctypes.data), pad, MI_MEM_HOST, None))
+    return out, tuple(pad)

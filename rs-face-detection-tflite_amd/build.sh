@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds libmiface.so (C ABI in include/mi_face.h) for gfx950 with hipcc. Cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+SRC="$HERE/csrc"
+OUT="$HERE/libmiface.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result -I"$HERE/../include")
+OBJ=()
+mkdir -p "$HERE/build"
+for f in tflite_graph.cpp plan.cpp host_glue.cpp engine.cpp capi.cpp kernels.hip block_kernels.hip preproc.hip; do
+  o="$HERE/build/${f%.*}.o"
+  if [[ ! -f "$o" || "$SRC/$f" -nt "$o" || -n "$(find "$SRC" -name '*.hpp' -newer "$o" -print -quit)" || "$HERE/../include/mi_face.h" -nt "$o" ]]; then
+    echo "  hipcc $f"
+    case "$f" in
+      *.hip) "$HIPCC" "${FLAGS[@]}" -c "$SRC/$f" -o "$o" ;;
+      *)     "$HIPCC" "${FLAGS[@]}" -x hip -c "$SRC/$f" -o "$o" ;;
+    esac
+  fi
+  OBJ+=("$o")
+done
+"$HIPCC" -shared -fPIC --offload-arch=gfx950 -o "$OUT" "${OBJ[@]}"
+echo "built $OUT"

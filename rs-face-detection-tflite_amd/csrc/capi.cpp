@@ -1,0 +1,715 @@
+// capi.cpp — extern "C" boundary (include/mi_face.h).  Translates exceptions into status codes + mi_last_error().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_face.h"
+#include "engine.hpp"
+#include "host_glue.hpp"
+#include "kernels.hpp"
+#include "preproc.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+struct ApiError : std::runtime_error {
+    int code;
+    ApiError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+template <typename F>
+int guarded(F&& f) {
+    try {
+        f();
+        return MI_OK;
+    } catch (const ApiError& e) {
+        g_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_error = "out of memory";
+        return MI_ENOMEM;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        std::string m = e.what();
+        if (m.rfind("tflite:", 0) == 0 || m.rfind("plan:", 0) == 0) return MI_EMODEL;
+        if (m.find("hip") != std::string::npos || m.find("HIP") != std::string::npos || m.find("device") != std::string::npos ||
+            m.find("kernel") != std::string::npos)
+            return MI_EDEVICE;
+        return MI_EINVAL;
+    } catch (...) {
+        g_error = "unknown error";
+        return MI_EINVAL;
+    }
+}
+
+std::vector<uint8_t> read_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw ApiError(MI_EIO, "cannot open model file '" + path + "'");
+    std::vector<uint8_t> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (data.empty()) throw ApiError(MI_EIO, "model file '" + path + "' is empty");
+    return data;
+}
+
+// small device scratch that grows on demand
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void* get(size_t bytes) {
+        if (bytes > cap) {
+            if (p) hipFree(p);
+            p = nullptr;
+            mi::hip_check(hipMalloc(&p, bytes), "hipMalloc scratch");
+            cap = bytes;
+        }
+        return p;
+    }
+    ~DeviceBuf() {
+        if (p) hipFree(p);
+    }
+};
+
+void require(bool ok, const char* msg) {
+    if (!ok) throw ApiError(MI_EINVAL, msg);
+}
+
+}  // namespace
+
+struct mi_model {
+    std::unique_ptr<mi::Model> m;
+};
+
+struct mi_fd {
+    mi_model model;
+    int kind = 0, in_w = 0, in_h = 0, n_anchors = 0;
+    std::vector<float> anchors;
+    float* d_anchors = nullptr;
+    DeviceBuf d_in, d_pad, d_out, d_counts, d_img;
+    ~mi_fd() {
+        if (d_anchors) hipFree(d_anchors);
+    }
+};
+
+struct mi_fl {
+    mi_model model;
+    int in_w = 0, in_h = 0;
+    DeviceBuf d_in, d_roi, d_size, d_lm, d_present, d_flag, d_img;
+};
+
+struct mi_iris {
+    mi_model model;
+    int in_w = 0, in_h = 0;
+    DeviceBuf d_in, d_roi, d_size, d_pad, d_flip, d_contour, d_iris, d_img;
+};
+
+extern "C" {
+
+const char* mi_last_error(void) { return g_error.c_str(); }
+const char* mi_version(void) { return "mi_face 0.1 (gfx950)"; }
+
+int mi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------ L0
+int mi_model_load_bytes(const uint8_t* tflite, size_t nbytes, int device, mi_model** out) {
+    return guarded([&] {
+        require(tflite && nbytes && out, "null argument");
+        auto h = std::make_unique<mi_model>();
+        h->m = std::make_unique<mi::Model>(tflite, nbytes, device);
+        *out = h.release();
+    });
+}
+
+int mi_model_load_file(const char* path, int device, mi_model** out) {
+    return guarded([&] {
+        require(path && out, "null argument");
+        auto bytes = read_file(path);
+        auto h = std::make_unique<mi_model>();
+        h->m = std::make_unique<mi::Model>(bytes.data(), bytes.size(), device);
+        *out = h.release();
+    });
+}
+
+void mi_model_free(mi_model* m) { delete m; }
+
+int mi_model_input_dims(const mi_model* m, int dims[4]) {
+    return guarded([&] {
+        require(m && dims, "null argument");
+        auto d = m->m->input_dims();
+        for (int i = 0; i < 4; i++) dims[i] = d[i];
+    });
+}
+
+int mi_model_num_outputs(const mi_model* m) { return m ? m->m->num_outputs() : MI_EINVAL; }
+
+int mi_model_output_dims(const mi_model* m, int index, int dims[4], int* rank) {
+    return guarded([&] {
+        require(m && dims, "null argument");
+        require(index >= 0 && index < m->m->num_outputs(), "output index out of range");
+        const auto& d = m->m->output_dims(index);
+        for (int i = 0; i < 4; i++) dims[i] = i < static_cast<int>(d.size()) ? d[i] : 1;
+        if (rank) *rank = static_cast<int>(d.size());
+    });
+}
+
+size_t mi_model_output_elems(const mi_model* m, int index) {
+    if (!m || index < 0 || index >= m->m->num_outputs()) return 0;
+    return m->m->output_elems(index);
+}
+
+int mi_model_run(mi_model* m, const float* in, int batch, float* const* outs, int mem, void* stream) {
+    return guarded([&] {
+        require(m && in && outs, "null argument");
+        require(batch > 0, "batch must be positive");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        m->m->run(in, batch, outs, mem, static_cast<hipStream_t>(stream));
+    });
+}
+
+int mi_model_debug_tensor(mi_model* m, int tensor_index, int frame, float* dst, size_t cap, size_t* n) {
+    return guarded([&] {
+        require(m && dst, "null argument");
+        size_t got = m->m->debug_tensor(tensor_index, frame, dst, cap);
+        if (n) *n = got;
+    });
+}
+
+size_t mi_model_describe(const mi_model* m, char* buf, size_t cap) {
+    if (!m) return 0;
+    std::string s = m->m->describe();
+    if (buf && cap) {
+        size_t k = std::min(cap - 1, s.size());
+        std::memcpy(buf, s.data(), k);
+        buf[k] = 0;
+    }
+    return s.size() + 1;
+}
+
+size_t mi_plan_describe(const uint8_t* tflite, size_t nbytes, int fuse_level, char* buf, size_t cap) {
+    size_t need = 0;
+    int rc = guarded([&] {
+        require(tflite && nbytes, "null argument");
+        std::string s = mi::build_plan(mi::parse_tflite(tflite, nbytes), fuse_level).describe();
+        if (buf && cap) {
+            size_t k = std::min(cap - 1, s.size());
+            std::memcpy(buf, s.data(), k);
+            buf[k] = 0;
+        }
+        need = s.size() + 1;
+    });
+    return rc == MI_OK ? need : 0;
+}
+
+int mi_model_set_option(mi_model* m, const char* key, int value) {
+    return guarded([&] {
+        require(m && key, "null argument");
+        m->m->set_option(key, value);
+    });
+}
+
+int mi_model_plan_stats(const mi_model* m, double* bytes_per_frame, double* macs_per_frame, int* launches) {
+    return guarded([&] {
+        require(m, "null argument");
+        if (bytes_per_frame) *bytes_per_frame = m->m->plan().bytes_per_frame;
+        if (macs_per_frame) *macs_per_frame = m->m->plan().macs_per_frame;
+        if (launches) {
+            int n = 0;
+            for (const auto& nd : m->m->plan().nodes) n += !(nd.kind == mi::Node::Reshape || nd.kind == mi::Node::Concat);
+            *launches = n;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ FaceDetection
+static void fd_finish_create(mi_fd* h, int kind) {
+    mi::SsdOptions opts;
+    if (!mi::ssd_options_for(kind, &opts)) throw ApiError(MI_EINVAL, "unsupported model type");
+    h->kind = kind;
+    auto d = h->model.m->input_dims();
+    h->in_h = d[1];
+    h->in_w = d[2];
+    if (d[3] != 3) throw ApiError(MI_EMODEL, "detector input must have 3 channels");
+    h->anchors = mi::ssd_generate_anchors(opts);
+    h->n_anchors = static_cast<int>(h->anchors.size() / 2);
+    if (h->model.m->num_outputs() < 2) throw ApiError(MI_EMODEL, "detector must have two outputs");
+    const auto& rb = h->model.m->output_dims(0);
+    if (rb.size() != 3 || rb[1] != h->n_anchors || rb[2] != 16 || static_cast<int>(h->model.m->output_elems(1)) != h->n_anchors)
+        throw ApiError(MI_EMODEL, "detector outputs do not match the SSD anchor layout");
+    if (h->in_h != opts.input_h || h->in_w != opts.input_w) throw ApiError(MI_EMODEL, "detector input size does not match SSD options");
+    mi::hip_check(hipMalloc(reinterpret_cast<void**>(&h->d_anchors), h->anchors.size() * sizeof(float)), "hipMalloc anchors");
+    mi::hip_check(hipMemcpy(h->d_anchors, h->anchors.data(), h->anchors.size() * sizeof(float), hipMemcpyHostToDevice), "upload anchors");
+}
+
+int mi_fd_create_from_bytes(int kind, const uint8_t* tflite, size_t nbytes, int device, mi_fd** out) {
+    return guarded([&] {
+        require(tflite && nbytes && out, "null argument");
+        auto h = std::make_unique<mi_fd>();
+        h->model.m = std::make_unique<mi::Model>(tflite, nbytes, device);
+        fd_finish_create(h.get(), kind);
+        *out = h.release();
+    });
+}
+
+int mi_fd_create(int kind, const char* model_dir, int device, mi_fd** out) {
+    return guarded([&] {
+        require(out, "null argument");
+        const char* file = mi::model_file_for(kind);
+        if (!file) throw ApiError(MI_EINVAL, "unsupported model type");
+        std::string dir = model_dir ? model_dir : "./models";  // face_detection.rs:157-161
+        auto bytes = read_file(dir + "/" + file);
+        auto h = std::make_unique<mi_fd>();
+        h->model.m = std::make_unique<mi::Model>(bytes.data(), bytes.size(), device);
+        fd_finish_create(h.get(), kind);
+        *out = h.release();
+    });
+}
+
+void mi_fd_free(mi_fd* h) { delete h; }
+mi_model* mi_fd_model(mi_fd* h) { return h ? &h->model : nullptr; }
+
+int mi_fd_input_size(const mi_fd* h, int* width, int* height) {
+    if (!h) return MI_EINVAL;
+    if (width) *width = h->in_w;
+    if (height) *height = h->in_h;
+    return MI_OK;
+}
+int mi_fd_num_anchors(const mi_fd* h) { return h ? h->n_anchors : MI_EINVAL; }
+int mi_fd_anchors(const mi_fd* h, float* out_xy, int cap) {
+    if (!h || !out_xy) return MI_EINVAL;
+    int n = std::min(cap, h->n_anchors);
+    std::memcpy(out_xy, h->anchors.data(), static_cast<size_t>(n) * 2 * sizeof(float));
+    return n;
+}
+
+// shared tail: raw device outputs -> detections
+static void fd_post(mi_fd* h, const float* d_boxes, const float* d_scores, int batch, const double* padding, mi_detection* out,
+                    int cap, int* counts, int mem, hipStream_t s) {
+    mi::PostArgs a;
+    a.raw_boxes = d_boxes;
+    a.raw_scores = d_scores;
+    a.anchors = h->d_anchors;
+    a.B = batch;
+    a.N = h->n_anchors;
+    a.cap = cap;
+    a.scale = static_cast<float>(h->in_h);  // decode_boxes(raw_boxes, input_shape[1] as f32) — face_detection.rs:259
+    if (mem == MI_MEM_DEVICE) {
+        a.padding = padding;
+        a.out = reinterpret_cast<float*>(out);
+        a.counts = counts;
+        int rc = mi::launch_postprocess(a, s);
+        if (rc) throw std::runtime_error(std::string("postprocess kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        return;
+    }
+    const double* d_pad = nullptr;
+    if (padding) {
+        d_pad = static_cast<const double*>(h->d_pad.get(sizeof(double) * 4 * batch));
+        mi::hip_check(hipMemcpyAsync(const_cast<double*>(d_pad), padding, sizeof(double) * 4 * batch, hipMemcpyHostToDevice, s), "H2D padding");
+    }
+    a.padding = d_pad;
+    a.out = static_cast<float*>(h->d_out.get(sizeof(mi_detection) * static_cast<size_t>(cap) * batch));
+    a.counts = static_cast<int*>(h->d_counts.get(sizeof(int) * batch));
+    int rc = mi::launch_postprocess(a, s);
+    if (rc) throw std::runtime_error(std::string("postprocess kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+    mi::hip_check(hipMemcpyAsync(out, a.out, sizeof(mi_detection) * static_cast<size_t>(cap) * batch, hipMemcpyDeviceToHost, s), "D2H detections");
+    mi::hip_check(hipMemcpyAsync(counts, a.counts, sizeof(int) * batch, hipMemcpyDeviceToHost, s), "D2H counts");
+    mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    for (int b = 0; b < batch; b++)
+        if (counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
+}
+
+int mi_fd_infer_tensor(mi_fd* h, const float* in, int batch, const double* padding, mi_detection* out, int cap_per_frame,
+                       int* counts, int mem, void* stream) {
+    return guarded([&] {
+        require(h && in && out && counts, "null argument");
+        require(batch > 0 && cap_per_frame > 0, "batch and cap_per_frame must be positive");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        const float* din = in;
+        if (mem == MI_MEM_HOST) {
+            size_t bytes = m.input_elems() * sizeof(float) * batch;
+            din = static_cast<const float*>(h->d_in.get(bytes));
+            mi::hip_check(hipMemcpyAsync(const_cast<float*>(din), in, bytes, hipMemcpyHostToDevice, s), "H2D input");
+        }
+        m.run_device(din, batch, s);
+        fd_post(h, m.output_device(0), m.output_device(1), batch, padding, out, cap_per_frame, counts, mem, s);
+        if (mem == MI_MEM_DEVICE && !stream) mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+
+int mi_fd_postprocess(mi_fd* h, const float* raw_boxes, const float* raw_scores, int batch, const double* padding,
+                      mi_detection* out, int cap_per_frame, int* counts, int mem, void* stream) {
+    return guarded([&] {
+        require(h && raw_boxes && raw_scores && out && counts, "null argument");
+        require(batch > 0 && cap_per_frame > 0, "batch and cap_per_frame must be positive");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        const float *db = raw_boxes, *ds = raw_scores;
+        if (mem == MI_MEM_HOST) {
+            size_t nb = sizeof(float) * 16 * h->n_anchors * batch, ns = sizeof(float) * h->n_anchors * batch;
+            char* p = static_cast<char*>(h->d_in.get(nb + ns));
+            mi::hip_check(hipMemcpyAsync(p, raw_boxes, nb, hipMemcpyHostToDevice, s), "H2D boxes");
+            mi::hip_check(hipMemcpyAsync(p + nb, raw_scores, ns, hipMemcpyHostToDevice, s), "H2D scores");
+            db = reinterpret_cast<const float*>(p);
+            ds = reinterpret_cast<const float*>(p + nb);
+        }
+        fd_post(h, db, ds, batch, padding, out, cap_per_frame, counts, mem, s);
+        if (mem == MI_MEM_DEVICE && !stream) mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+
+int mi_fd_infer_image(mi_fd* h, const uint8_t* rgb, int width, int height, int stride, const mi_rect* roi, mi_detection* out,
+                      int cap, int* count) {
+    return guarded([&] {
+        require(h && rgb && out && count, "null argument");
+        require(width > 0 && height > 0 && stride >= 3 * width && cap > 0, "bad image geometry");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = m.stream();
+        float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
+        double pad[4];
+        // image_to_tensor(image, roi, (w,h), keep_aspect_ratio = true, (-1,1), flip = false) — face_detection.rs:219
+        mi::image_to_tensor_device(rgb, width, height, stride, roi, h->in_w, h->in_h, true, -1.0, 1.0, false, d_t, pad, h->d_img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, h->in_w, h->in_h, true)), s);
+        m.run_device(d_t, 1, s);
+        fd_post(h, m.output_device(0), m.output_device(1), 1, pad, out, cap, count, MI_MEM_HOST, s);
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ FaceLandmark
+static void fl_finish_create(mi_fl* h) {
+    auto d = h->model.m->input_dims();
+    h->in_h = d[1];
+    h->in_w = d[2];
+    // face_landmark.rs:241-247: last dim of outputs()[0] must hold NUM_DIMS * NUM_LANDMARKS = 1404 values
+    if (h->model.m->num_outputs() < 2 || h->model.m->output_dims(0).back() < 3 * MI_NUM_FACE_LANDMARKS)
+        throw ApiError(MI_EMODEL, "incompatible model: mesh output narrower than 1404");
+}
+
+int mi_fl_create_from_bytes(const uint8_t* tflite, size_t nbytes, int device, mi_fl** out) {
+    return guarded([&] {
+        require(tflite && nbytes && out, "null argument");
+        auto h = std::make_unique<mi_fl>();
+        h->model.m = std::make_unique<mi::Model>(tflite, nbytes, device);
+        fl_finish_create(h.get());
+        *out = h.release();
+    });
+}
+
+int mi_fl_create(const char* model_path, int device, mi_fl** out) {
+    return guarded([&] {
+        require(out, "null argument");
+        auto bytes = read_file(model_path ? model_path : "./models/face_landmark.tflite");  // face_landmark.rs:211-215
+        auto h = std::make_unique<mi_fl>();
+        h->model.m = std::make_unique<mi::Model>(bytes.data(), bytes.size(), device);
+        fl_finish_create(h.get());
+        *out = h.release();
+    });
+}
+
+void mi_fl_free(mi_fl* h) { delete h; }
+mi_model* mi_fl_model(mi_fl* h) { return h ? &h->model : nullptr; }
+
+int mi_fl_infer_tensor(mi_fl* h, const float* in, int batch, const mi_rect* rois, const int* image_sizes, float* landmarks,
+                       int* present, float* raw_flags, int mem, void* stream) {
+    return guarded([&] {
+        require(h && in && landmarks && present, "null argument");
+        require(batch > 0, "batch must be positive");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        require(!rois || image_sizes, "image_sizes is required when rois are given");
+        static_assert(sizeof(mi_rect) == sizeof(mi::RectD), "mi_rect layout");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        const size_t lm_bytes = sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * batch;
+        mi::ProjArgs a;
+        a.B = batch;
+        a.n = MI_NUM_FACE_LANDMARKS;
+        a.tensor_w = h->in_w;
+        a.tensor_h = h->in_h;
+        const float* din = in;
+        if (mem == MI_MEM_HOST) {
+            size_t bytes = m.input_elems() * sizeof(float) * batch;
+            din = static_cast<const float*>(h->d_in.get(bytes));
+            mi::hip_check(hipMemcpyAsync(const_cast<float*>(din), in, bytes, hipMemcpyHostToDevice, s), "H2D input");
+            if (rois) {
+                a.roi = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect) * batch));
+                mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(a.roi), rois, sizeof(mi_rect) * batch, hipMemcpyHostToDevice, s), "H2D rois");
+                a.image_size = static_cast<const int*>(h->d_size.get(sizeof(int) * 2 * batch));
+                mi::hip_check(hipMemcpyAsync(const_cast<int*>(a.image_size), image_sizes, sizeof(int) * 2 * batch, hipMemcpyHostToDevice, s), "H2D sizes");
+            }
+            a.out = static_cast<float*>(h->d_lm.get(lm_bytes));
+            a.present = static_cast<int*>(h->d_present.get(sizeof(int) * batch));
+            a.raw_flag_out = static_cast<float*>(h->d_flag.get(sizeof(float) * batch));
+        } else {
+            a.roi = reinterpret_cast<const mi::RectD*>(rois);
+            a.image_size = image_sizes;
+            a.out = landmarks;
+            a.present = present;
+            a.raw_flag_out = raw_flags;
+        }
+        m.run_device(din, batch, s);
+        a.raw = m.output_device(0);
+        a.raw_fs = static_cast<long>(m.output_elems(0));
+        a.flag = m.output_device(1) + (m.output_elems(1) - 1);  // `flatten[flatten.len() - 1]` — face_landmark.rs:292-293
+        a.flag_fs = static_cast<long>(m.output_elems(1));
+        int rc = mi::launch_project(a, s);
+        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (mem == MI_MEM_HOST) {
+            mi::hip_check(hipMemcpyAsync(landmarks, a.out, lm_bytes, hipMemcpyDeviceToHost, s), "D2H landmarks");
+            mi::hip_check(hipMemcpyAsync(present, a.present, sizeof(int) * batch, hipMemcpyDeviceToHost, s), "D2H present");
+            if (raw_flags) mi::hip_check(hipMemcpyAsync(raw_flags, a.raw_flag_out, sizeof(float) * batch, hipMemcpyDeviceToHost, s), "D2H flags");
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        } else if (!stream) {
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+    });
+}
+
+int mi_fl_infer_image(mi_fl* h, const uint8_t* rgb, int width, int height, int stride, const mi_rect* roi, mi_landmark* out,
+                      int cap, int* count) {
+    return guarded([&] {
+        require(h && rgb && out && count, "null argument");
+        require(width > 0 && height > 0 && stride >= 3 * width, "bad image geometry");
+        require(cap >= MI_NUM_FACE_LANDMARKS, "output capacity must be at least 468");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = m.stream();
+        float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
+        double pad[4];
+        // image_to_tensor(image, roi, (192,192), keep_aspect_ratio = false, (0,1), false) — face_landmark.rs:250
+        mi::image_to_tensor_device(rgb, width, height, stride, roi, h->in_w, h->in_h, false, 0.0, 1.0, false, d_t, pad, h->d_img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, h->in_w, h->in_h, false)), s);
+        std::vector<float> lm(3 * MI_NUM_FACE_LANDMARKS);
+        int present = 0;
+        int size[2] = {width, height};
+        mi::ProjArgs a;
+        a.B = 1; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = h->in_w; a.tensor_h = h->in_h;
+        if (roi) {
+            a.roi = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect)));
+            mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(a.roi), roi, sizeof(mi_rect), hipMemcpyHostToDevice, s), "H2D roi");
+            a.image_size = static_cast<const int*>(h->d_size.get(sizeof(int) * 2));
+            mi::hip_check(hipMemcpyAsync(const_cast<int*>(a.image_size), size, sizeof(size), hipMemcpyHostToDevice, s), "H2D size");
+        }
+        a.out = static_cast<float*>(h->d_lm.get(sizeof(float) * lm.size()));
+        a.present = static_cast<int*>(h->d_present.get(sizeof(int)));
+        m.run_device(d_t, 1, s);
+        a.raw = m.output_device(0);
+        a.raw_fs = static_cast<long>(m.output_elems(0));
+        a.flag = m.output_device(1) + (m.output_elems(1) - 1);
+        a.flag_fs = static_cast<long>(m.output_elems(1));
+        int rc = mi::launch_project(a, s);
+        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        mi::hip_check(hipMemcpyAsync(lm.data(), a.out, sizeof(float) * lm.size(), hipMemcpyDeviceToHost, s), "D2H landmarks");
+        mi::hip_check(hipMemcpyAsync(&present, a.present, sizeof(int), hipMemcpyDeviceToHost, s), "D2H present");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        *count = 0;
+        if (present) {
+            for (int i = 0; i < MI_NUM_FACE_LANDMARKS; i++) out[i] = mi_landmark{lm[3 * i], lm[3 * i + 1], lm[3 * i + 2]};
+            *count = MI_NUM_FACE_LANDMARKS;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ IrisLandmark
+static void iris_finish_create(mi_iris* h) {
+    auto d = h->model.m->input_dims();
+    h->in_h = d[1];
+    h->in_w = d[2];
+    // iris_landmark.rs:172-184
+    if (h->model.m->num_outputs() < 2 || h->model.m->output_dims(0).back() != 3 * MI_NUM_EYE_LANDMARKS ||
+        h->model.m->output_dims(1).back() != 3 * MI_NUM_IRIS_LANDMARKS)
+        throw ApiError(MI_EMODEL, "unexpected number of eye landmarks");
+}
+
+int mi_iris_create_from_bytes(const uint8_t* tflite, size_t nbytes, int device, mi_iris** out) {
+    return guarded([&] {
+        require(tflite && nbytes && out, "null argument");
+        auto h = std::make_unique<mi_iris>();
+        h->model.m = std::make_unique<mi::Model>(tflite, nbytes, device);
+        iris_finish_create(h.get());
+        *out = h.release();
+    });
+}
+
+int mi_iris_create(const char* model_path, int device, mi_iris** out) {
+    return guarded([&] {
+        require(out, "null argument");
+        auto bytes = read_file(model_path ? model_path : "./models/iris_landmark.tflite");  // iris_landmark.rs:145-149
+        auto h = std::make_unique<mi_iris>();
+        h->model.m = std::make_unique<mi::Model>(bytes.data(), bytes.size(), device);
+        iris_finish_create(h.get());
+        *out = h.release();
+    });
+}
+
+void mi_iris_free(mi_iris* h) { delete h; }
+mi_model* mi_iris_model(mi_iris* h) { return h ? &h->model : nullptr; }
+
+static void iris_project(mi_iris* h, int batch, const mi::RectD* d_roi, const int* d_size, const double* d_pad, const int* d_flip,
+                         float* d_contour, float* d_iris, hipStream_t s) {
+    mi::Model& m = *h->model.m;
+    for (int k = 0; k < 2; k++) {
+        mi::ProjArgs a;
+        a.B = batch;
+        a.n = k == 0 ? MI_NUM_EYE_LANDMARKS : MI_NUM_IRIS_LANDMARKS;
+        a.tensor_w = h->in_w;
+        a.tensor_h = h->in_h;
+        a.roi = d_roi;
+        a.image_size = d_size;
+        a.padding = d_pad;
+        a.flip = d_flip;
+        a.raw = m.output_device(k);
+        a.raw_fs = static_cast<long>(m.output_elems(k));
+        a.out = k == 0 ? d_contour : d_iris;
+        int rc = mi::launch_project(a, s);
+        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+    }
+}
+
+int mi_iris_infer_tensor(mi_iris* h, const float* in, int batch, const mi_rect* rois, const int* image_sizes, const double* padding,
+                         const int* is_right_eye, float* contour, float* iris, int mem, void* stream) {
+    return guarded([&] {
+        require(h && in && contour && iris, "null argument");
+        require(batch > 0, "batch must be positive");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        require(!rois || image_sizes, "image_sizes is required when rois are given");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        const size_t cb = sizeof(float) * 3 * MI_NUM_EYE_LANDMARKS * batch, ib = sizeof(float) * 3 * MI_NUM_IRIS_LANDMARKS * batch;
+        if (mem == MI_MEM_DEVICE) {
+            m.run_device(in, batch, s);
+            iris_project(h, batch, reinterpret_cast<const mi::RectD*>(rois), image_sizes, padding, is_right_eye, contour, iris, s);
+            if (!stream) mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+            return;
+        }
+        size_t bytes = m.input_elems() * sizeof(float) * batch;
+        float* din = static_cast<float*>(h->d_in.get(bytes));
+        mi::hip_check(hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, s), "H2D input");
+        const mi::RectD* d_roi = nullptr;
+        const int *d_size = nullptr, *d_flip = nullptr;
+        const double* d_pad = nullptr;
+        if (rois) {
+            d_roi = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect) * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_roi), rois, sizeof(mi_rect) * batch, hipMemcpyHostToDevice, s), "H2D rois");
+            d_size = static_cast<const int*>(h->d_size.get(sizeof(int) * 2 * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<int*>(d_size), image_sizes, sizeof(int) * 2 * batch, hipMemcpyHostToDevice, s), "H2D sizes");
+        }
+        if (padding) {
+            d_pad = static_cast<const double*>(h->d_pad.get(sizeof(double) * 4 * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<double*>(d_pad), padding, sizeof(double) * 4 * batch, hipMemcpyHostToDevice, s), "H2D padding");
+        }
+        if (is_right_eye) {
+            d_flip = static_cast<const int*>(h->d_flip.get(sizeof(int) * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<int*>(d_flip), is_right_eye, sizeof(int) * batch, hipMemcpyHostToDevice, s), "H2D flip");
+        }
+        float* dc = static_cast<float*>(h->d_contour.get(cb));
+        float* di = static_cast<float*>(h->d_iris.get(ib));
+        m.run_device(din, batch, s);
+        iris_project(h, batch, d_roi, d_size, d_pad, d_flip, dc, di, s);
+        mi::hip_check(hipMemcpyAsync(contour, dc, cb, hipMemcpyDeviceToHost, s), "D2H contour");
+        mi::hip_check(hipMemcpyAsync(iris, di, ib, hipMemcpyDeviceToHost, s), "D2H iris");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+
+int mi_iris_infer_image(mi_iris* h, const uint8_t* rgb, int width, int height, int stride, const mi_rect* roi, int is_right_eye,
+                        mi_landmark* contour71, mi_landmark* iris5) {
+    return guarded([&] {
+        require(h && rgb && contour71 && iris5, "null argument");
+        require(width > 0 && height > 0 && stride >= 3 * width, "bad image geometry");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = m.stream();
+        float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
+        double pad[4];
+        // image_to_tensor(image, roi, (64,64), keep_aspect_ratio = true, (0,1), is_right_eye) — iris_landmark.rs:188-189
+        mi::image_to_tensor_device(rgb, width, height, stride, roi, h->in_w, h->in_h, true, 0.0, 1.0, is_right_eye != 0, d_t, pad, h->d_img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, h->in_w, h->in_h, true)), s);
+        int size[2] = {width, height}, flip = is_right_eye != 0;
+        const mi::RectD* d_roi = nullptr;
+        const int* d_size = nullptr;
+        if (roi) {
+            d_roi = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect)));
+            mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_roi), roi, sizeof(mi_rect), hipMemcpyHostToDevice, s), "H2D roi");
+            d_size = static_cast<const int*>(h->d_size.get(sizeof(int) * 2));
+            mi::hip_check(hipMemcpyAsync(const_cast<int*>(d_size), size, sizeof(size), hipMemcpyHostToDevice, s), "H2D size");
+        }
+        double* d_pad = static_cast<double*>(h->d_pad.get(sizeof(double) * 4));
+        mi::hip_check(hipMemcpyAsync(d_pad, pad, sizeof(pad), hipMemcpyHostToDevice, s), "H2D padding");
+        int* d_flip = static_cast<int*>(h->d_flip.get(sizeof(int)));
+        mi::hip_check(hipMemcpyAsync(d_flip, &flip, sizeof(int), hipMemcpyHostToDevice, s), "H2D flip");
+        float* dc = static_cast<float*>(h->d_contour.get(sizeof(float) * 3 * MI_NUM_EYE_LANDMARKS));
+        float* di = static_cast<float*>(h->d_iris.get(sizeof(float) * 3 * MI_NUM_IRIS_LANDMARKS));
+        m.run_device(d_t, 1, s);
+        iris_project(h, 1, d_roi, d_size, d_pad, d_flip, dc, di, s);
+        float c[3 * MI_NUM_EYE_LANDMARKS], ir[3 * MI_NUM_IRIS_LANDMARKS];
+        mi::hip_check(hipMemcpyAsync(c, dc, sizeof(c), hipMemcpyDeviceToHost, s), "D2H contour");
+        mi::hip_check(hipMemcpyAsync(ir, di, sizeof(ir), hipMemcpyDeviceToHost, s), "D2H iris");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        for (int i = 0; i < MI_NUM_EYE_LANDMARKS; i++) contour71[i] = mi_landmark{c[3 * i], c[3 * i + 1], c[3 * i + 2]};
+        for (int i = 0; i < MI_NUM_IRIS_LANDMARKS; i++) iris5[i] = mi_landmark{ir[3 * i], ir[3 * i + 1], ir[3 * i + 2]};
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+int mi_face_detection_to_roi(const mi_detection* det, int image_w, int image_h, mi_rect* out) {
+    return guarded([&] {
+        require(det && out, "null argument");
+        // Detection::scaled_by_image_size multiplies in f32 (types.rs:237-245); keypoints 0/1 = eyes (face_detection.rs:91-98)
+        const float w = static_cast<float>(image_w), hgt = static_cast<float>(image_h);
+        const float lx = det->data[4] * w, ly = det->data[5] * hgt, rx = det->data[6] * w, ry = det->data[7] * hgt;
+        const double kp[4] = {lx, ly, rx, ry};
+        const double bbox[4] = {det->data[0], det->data[1], det->data[2], det->data[3]};
+        if (!mi::bbox_to_roi(bbox, image_w, image_h, kp, 1.5, 1.5, 1, out)) throw ApiError(MI_EINVAL, "bbox must be normalized");
+    });
+}
+
+int mi_iris_roi_from_face_landmarks(const mi_landmark* lm, int image_w, int image_h, mi_rect* left_eye, mi_rect* right_eye) {
+    return guarded([&] {
+        require(lm && left_eye && right_eye, "null argument");
+        const int idx[2][2] = {{33, 133}, {362, 263}};  // iris_landmark.rs:29-35
+        mi_rect* outs[2] = {left_eye, right_eye};
+        for (int e = 0; e < 2; e++) {
+            const mi_landmark &a = lm[idx[e][0]], &b = lm[idx[e][1]];
+            const double bbox[4] = {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmax(a.x, b.x), std::fmax(a.y, b.y)};
+            const double kp[4] = {a.x, a.y, b.x, b.y};
+            if (!mi::bbox_to_roi(bbox, image_w, image_h, kp, 2.3, 2.3, 1, outs[e])) throw ApiError(MI_EINVAL, "bbox must be normalized");
+        }
+    });
+}
+
+int mi_image_to_tensor(int device, const uint8_t* rgb, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
+                       int keep_aspect_ratio, double range_min, double range_max, int flip_horizontal, float* out,
+                       double padding_out[4], int mem, void* stream) {
+    return guarded([&] {
+        require(rgb && out && padding_out, "null argument");
+        require(width > 0 && height > 0 && stride >= 3 * width && out_w > 0 && out_h > 0, "bad image geometry");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) throw ApiError(MI_EDEVICE, "no such HIP device");
+        mi::hip_check(hipSetDevice(device), "hipSetDevice");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        DeviceBuf img, outbuf;
+        float* d_out = out;
+        size_t ob = sizeof(float) * 3 * out_w * out_h;
+        if (mem == MI_MEM_HOST) d_out = static_cast<float*>(outbuf.get(ob));
+        mi::image_to_tensor_device(rgb, width, height, stride, roi, out_w, out_h, keep_aspect_ratio != 0, range_min, range_max,
+                                   flip_horizontal != 0, d_out, padding_out, img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, out_w, out_h, keep_aspect_ratio != 0)), s);
+        if (mem == MI_MEM_HOST) mi::hip_check(hipMemcpyAsync(out, d_out, ob, hipMemcpyDeviceToHost, s), "D2H tensor");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+
+}  // extern "C"

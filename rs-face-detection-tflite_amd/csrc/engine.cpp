@@ -1,0 +1,338 @@
+// engine.cpp — see engine.hpp.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+namespace mi {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+namespace {
+void same_pad(int in, int k, int stride, int out, int* before) {
+    int total = std::max(0, (out - 1) * stride + k - in);
+    *before = total / 2;
+}
+long align_up(long v, long a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+Model::Model(const uint8_t* bytes, size_t n, int device) : device_(device), blob_(bytes, bytes + n) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        throw std::runtime_error("no HIP device visible: the MI355X kernels cannot run (no CPU fallback exists)");
+    if (device < 0 || device >= count) throw std::runtime_error("device ordinal out of range");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hipDeviceProp_t prop;
+    hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        throw std::runtime_error(std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    rebuild();
+}
+
+Model::~Model() {
+    hipSetDevice(device_);
+    invalidate_graphs();
+    if (d_weights_) hipFree(d_weights_);
+    if (d_arena_) hipFree(d_arena_);
+    if (d_in_stage_) hipFree(d_in_stage_);
+    for (float* p : d_out_)
+        if (p) hipFree(p);
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+void Model::invalidate_graphs() {
+    for (auto& kv : graphs_) hipGraphExecDestroy(kv.second);
+    graphs_.clear();
+}
+
+void Model::set_option(const std::string& key, int value) {
+    if (key == "chunk") chunk_ = std::max(0, value);
+    else if (key == "graph") use_graph_ = value != 0;
+    else if (key == "fuse") { fuse_level_ = std::min(2, std::max(0, value)); dirty_ = true; }
+    else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
+    else throw std::runtime_error("unknown option '" + key + "'");
+    invalidate_graphs();
+    chunk_cap_ = 0;  // arena is re-laid out on the next run
+}
+
+void Model::rebuild() {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    invalidate_graphs();
+    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_);
+    const Graph& g = plan_.graph;
+    if (!reuse_) {  // debugging layout: every tensor keeps its own slot
+        long off = 0;
+        for (size_t t = 0; t < g.tensors.size(); t++)
+            if (plan_.root_offset[t] >= 0) { plan_.root_offset[t] = off; off += plan_.root_elems[t]; }
+        plan_.arena_floats_per_frame = off;
+    }
+    // ---- pack every constant the launches need into one device blob
+    std::vector<float> host;
+    auto put = [&](const std::vector<float>& v) {
+        long off = align_up(static_cast<long>(host.size()), 64);
+        host.resize(static_cast<size_t>(off) + v.size(), 0.f);
+        std::copy(v.begin(), v.end(), host.begin() + off);
+        return off;
+    };
+    const size_t NN = plan_.nodes.size();
+    node_w_.assign(NN, -1); node_b_.assign(NN, -1); node_w2_.assign(NN, -1); node_b2_.assign(NN, -1); node_alpha_.assign(NN, -1);
+    for (size_t i = 0; i < NN; i++) {
+        const Node& n = plan_.nodes[i];
+        if (n.b >= 0) node_b_[i] = put(g.tensors[n.b].f32);
+        if (n.b2 >= 0) node_b2_[i] = put(g.tensors[n.b2].f32);
+        if (n.alpha >= 0) node_alpha_[i] = put(g.tensors[n.alpha].f32);
+        if (n.kind == Node::Conv) {
+            const auto& ws = g.tensors[n.w].shape;  // [O][KH][KW][I]
+            const auto& src = g.tensors[n.w].f32;
+            int O = ws[0], KH = ws[1], KW = ws[2], I = ws[3], Cop = (O + 3) & ~3;
+            std::vector<float> r(static_cast<size_t>(KH) * KW * I * Cop, 0.f);
+            for (int o = 0; o < O; o++)
+                for (int ky = 0; ky < KH; ky++)
+                    for (int kx = 0; kx < KW; kx++)
+                        for (int c = 0; c < I; c++)
+                            r[((static_cast<size_t>(ky) * KW + kx) * I + c) * Cop + o] = src[((static_cast<size_t>(o) * KH + ky) * KW + kx) * I + c];
+            node_w_[i] = put(r);
+        } else if (n.kind == Node::Dw) {
+            node_w_[i] = put(g.tensors[n.w].f32);
+        } else if (n.kind == Node::Block) {
+            node_w_[i] = put(g.tensors[n.w].f32);
+            const auto& ws = g.tensors[n.w2].shape;  // [O][1][1][I]
+            const auto& src = g.tensors[n.w2].f32;
+            int O = ws[0], I = ws[3], Cp, Cop;
+            block_weight_dims(I, O, &Cp, &Cop);
+            std::vector<float> r(static_cast<size_t>(Cop) * Cp, 0.f);
+            for (int o = 0; o < O; o++)
+                for (int c = 0; c < I; c++) r[static_cast<size_t>(o) * Cp + c] = src[static_cast<size_t>(o) * I + c];
+            node_w2_[i] = put(r);
+        }
+    }
+    if (d_weights_) hip_check(hipFree(d_weights_), "hipFree");
+    d_weights_ = nullptr;
+    hip_check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(host.size(), 64) * sizeof(float)), "hipMalloc weights");
+    hip_check(hipMemcpy(d_weights_, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice), "upload weights");
+    dirty_ = false;
+    chunk_cap_ = 0;
+}
+
+void Model::ensure_capacity(int batch) {
+    int chunk = chunk_ > 0 ? std::min(chunk_, batch) : batch;
+    if (chunk > chunk_cap_) {
+        invalidate_graphs();
+        if (d_arena_) hip_check(hipFree(d_arena_), "hipFree arena");
+        d_arena_ = nullptr;
+        arena_floats_ = static_cast<size_t>(plan_.arena_floats_per_frame) * chunk;
+        hip_check(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(arena_floats_, 64) * sizeof(float)), "hipMalloc arena");
+        chunk_cap_ = chunk;
+    }
+    if (batch > batch_cap_) {
+        invalidate_graphs();
+        for (float* p : d_out_)
+            if (p) hip_check(hipFree(p), "hipFree out");
+        d_out_.assign(num_outputs(), nullptr);
+        for (int k = 0; k < num_outputs(); k++)
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d_out_[k]), output_elems(k) * sizeof(float) * batch), "hipMalloc outputs");
+        batch_cap_ = batch;
+    }
+}
+
+const float* Model::tensor_ptr(int t, const float* in, int chunk_start, long* fs) const {
+    const Graph& g = plan_.graph;
+    const Storage& s = plan_.storage[t];
+    *fs = s.frame_stride;
+    if (s.root == plan_.storage[g.inputs[0]].root) return in + static_cast<long>(chunk_start) * s.frame_stride + s.offset;
+    return tensor_ptr_mut(t, chunk_start, fs);
+}
+
+float* Model::tensor_ptr_mut(int t, int chunk_start, long* fs) const {
+    const Graph& g = plan_.graph;
+    const Storage& s = plan_.storage[t];
+    *fs = s.frame_stride;
+    for (size_t k = 0; k < g.outputs.size(); k++)
+        if (plan_.storage[g.outputs[k]].root == s.root) return d_out_[k] + static_cast<long>(chunk_start) * s.frame_stride + s.offset;
+    if (s.root == plan_.storage[g.inputs[0]].root) throw std::runtime_error("plan writes into the graph input");
+    long off = plan_.root_offset[s.root];
+    if (off < 0) throw std::runtime_error("tensor has no storage");
+    return d_arena_ + off * chunk_cap_ + s.offset;
+}
+
+void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s) {
+    const Graph& g = plan_.graph;
+    for (size_t i = 0; i < plan_.nodes.size(); i++) {
+        const Node& n = plan_.nodes[i];
+        if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;  // views
+        const auto& si = g.tensors[n.in[0]].shape;
+        const auto& so = g.tensors[n.out].shape;
+        auto dim = [](const std::vector<int>& v, size_t d) { return d < v.size() ? v[d] : 1; };
+        Epilogue ep;
+        ep.bias = (n.kind == Node::Block ? node_b2_[i] : node_b_[i]) >= 0 ? d_weights_ + (n.kind == Node::Block ? node_b2_[i] : node_b_[i]) : nullptr;
+        ep.alpha = node_alpha_[i] >= 0 ? d_weights_ + node_alpha_[i] : nullptr;
+        ep.act = n.act;
+        if (n.res >= 0) {
+            const auto& sr = g.tensors[n.res].shape;
+            ep.res = tensor_ptr(n.res, in, chunk_start, &ep.res_fs);
+            ep.res_mode = n.res_mode;
+            ep.res_C = sr.back();
+            ep.res_H = dim(sr, 1);
+            ep.res_W = dim(sr, 2);
+        }
+        int rc = 0;
+        long in_fs = 0, out_fs = 0;
+        const float* ip = tensor_ptr(n.in[0], in, chunk_start, &in_fs);
+        float* op = tensor_ptr_mut(n.out, chunk_start, &out_fs);
+        switch (n.kind) {
+            case Node::Conv: {
+                ConvArgs a;
+                a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
+                a.w = d_weights_ + node_w_[i];
+                a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2]; a.Co = so[3]; a.Cop = (a.Co + 3) & ~3;
+                a.KH = n.KH; a.KW = n.KW; a.sh = n.sh; a.sw = n.sw;
+                if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
+                a.ep = ep;
+                rc = launch_conv(a, s);
+                break;
+            }
+            case Node::Dw: {
+                DwArgs a;
+                a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
+                a.w = d_weights_ + node_w_[i];
+                a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2];
+                a.KH = n.KH; a.KW = n.KW; a.sh = n.sh; a.sw = n.sw;
+                if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
+                a.ep = ep;
+                rc = launch_dw(a, s);
+                break;
+            }
+            case Node::Block: {
+                BlockArgs a;
+                a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
+                a.w_dw = d_weights_ + node_w_[i];
+                a.b_dw = node_b_[i] >= 0 ? d_weights_ + node_b_[i] : nullptr;
+                a.w_pw = d_weights_ + node_w2_[i];
+                a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2]; a.Co = so[3];
+                a.sh = n.sh; a.sw = n.sw;
+                if (n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
+                a.ep = ep;
+                rc = launch_block(a, s);
+                break;
+            }
+            default: {
+                EltArgs a;
+                a.a = ip; a.a_fs = in_fs; a.out = op; a.out_fs = out_fs; a.alpha = ep.alpha; a.act = n.act;
+                a.B = F; a.H = dim(si, 1); a.W = dim(si, 2); a.C = si.back();
+                a.Ho = dim(so, 1); a.Wo = dim(so, 2); a.Co = so.back();
+                if (si.size() != 4) { a.H = 1; a.W = 1; a.C = static_cast<int>(g.tensors[n.in[0]].elems()); a.Ho = a.Wo = 1; a.Co = a.C; }
+                if (n.kind == Node::Add) {
+                    a.b = tensor_ptr(n.in[1], in, chunk_start, &a.b_fs);
+                    rc = launch_add(a, s);
+                } else if (n.kind == Node::Act) {
+                    rc = launch_act(a, s);
+                } else if (n.kind == Node::MaxPool) {
+                    a.p0 = n.filter_h; a.p1 = n.filter_w; a.p2 = n.sh; a.p3 = n.sw;
+                    rc = launch_maxpool(a, s);
+                } else if (n.kind == Node::Pad) {
+                    const auto& pv = g.tensors[n.pads].i32;
+                    if (pv[0] != 0 || pv[1] != 0) throw std::runtime_error("PAD on the batch axis unsupported");
+                    a.p0 = pv[2]; a.p1 = pv[4]; a.p2 = pv[6];
+                    rc = launch_padc(a, s);
+                } else if (n.kind == Node::Resize) {
+                    a.p0 = n.half_pixel; a.p1 = n.align_corners;
+                    rc = launch_resize2x(a, s);
+                } else if (n.kind == Node::DepthToSpace) {
+                    a.p0 = n.block_size;
+                    rc = launch_depth_to_space(a, s);
+                } else {
+                    throw std::runtime_error("internal: unhandled node kind");
+                }
+            }
+        }
+        if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+    }
+    last_chunk_frames_ = F;
+}
+
+void Model::enqueue_all(const float* in, int batch, hipStream_t s) {
+    int chunk = chunk_cap_;
+    for (int start = 0; start < batch; start += chunk) enqueue_chunk(in, start, std::min(chunk, batch - start), s);
+}
+
+void Model::run_device(const float* in, int batch, hipStream_t stream) {
+    if (batch <= 0) throw std::runtime_error("batch must be positive");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (dirty_) rebuild();
+    ensure_capacity(batch);
+    hipStream_t s = stream ? stream : stream_;
+    if (!use_graph_) {
+        enqueue_all(in, batch, s);
+        return;
+    }
+    GraphKey key{in, batch};
+    auto it = graphs_.find(key);
+    if (it == graphs_.end()) {
+        if (graphs_.size() > 16) invalidate_graphs();
+        hipGraph_t graph = nullptr;
+        hip_check(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        try {
+            enqueue_all(in, batch, s);
+        } catch (...) {
+            hipStreamEndCapture(s, &graph);
+            if (graph) hipGraphDestroy(graph);
+            throw;
+        }
+        hip_check(hipStreamEndCapture(s, &graph), "hipStreamEndCapture");
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        hip_check(e, "hipGraphInstantiate");
+        it = graphs_.emplace(key, exec).first;
+    }
+    hip_check(hipGraphLaunch(it->second, s), "hipGraphLaunch");
+}
+
+void Model::run(const float* in, int batch, float* const* outs, int mem, hipStream_t stream) {
+    if (!in || !outs) throw std::runtime_error("null tensor pointer");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hipStream_t s = stream ? stream : stream_;
+    const float* din = in;
+    if (mem == 0) {
+        size_t need = input_elems() * static_cast<size_t>(batch);
+        if (need > in_stage_floats_) {
+            invalidate_graphs();
+            if (d_in_stage_) hip_check(hipFree(d_in_stage_), "hipFree stage");
+            d_in_stage_ = nullptr;
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d_in_stage_), need * sizeof(float)), "hipMalloc stage");
+            in_stage_floats_ = need;
+        }
+        hip_check(hipMemcpyAsync(d_in_stage_, in, need * sizeof(float), hipMemcpyHostToDevice, s), "H2D input");
+        din = d_in_stage_;
+    }
+    run_device(din, batch, s);
+    for (int k = 0; k < num_outputs(); k++) {
+        if (!outs[k]) continue;
+        hip_check(hipMemcpyAsync(outs[k], d_out_[k], output_elems(k) * sizeof(float) * batch,
+                                 mem == 0 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s), "copy outputs");
+    }
+    if (mem == 0 || !stream) hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+}
+
+size_t Model::debug_tensor(int tensor, int frame, float* dst, size_t cap) {
+    const Graph& g = plan_.graph;
+    if (tensor < 0 || tensor >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tensor index out of range");
+    if (frame < 0 || frame >= last_chunk_frames_) throw std::runtime_error("frame outside the last chunk");
+    const Storage& st = plan_.storage[tensor];
+    bool produced = false;
+    for (const Node& n : plan_.nodes) produced |= (n.out == tensor);
+    if (!produced) throw std::runtime_error("tensor was fused away (or is an input/constant)");
+    long fs;
+    float* p = tensor_ptr_mut(tensor, 0, &fs);
+    size_t n = std::min(cap, g.tensors[tensor].elems());
+    hip_check(hipDeviceSynchronize(), "sync");
+    hip_check(hipMemcpy(dst, p + static_cast<long>(frame) * fs, n * sizeof(float), hipMemcpyDeviceToHost), "D2H debug");
+    (void)st;
+    return n;
+}
+
+}  // namespace mi

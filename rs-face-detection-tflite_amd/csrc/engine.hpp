@@ -1,0 +1,85 @@
+// engine.hpp — device-side model instance: weights in HBM, activation arena, launch plan, hipGraph replay.
+//
+// Replaces the interpreter the reference rebuilds on every call (`InterpreterBuilder::build` + `allocate_tensors`
+// + `invoke`, /root/reference/src/face_detection_lite/face_detection.rs:207-235): here lowering, weight upload and
+// arena planning happen once per handle and `run` only enqueues kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "plan.hpp"
+
+namespace mi {
+
+void hip_check(hipError_t e, const char* what);
+
+class Model {
+   public:
+    Model(const uint8_t* bytes, size_t n, int device);
+    ~Model();
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
+
+    int device() const { return device_; }
+    const Graph& graph() const { return plan_.graph; }
+    const Plan& plan() const { return plan_; }
+    std::vector<int> input_dims() const { return plan_.graph.tensors[plan_.graph.inputs[0]].shape; }
+    int num_outputs() const { return static_cast<int>(plan_.graph.outputs.size()); }
+    const std::vector<int>& output_dims(int i) const { return plan_.graph.tensors[plan_.graph.outputs.at(i)].shape; }
+    size_t output_elems(int i) const { return plan_.graph.tensors[plan_.graph.outputs.at(i)].elems(); }
+    size_t input_elems() const { return plan_.graph.tensors[plan_.graph.inputs[0]].elems(); }
+
+    // Enqueue the network for `batch` frames. `in` is a DEVICE pointer [batch, H, W, C]. Results land in the
+    // model-owned device buffers returned by output_device(i) ([batch, output_elems(i)]).
+    void run_device(const float* in, int batch, hipStream_t stream);
+    // Full boundary call (host or device user buffers).
+    void run(const float* in, int batch, float* const* outs, int mem, hipStream_t stream);
+    float* output_device(int i) const { return d_out_.at(i); }
+    hipStream_t stream() const { return stream_; }
+
+    void set_option(const std::string& key, int value);
+    size_t debug_tensor(int tensor, int frame, float* dst, size_t cap);
+    std::string describe() const { return plan_.describe(); }
+
+   private:
+    void rebuild();                       // (re)lower + upload weights for the current options
+    void ensure_capacity(int batch);
+    void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s);
+    void enqueue_all(const float* in, int batch, hipStream_t s);
+    const float* tensor_ptr(int t, const float* in, int chunk_start, long* frame_stride) const;
+    float* tensor_ptr_mut(int t, int chunk_start, long* frame_stride) const;
+    void invalidate_graphs();
+
+    int device_ = 0;
+    std::vector<uint8_t> blob_;
+    Plan plan_;
+    int fuse_level_ = 1, chunk_ = 0, use_graph_ = 1, reuse_ = 1;
+    bool dirty_ = true;
+
+    float* d_weights_ = nullptr;
+    std::vector<long> node_w_, node_b_, node_w2_, node_b2_, node_alpha_;  // float offsets into d_weights_ (-1 none)
+
+    float* d_arena_ = nullptr;
+    size_t arena_floats_ = 0;
+    int chunk_cap_ = 0;      // frames per chunk the arena is laid out for
+    int batch_cap_ = 0;      // frames the output buffers hold
+    std::vector<float*> d_out_;
+    float* d_in_stage_ = nullptr;
+    size_t in_stage_floats_ = 0;
+    int last_chunk_frames_ = 0;
+
+    hipStream_t stream_ = nullptr;
+    struct GraphKey {
+        const float* in;
+        int batch;
+        bool operator<(const GraphKey& o) const { return in != o.in ? in < o.in : batch < o.batch; }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs_;
+};
+
+}  // namespace mi

@@ -1,0 +1,521 @@
+// kernels.hip — hand-written HIP kernels for gfx950 (MI355X, CDNA4; 64-wide wavefronts).
+//
+// Network side (replaces the TensorFlow-Lite CPU kernels behind `interpreter.invoke()`,
+// /root/reference/src/face_detection_lite/face_detection.rs:235, face_landmark.rs:265, iris_landmark.rs:203):
+//   conv_generic_kernel   k x k convolution (stem 5x5/3x3 s2, 2x2 s2, tiny-spatial heads) + fused epilogue
+//   dw3x3_kernel          depthwise 3x3 + bias (+activation)                       (un-fused plans only)
+//   block kernels         see block_kernels.hip (fused DW3x3 -> MFMA 1x1 -> skip -> activation)
+//   element-wise fallbacks for graphs the fuser does not recognise
+// Host-glue side (replaces Rust code of the reference crate itself):
+//   ssd_postprocess_kernel  face_detection.rs:269-362 + nms.rs:56-144 + transform.rs:115-142, one workgroup/frame
+//   project_landmarks_kernel transform.rs:351-432
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace mi {
+
+// ------------------------------------------------------------------------------------------------ epilogue
+__device__ __forceinline__ float apply_act(float v, int act, const float* __restrict__ alpha, int c) {
+    switch (act) {
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_RELU6: return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+        case ACT_PRELU: return v >= 0.f ? v : alpha[c] * v;
+        default: return v;
+    }
+}
+
+// skip-connection value for output pixel (b, oy, ox), channel c (see ResMode in kernels.hpp)
+__device__ __forceinline__ float load_res(const Epilogue& ep, int b, int oy, int ox, int Wo, int c) {
+    if (ep.res_mode == RES_NONE || c >= ep.res_C) return 0.f;
+    const float* r = ep.res + (long)b * ep.res_fs;
+    if (ep.res_mode == RES_DIRECT) return r[((long)oy * Wo + ox) * ep.res_C + c];
+    if (ep.res_mode == RES_MAXPOOL) {
+        const float* p = r + ((long)(2 * oy) * ep.res_W + 2 * ox) * ep.res_C + c;
+        float m0 = fmaxf(p[0], p[ep.res_C]);
+        const float* q = p + (long)ep.res_W * ep.res_C;
+        float m1 = fmaxf(q[0], q[ep.res_C]);
+        return fmaxf(m0, m1);
+    }
+    // RES_UP2X: TFLite ResizeBilinear, half_pixel_centers, scale 1/2 (see resize2x_kernel)
+    float iy = ((float)oy + 0.5f) * 0.5f - 0.5f, ix = ((float)ox + 0.5f) * 0.5f - 0.5f;
+    int y0 = max((int)floorf(iy), 0), y1 = min((int)ceilf(iy), ep.res_H - 1);
+    int x0 = max((int)floorf(ix), 0), x1 = min((int)ceilf(ix), ep.res_W - 1);
+    float dy = iy - (float)y0, dx = ix - (float)x0;
+    float p00 = r[((long)y0 * ep.res_W + x0) * ep.res_C + c], p01 = r[((long)y0 * ep.res_W + x1) * ep.res_C + c];
+    float p10 = r[((long)y1 * ep.res_W + x0) * ep.res_C + c], p11 = r[((long)y1 * ep.res_W + x1) * ep.res_C + c];
+    return p00 * (1 - dy) * (1 - dx) + p10 * dy * (1 - dx) + p01 * (1 - dy) * dx + p11 * dy * dx;
+}
+
+// ------------------------------------------------------------------------------------------------ generic conv
+// One thread = one output pixel x 4 consecutive output channels.  Threads of a wave that share a pixel read the
+// same input scalar (broadcast) and consecutive float4s of the [KH][KW][C][Cop] filter (coalesced, L1/L2 resident).
+__global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
+    const int G = a.Cop >> 2;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)a.B * a.Ho * a.Wo * G;
+    if (idx >= total) return;
+    int g = (int)(idx % G);
+    long p = idx / G;
+    int ox = (int)(p % a.Wo);
+    long q = p / a.Wo;
+    int oy = (int)(q % a.Ho);
+    int b = (int)(q / a.Ho);
+    const float* in = a.in + (long)b * a.in_fs;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < a.KH; ky++) {
+        int iy = oy * a.sh - a.pt + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kx = 0; kx < a.KW; kx++) {
+            int ix = ox * a.sw - a.pl + kx;
+            if (ix < 0 || ix >= a.W) continue;
+            const float* ip = in + ((long)iy * a.W + ix) * a.C;
+            const float4* wp = reinterpret_cast<const float4*>(a.w + ((long)(ky * a.KW + kx) * a.C) * a.Cop) + g;
+            for (int c = 0; c < a.C; c++) {
+                float x = ip[c];
+                float4 w = wp[(long)c * G];
+                acc.x = fmaf(x, w.x, acc.x);
+                acc.y = fmaf(x, w.y, acc.y);
+                acc.z = fmaf(x, w.z, acc.z);
+                acc.w = fmaf(x, w.w, acc.w);
+            }
+        }
+    }
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    float* op = a.out + (long)b * a.out_fs + ((long)oy * a.Wo + ox) * a.Co;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int c = 4 * g + j;
+        if (c < a.Co) {
+            float r = v[j] + (a.ep.bias ? a.ep.bias[c] : 0.f);
+            r += load_res(a.ep, b, oy, ox, a.Wo, c);
+            op[c] = apply_act(r, a.ep.act, a.ep.alpha, c);
+        }
+    }
+}
+
+int launch_conv(const ConvArgs& a, void* stream) {
+    long total = (long)a.B * a.Ho * a.Wo * (a.Cop >> 2);
+    if (total <= 0) return 0;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(conv_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise 3x3
+// One thread = one output pixel x V consecutive channels (V = 4/2/1 by alignment).  HBM-bound: 9 MAC per 8 bytes.
+template <int V>
+__global__ __launch_bounds__(256) void dw_kernel(DwArgs a) {
+    const int G = a.C / V;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)a.B * a.Ho * a.Wo * G;
+    if (idx >= total) return;
+    int g = (int)(idx % G);
+    long p = idx / G;
+    int ox = (int)(p % a.Wo);
+    long q = p / a.Wo;
+    int oy = (int)(q % a.Ho);
+    int b = (int)(q / a.Ho);
+    const float* in = a.in + (long)b * a.in_fs + g * V;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = 0.f;
+    for (int ky = 0; ky < a.KH; ky++) {
+        int iy = oy * a.sh - a.pt + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kx = 0; kx < a.KW; kx++) {
+            int ix = ox * a.sw - a.pl + kx;
+            if (ix < 0 || ix >= a.W) continue;
+            const float* ip = in + ((long)iy * a.W + ix) * a.C;
+            const float* wp = a.w + (long)(ky * a.KW + kx) * a.C + g * V;
+#pragma unroll
+            for (int j = 0; j < V; j++) acc[j] = fmaf(ip[j], wp[j], acc[j]);
+        }
+    }
+    float* op = a.out + (long)b * a.out_fs + ((long)oy * a.Wo + ox) * a.C + g * V;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        int c = g * V + j;
+        float r = acc[j] + (a.ep.bias ? a.ep.bias[c] : 0.f);
+        r += load_res(a.ep, b, oy, ox, a.Wo, c);
+        op[j] = apply_act(r, a.ep.act, a.ep.alpha, c);
+    }
+}
+
+int launch_dw(const DwArgs& a, void* stream) {
+    int V = (a.C % 4 == 0) ? 4 : (a.C % 2 == 0 ? 2 : 1);
+    long total = (long)a.B * a.Ho * a.Wo * (a.C / V);
+    if (total <= 0) return 0;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (V == 4) hipLaunchKernelGGL(dw_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    else if (V == 2) hipLaunchKernelGGL(dw_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(dw_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise fallbacks
+__global__ void add_kernel(EltArgs a) {  // out = act(a + b), same shape
+    long per = (long)a.H * a.W * a.C;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    float v = a.a[(long)b * a.a_fs + e] + a.b[(long)b * a.b_fs + e];
+    a.out[(long)b * a.out_fs + e] = apply_act(v, a.act, a.alpha, (int)(e % a.C));
+}
+__global__ void act_kernel(EltArgs a) {
+    long per = (long)a.H * a.W * a.C;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    a.out[(long)b * a.out_fs + e] = apply_act(a.a[(long)b * a.a_fs + e], a.act, a.alpha, (int)(e % a.C));
+}
+// MAX_POOL_2D: p0 = filter_h, p1 = filter_w, p2 = stride_h, p3 = stride_w; SAME/VALID pads folded into Ho/Wo + H/W clip
+__global__ void maxpool_kernel(EltArgs a, int pt, int pl) {
+    long per = (long)a.Ho * a.Wo * a.C;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    int c = (int)(e % a.C);
+    int ox = (int)((e / a.C) % a.Wo), oy = (int)(e / ((long)a.C * a.Wo));
+    float m = -INFINITY;
+    for (int ky = 0; ky < a.p0; ky++) {
+        int iy = oy * a.p2 - pt + ky;
+        if (iy < 0 || iy >= a.H) continue;
+        for (int kx = 0; kx < a.p1; kx++) {
+            int ix = ox * a.p3 - pl + kx;
+            if (ix < 0 || ix >= a.W) continue;
+            m = fmaxf(m, a.a[(long)b * a.a_fs + ((long)iy * a.W + ix) * a.C + c]);
+        }
+    }
+    a.out[(long)b * a.out_fs + e] = m;
+}
+// PAD with zeros: p0 = top, p1 = left, p2 = channel-before; output dims Ho, Wo, Co
+__global__ void pad_kernel(EltArgs a) {
+    long per = (long)a.Ho * a.Wo * a.Co;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    int c = (int)(e % a.Co) - a.p2;
+    int x = (int)((e / a.Co) % a.Wo) - a.p1, y = (int)(e / ((long)a.Co * a.Wo)) - a.p0;
+    float v = 0.f;
+    if (c >= 0 && c < a.C && x >= 0 && x < a.W && y >= 0 && y < a.H) v = a.a[(long)b * a.a_fs + ((long)y * a.W + x) * a.C + c];
+    a.out[(long)b * a.out_fs + e] = v;
+}
+// RESIZE_BILINEAR (half_pixel_centers = p0, align_corners = p1), arbitrary sizes; TFLite reference formula.
+__global__ void resize_kernel(EltArgs a) {
+    long per = (long)a.Ho * a.Wo * a.C;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    int c = (int)(e % a.C);
+    int ox = (int)((e / a.C) % a.Wo), oy = (int)(e / ((long)a.C * a.Wo));
+    float hs = (a.p1 && a.Ho > 1) ? (float)(a.H - 1) / (float)(a.Ho - 1) : (float)a.H / (float)a.Ho;
+    float ws = (a.p1 && a.Wo > 1) ? (float)(a.W - 1) / (float)(a.Wo - 1) : (float)a.W / (float)a.Wo;
+    float iy = a.p0 ? ((float)oy + 0.5f) * hs - 0.5f : (float)oy * hs;
+    float ix = a.p0 ? ((float)ox + 0.5f) * ws - 0.5f : (float)ox * ws;
+    int y0 = max((int)floorf(iy), 0), y1 = min((int)ceilf(iy), a.H - 1);
+    int x0 = max((int)floorf(ix), 0), x1 = min((int)ceilf(ix), a.W - 1);
+    float dy = iy - (float)y0, dx = ix - (float)x0;
+    const float* r = a.a + (long)b * a.a_fs;
+    float p00 = r[((long)y0 * a.W + x0) * a.C + c], p01 = r[((long)y0 * a.W + x1) * a.C + c];
+    float p10 = r[((long)y1 * a.W + x0) * a.C + c], p11 = r[((long)y1 * a.W + x1) * a.C + c];
+    a.out[(long)b * a.out_fs + e] = p00 * (1 - dy) * (1 - dx) + p10 * dy * (1 - dx) + p01 * (1 - dy) * dx + p11 * dy * dx;
+}
+// DEPTH_TO_SPACE: p0 = block size
+__global__ void d2s_kernel(EltArgs a) {
+    long per = (long)a.Ho * a.Wo * a.Co;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    int c = (int)(e % a.Co);
+    int ox = (int)((e / a.Co) % a.Wo), oy = (int)(e / ((long)a.Co * a.Wo));
+    int bs = a.p0;
+    int iy = oy / bs, ix = ox / bs, ic = ((oy % bs) * bs + (ox % bs)) * a.Co + c;
+    a.out[(long)b * a.out_fs + e] = a.a[(long)b * a.a_fs + ((long)iy * a.W + ix) * a.C + ic];
+}
+// strided frame copy: per-frame `C` floats (H = W = 1)
+__global__ void copy_kernel(EltArgs a) {
+    long per = (long)a.C;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per * a.B) return;
+    int b = (int)(idx / per);
+    long e = idx % per;
+    a.out[(long)b * a.out_fs + e] = a.a[(long)b * a.a_fs + e];
+}
+
+static inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
+int launch_add(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.H * a.W * a.C;
+    if (n > 0) hipLaunchKernelGGL(add_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+}
+int launch_act(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.H * a.W * a.C;
+    if (n > 0) hipLaunchKernelGGL(act_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+}
+int launch_maxpool(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.Ho * a.Wo * a.C;
+    // TF SAME pads (only non-zero for odd inputs): total = max(0,(out-1)*stride + filter - in), before = total/2
+    int tph = (a.Ho - 1) * a.p2 + a.p0 - a.H, tpw = (a.Wo - 1) * a.p3 + a.p1 - a.W;
+    int pt = tph > 0 ? tph / 2 : 0, pl = tpw > 0 ? tpw / 2 : 0;
+    if (n > 0) hipLaunchKernelGGL(maxpool_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a, pt, pl);
+    return (int)hipGetLastError();
+}
+int launch_padc(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.Ho * a.Wo * a.Co;
+    if (n > 0) hipLaunchKernelGGL(pad_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+}
+int launch_resize2x(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.Ho * a.Wo * a.C;
+    if (n > 0) hipLaunchKernelGGL(resize_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+}
+int launch_depth_to_space(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.Ho * a.Wo * a.Co;
+    if (n > 0) hipLaunchKernelGGL(d2s_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+}
+int launch_copy_strided(const EltArgs& a, void* s) {
+    long n = (long)a.B * a.C;
+    if (n > 0) hipLaunchKernelGGL(copy_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ SSD post-processing
+// One 256-thread workgroup per frame.  Restates, on the device, the tail of FaceDetection::infer
+// (face_detection.rs:259-265): decode_boxes (269-296), get_sigmoid_score (300-314), convert_to_detections
+// (317-362), non_maximum_suppression(weighted) (nms.rs:56-144) and detection_letterbox_removal (transform.rs:115-142).
+// Ordering/dtype rules kept bit-for-bit: true f32 division by `scale`, score clamp to
+// +-80, `sigmoid(x) > 0.5` on the f32 sigmoid, stable descending sort == sort by (score desc, anchor index asc),
+// IoU in f64 on f32 coordinates with strict `> 0.3`, weighted sums accumulated in sorted order in f32 with separate
+// multiply and add (no FMA), output score = head score, stop when nothing was removed.
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+// feature f (0..15) of the decoded detection of anchor `a` (face_detection.rs:274-293)
+__device__ __forceinline__ float decode_feature(const float* __restrict__ rb, const float* __restrict__ anchors, int a, int f,
+                                                float scale) {
+    const float* r = rb + (long)a * 16;
+    float anc = anchors[2 * a + (f & 1)];
+    if (f < 4) {
+        float c = __fadd_rn(__fdiv_rn(r[f & 1], scale), anc);            // centre + anchor
+        float h = __fdiv_rn(__fdiv_rn(r[2 + (f & 1)], scale), 2.0f);     // size / 2 (no anchor term)
+        return f < 2 ? __fsub_rn(c, h) : __fadd_rn(c, h);
+    }
+    return __fadd_rn(__fdiv_rn(r[f], scale), anc);
+}
+
+__device__ __forceinline__ double iou_f64(const float* b1, const float* b2) {  // nms.rs:5-17, types.rs:123-159
+    double x0 = fmax((double)b1[0], (double)b2[0]), y0 = fmax((double)b1[1], (double)b2[1]);
+    double x1 = fmin((double)b1[2], (double)b2[2]), y1 = fmin((double)b1[3], (double)b2[3]);
+    if (!(x0 < x1 && y0 < y1)) return 0.0;
+    double iw = x1 - x0, ih = y1 - y0;
+    double ia = (iw <= 0.0 || ih <= 0.0) ? 0.0 : iw * ih;
+    double w1 = (double)b1[2] - (double)b1[0], h1 = (double)b1[3] - (double)b1[1];
+    double w2 = (double)b2[2] - (double)b2[0], h2 = (double)b2[3] - (double)b2[1];
+    double a1 = (w1 <= 0.0 || h1 <= 0.0) ? 0.0 : w1 * h1;
+    double a2 = (w2 <= 0.0 || h2 <= 0.0) ? 0.0 : w2 * h2;
+    double den = a1 + a2 - ia;
+    return den > 0.0 ? ia / den : 0.0;
+}
+
+template <int NP>  // NP = power of two >= number of anchors
+__global__ __launch_bounds__(256) void ssd_postprocess_kernel(PostArgs a) {
+    __shared__ unsigned long long keys[NP];   // (~score bits) << 32 | anchor index; sorted ascending
+    __shared__ float boxes[NP][4];            // decoded (xmin,ymin,xmax,ymax) per sorted position (first M valid)
+    __shared__ unsigned char state[NP];       // 1 = still in `remaining`, 2 = candidate of the current head
+    __shared__ int s_count, s_removed, s_head;
+    __shared__ float s_w[17];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float* rb = a.raw_boxes + (long)b * a.N * 16;
+    const float* rs = a.raw_scores + (long)b * a.N;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    // --- threshold + validity (convert_to_detections); order-insensitive compaction, the sort restores the order
+    for (int i = tid; i < a.N; i += 256) {
+        float x = rs[i];
+        x = x < -80.0f ? -80.0f : (x > 80.0f ? 80.0f : x);
+        float s = sigmoid_f32(x);
+        if (s > 0.5f) {
+            float x0 = decode_feature(rb, a.anchors, i, 0, a.scale), y0 = decode_feature(rb, a.anchors, i, 1, a.scale);
+            float x1 = decode_feature(rb, a.anchors, i, 2, a.scale), y1 = decode_feature(rb, a.anchors, i, 3, a.scale);
+            if (x1 > x0 && y1 > y0) {
+                int slot = atomicAdd(&s_count, 1);
+                keys[slot] = ((unsigned long long)(0xFFFFFFFFu - __float_as_uint(s)) << 32) | (unsigned)i;
+            }
+        }
+    }
+    __syncthreads();
+    const int M = s_count;
+    int P = 1;
+    while (P < M) P <<= 1;
+    for (int i = M + tid; i < P; i += 256) keys[i] = ~0ull;
+    __syncthreads();
+    // --- bitonic sort of P keys (unique keys => deterministic, equals the reference's stable sort)
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 256) {
+                int l = i ^ j;
+                if (l > i) {
+                    unsigned long long x = keys[i], y = keys[l];
+                    bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < M; i += 256) {
+        int an = (int)(keys[i] & 0xFFFFFFFFu);
+#pragma unroll
+        for (int f = 0; f < 4; f++) boxes[i][f] = decode_feature(rb, a.anchors, an, f, a.scale);
+        state[i] = 1;
+    }
+    if (tid == 0) s_head = 0;
+    __syncthreads();
+    // letterbox constants (transform.rs:116-141)
+    float lb_l = 0.f, lb_t = 0.f, lb_hs = 1.f, lb_vs = 1.f;
+    bool lb_bad = false;
+    if (a.padding) {
+        const double* pd = a.padding + (long)b * 4;
+        double hs = 1.0 - (pd[0] + pd[2]), vs = 1.0 - (pd[1] + pd[3]);
+        lb_bad = !(hs > 2.220446049250313e-16) || !(vs > 2.220446049250313e-16);
+        lb_l = (float)pd[0]; lb_t = (float)pd[1]; lb_hs = (float)hs; lb_vs = (float)vs;
+    }
+    int nout = 0;
+    const double thr = (double)0.3f;  // MIN_SUPPRESSION_THRESHOLD as f64 (face_detection.rs:139, nms.rs:87)
+    float* outp = a.out + (long)b * a.cap * 17;
+    while (true) {
+        // head = first entry of `remaining`
+        if (tid == 0) {
+            int h = s_head;
+            while (h < M && state[h] == 0) h++;
+            s_head = h;
+            s_removed = 0;
+        }
+        __syncthreads();
+        const int head = s_head;
+        if (head >= M) break;
+        const float head_score = __uint_as_float(0xFFFFFFFFu - (unsigned)(keys[head] >> 32));
+        // (head.score < MIN_SCORE cannot happen: every kept score is > 0.5 — nms.rs:69-73)
+        int removed = 0;
+        for (int i = head + tid; i < M; i += 256) {
+            if (state[i] == 0) continue;
+            double sim = iou_f64(boxes[i], boxes[head]);
+            if (sim > thr) { state[i] = 2; removed++; }
+        }
+        if (removed) atomicAdd(&s_removed, removed);
+        __syncthreads();
+        const int nrem = s_removed;
+        // weighted merge (nms.rs:94-112): lanes 0..15 own one feature each, lane 16 owns total_score; sequential
+        // f32 accumulation in sorted order, separate multiply and add.
+        if (tid < 17) {
+            float acc = 0.0f;
+            if (nrem > 0) {
+                for (int i = head; i < M; i++) {
+                    if (state[i] != 2) continue;
+                    unsigned long long k = keys[i];
+                    float s = __uint_as_float(0xFFFFFFFFu - (unsigned)(k >> 32));
+                    if (tid == 16) acc = __fadd_rn(acc, s);
+                    else acc = __fadd_rn(acc, __fmul_rn(decode_feature(rb, a.anchors, (int)(k & 0xFFFFFFFFu), tid, a.scale), s));
+                }
+            } else if (tid < 16) {
+                acc = decode_feature(rb, a.anchors, (int)(keys[head] & 0xFFFFFFFFu), tid, a.scale);  // detection.clone()
+            }
+            s_w[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < 17 && nout < a.cap) {
+            float v;
+            if (tid == 16) v = head_score;
+            else {
+                v = nrem > 0 ? __fdiv_rn(s_w[tid], s_w[16]) : s_w[tid];
+                if (a.padding)  // detection_letterbox_removal: (v - left) / h_scale, (v - top) / v_scale
+                    v = (tid & 1) ? __fdiv_rn(__fsub_rn(v, lb_t), lb_vs) : __fdiv_rn(__fsub_rn(v, lb_l), lb_hs);
+            }
+            outp[(long)nout * 17 + tid] = v;
+        }
+        nout++;
+        for (int i = head + tid; i < M; i += 256)
+            if (state[i] == 2) state[i] = 0;
+        __syncthreads();
+        if (nrem == 0) break;  // "number of indexed scores didn't change" (nms.rs:117-119)
+    }
+    if (tid == 0) a.counts[b] = lb_bad ? -1 : nout;  // -1: the reference's letterbox assert! would have fired
+}
+
+int launch_postprocess(const PostArgs& a, void* stream) {
+    if (a.B <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.N <= 1024) hipLaunchKernelGGL(ssd_postprocess_kernel<1024>, dim3(a.B), dim3(256), 0, s, a);
+    else if (a.N <= 2048) hipLaunchKernelGGL(ssd_postprocess_kernel<2048>, dim3(a.B), dim3(256), 0, s, a);
+    else if (a.N <= 4096) hipLaunchKernelGGL(ssd_postprocess_kernel<4096>, dim3(a.B), dim3(256), 0, s, a);
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ landmark projection
+// project_landmarks (transform.rs:351-432); one thread per landmark; f32/f64 mix kept as in the Rust source.
+__global__ void project_landmarks_kernel(ProjArgs a) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)a.B * a.n) return;
+    int b = (int)(idx / a.n), i = (int)(idx % a.n);
+    const float* r = a.raw + (long)b * a.raw_fs + 3 * i;
+    float wf = (float)a.tensor_w, hf = (float)a.tensor_h;
+    float x = __fdiv_rn(r[0], wf), y = __fdiv_rn(r[1], hf), z = __fdiv_rn(r[2], wf);
+    if (a.flip && a.flip[b]) x = __fadd_rn(__fmul_rn(x, -1.0f), 1.0f);
+    if (a.padding) {
+        const double* pd = a.padding + (long)b * 4;
+        if (!(pd[0] == 0.0 && pd[1] == 0.0 && pd[2] == 0.0 && pd[3] == 0.0)) {
+            double hs = 1.0 - (pd[0] + pd[2]), vs = 1.0 - (pd[1] + pd[3]);
+            x = (float)(((double)x - pd[0]) / hs);
+            y = (float)(((double)y - pd[1]) / vs);
+            z = (float)(((double)z - 0.) / hs);
+        }
+    }
+    if (i == 0 && a.flag) {
+        float fl = a.flag[(long)b * a.flag_fs];
+        if (a.present) a.present[b] = sigmoid_f32(fl) <= 0.5f ? 0 : 1;
+        if (a.raw_flag_out) a.raw_flag_out[b] = fl;
+    }
+    if (a.roi) {
+        const RectD ro = a.roi[b];
+        double xc = ro.x_center, yc = ro.y_center, w = ro.width, h = ro.height, rot = ro.rotation;
+        if (!ro.normalized) {  // Rect::scaled(size, true): multiply by the reciprocal (types.rs:67)
+            double sx = 1.0 / (double)a.image_size[2 * b], sy = 1.0 / (double)a.image_size[2 * b + 1];
+            xc *= sx; yc *= sy; w *= sx; h *= sy;
+        }
+        float m00 = (float)cos(rot), m01 = (float)sin(rot), m10 = (float)(-sin(rot)), m11 = m00;
+        x = __fsub_rn(x, 0.5f); y = __fsub_rn(y, 0.5f); z = __fsub_rn(z, 0.0f);
+        float rz = __fmul_rn(z, 0.0f);
+        float rx = __fadd_rn(__fadd_rn(__fmul_rn(x, m00), __fmul_rn(y, m10)), __fmul_rn(rz, 1.0f));
+        float ry = __fadd_rn(__fadd_rn(__fmul_rn(x, m01), __fmul_rn(y, m11)), __fmul_rn(rz, 1.0f));
+        float rzz = __fadd_rn(__fadd_rn(__fmul_rn(x, 0.0f), __fmul_rn(y, 0.0f)), __fmul_rn(rz, 1.0f));
+        x = __fadd_rn(__fmul_rn(x, 0.f), rx);
+        y = __fadd_rn(__fmul_rn(y, 0.f), ry);
+        z = __fadd_rn(__fmul_rn(z, 1.f), rzz);
+        x = (float)((double)x * w + xc);
+        y = (float)((double)y * h + yc);
+        z = (float)((double)z * w + 0.);
+    }
+    float* o = a.out + ((long)b * a.n + i) * 3;
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+int launch_project(const ProjArgs& a, void* stream) {
+    long n = (long)a.B * a.n;
+    if (n > 0) hipLaunchKernelGGL(project_landmarks_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mi

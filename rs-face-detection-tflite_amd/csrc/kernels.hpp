@@ -1,0 +1,125 @@
+// kernels.hpp — launch descriptors shared between the planner (host) and the HIP kernels (kernels.hip).
+// Activations are f32 NHWC; every tensor is addressed as base + frame * frame_stride (+ pixel * C + c), so that
+// RESHAPE is a view and CONCATENATION is done by producers writing straight into the concatenated buffer.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+namespace mi {
+
+enum ActKind : int { ACT_NONE = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_PRELU = 3 };
+// How the skip connection of a BlazeBlock is read inside the fused epilogue:
+//   RES_DIRECT  : skip[c] = res[pixel][c] for c < res_C, 0 above (channel PAD fused)
+//   RES_MAXPOOL : skip[c] = max over the 2x2 stride-2 window of the (2Ho x 2Wo) source, c < res_C (MAX_POOL_2D fused)
+//   RES_UP2X    : skip[c] = bilinear x2 upsample (half_pixel_centers) of a (Ho/2 x Wo/2) source (RESIZE_BILINEAR fused)
+enum ResMode : int { RES_NONE = 0, RES_DIRECT = 1, RES_MAXPOOL = 2, RES_UP2X = 3 };
+
+struct Epilogue {
+    const float* bias = nullptr;   // [Co] or null
+    const float* alpha = nullptr;  // PReLU slopes [Co]
+    const float* res = nullptr;    // skip-connection source
+    long res_fs = 0;               // frame stride of res (floats)
+    int res_mode = RES_NONE;
+    int res_C = 0;                 // channels present in res (pixel stride of res)
+    int res_W = 0, res_H = 0;      // source spatial size (RES_MAXPOOL / RES_UP2X)
+    int act = ACT_NONE;
+};
+
+struct ConvArgs {
+    const float* in = nullptr;
+    const float* w = nullptr;   // [KH][KW][C][Cop]   (Cop = Co rounded up to 4, zero padded)
+    float* out = nullptr;
+    long in_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, Cop = 0;
+    int KH = 1, KW = 1, sh = 1, sw = 1, pt = 0, pl = 0;
+    Epilogue ep;
+};
+
+struct DwArgs {
+    const float* in = nullptr;
+    const float* w = nullptr;   // [3][3][C]
+    float* out = nullptr;
+    long in_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0;
+    int KH = 3, KW = 3, sh = 1, sw = 1, pt = 0, pl = 0;
+    Epilogue ep;
+};
+
+// Fused BlazeBlock: DW3x3(+bias) -> PW1x1 (MFMA f32) -> +bias +skip -> activation, one kernel, DW result never
+// leaves the CU.  w_dw [3][3][C]; w_pw packed for the MFMA B/A operand by pack_pw_weights().
+struct BlockArgs {
+    const float* in = nullptr;
+    const float* w_dw = nullptr;
+    const float* b_dw = nullptr;
+    const float* w_pw = nullptr;  // [Cop][Cp] row-major (out channel major), zero padded: Cp = C up to 4, Cop = Co up to 16/32
+    float* out = nullptr;
+    long in_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0;
+    int sh = 1, sw = 1, pt = 0, pl = 0;
+    int has_dw = 1;               // 0: plain pointwise conv (no depthwise stage)
+    Epilogue ep;
+};
+
+struct EltArgs {  // ADD / activation / MAX_POOL / channel PAD / RESIZE / DEPTH_TO_SPACE fallbacks (un-fused graphs)
+    const float* a = nullptr;
+    const float* b = nullptr;
+    const float* alpha = nullptr;
+    float* out = nullptr;
+    long a_fs = 0, b_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0;
+    int act = ACT_NONE;
+    int p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // op-specific ints (pool filter/stride, pad offsets, block size, flags)
+};
+
+struct PostArgs {  // fused SSD decode + sigmoid + threshold + weighted NMS + letterbox removal, one workgroup/frame
+    const float* raw_boxes = nullptr;   // [B][N][16]
+    const float* raw_scores = nullptr;  // [B][N]
+    const float* anchors = nullptr;     // [N][2]
+    const double* padding = nullptr;    // [B][4] or null
+    float* out = nullptr;               // [B][cap][17]
+    int* counts = nullptr;              // [B]; -1 where the reference's letterbox-scale assert would fire
+    int B = 0, N = 0, cap = 0;
+    float scale = 1.f;
+};
+
+struct RectD {  // layout-compatible with mi_rect (include/mi_face.h) / Rect (types.rs:24-36)
+    double x_center, y_center, width, height, rotation;
+    int normalized;
+    int pad_;
+};
+
+struct ProjArgs {  // project_landmarks, one thread per landmark
+    const float* raw = nullptr;   // [B][raw_fs] (first n*3 floats used)
+    long raw_fs = 0;
+    const RectD* roi = nullptr;   // [B] or null
+    const int* image_size = nullptr;  // [B][2] (w,h) or null
+    const float* flag = nullptr;      // optional face-flag logits [B][flag_fs]
+    long flag_fs = 0;
+    int* present = nullptr;           // [B] sigmoid(flag) > 0.5  (face_landmark.rs:292-296)
+    float* raw_flag_out = nullptr;    // [B] or null
+    const double* padding = nullptr;  // [B][4] or null
+    const int* flip = nullptr;        // [B] or null
+    float* out = nullptr;             // [B][n][3]
+    int B = 0, n = 0, tensor_w = 1, tensor_h = 1;
+};
+
+// ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).
+int launch_conv(const ConvArgs& a, void* stream);
+int launch_dw(const DwArgs& a, void* stream);
+int launch_block(const BlockArgs& a, void* stream);
+bool block_kernel_supports(const BlockArgs& a);
+int launch_add(const EltArgs& a, void* stream);
+int launch_act(const EltArgs& a, void* stream);
+int launch_maxpool(const EltArgs& a, void* stream);
+int launch_padc(const EltArgs& a, void* stream);
+int launch_resize2x(const EltArgs& a, void* stream);
+int launch_depth_to_space(const EltArgs& a, void* stream);
+int launch_copy_strided(const EltArgs& a, void* stream);
+int launch_postprocess(const PostArgs& a, void* stream);
+int launch_project(const ProjArgs& a, void* stream);
+
+// Pointwise weight packing for the fused block kernel: [Co][C] (TFLite [O,1,1,I]) -> [Cop][Cp] zero padded.
+void block_weight_dims(int C, int Co, int* Cp, int* Cop);
+
+}  // namespace mi

@@ -1,0 +1,355 @@
+// plan.cpp — graph rewriting + activation-arena planning (see plan.hpp).
+#include "plan.hpp"
+
+#include <algorithm>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace mi {
+namespace {
+
+int act_of(FusedAct a) {
+    switch (a) {
+        case FusedAct::None: return ACT_NONE;
+        case FusedAct::Relu: return ACT_RELU;
+        case FusedAct::Relu6: return ACT_RELU6;
+    }
+    throw std::runtime_error("plan: unsupported fused activation");
+}
+
+struct Rewriter {
+    Graph& g;
+    std::vector<Node>& nodes;
+
+    std::vector<int> consumers(int t) const {
+        std::vector<int> c;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (nodes[i].dead) continue;
+            for (int x : nodes[i].in)
+                if (x == t) c.push_back(static_cast<int>(i));
+            if (nodes[i].res == t) c.push_back(static_cast<int>(i));
+        }
+        return c;
+    }
+    int producer(int t) const {
+        for (size_t i = 0; i < nodes.size(); i++)
+            if (!nodes[i].dead && nodes[i].out == t) return static_cast<int>(i);
+        return -1;
+    }
+    bool is_graph_output(int t) const { return std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end(); }
+    const std::vector<int>& shape(int t) const { return g.tensors[t].shape; }
+
+    // Fold ADD / activation that exclusively consume node i's output into node i; the fused node takes the
+    // position of the last folded op so that every operand (e.g. the skip tensor) is already available there.
+    void fuse_epilogues() {
+        for (size_t i = 0; i < nodes.size(); i++) {
+            for (;;) {
+                Node& n = nodes[i];
+                if (n.dead || !(n.kind == Node::Conv || n.kind == Node::Dw)) break;
+                if (is_graph_output(n.out)) break;
+                std::vector<int> cons = consumers(n.out);
+                if (cons.size() != 1) break;
+                int ci = cons[0];
+                if (ci <= static_cast<int>(i)) break;
+                Node& c = nodes[ci];
+                Node fused = n;
+                if (c.kind == Node::Add && n.res < 0 && n.act == ACT_NONE && c.in.size() == 2) {
+                    int other = c.in[0] == n.out ? c.in[1] : c.in[0];
+                    if (other == n.out || g.tensors[other].is_const) break;
+                    if (shape(other) != shape(n.out)) break;
+                    fused.res = other;
+                    fused.res_mode = RES_DIRECT;
+                    fused.act = c.act;
+                } else if (c.kind == Node::Act && n.act == ACT_NONE) {
+                    fused.act = c.act;
+                    fused.alpha = c.alpha;
+                } else {
+                    break;
+                }
+                fused.out = c.out;
+                fused.src_ops.insert(fused.src_ops.end(), c.src_ops.begin(), c.src_ops.end());
+                n.dead = true;
+                nodes[ci] = fused;
+                i = static_cast<size_t>(ci);  // continue folding from the new position
+            }
+        }
+        // Skip-path simplification: res <- PAD(channels) <- MAX_POOL 2x2/2 | RESIZE x2, each with a single consumer.
+        for (size_t i = 0; i < nodes.size(); i++) {
+            Node& n = nodes[i];
+            if (n.dead || n.res < 0 || n.res_mode != RES_DIRECT) continue;
+            int p = producer(n.res);
+            if (p >= 0 && nodes[p].kind == Node::Pad && consumers(n.res).size() == 1 && !is_graph_output(n.res)) {
+                const Node& pd = nodes[p];
+                const auto& pv = g.tensors[pd.pads].i32;
+                const auto& si = shape(pd.in[0]);
+                bool channel_only = pv.size() == 8 && pv[0] == 0 && pv[1] == 0 && pv[2] == 0 && pv[3] == 0 && pv[4] == 0 &&
+                                    pv[5] == 0 && pv[6] == 0 && si.size() == 4;
+                if (channel_only) {
+                    n.res = pd.in[0];
+                    n.src_ops.insert(n.src_ops.end(), pd.src_ops.begin(), pd.src_ops.end());
+                    nodes[p].dead = true;
+                    p = producer(n.res);
+                }
+            }
+            if (p >= 0 && consumers(n.res).size() == 1 && !is_graph_output(n.res)) {
+                const Node& q = nodes[p];
+                const auto& si = shape(q.in.empty() ? n.res : q.in[0]);
+                const auto& so = shape(n.res);
+                if (q.kind == Node::MaxPool && q.filter_h == 2 && q.filter_w == 2 && q.sh == 2 && q.sw == 2 && q.act == ACT_NONE &&
+                    si.size() == 4 && si[1] == 2 * so[1] && si[2] == 2 * so[2]) {
+                    n.res = q.in[0];
+                    n.res_mode = RES_MAXPOOL;
+                    n.src_ops.insert(n.src_ops.end(), q.src_ops.begin(), q.src_ops.end());
+                    nodes[p].dead = true;
+                } else if (q.kind == Node::Resize && q.half_pixel && !q.align_corners && si.size() == 4 && so[1] == 2 * si[1] &&
+                           so[2] == 2 * si[2]) {
+                    n.res = q.in[0];
+                    n.res_mode = RES_UP2X;
+                    n.src_ops.insert(n.src_ops.end(), q.src_ops.begin(), q.src_ops.end());
+                    nodes[p].dead = true;
+                }
+            }
+        }
+    }
+
+    // DEPTHWISE 3x3 -> CONV 1x1 (stride 1) with the depthwise result consumed only by that conv.
+    void fuse_blocks() {
+        for (size_t i = 0; i < nodes.size(); i++) {
+            Node& d = nodes[i];
+            if (d.dead || d.kind != Node::Dw || d.act != ACT_NONE || d.res >= 0 || is_graph_output(d.out)) continue;
+            if (d.KH != 3 || d.KW != 3) continue;
+            std::vector<int> cons = consumers(d.out);
+            if (cons.size() != 1) continue;
+            Node& c = nodes[cons[0]];
+            if (c.kind != Node::Conv || c.KH != 1 || c.KW != 1 || c.sh != 1 || c.sw != 1 || c.in[0] != d.out) continue;
+            if (c.res == d.out) continue;
+            Node f = c;
+            f.kind = Node::Block;
+            f.in = d.in;
+            f.w2 = c.w; f.b2 = c.b;
+            f.w = d.w; f.b = d.b;
+            f.KH = d.KH; f.KW = d.KW; f.sh = d.sh; f.sw = d.sw; f.padding = d.padding;
+            f.src_ops = d.src_ops;
+            f.src_ops.insert(f.src_ops.end(), c.src_ops.begin(), c.src_ops.end());
+            d.dead = true;
+            c = f;
+        }
+    }
+};
+
+void same_pad(int in, int k, int stride, int& before, int& out) {
+    out = (in + stride - 1) / stride;
+    int total = std::max(0, (out - 1) * stride + k - in);
+    before = total / 2;
+}
+
+}  // namespace
+
+Plan build_plan(Graph graph, int fuse_level) {
+    Plan plan;
+    plan.graph = std::move(graph);
+    plan.fuse_level = fuse_level;
+    Graph& g = plan.graph;
+    std::vector<Node> nodes;
+    for (size_t oi = 0; oi < g.ops.size(); oi++) {
+        const OpInfo& op = g.ops[oi];
+        Node n;
+        n.out = op.outputs[0];
+        n.src_ops = {static_cast<int>(oi)};
+        auto need_const = [&](int t, const char* what) {
+            if (t < 0 || !g.tensors[t].is_const) throw std::runtime_error(std::string("plan: ") + what + " must be a constant tensor");
+        };
+        switch (op.op) {
+            case BuiltinOp::Conv2D:
+            case BuiltinOp::DepthwiseConv2D: {
+                n.kind = op.op == BuiltinOp::Conv2D ? Node::Conv : Node::Dw;
+                n.in = {op.inputs.at(0)};
+                n.w = op.inputs.at(1);
+                need_const(n.w, "convolution filter");
+                n.b = op.inputs.size() > 2 ? op.inputs[2] : -1;
+                if (n.b >= 0) need_const(n.b, "convolution bias");
+                const auto& ws = g.tensors[n.w].shape;
+                if (ws.size() != 4) throw std::runtime_error("plan: convolution filter must be rank 4");
+                n.KH = ws[1]; n.KW = ws[2];
+                n.sh = op.stride_h; n.sw = op.stride_w;
+                n.padding = op.padding;
+                n.act = act_of(op.act);
+                if (n.kind == Node::Dw && (op.depth_multiplier != 1 || ws[0] != 1 || ws[3] != g.tensors[n.in[0]].shape.at(3)))
+                    throw std::runtime_error("plan: depthwise conv with depth_multiplier != 1 unsupported");
+                if (n.kind == Node::Conv && ws[3] != g.tensors[n.in[0]].shape.at(3))
+                    throw std::runtime_error("plan: convolution channel mismatch");
+                break;
+            }
+            case BuiltinOp::Add:
+                n.kind = Node::Add;
+                n.in = {op.inputs.at(0), op.inputs.at(1)};
+                n.act = act_of(op.act);
+                if (g.tensors[n.in[0]].shape != g.tensors[n.in[1]].shape) throw std::runtime_error("plan: broadcasting ADD unsupported");
+                break;
+            case BuiltinOp::Relu:
+                n.kind = Node::Act; n.in = {op.inputs.at(0)}; n.act = ACT_RELU;
+                break;
+            case BuiltinOp::Prelu:
+                n.kind = Node::Act; n.in = {op.inputs.at(0)}; n.act = ACT_PRELU; n.alpha = op.inputs.at(1);
+                need_const(n.alpha, "PRELU alpha");
+                if (static_cast<int>(g.tensors[n.alpha].elems()) != g.tensors[n.in[0]].shape.back())
+                    throw std::runtime_error("plan: PRELU alpha must be per-channel");
+                break;
+            case BuiltinOp::MaxPool2D:
+                n.kind = Node::MaxPool; n.in = {op.inputs.at(0)};
+                n.filter_h = op.filter_h; n.filter_w = op.filter_w; n.sh = op.stride_h; n.sw = op.stride_w;
+                n.padding = op.padding; n.act = act_of(op.act);
+                break;
+            case BuiltinOp::Pad:
+                n.kind = Node::Pad; n.in = {op.inputs.at(0)}; n.pads = op.inputs.at(1);
+                need_const(n.pads, "PAD paddings");
+                if (g.tensors[n.pads].i32.size() != 8) throw std::runtime_error("plan: PAD expects rank-4 paddings");
+                break;
+            case BuiltinOp::Reshape:
+                n.kind = Node::Reshape; n.in = {op.inputs.at(0)};
+                break;
+            case BuiltinOp::Concatenation:
+                n.kind = Node::Concat; n.in = op.inputs; n.axis = op.axis;
+                if (op.act != FusedAct::None) throw std::runtime_error("plan: CONCATENATION with activation unsupported");
+                break;
+            case BuiltinOp::ResizeBilinear:
+                n.kind = Node::Resize; n.in = {op.inputs.at(0)};
+                n.half_pixel = op.half_pixel_centers; n.align_corners = op.align_corners;
+                break;
+            case BuiltinOp::DepthToSpace:
+                n.kind = Node::DepthToSpace; n.in = {op.inputs.at(0)}; n.block_size = op.block_size;
+                break;
+            default:
+                throw std::runtime_error("plan: builtin operator " + std::to_string(op.raw_code) + " unsupported");
+        }
+        for (int t : n.in)
+            if (t < 0 || g.tensors[t].is_const) throw std::runtime_error("plan: constant activation inputs unsupported");
+        nodes.push_back(std::move(n));
+    }
+
+    Rewriter rw{g, nodes};
+    if (fuse_level >= 1) rw.fuse_epilogues();
+    if (fuse_level >= 2) rw.fuse_blocks();
+    for (auto& n : nodes)
+        if (!n.dead) plan.nodes.push_back(n);
+
+    // ---- storage: RESHAPE = view of its input; CONCATENATION inputs live inside the joined buffer.
+    const int NT = static_cast<int>(g.tensors.size());
+    plan.storage.resize(NT);
+    for (int t = 0; t < NT; t++) plan.storage[t] = Storage{t, 0, static_cast<long>(g.tensors[t].elems())};
+    for (int i = static_cast<int>(plan.nodes.size()) - 1; i >= 0; i--) {
+        const Node& n = plan.nodes[i];
+        if (n.kind == Node::Reshape) {
+            plan.storage[n.in[0]] = plan.storage[n.out];
+        } else if (n.kind == Node::Concat) {
+            const auto& so = g.tensors[n.out].shape;
+            int axis = n.axis < 0 ? n.axis + static_cast<int>(so.size()) : n.axis;
+            long outer = 1;
+            for (int d = 1; d < axis; d++) outer *= so[d];
+            if (axis < 1 || outer != 1) throw std::runtime_error("plan: CONCATENATION must join the first non-batch axis");
+            long off = 0;
+            for (int t : n.in) {
+                if (plan.storage[t].root != t) throw std::runtime_error("plan: tensor feeds two concatenations/views");
+                plan.storage[t] = Storage{plan.storage[n.out].root, plan.storage[n.out].offset + off, plan.storage[n.out].frame_stride};
+                off += static_cast<long>(g.tensors[t].elems());
+            }
+        }
+    }
+    // views created above must be propagated forward to tensors whose storage pointed at an intermediate root
+    for (int pass = 0; pass < 4; pass++)
+        for (int t = 0; t < NT; t++) {
+            Storage& s = plan.storage[t];
+            const Storage& r = plan.storage[s.root];
+            if (r.root != s.root) s = Storage{r.root, r.offset + s.offset, r.frame_stride};
+        }
+
+    // ---- liveness + first-fit arena (offsets in floats per frame; scaled by the chunk size at run time)
+    const int NN = static_cast<int>(plan.nodes.size());
+    std::vector<int> first(NT, -2), last(NT, -2);
+    auto touch = [&](int t, int step) {
+        if (t < 0 || g.tensors[t].is_const) return;
+        int r = plan.storage[t].root;
+        if (first[r] == -2 || step < first[r]) first[r] = step;
+        if (step > last[r]) last[r] = step;
+    };
+    touch(g.inputs[0], -1);
+    for (int i = 0; i < NN; i++) {
+        for (int t : plan.nodes[i].in) touch(t, i);
+        touch(plan.nodes[i].res, i);
+        touch(plan.nodes[i].out, i);
+    }
+    for (int t : g.outputs) touch(t, NN);
+    plan.root_offset.assign(NT, -1);
+    plan.root_elems.assign(NT, 0);
+    struct Live { long off, size; int until; };
+    std::vector<Live> live;
+    std::vector<int> order;
+    for (int t = 0; t < NT; t++)
+        if (first[t] != -2 && plan.storage[t].root == t && !g.tensors[t].is_const) order.push_back(t);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+    long high = 0;
+    for (int t : order) {
+        long size = (plan.storage[t].frame_stride + 63) & ~63L;  // 256-byte granules
+        // buffers whose last reader is an earlier step than this tensor's first writer can be recycled
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.until < first[t]; }), live.end());
+        std::sort(live.begin(), live.end(), [](const Live& a, const Live& b) { return a.off < b.off; });
+        long off = 0;
+        for (const Live& l : live) {
+            if (off + size <= l.off) break;
+            off = std::max(off, l.off + l.size);
+        }
+        plan.root_offset[t] = off;
+        plan.root_elems[t] = size;
+        live.push_back({off, size, last[t]});
+        high = std::max(high, off + size);
+    }
+    plan.arena_floats_per_frame = high;
+
+    // ---- algorithmic traffic / MACs of the plan as launched (per frame)
+    double bytes = 0, macs = 0;
+    for (const Node& n : plan.nodes) {
+        auto elems = [&](int t) { return t >= 0 ? static_cast<double>(g.tensors[t].elems()) : 0.0; };
+        if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
+        for (int t : n.in) bytes += 4 * elems(t);
+        bytes += 4 * elems(n.out);
+        if (n.res >= 0) bytes += 4 * elems(n.res);
+        for (int c : {n.w, n.b, n.w2, n.b2, n.alpha}) bytes += 4 * elems(c);
+        const auto& so = g.tensors[n.out].shape;
+        if (n.kind == Node::Conv) macs += elems(n.out) * n.KH * n.KW * g.tensors[n.in[0]].shape[3];
+        if (n.kind == Node::Dw) macs += elems(n.out) * n.KH * n.KW;
+        if (n.kind == Node::Block) {
+            int C = g.tensors[n.in[0]].shape[3];
+            macs += static_cast<double>(so[1]) * so[2] * C * (n.KH * n.KW + so[3]);
+        }
+    }
+    plan.bytes_per_frame = bytes;
+    plan.macs_per_frame = macs;
+    (void)same_pad;
+    return plan;
+}
+
+std::string Plan::describe() const {
+    static const char* kinds[] = {"conv", "dw", "block", "add", "act", "maxpool", "pad", "reshape", "concat", "resize", "d2s"};
+    static const char* acts[] = {"", "+relu", "+relu6", "+prelu"};
+    static const char* res[] = {"", "+skip", "+skip(maxpool)", "+skip(up2x)"};
+    std::ostringstream os;
+    os << "# fuse_level=" << fuse_level << " launches=" << nodes.size() << " arena_floats_per_frame=" << arena_floats_per_frame
+       << " bytes_per_frame=" << static_cast<long long>(bytes_per_frame) << " macs_per_frame=" << static_cast<long long>(macs_per_frame) << "\n";
+    for (const Node& n : nodes) {
+        const auto& si = graph.tensors[n.in[0]].shape;
+        const auto& so = graph.tensors[n.out].shape;
+        os << kinds[n.kind] << acts[n.act] << res[n.res_mode] << " t" << n.in[0] << "[";
+        for (size_t d = 1; d < si.size(); d++) os << (d > 1 ? "x" : "") << si[d];
+        os << "] -> t" << n.out << "[";
+        for (size_t d = 1; d < so.size(); d++) os << (d > 1 ? "x" : "") << so[d];
+        os << "]";
+        if (n.kind == Node::Conv || n.kind == Node::Dw || n.kind == Node::Block) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
+        os << " ops{";
+        for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
+        os << "}\n";
+    }
+    return os.str();
+}
+
+}  // namespace mi

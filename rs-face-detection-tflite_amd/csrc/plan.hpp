@@ -1,0 +1,64 @@
+// plan.hpp — lowering of a parsed .tflite graph to a list of fused kernel launches (host side).
+//
+// The reference executes these graphs op by op inside TensorFlow-Lite (`interpreter.invoke()`,
+// /root/reference/src/face_detection_lite/face_detection.rs:235).  Here the graph is rewritten once, at load:
+//   level 0  one launch per builtin op (RESHAPE = view, CONCATENATION = producers write into the joined buffer)
+//   level 1  ADD / RELU / PRELU / MAX_POOL_2D-skip / channel-PAD-skip / RESIZE_BILINEAR-skip folded into the
+//            producing convolution's epilogue
+//   level 2  DEPTHWISE_CONV_2D -> CONV_2D 1x1 (-> skip -> activation) fused into one BlazeBlock kernel
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "tflite_graph.hpp"
+
+namespace mi {
+
+struct Node {
+    enum Kind { Conv, Dw, Block, Add, Act, MaxPool, Pad, Reshape, Concat, Resize, DepthToSpace } kind = Conv;
+    std::vector<int> in;   // activation inputs (tensor ids)
+    int out = -1;
+    bool dead = false;
+    // convolution parameters (Conv / Dw / Block: the depthwise stage)
+    int w = -1, b = -1;
+    int KH = 1, KW = 1, sh = 1, sw = 1;
+    Padding padding = Padding::Same;
+    // Block: pointwise stage
+    int w2 = -1, b2 = -1;
+    // fused epilogue
+    int act = ACT_NONE;
+    int alpha = -1;
+    int res = -1;
+    int res_mode = RES_NONE;
+    // misc
+    int pads = -1;                 // PAD: paddings tensor
+    int axis = 0;                  // CONCAT
+    int filter_h = 1, filter_w = 1;
+    int block_size = 1;
+    bool half_pixel = false, align_corners = false;
+    std::vector<int> src_ops;      // indices of the .tflite operators folded into this node (for describe())
+};
+
+struct Storage {
+    int root = -1;        // tensor id that owns the buffer
+    long offset = 0;      // floats from the root's frame start
+    long frame_stride = 0;
+};
+
+struct Plan {
+    Graph graph;
+    std::vector<Node> nodes;            // live nodes in execution order
+    std::vector<Storage> storage;       // per tensor
+    std::vector<long> root_offset;      // per tensor (valid for roots): float offset inside the arena, per frame-slot
+    std::vector<long> root_elems;       // per root: floats per frame
+    long arena_floats_per_frame = 0;
+    int fuse_level = 2;
+    double bytes_per_frame = 0, macs_per_frame = 0;
+    std::string describe() const;
+};
+
+Plan build_plan(Graph g, int fuse_level);
+
+}  // namespace mi

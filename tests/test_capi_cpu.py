@@ -1,0 +1,56 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/mi_face.h declares, lowers every
+shipped graph without a GPU, and refuses to run without one (no silent CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import MODEL_FILES, ROOT, model_path
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "mi_face.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(mi):
+    L = ctypes.CDLL(mi.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(L, n), "libmiface.so does not export %s" % n
+    assert set(mi.EXPORTS) == set(names)
+
+
+@pytest.mark.parametrize("name", list(MODEL_FILES))
+def test_lowering_without_gpu(mi, name):
+    blob = open(model_path(name), "rb").read()
+    p0, p1, p2 = (mi.plan_describe(blob, lvl) for lvl in (0, 1, 2))
+    n0, n1, n2 = (int(re.search(r"launches=(\d+)", p).group(1)) for p in (p0, p1, p2))
+    assert n0 > n1 > n2
+    assert "block" in p2 and "block" not in p1
+    macs = [int(re.search(r"macs_per_frame=(\d+)", p).group(1)) for p in (p0, p1, p2)]
+    assert macs[0] == macs[1] == macs[2]
+
+
+def test_back_plan_matches_survey_numbers(mi):
+    p = mi.plan_describe(open(model_path("back"), "rb").read(), 0)
+    assert "macs_per_frame=188749824" in p        # SURVEY.md §8d, back 256^2
+
+
+def test_malformed_model_is_an_error_not_a_crash(mi):
+    with pytest.raises(mi.MiError):
+        mi.plan_describe(b"\x00" * 64, 2)
+    blob = open(model_path("front"), "rb").read()
+    with pytest.raises(mi.MiError):
+        mi.plan_describe(blob[: len(blob) // 3], 2)
+
+
+def test_no_cpu_fallback(mi):
+    if mi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(mi.MiError) as e:
+        mi.FaceDetection(mi.FaceDetectionModel.BackCamera)
+    assert e.value.code == -4

@@ -1,0 +1,306 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the C oracle on the same inputs.
+
+Tolerances (north_star "within a stated fp32 tolerance, boxes within 1e-3 IoU"):
+  raw network outputs   |d| <= 1e-4 * max(1, max|x|)   (f32 convolution re-association; TFLite itself is not
+                                                         bit-reproducible across its kernels)
+  detections            identical count and order; coordinates <= 1e-5; box IoU >= 0.999
+  post-processing alone (same raw inputs) — bit-exact except the score, which depends on the device expf (<= 2 ulp)
+  landmarks             <= 1e-5 normalised units
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MODEL_FILES, model_path, seeded_input
+
+pytestmark = pytest.mark.gpu
+
+RAW_TOL = 1e-4
+
+
+def _raw_close(got, ref):
+    ref = ref.reshape(got.shape)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= RAW_TOL * scale, "max|diff| %.3e > %.1e * %.1f" % (err, RAW_TOL, scale)
+    return err
+
+
+def _iou(a, b):
+    x0, y0, x1, y1 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+    inter = max(0.0, x1 - x0) * max(0.0, y1 - y0)
+    ua = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter
+    return inter / ua if ua > 0 else 1.0
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def gpu(mi):
+    if mi.device_count() < 1:
+        pytest.fail("no HIP device: the GPU suite must run on an MI355X box")
+    return mi
+
+
+@pytest.mark.parametrize("name", list(MODEL_FILES))
+@pytest.mark.parametrize("fuse", [0, 1, 2])
+def test_network_raw_outputs_vs_oracle(gpu, oracle, name, fuse):
+    m = gpu.Model(model_path(name))
+    m.set_option("fuse", fuse)
+    om = oracle.Model(model_path(name))
+    x = seeded_input(name, 5, 4321, m.input_dims[1:3])
+    outs = m.run(x)
+    refs = om.run(x, nthreads=5)
+    for o, r in zip(outs, refs):
+        _raw_close(o, r)
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
+def test_network_matches_committed_golden(gpu, gold, name):
+    m = gpu.Model(model_path(name))
+    x = seeded_input(name, 2, 1234, m.input_dims[1:3])
+    for k, o in enumerate(m.run(x)):
+        _raw_close(o.reshape(2, -1), gold["noise_%s_out%d" % (name, k)])
+    m.close()
+
+
+def test_chunking_graph_and_batch_invariance(gpu):
+    """Frames are independent: any chunking / hipGraph replay / batch position gives bit-identical results."""
+    m = gpu.Model(model_path("front"))
+    x = seeded_input("front", 13, 5, m.input_dims[1:3])
+    base = [o.copy() for o in m.run(x)]
+    for chunk, graph in ((4, 0), (4, 1), (0, 1), (1, 0)):
+        m.set_option("chunk", chunk)
+        m.set_option("graph", graph)
+        for rep in range(2):
+            for a, b in zip(m.run(x), base):
+                np.testing.assert_array_equal(a, b)
+    # frame 7 alone == frame 7 inside the batch
+    for a, b in zip(m.run(x[7:8]), base):
+        np.testing.assert_array_equal(a[0], b[7])
+    m.close()
+
+
+def test_device_pointer_path_matches_host_path(gpu):
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path("back"))
+    x = seeded_input("back", 3, 11, m.input_dims[1:3])
+    host = m.run(x)
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    dev = m.run(xd)
+    torch.cuda.synchronize()
+    for a, b in zip(host, dev):
+        np.testing.assert_array_equal(a, b.cpu().numpy())
+    m.close()
+
+
+def test_postprocess_bit_exact_vs_oracle(gpu, oracle, gold):
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    np.testing.assert_array_equal(fd.anchors(), gold["anchors_back"])
+    out, counts = fd.postprocess(gold["nms_raw_boxes"], gold["nms_raw_scores"], gold["nms_pads"], cap=256)
+    for f in range(4):
+        ref = gold["nms_dets_%d" % f]
+        assert counts[f] == len(ref)
+        got = out[f, : len(ref)]
+        # score differs only through the device expf; everything else is the same IEEE operation sequence
+        np.testing.assert_allclose(got[:, 16], ref[:, 16], rtol=3e-7)
+        np.testing.assert_allclose(got[:, :16], ref[:, :16], rtol=0, atol=2e-6)
+    fd.close()
+
+
+def test_postprocess_edge_cases(gpu, oracle):
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    anchors = fd.anchors()
+    rb = np.zeros((3, 896, 16), np.float32)
+    rb[:, :, 2:4] = 30.0
+    sc = np.full((3, 896), -10.0, np.float32)
+    sc[1, 100] = 4.0            # single detection
+    sc[2, 100] = 1e-9           # sigmoid rounds to exactly 0.5 -> dropped
+    out, counts = fd.postprocess(rb, sc, None, cap=8)
+    assert list(counts) == [0, 1, 0]
+    ref = oracle.fd_postprocess(rb[1], sc[1], anchors, 256.0)
+    np.testing.assert_allclose(out[1, 0], ref[0], atol=1e-7)
+    # capacity smaller than the number of outputs: count still reports all of them
+    sc2 = np.full((1, 896), 5.0, np.float32)
+    rb2 = np.zeros((1, 896, 16), np.float32)
+    rb2[:, :, 2:4] = 4.0        # tiny boxes on distinct anchors -> no merging between cells
+    out2, counts2 = fd.postprocess(rb2, sc2, None, cap=4)
+    ref2 = oracle.fd_postprocess(rb2[0], sc2[0], anchors, 256.0)
+    assert counts2[0] == len(ref2) and counts2[0] > 4
+    np.testing.assert_allclose(out2[0], ref2[:4], atol=1e-6)
+    # the reference's letterbox assert -> MI_ERANGE
+    with pytest.raises(gpu.MiError) as e:
+        fd.postprocess(rb2, sc2, np.array([[0.5, 0, 0.5, 0]]), cap=4)
+    assert e.value.code == -5
+    fd.close()
+
+
+@pytest.mark.parametrize("kind,name", [("BackCamera", "back"), ("FrontCamera", "front"), ("Short", "short"), ("Full", "full")])
+def test_detector_tensor_path_vs_oracle(gpu, oracle, gold, kind, name):
+    """Config 2 shape at test size: face-bearing + noise frames through net + decode + NMS."""
+    fd = gpu.FaceDetection(getattr(gpu.FaceDetectionModel, kind))
+    om = oracle.Model(model_path(name))
+    W, H = fd.input_size
+    x = seeded_input(name, 6, 77, (H, W)) * 0.25
+    if name == "back":
+        face = gold["man_back_u8"].astype(np.float64) * 2.0 / 255.0 - 1.0
+        x[0] = face.astype(np.float32)
+        x[3] = np.roll(face, (9, -14), axis=(0, 1)).astype(np.float32)
+        x[5] = (np.roll(face, (-20, 25), axis=(0, 1)) * 0.9).astype(np.float32)
+    out, counts = fd.infer_tensor(x, cap=32)
+    rb, rs = om.run(x, nthreads=6)
+    anchors = oracle.ssd_anchors({"back": oracle.FD_BACK, "front": oracle.FD_FRONT, "short": oracle.FD_SHORT, "full": oracle.FD_FULL}[name])
+    total = 0
+    for f in range(6):
+        ref = oracle.fd_postprocess(rb[f], rs[f], anchors, float(H))
+        assert counts[f] == len(ref), "frame %d" % f
+        total += len(ref)
+        for g, r in zip(out[f, : len(ref)], ref):
+            assert _iou(g[:4], r[:4]) >= 0.999
+            np.testing.assert_allclose(g, r, atol=2e-5)
+    if name == "back":
+        assert total >= 3
+    fd.close()
+
+
+def test_landmark_tensor_path_vs_oracle(gpu, oracle, gold):
+    fl = gpu.FaceLandmark()
+    om = oracle.Model(model_path("landmark"))
+    x = seeded_input("landmark", 4, 3, (192, 192))
+    x[1] = gold["man_face_u8"].astype(np.float32) / np.float32(255.0)
+    g = gold["man_face_roi"]
+    roi = gpu.Rect(*[float(v) for v in g[:5]], int(g[5]))
+    rois = [roi, roi, gpu.Rect(270.0, 180.0, 200.0, 210.0, 0.3, 0), gpu.Rect(0.5, 0.5, 1.0, 1.0, 0.0, 1)]
+    sizes = [(540, 360)] * 4
+    lm, present, flags = fl.infer_tensor(x, rois=rois, image_sizes=sizes)
+    raw, flag = om.run(x, nthreads=4)
+    for f in range(4):
+        _raw_close(flags[f:f + 1], flag[f].reshape(-1)[-1:])
+        assert present[f] == oracle.lib().orc_face_flag_passes(float(flag[f].reshape(-1)[-1]))
+        oroi = oracle.Rect(rois[f].x_center, rois[f].y_center, rois[f].width, rois[f].height, rois[f].rotation, rois[f].normalized)
+        ref = oracle.project_landmarks(raw[f], (192, 192), sizes[f], roi=oroi)
+        np.testing.assert_allclose(lm[f], ref, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    assert present[1] == 1
+    np.testing.assert_allclose(lm[1], gold["man_face_landmarks"], atol=1e-5)
+    # no ROI: plain normalisation
+    lm2, _, _ = fl.infer_tensor(x[:2])
+    ref = oracle.project_landmarks(raw[0], (192, 192), (1, 1))
+    np.testing.assert_allclose(lm2[0], ref, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+    fl.close()
+
+
+def test_iris_tensor_path_vs_oracle(gpu, oracle, gold):
+    ir = gpu.IrisLandmark()
+    x = np.stack([gold["man_eye_right_u8"], gold["man_eye_left_u8"]]).astype(np.float32) / np.float32(255.0)
+    rois, pads = [], []
+    for tag in ("right", "left"):
+        g = gold["man_eye_%s_roi" % tag]
+        rois.append(gpu.Rect(*[float(v) for v in g[:5]], int(g[5])))
+        pads.append(gold["man_eye_%s_pad" % tag])
+    contour, iris = ir.infer_tensor(x, rois=rois, image_sizes=[(540, 360)] * 2, padding=np.array(pads), is_right_eye=[1, 0])
+    for k, tag in enumerate(("right", "left")):
+        np.testing.assert_allclose(contour[k], gold["man_eye_%s_contour" % tag], atol=1e-5)
+        np.testing.assert_allclose(iris[k], gold["man_eye_%s_iris" % tag], atol=1e-5)
+    ir.close()
+
+
+def test_image_to_tensor_vs_oracle(gpu, oracle, gold, man_image):
+    """Device pre-processing: +-1 LSB of the u8 image, i.e. <= range/255 in the tensor."""
+    cases = [
+        (None, (256, 256), True, (-1., 1.), False),
+        (None, (128, 128), True, (-1., 1.), False),
+        (gold["man_face_roi"], (192, 192), False, (0., 1.), False),
+        (gold["man_eye_right_roi"], (64, 64), True, (0., 1.), True),
+        (gold["man_eye_left_roi"], (64, 64), True, (0., 1.), False),
+        (np.array([300.0, 150.0, 333.0, 217.0, -0.7, 0]), (192, 192), True, (0., 1.), False),
+    ]
+    for roi, size, keep, rng, flip in cases:
+        r = gpu.Rect(*[float(v) for v in roi[:5]], int(roi[5])) if roi is not None else None
+        o = oracle.Rect(*[float(v) for v in roi[:5]], int(roi[5])) if roi is not None else None
+        got, pad = gpu.image_to_tensor(man_image, r, size, keep, rng, flip)
+        ref, rpad = oracle.image_to_tensor(man_image, o, size, keep, rng, flip)
+        np.testing.assert_allclose(pad, rpad, rtol=1e-12, atol=0)
+        lsb = (rng[1] - rng[0]) / 255.0
+        diff = np.abs(got - ref)
+        assert diff.max() <= lsb * 1.001, diff.max() / lsb
+        assert (diff > 0).mean() < 0.01
+
+
+def test_full_pipeline_on_man_jpg(gpu, oracle, gold, man_image):
+    """README.md:27-46 flow through the reference-shaped API; pinned by the reference's own rendering (+-2 px)."""
+    H, W = man_image.shape[:2]
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    faces = fd.infer(man_image, None)
+    assert len(faces) == 1
+    ref = gold["man_back_dets"][0]
+    got = np.concatenate([faces[0].data.reshape(-1), [faces[0].score]])
+    assert _iou(got[:4], ref[:4]) >= 0.999
+    np.testing.assert_allclose(got, ref, atol=2e-3)      # device pre-processing may differ by 1 LSB per pixel
+    xmin, ymin, xmax, ymax = faces[0].bbox()
+    assert int(xmin * W) == 195 and int(ymin * H) == 74 and int((xmax - xmin) * W) == 139 and int((ymax - ymin) * H) == 139
+    roi = gpu.face_detection_to_roi(faces[0], (W, H))
+    lms = gpu.FaceLandmark().infer(man_image, roi)
+    assert len(lms) == 468
+    arr = np.array([[l.x, l.y, l.z] for l in lms])
+    np.testing.assert_allclose(arr, gold["man_face_landmarks"], atol=3e-3)
+    left, right = gpu.iris_roi_from_face_landmarks(lms, (W, H))
+    iris = gpu.IrisLandmark()
+    r = iris.infer(man_image, right, True)
+    l = iris.infer(man_image, left, False)
+    assert len(r.contour) == 71 and len(r.iris) == 5 and len(l.eyeball_contour()) == 15
+    np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in r.contour]), gold["man_eye_right_contour"], atol=5e-3)
+    np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in l.iris]), gold["man_eye_left_iris"], atol=5e-3)
+    # a frame without a face: empty Vec, like the reference
+    assert fd.infer(np.zeros((240, 320, 3), np.uint8), None) == []
+    assert gpu.FaceLandmark().infer(np.zeros((240, 320, 3), np.uint8), None) == []
+
+
+def test_batch256_properties(gpu, gold):
+    """BASELINE config 2 at full size (256 frames 256x256): size-independent properties instead of an oracle run."""
+    torch = pytest.importorskip("torch")
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    face = (gold["man_back_u8"].astype(np.float64) * 2.0 / 255.0 - 1.0).astype(np.float32)
+    rs = np.random.RandomState(0)
+    x = np.empty((256, 256, 256, 3), np.float32)
+    shifts = []
+    for b in range(256):
+        if b % 2 == 0:
+            x[b] = rs.uniform(-1, 1, (256, 256, 3)).astype(np.float32)
+            shifts.append(None)
+        else:
+            dy, dx = int(rs.randint(-32, 33)), int(rs.randint(-32, 33))
+            x[b] = np.roll(face, (dy, dx), axis=(0, 1))
+            shifts.append((dy, dx))
+    xd = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    out, counts = fd.infer_tensor(xd, cap=16)
+    torch.cuda.synchronize()
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    # (1) permutation equivariance: reversing the batch reverses the results bit-for-bit
+    out_r, counts_r = fd.infer_tensor(torch.flip(xd, dims=[0]).contiguous(), cap=16)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(counts_r.cpu().numpy()[::-1], counts)
+    np.testing.assert_array_equal(out_r.cpu().numpy()[::-1], out)
+    # (2) every face-bearing frame finds the face; shifting the image shifts the box by the same number of pixels
+    base = gold["man_back_dets"][0]
+    pad = gold["man_back_pad"]
+    for b in range(1, 256, 2):
+        assert counts[b] >= 1
+        dy, dx = shifts[b]
+        d = out[b, 0]
+        cx = (d[0] + d[2]) / 2 * 256 - dx
+        cy = (d[1] + d[3]) / 2 * 256 - dy
+        bx = ((base[0] + base[2]) / 2 * (1 - 2 * pad[0]) + pad[0]) * 256
+        by = ((base[1] + base[3]) / 2 * (1 - 2 * pad[1]) + pad[1]) * 256
+        assert abs(cx - bx) < 6 and abs(cy - by) < 6
+    # (3) sortedness: detections of a frame are in non-increasing score order, all above threshold
+    for b in range(256):
+        s = out[b, : min(counts[b], 16), 16]
+        assert np.all(np.diff(s) <= 0) and np.all(s > 0.5)
+    fd.close()

@@ -1,0 +1,118 @@
+"""CPU tests of the oracle (test infrastructure): golden regression, independent cross-check, glue properties.
+PARITY UNPINNED — see oracle/c/oracle.h."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MODEL_FILES, model_path, seeded_input
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "golden.npz"))
+
+
+@pytest.mark.parametrize("name", list(MODEL_FILES))
+def test_oracle_matches_golden_noise(oracle, gold, name):
+    m = oracle.Model(model_path(name))
+    x = seeded_input(name, 2, 1234, m.input_dims[1:3])
+    outs = m.run(x, nthreads=2)
+    for k, o in enumerate(outs):
+        g = gold["noise_%s_out%d" % (name, k)]
+        np.testing.assert_allclose(o.reshape(2, -1), g, rtol=0, atol=1e-4 * max(1.0, float(np.abs(g).max())))
+
+
+@pytest.mark.parametrize("name", ["front", "landmark", "iris", "full"])
+def test_oracle_vs_independent_torch_eval(oracle, name):
+    torch = pytest.importorskip("torch")
+    from oracle.np import evaluate, tfl3
+    m = oracle.Model(model_path(name))
+    x = seeded_input(name, 1, 99, m.input_dims[1:3])
+    ref = evaluate.run(tfl3.load(model_path(name)), x)
+    for a, b in zip(ref, m.run(x)):
+        err = np.abs(a.reshape(b.shape) - b) / np.maximum(1.0, np.abs(b))
+        assert err.max() <= 1e-4
+
+
+def test_anchor_counts_and_layout(oracle, gold):
+    a = oracle.ssd_anchors(oracle.FD_BACK)
+    assert a.shape == (896, 2)
+    np.testing.assert_array_equal(a, gold["anchors_back"])
+    # 16x16 cells x 2 then 8x8 cells x 6, y-major, centres (x+0.5)/fm
+    assert a[0, 0] == np.float32(0.5) / np.float32(16) and a[0, 1] == np.float32(0.5) / np.float32(16)
+    assert np.array_equal(a[0], a[1]) and a[2, 0] == np.float32(1.5) / np.float32(16)
+    assert a[512, 0] == np.float32(0.5) / np.float32(8)
+    assert oracle.ssd_anchors(oracle.FD_FRONT).shape == (896, 2)
+    assert oracle.ssd_anchors(oracle.FD_SHORT).shape == (896, 2)
+    f = oracle.ssd_anchors(oracle.FD_FULL)
+    assert f.shape == (2304, 2) and np.array_equal(f, oracle.ssd_anchors(oracle.FD_FULL_SPARSE))
+
+
+def test_man_pipeline_matches_golden(oracle, gold, man_image):
+    H, W = man_image.shape[:2]
+    t, pad = oracle.image_to_tensor(man_image, None, (256, 256), True, (-1., 1.), False)
+    u8 = np.round((t + 1.0) * 255.0 / 2.0).astype(np.uint8)
+    np.testing.assert_array_equal(u8, gold["man_back_u8"])
+    np.testing.assert_allclose(pad, gold["man_back_pad"])
+    fd = oracle.Model(model_path("back"))
+    rb, rs = fd.run(t[None])
+    dets = oracle.fd_postprocess(rb[0], rs[0], oracle.ssd_anchors(oracle.FD_BACK), 256.0, pad)
+    np.testing.assert_allclose(dets, gold["man_back_dets"], atol=1e-5)
+
+
+def test_nms_golden_and_properties(oracle, gold):
+    anchors = gold["anchors_back"]
+    for f in range(4):
+        d = oracle.fd_postprocess(gold["nms_raw_boxes"][f], gold["nms_raw_scores"][f], anchors, 256.0, gold["nms_pads"][f])
+        np.testing.assert_array_equal(d, gold["nms_dets_%d" % f])
+        # outputs come out in non-increasing head-score order and every score passed the 0.5 threshold
+        assert np.all(np.diff(d[:, 16]) <= 0) and np.all(d[:, 16] > 0.5)
+
+
+def test_nms_empty_and_single(oracle):
+    anchors = oracle.ssd_anchors(oracle.FD_BACK)
+    rb = np.zeros((896, 16), np.float32)
+    assert len(oracle.fd_postprocess(rb, np.full(896, -10.0, np.float32), anchors, 256.0)) == 0
+    rb[:, 2:4] = 30.0
+    sc = np.full(896, -10.0, np.float32)
+    sc[100] = 4.0
+    d = oracle.fd_postprocess(rb, sc, anchors, 256.0)
+    assert len(d) == 1
+    ax, ay = anchors[100]
+    np.testing.assert_allclose(d[0, :4], [ax - 30 / 512, ay - 30 / 512, ax + 30 / 512, ay + 30 / 512], atol=1e-7)
+    # sigmoid(x) > 0.5 is evaluated on the f32 sigmoid: a tiny positive logit rounds to exactly 0.5 and is dropped
+    sc[100] = 1e-9
+    assert len(oracle.fd_postprocess(rb, sc, anchors, 256.0)) == 0
+
+
+def test_letterbox_guard(oracle):
+    anchors = oracle.ssd_anchors(oracle.FD_BACK)
+    rb = np.zeros((896, 16), np.float32)
+    rb[:, 2:4] = 30.0
+    sc = np.full(896, 5.0, np.float32)
+    with pytest.raises(RuntimeError):
+        oracle.fd_postprocess(rb, sc, anchors, 256.0, (0.5, 0.0, 0.5, 0.0))
+
+
+def test_project_landmarks_identity_and_flip(oracle):
+    raw = np.array([96, 48, 19.2, 0, 192, -9.6], np.float32)
+    out = oracle.project_landmarks(raw, (192, 192), (640, 480))
+    np.testing.assert_allclose(out, [[0.5, 0.25, 0.1], [0.0, 1.0, -0.05]], atol=1e-7)
+    out = oracle.project_landmarks(raw, (192, 192), (640, 480), flip=True)
+    np.testing.assert_allclose(out[:, 0], [0.5, 1.0], atol=1e-7)
+    roi = oracle.Rect(0.5, 0.5, 0.5, 0.25, np.pi / 2, 1)
+    out = oracle.project_landmarks(np.array([192, 96, 0], np.float32), (192, 192), (640, 480), roi=roi)
+    # (1.0,0.5) -> centred (0.5,0) -> rotated by +90deg (0,0.5) -> scaled (0,0.125) -> + centre
+    np.testing.assert_allclose(out[0], [0.5, 0.625, 0.0], atol=1e-6)
+
+
+def test_roi_helpers(oracle, gold):
+    roi = oracle.face_detection_to_roi(gold["man_back_dets"][0], (540, 360))
+    np.testing.assert_allclose([roi.x_center, roi.y_center, roi.width, roi.height, roi.rotation, roi.normalized],
+                               gold["man_face_roi"], rtol=1e-12)
+    # SquareLong: the ROI is square in pixels
+    assert abs(roi.width * 540 - roi.height * 360) < 1e-9
+    l, r = oracle.iris_rois_from_face_landmarks(gold["man_face_landmarks"], (540, 360))
+    np.testing.assert_allclose([l.x_center, l.y_center, l.width, l.height, l.rotation], gold["man_eye_left_roi"][:5], rtol=1e-12)
+    np.testing.assert_allclose([r.x_center, r.y_center, r.width, r.height, r.rotation], gold["man_eye_right_roi"][:5], rtol=1e-12)
