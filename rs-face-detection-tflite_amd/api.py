@@ -114,6 +114,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run rs-face-detection-tflite_amd/build.sh (hipcc, gfx950). "
                           "There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64; when both live in one process torch must be loaded first so that the
+    # two share one HIP runtime (otherwise torch later reports "No HIP GPUs are available").  torch is only plumbing
+    # here (device buffers, streams, torch.distributed) — set MIFACE_NO_TORCH=1 to skip it entirely.
+    if not os.environ.get("MIFACE_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, fp, ip, dp = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.mi_last_error.restype = C.c_char_p

@@ -99,14 +99,22 @@ void Model::rebuild() {
         } else if (n.kind == Node::Dw) {
             node_w_[i] = put(g.tensors[n.w].f32);
         } else if (n.kind == Node::Block) {
-            node_w_[i] = put(g.tensors[n.w].f32);
-            const auto& ws = g.tensors[n.w2].shape;  // [O][1][1][I]
+            if (n.w >= 0) node_w_[i] = put(g.tensors[n.w].f32);
+            // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
+            // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
+            const auto& ws = g.tensors[n.w2].shape;
             const auto& src = g.tensors[n.w2].f32;
             int O = ws[0], I = ws[3], Cp, Cop;
             block_weight_dims(I, O, &Cp, &Cop);
+            const int Ch = Cp / 2, MT = Cop / 32;
             std::vector<float> r(static_cast<size_t>(Cop) * Cp, 0.f);
-            for (int o = 0; o < O; o++)
-                for (int c = 0; c < I; c++) r[static_cast<size_t>(o) * Cp + c] = src[static_cast<size_t>(o) * I + c];
+            for (int mt = 0; mt < MT; mt++)
+                for (int j = 0; j < Ch / 4; j++)
+                    for (int l = 0; l < 64; l++)
+                        for (int e2 = 0; e2 < 4; e2++) {
+                            int o = mt * 32 + (l & 31), c = (l >> 5) * Ch + 4 * j + e2;
+                            if (o < O && c < I) r[((static_cast<size_t>(mt) * (Ch / 4) + j) * 64 + l) * 4 + e2] = src[static_cast<size_t>(o) * I + c];
+                        }
             node_w2_[i] = put(r);
         }
     }
@@ -209,12 +217,13 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             case Node::Block: {
                 BlockArgs a;
                 a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
-                a.w_dw = d_weights_ + node_w_[i];
+                a.has_dw = n.w >= 0;
+                a.w_dw = a.has_dw ? d_weights_ + node_w_[i] : nullptr;
                 a.b_dw = node_b_[i] >= 0 ? d_weights_ + node_b_[i] : nullptr;
                 a.w_pw = d_weights_ + node_w2_[i];
                 a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2]; a.Co = so[3];
                 a.sh = n.sh; a.sw = n.sw;
-                if (n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
+                if (a.has_dw && n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
                 rc = launch_block(a, s);
                 break;

@@ -58,7 +58,7 @@ class Model {
     int device_ = 0;
     std::vector<uint8_t> blob_;
     Plan plan_;
-    int fuse_level_ = 1, chunk_ = 0, use_graph_ = 1, reuse_ = 1;
+    int fuse_level_ = 2, chunk_ = 0, use_graph_ = 1, reuse_ = 1;
     bool dirty_ = true;
 
     float* d_weights_ = nullptr;

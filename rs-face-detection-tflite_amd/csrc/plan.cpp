@@ -43,8 +43,8 @@ struct Rewriter {
     // Fold ADD / activation that exclusively consume node i's output into node i; the fused node takes the
     // position of the last folded op so that every operand (e.g. the skip tensor) is already available there.
     void fuse_epilogues() {
-        for (size_t i = 0; i < nodes.size(); i++) {
-            for (;;) {
+        for (size_t start = 0; start < nodes.size(); start++) {
+            for (size_t i = start;;) {
                 Node& n = nodes[i];
                 if (n.dead || !(n.kind == Node::Conv || n.kind == Node::Dw)) break;
                 if (is_graph_output(n.out)) break;
@@ -113,6 +113,32 @@ struct Rewriter {
         }
     }
 
+    // Would the fused MFMA kernel take this node? (shape-level check with placeholder, 16-byte aligned pointers)
+    bool block_supported(const Node& f) const {
+        const auto& si = shape(f.in[0]);
+        const auto& so = shape(f.out);
+        if (si.size() != 4 || so.size() != 4) return false;
+        BlockArgs a;
+        a.in = reinterpret_cast<const float*>(0x1000);
+        a.out = reinterpret_cast<float*>(0x2000);
+        a.in_fs = static_cast<long>(g.tensors[f.in[0]].elems());
+        a.out_fs = static_cast<long>(g.tensors[f.out].elems());
+        a.B = 1; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2]; a.Co = so[3];
+        a.sh = f.sh; a.sw = f.sw;
+        a.has_dw = f.w >= 0;
+        if (a.has_dw && f.padding == Padding::Same) {
+            a.pt = std::max(0, (a.Ho - 1) * a.sh + 3 - a.H) / 2;
+            a.pl = std::max(0, (a.Wo - 1) * a.sw + 3 - a.W) / 2;
+        }
+        if (f.res >= 0) {
+            a.ep.res = f.res == f.in[0] ? a.in : reinterpret_cast<const float*>(0x3000);
+            a.ep.res_fs = static_cast<long>(g.tensors[f.res].elems());
+            a.ep.res_mode = f.res_mode;
+            a.ep.res_C = shape(f.res).back();
+        }
+        return block_kernel_supports(a);
+    }
+
     // DEPTHWISE 3x3 -> CONV 1x1 (stride 1) with the depthwise result consumed only by that conv.
     void fuse_blocks() {
         for (size_t i = 0; i < nodes.size(); i++) {
@@ -132,7 +158,18 @@ struct Rewriter {
             f.KH = d.KH; f.KW = d.KW; f.sh = d.sh; f.sw = d.sw; f.padding = d.padding;
             f.src_ops = d.src_ops;
             f.src_ops.insert(f.src_ops.end(), c.src_ops.begin(), c.src_ops.end());
+            if (!block_supported(f)) continue;
             d.dead = true;
+            c = f;
+        }
+        // remaining plain 1x1 stride-1 convolutions also run on the MFMA kernel (no depthwise stage: w = -1)
+        for (Node& c : nodes) {
+            if (c.dead || c.kind != Node::Conv || c.KH != 1 || c.KW != 1 || c.sh != 1 || c.sw != 1) continue;
+            Node f = c;
+            f.kind = Node::Block;
+            f.w2 = c.w; f.b2 = c.b;
+            f.w = -1; f.b = -1;
+            if (!block_supported(f)) continue;
             c = f;
         }
     }
@@ -313,14 +350,14 @@ Plan build_plan(Graph graph, int fuse_level) {
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
         for (int t : n.in) bytes += 4 * elems(t);
         bytes += 4 * elems(n.out);
-        if (n.res >= 0) bytes += 4 * elems(n.res);
+        if (n.res >= 0 && !(n.kind == Node::Block && n.res == n.in[0])) bytes += 4 * elems(n.res);
         for (int c : {n.w, n.b, n.w2, n.b2, n.alpha}) bytes += 4 * elems(c);
         const auto& so = g.tensors[n.out].shape;
         if (n.kind == Node::Conv) macs += elems(n.out) * n.KH * n.KW * g.tensors[n.in[0]].shape[3];
         if (n.kind == Node::Dw) macs += elems(n.out) * n.KH * n.KW;
         if (n.kind == Node::Block) {
             int C = g.tensors[n.in[0]].shape[3];
-            macs += static_cast<double>(so[1]) * so[2] * C * (n.KH * n.KW + so[3]);
+            macs += static_cast<double>(so[1]) * so[2] * C * ((n.w >= 0 ? n.KH * n.KW : 0) + so[3]);
         }
     }
     plan.bytes_per_frame = bytes;
@@ -344,7 +381,8 @@ std::string Plan::describe() const {
         os << "] -> t" << n.out << "[";
         for (size_t d = 1; d < so.size(); d++) os << (d > 1 ? "x" : "") << so[d];
         os << "]";
-        if (n.kind == Node::Conv || n.kind == Node::Dw || n.kind == Node::Block) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
+        if (n.kind == Node::Conv || n.kind == Node::Dw || (n.kind == Node::Block && n.w >= 0)) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
+        if (n.kind == Node::Block && n.w < 0) os << " pointwise";
         os << " ops{";
         for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
         os << "}\n";
