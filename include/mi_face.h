@@ -108,6 +108,11 @@ int mi_model_set_option(mi_model *m, const char *key, int value);
 /* Host-only: parse + lower a .tflite blob WITHOUT touching a GPU and write the launch plan text (same format as
  * mi_model_describe). Returns bytes needed (incl. NUL), 0 on error (see mi_last_error). Used by CPU-side tests. */
 size_t mi_plan_describe(const uint8_t *tflite, size_t nbytes, int fuse_level, char *buf, size_t cap);
+/* Measurement aid: runs the plan `reps` times with eager launches and a HIP event between consecutive launches on the
+ * handle's stream; writes a JSON array with one record per launch {"kernel","shape","ms","bytes","macs"} (ms = average
+ * duration, bytes/macs = algorithmic work of that launch for `batch` frames). in_device = DEVICE pointer.
+ * Returns bytes needed (incl. NUL), 0 on error. */
+size_t mi_model_profile(mi_model *m, const float *in_device, int batch, int reps, char *buf, size_t cap);
 /* Algorithmic traffic of the launch plan per frame (bytes read+written by the kernels as launched, weights
  * included once) and MACs per frame; used by bench.py for the roofline figure. */
 int mi_model_plan_stats(const mi_model *m, double *bytes_per_frame, double *macs_per_frame, int *launches);

@@ -30,7 +30,7 @@ EXPORTS = [
     "mi_last_error", "mi_device_count", "mi_version",
     "mi_model_load_file", "mi_model_load_bytes", "mi_model_free", "mi_model_input_dims", "mi_model_num_outputs",
     "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
-    "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats",
+    "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image",
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
@@ -143,6 +143,8 @@ def lib():
     L.mi_plan_describe.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
     L.mi_plan_describe.restype = C.c_size_t
     L.mi_model_plan_stats.argtypes = [vp, dp, dp, ip]
+    L.mi_model_profile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.mi_model_profile.restype = C.c_size_t
     L.mi_fd_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.mi_fd_create_from_bytes.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
     L.mi_fd_free.argtypes = [vp]
@@ -259,6 +261,19 @@ class Model:
         b, m, n = C.c_double(), C.c_double(), C.c_int()
         _check(self.L.mi_model_plan_stats(self.h, C.byref(b), C.byref(m), C.byref(n)))
         return b.value, m.value, n.value
+
+    def profile(self, x_device, reps=5):
+        """Per-launch HIP-event timing (x_device: torch CUDA tensor). Returns a list of dicts."""
+        import json
+        p, mem = _ptr(x_device)
+        if mem != MI_MEM_DEVICE:
+            raise ValueError("profile() needs a device tensor")
+        B = int(x_device.shape[0])
+        cap = 1 << 20
+        buf = C.create_string_buffer(cap)
+        if self.L.mi_model_profile(self.h, p, B, reps, buf, cap) == 0:
+            raise MiError(-1, self.L.mi_last_error().decode())
+        return json.loads(buf.value.decode())
 
     def run(self, x, outs=None, stream=None):
         """x: numpy [B,H,W,C] f32 (host) or torch CUDA tensor. Returns list of outputs in the same memory space."""

@@ -217,6 +217,30 @@ int mi_model_set_option(mi_model* m, const char* key, int value) {
     });
 }
 
+size_t mi_model_profile(mi_model* m, const float* in_device, int batch, int reps, char* buf, size_t cap) {
+    size_t need = 0;
+    int rc = guarded([&] {
+        require(m && in_device, "null argument");
+        require(batch > 0 && reps > 0, "batch and reps must be positive");
+        auto stats = m->m->profile(in_device, batch, reps, nullptr);
+        std::string s = "[";
+        char line[512];
+        for (size_t i = 0; i < stats.size(); i++) {
+            std::snprintf(line, sizeof line, "%s{\"kernel\": \"%s\", \"shape\": \"%s\", \"ms\": %.6f, \"bytes\": %.0f, \"macs\": %.0f}", i ? ", " : "",
+                          stats[i].kernel.c_str(), stats[i].detail.c_str(), stats[i].ms, stats[i].bytes, stats[i].macs);
+            s += line;
+        }
+        s += "]";
+        if (buf && cap) {
+            size_t k = std::min(cap - 1, s.size());
+            std::memcpy(buf, s.data(), k);
+            buf[k] = 0;
+        }
+        need = s.size() + 1;
+    });
+    return rc == MI_OK ? need : 0;
+}
+
 int mi_model_plan_stats(const mi_model* m, double* bytes_per_frame, double* macs_per_frame, int* launches) {
     return guarded([&] {
         require(m, "null argument");

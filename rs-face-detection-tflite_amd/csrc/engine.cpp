@@ -167,8 +167,87 @@ float* Model::tensor_ptr_mut(int t, int chunk_start, long* fs) const {
     return d_arena_ + off * chunk_cap_ + s.offset;
 }
 
-void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s) {
+std::string Model::node_label(const Node& n) const {
     const Graph& g = plan_.graph;
+    switch (n.kind) {
+        case Node::Conv: return "conv_generic_kernel";
+        case Node::Dw: return "dw_kernel";
+        case Node::Block: {
+            const int Co = g.tensors[n.out].shape.back();
+            const int MT = (Co + 31) / 32, MTG = std::min(4, MT), PG = MT <= 2 ? 2 : 1;
+            return "block_kernel<" + std::to_string(MTG) + "," + std::to_string(n.w >= 0 ? n.sh : 1) + "," + (n.w >= 0 ? "3" : "1") + "," + std::to_string(PG) + ">";
+        }
+        case Node::Add: return "add_kernel";
+        case Node::Act: return "act_kernel";
+        case Node::MaxPool: return "maxpool_kernel";
+        case Node::Pad: return "pad_kernel";
+        case Node::Resize: return "resize_kernel";
+        case Node::DepthToSpace: return "d2s_kernel";
+        default: return "view";
+    }
+}
+
+std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int reps, hipStream_t stream) {
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    if (dirty_) rebuild();
+    const int saved_chunk = chunk_;
+    ensure_capacity(batch);
+    hipStream_t s = stream ? stream : stream_;
+    const Graph& g = plan_.graph;
+    std::vector<LaunchStat> stats;
+    for (const Node& n : plan_.nodes) {
+        if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
+        LaunchStat st;
+        st.kernel = node_label(n);
+        auto elems = [&](int t) { return t >= 0 ? static_cast<double>(g.tensors[t].elems()) : 0.0; };
+        double per_frame = 4 * elems(n.out);
+        for (int t : n.in) per_frame += 4 * elems(t);
+        if (n.res >= 0 && !(n.kind == Node::Block && n.res == n.in[0])) per_frame += 4 * elems(n.res);
+        double weights = 0;
+        for (int c : {n.w, n.b, n.w2, n.b2, n.alpha}) weights += 4 * elems(c);
+        st.bytes = per_frame * batch + weights;
+        const auto& si = g.tensors[n.in[0]].shape;
+        const auto& so = g.tensors[n.out].shape;
+        if (n.kind == Node::Conv) st.macs = elems(n.out) * n.KH * n.KW * si.back() * batch;
+        if (n.kind == Node::Dw) st.macs = elems(n.out) * n.KH * n.KW * batch;
+        if (n.kind == Node::Block) st.macs = elems(n.out) / so.back() * si.back() * ((n.w >= 0 ? 9 : 0) + so.back()) * batch;
+        std::string d;
+        for (size_t k = 1; k < si.size(); k++) d += (k > 1 ? "x" : "") + std::to_string(si[k]);
+        d += "->";
+        for (size_t k = 1; k < so.size(); k++) d += (k > 1 ? "x" : "") + std::to_string(so[k]);
+        st.detail = d;
+        stats.push_back(st);
+    }
+    const size_t nl = stats.size();
+    const int nchunks = (batch + chunk_cap_ - 1) / chunk_cap_;
+    std::vector<hipEvent_t> marks;
+    for (int r = 0; r < reps; r++) {
+        marks.clear();
+        for (int start = 0; start < batch; start += chunk_cap_) enqueue_chunk(in, start, std::min(chunk_cap_, batch - start), s, &marks);
+        hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        if (marks.size() != static_cast<size_t>(nchunks) * (nl + 1)) throw std::runtime_error("internal: profile marks mismatch");
+        for (int c = 0; c < nchunks; c++)
+            for (size_t i = 0; i < nl; i++) {
+                float ms = 0;
+                hip_check(hipEventElapsedTime(&ms, marks[c * (nl + 1) + i], marks[c * (nl + 1) + i + 1]), "hipEventElapsedTime");
+                stats[i].ms += ms / reps;
+            }
+        for (hipEvent_t ev : marks) hipEventDestroy(ev);
+    }
+    (void)saved_chunk;
+    return stats;
+}
+
+void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s, std::vector<hipEvent_t>* marks) {
+    const Graph& g = plan_.graph;
+    auto mark = [&] {
+        if (!marks) return;
+        hipEvent_t ev;
+        hip_check(hipEventCreate(&ev), "hipEventCreate");
+        hip_check(hipEventRecord(ev, s), "hipEventRecord");
+        marks->push_back(ev);
+    };
+    mark();
     for (size_t i = 0; i < plan_.nodes.size(); i++) {
         const Node& n = plan_.nodes[i];
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;  // views
@@ -259,6 +338,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             }
         }
         if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        mark();
     }
     last_chunk_frames_ = F;
 }

@@ -42,6 +42,14 @@ class Model {
     float* output_device(int i) const { return d_out_.at(i); }
     hipStream_t stream() const { return stream_; }
 
+    // Per-launch timing with HIP events on the stream the kernels are launched on (eager launches, whole batch in one
+    // chunk layout as configured). Returns one record per launch: kernel label, avg milliseconds, algorithmic bytes
+    // and MACs for `batch` frames.
+    struct LaunchStat {
+        std::string kernel, detail;
+        double ms = 0, bytes = 0, macs = 0;
+    };
+    std::vector<LaunchStat> profile(const float* in, int batch, int reps, hipStream_t stream);
     void set_option(const std::string& key, int value);
     size_t debug_tensor(int tensor, int frame, float* dst, size_t cap);
     std::string describe() const { return plan_.describe(); }
@@ -49,7 +57,8 @@ class Model {
    private:
     void rebuild();                       // (re)lower + upload weights for the current options
     void ensure_capacity(int batch);
-    void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s);
+    void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s, std::vector<hipEvent_t>* marks = nullptr);
+    std::string node_label(const Node& n) const;
     void enqueue_all(const float* in, int batch, hipStream_t s);
     const float* tensor_ptr(int t, const float* in, int chunk_start, long* frame_stride) const;
     float* tensor_ptr_mut(int t, int chunk_start, long* frame_stride) const;
