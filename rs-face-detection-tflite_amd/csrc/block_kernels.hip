@@ -1,7 +1,7 @@
 // block_kernels.hip — the hot kernel: one fused BlazeBlock per launch on gfx950 (CDNA4).
 //
-//   out = act( PW1x1( DW3x3(in) + b_dw ) + b_pw + skip )            (HAS_DW)      or
-//   out = act( PW1x1( in ) + b_pw + skip )                           (pointwise only)
+//   out = act( PW1x1( DW3x3(in) + b_dw ) + b_pw + skip )            (KS = 3)      or
+//   out = act( PW1x1( in ) + b_pw + skip )                           (KS = 1, pointwise only)
 //
 // replaces the DEPTHWISE_CONV_2D -> CONV_2D(1x1) -> ADD -> RELU/PRELU op chain (+ MAX_POOL_2D / channel PAD on the skip
 // path) that TensorFlow-Lite runs op by op behind `interpreter.invoke()` (/root/reference/src/face_detection_lite/
@@ -9,24 +9,29 @@
 //
 // Design (HBM-bound: every activation byte is read once and written once):
 //   * one 256-thread workgroup owns a band of output rows of ONE frame and walks down it.  Input rows live in an LDS
-//     ring (NR = (R-1)*S + 3 rows for R output rows per step); each input row is fetched from HBM exactly once per band
-//     (2 halo rows per band are the only re-reads).  Rows of an NHWC frame are contiguous, so the 16 B/lane loads and
-//     stores are fully coalesced.
+//     ring (NR = (R-1)*S + KS rows for R output rows per step); each input row is fetched from HBM exactly once per band
+//     (KS-S halo rows per band are the only re-reads).  The rows a step adds are one contiguous block of the NHWC frame,
+//     so the 16 B/lane loads (and the stores) are fully coalesced.  Bands are sized so that the grid is about one
+//     resident wave of workgroups (2 per CU): the prologue is paid once per ~64 rows.
 //   * the next step's rows are issued into registers BEFORE the current step is computed and written to LDS after it
-//     (issue-early / write-late), so HBM latency hides under the DW + MFMA work; 2-3 workgroups per CU cover the rest.
+//     (issue-early / write-late), so HBM latency hides under the DW + MFMA work.  The hot variants contain no other
+//     global load in the compute phase (bias/slopes/weights sit in LDS): vmcnt is in-order, a stray load would drain it.
 //   * LDS pixel stride is Cp + 4 floats: with Cp a multiple of 8 the 16 lanes of a ds_read_b128 group hit 16 distinct
 //     4-bank slots (conflict-free) when each lane reads its own pixel.
 //   * depthwise 3x3 on the VALU, 4 channels (one float4) at a time, computed directly in the MFMA operand layout:
 //     lane l = (pixel l&31, k-half l>>5) owns the channels [h*Cp/2, (h+1)*Cp/2) of its pixel, so the DW result IS the
 //     B operand of v_mfma_f32_32x32x2_f32 (B[k = l>>5][n = l&31]) with the contraction index permuted consistently in
 //     the pre-packed A operand (pointwise weights, M = 32 output channels per tile).  No LDS round trip for DW outputs.
+//     LDS reads run one filter row ahead of the FMAs that consume them.
 //   * exact f32 MFMA (same numerics as an fmaf chain); D layout gives each lane 4 consecutive output channels per
 //     register quad -> float4 epilogue: + bias + skip (from the LDS ring when the skip is the block input, incl. the
-//     fused 2x2 max-pool of stride-2 blocks and the zero channel-pad) -> ReLU/PReLU -> 16-byte stores.
+//     fused 2x2 max-pool of stride-2 blocks and the zero channel-pad) -> activation -> 16-byte stores.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 
 #include "kernels.hpp"
 
@@ -36,9 +41,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int kPrefetch = 8;        // float4 registers per thread for the next step's rows
-constexpr int kLdsBudget = 64 * 1024;
-constexpr int kALdsMax = 40 * 1024; // pointwise weights are staged in LDS when they fit in this many bytes
+constexpr int kPrefetch = 8;          // float4 registers per thread for the next step's rows
+constexpr int kALdsMax = 40 * 1024;   // pointwise weights are staged in LDS when they fit in this many bytes
+constexpr int kCUs = 256;
+
+int lds_budget() {
+    static const int v = getenv("MI_BLOCK_LDS") ? atoi(getenv("MI_BLOCK_LDS")) : 80 * 1024;  // tuning aid
+    return v;
+}
 
 struct BlockGeom {
     int Cp, Ch, C4;        // padded channels (mult of 8), channels per k-half, float4s per real pixel
@@ -47,12 +57,18 @@ struct BlockGeom {
     int band, bands;       // output rows per workgroup, workgroups per frame
     int MT;                // 32-row output-channel tiles
     int a_lds;             // pointwise weights staged in LDS
-    int off_wdw, off_bdw, off_a;  // LDS offsets in floats
+    int off_wdw, off_bdw, off_a, off_bias, off_alpha;  // LDS offsets in floats
     int res_lds;           // skip connection served from the LDS ring
     int lds_bytes;
+    int PG;
+    unsigned long long* stamps;  // diagnostic builds only (MI_BLOCK_STAMPS): 8 accumulators per wave
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 max4(float4 a, float4 b, float4 c, float4 d) {
+    return make_float4(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)),
+                       fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w)));
+}
 
 __device__ __forceinline__ float4 res_from_global(const Epilogue& ep, int b, int oy, int ox, int Wo, int ch) {
     // generic float4 skip read (channels ch..ch+3 < res_C guaranteed by the caller)
@@ -60,9 +76,7 @@ __device__ __forceinline__ float4 res_from_global(const Epilogue& ep, int b, int
     if (ep.res_mode == RES_DIRECT) return ld4(r + ((long)oy * Wo + ox) * ep.res_C + ch);
     if (ep.res_mode == RES_MAXPOOL) {
         const float* p = r + ((long)(2 * oy) * ep.res_W + 2 * ox) * ep.res_C + ch;
-        float4 a = ld4(p), b4 = ld4(p + ep.res_C), c = ld4(p + (long)ep.res_W * ep.res_C), d = ld4(p + (long)ep.res_W * ep.res_C + ep.res_C);
-        return make_float4(fmaxf(fmaxf(a.x, b4.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, b4.y), fmaxf(c.y, d.y)),
-                           fmaxf(fmaxf(a.z, b4.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, b4.w), fmaxf(c.w, d.w)));
+        return max4(ld4(p), ld4(p + ep.res_C), ld4(p + (long)ep.res_W * ep.res_C), ld4(p + (long)ep.res_W * ep.res_C + ep.res_C));
     }
     // RES_UP2X (TFLite ResizeBilinear, half_pixel_centers)
     float iy = ((float)oy + 0.5f) * 0.5f - 0.5f, ix = ((float)ox + 0.5f) * 0.5f - 0.5f;
@@ -77,14 +91,17 @@ __device__ __forceinline__ float4 res_from_global(const Epilogue& ep, int b, int
 }
 
 // MTG: output-channel tiles kept in accumulators at once; S: stride; KS: 3 (depthwise stage) or 1 (pointwise only);
-// PG: 32-pixel groups per wave per step.
-template <int MTG, int S, int KS, int PG>
+// PG: 32-pixel groups per wave per step; SLOW: variants that may stream the pointwise weights from global/L2 and read
+// the skip from global memory (large-channel / cross-tensor-skip layers; small, never on the hot path).
+template <int MTG, int S, int KS, int PG, bool SLOW>
 __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tile = lds;
     const float* wdw = lds + g.off_wdw;
     const float* bdw = lds + g.off_bdw;
     const float* aL = lds + g.off_a;
+    const float* biasL = lds + g.off_bias;    // [Cop] pointwise bias (0 when absent)
+    const float* alphaL = lds + g.off_alpha;  // [Cop] negative-side slope of the activation
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
@@ -93,8 +110,9 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
     const int iy_base = oy0 * S - a.pt;  // input row held by ring slot 0 at band start
     const float* in = a.in + (long)b * a.in_fs;
     const int rowf4 = a.W * g.C4;        // float4s of one real input row
+    const int Cop = g.MT * 32;
 
-    // ---- prologue: clear the ring (pad pixels / out-of-image rows stay zero), stage weights, load the first rows
+    // ---- prologue: clear the ring (pad pixels / out-of-image rows stay zero), stage constants, load the first rows
     for (int i = tid; i < (g.NR * g.RS) >> 2; i += 256) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KS == 3) {
         for (int i = tid; i < 9 * g.Cp; i += 256) {
@@ -103,60 +121,91 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
         }
         for (int i = tid; i < g.Cp; i += 256) lds[g.off_bdw + i] = (i < a.C && a.b_dw) ? a.b_dw[i] : 0.f;
     }
+    for (int i = tid; i < Cop; i += 256) {
+        lds[g.off_bias + i] = (i < a.Co && a.ep.bias) ? a.ep.bias[i] : 0.f;
+        // negative-side slope: PReLU alpha, 0 for ReLU/ReLU6, 1 for "no activation"
+        lds[g.off_alpha + i] = (i < a.Co && a.ep.act == ACT_PRELU) ? a.ep.alpha[i] : (a.ep.act == ACT_NONE ? 1.f : 0.f);
+    }
     if (g.a_lds)
         for (int i = tid; i < (g.MT * 32 * g.Cp) >> 2; i += 256) reinterpret_cast<float4*>(lds + g.off_a)[i] = ld4(a.w_pw + 4 * (long)i);
+
+    // prefetch geometry: float4 number (tid + 256k) of the contiguous block of new rows -> (row, LDS offset in its slot)
+    int pf_pack[kPrefetch];  // row << 20 | LDS float offset within the row slot
+#pragma unroll
+    for (int k = 0; k < kPrefetch; k++) {
+        int i = tid + k * 256;
+        int r = 0;
+#pragma unroll
+        for (int t = 1; t < kPrefetch; t++) r += (i >= t * rowf4) ? 1 : 0;
+        int e = i - r * rowf4;
+        int px = e / g.C4;
+        pf_pack[k] = (r << 20) | ((px + 1) * g.PS + 4 * (e - px * g.C4));
+    }
     __syncthreads();
     {
         const int nrows = min(g.NR, (oy1 - oy0 - 1) * S + KS);
-        for (int i = tid; i < nrows * rowf4; i += 256) {
-            int r = i / rowf4, e = i - r * rowf4;
-            int px = e / g.C4, c4 = e - px * g.C4;
+        for (int r = 0; r < nrows; r++) {
             int iy = iy_base + r;
-            if (iy >= 0 && iy < a.H)
-                *reinterpret_cast<float4*>(tile + r * g.RS + (px + 1) * g.PS + 4 * c4) = ld4(in + ((long)iy * a.W + px) * a.C + 4 * c4);
+            if (iy < 0 || iy >= a.H) continue;
+            const float* src = in + (long)iy * a.W * a.C;
+            for (int e = tid; e < rowf4; e += 256) {
+                int px = e / g.C4;
+                *reinterpret_cast<float4*>(tile + r * g.RS + (px + 1) * g.PS + 4 * (e - px * g.C4)) = ld4(src + 4 * e);
+            }
         }
     }
     __syncthreads();
 
+    // ---- step-invariant lane geometry: pixel slot -> (row within step, column)
+    int rp[PG], ox[PG];
+#pragma unroll
+    for (int p = 0; p < PG; p++) {
+        int q = (wave * PG + p) * 32 + pl;
+        rp[p] = q / a.Wo;
+        ox[p] = q - rp[p] * a.Wo;
+    }
+    const float hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY;
+    const int rk = a.ep.res_mode == RES_NONE ? 0 : (!g.res_lds ? 3 : (a.ep.res_mode == RES_DIRECT ? 1 : 2));
+
     const int nsteps = (oy1 - oy0 + g.R - 1) / g.R;
+    int ring0 = 0;  // ring slot of the first input row of the current step
+#ifdef MI_BLOCK_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#define MI_STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_STAMP(k)
+#endif
     for (int step = 0; step < nsteps; step++) {
         const int oys = oy0 + step * g.R;                  // first output row of this step
-        // ---- issue the loads of the rows the NEXT step adds to the ring (kept in registers across the compute phase)
+        auto wrap = [&](int x) { return x >= g.NR ? x - g.NR : x; };  // x < 2*NR
+        // ---- issue the loads of the rows the NEXT step adds to the ring (kept in registers across the compute phase).
+        // They are consecutive rows of the frame = one contiguous block; rows below the image stay zero.
         float4 pf[kPrefetch];
-        const int new_lo = (oys - oy0 + g.R - 1) * S + KS; // ring-relative index of the first new row
+        const int new_lo = (oys - oy0 + g.R - 1) * S + KS; // band-relative index of the first new row
         const bool more = step + 1 < nsteps;
         const int new_n = more ? min(g.R, oy1 - (oys + g.R)) * S : 0;  // rows the next step really needs
         if (more) {
+            const int iy_first = iy_base + new_lo;          // >= 0 always (new rows lie below rows already loaded)
+            const int in_image = min(new_n, a.H - iy_first) * rowf4;
+            const float* src = in + (long)iy_first * a.W * a.C;
 #pragma unroll
             for (int k = 0; k < kPrefetch; k++) {
                 int i = tid + k * 256;
                 pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < new_n * rowf4) {
-                    int r = i / rowf4, e = i - r * rowf4;
-                    int px = e / g.C4, c4 = e - px * g.C4;
-                    int iy = iy_base + new_lo + r;
-                    if (iy >= 0 && iy < a.H) pf[k] = ld4(in + ((long)iy * a.W + px) * a.C + 4 * c4);
-                }
+                if (i < in_image) pf[k] = ld4(src + 4 * i);
             }
         }
 
+        MI_STAMP(0)
         // ---- compute: this wave's PG groups of 32 output pixels
-        int q[PG], oy[PG], ox[PG];
         bool valid[PG];
         int base[PG][KS];  // LDS float offset of tap row ky, kx = 0, channel h*Ch
 #pragma unroll
         for (int p = 0; p < PG; p++) {
-            q[p] = (wave * PG + p) * 32 + pl;
-            int r = q[p] / a.Wo;
-            oy[p] = oys + r;
-            ox[p] = q[p] - r * a.Wo;
-            valid[p] = r < g.R && oy[p] < oy1;
-            int oyc = valid[p] ? oy[p] : oys, oxc = valid[p] ? ox[p] : 0;
+            valid[p] = rp[p] < g.R && oys + rp[p] < oy1;
+            int rr = valid[p] ? rp[p] : 0, oxc = valid[p] ? ox[p] : 0;
 #pragma unroll
-            for (int ky = 0; ky < KS; ky++) {
-                int rel = (oyc - oy0) * S + ky;
-                base[p][ky] = (rel % g.NR) * g.RS + (oxc * S - a.pl + 1) * g.PS + h * g.Ch;
-            }
+            for (int ky = 0; ky < KS; ky++) base[p][ky] = wrap(ring0 + rr * S + ky) * g.RS + (oxc * S - a.pl + 1) * g.PS + h * g.Ch;
         }
         for (int mt0 = 0; mt0 < g.MT; mt0 += MTG) {
             f32x16 D[PG][MTG];
@@ -167,24 +216,57 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) D[p][m][e] = 0.f;
             for (int j = 0; j < (g.Ch >> 2); j++) {
+                // A fragments of tiles mt0.., k-steps 4j..4j+3: packed [mt][j][lane][4]
+                float4 av[MTG];
+#pragma unroll
+                for (int m = 0; m < MTG; m++) {
+                    int mt = min(mt0 + m, g.MT - 1);
+                    long ao = (((long)mt * (g.Ch >> 2) + j) * 64 + lane) * 4;
+                    av[m] = (SLOW && !g.a_lds) ? ld4(a.w_pw + ao) : ld4(aL + ao);
+                }
                 float4 bf[PG];
                 if (KS == 3) {
+                    // depthwise 3x3 for 4 channels of this lane's k-half; loads are issued one filter row ahead of the
+                    // FMAs that consume them (explicit double buffer: the LDS latency hides under the previous row's math)
+                    const float* wj = wdw + h * g.Ch + 4 * j;
+                    float4 wq[3], dq[PG][3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        wq[kx] = ld4(wj + kx * g.Cp);
+#pragma unroll
+                        for (int p = 0; p < PG; p++) dq[p][kx] = ld4(tile + base[p][0] + kx * g.PS + 4 * j);
+                    }
 #pragma unroll
                     for (int p = 0; p < PG; p++) bf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int ky = 0; ky < 3; ky++)
+                    for (int ky = 0; ky < 3; ky++) {
+                        float4 wn[3], dn[PG][3];
+                        if (ky < 2) {
 #pragma unroll
-                        for (int kx = 0; kx < 3; kx++) {
-                            float4 w = ld4(wdw + (ky * 3 + kx) * g.Cp + h * g.Ch + 4 * j);
+                            for (int kx = 0; kx < 3; kx++) {
+                                wn[kx] = ld4(wj + ((ky + 1) * 3 + kx) * g.Cp);
 #pragma unroll
-                            for (int p = 0; p < PG; p++) {
-                                float4 d = ld4(tile + base[p][ky] + kx * g.PS + 4 * j);
-                                bf[p].x = fmaf(d.x, w.x, bf[p].x);
-                                bf[p].y = fmaf(d.y, w.y, bf[p].y);
-                                bf[p].z = fmaf(d.z, w.z, bf[p].z);
-                                bf[p].w = fmaf(d.w, w.w, bf[p].w);
+                                for (int p = 0; p < PG; p++) dn[p][kx] = ld4(tile + base[p][ky + 1 < KS ? ky + 1 : 0] + kx * g.PS + 4 * j);
                             }
                         }
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+                            for (int p = 0; p < PG; p++) {
+                                bf[p].x = fmaf(dq[p][kx].x, wq[kx].x, bf[p].x);
+                                bf[p].y = fmaf(dq[p][kx].y, wq[kx].y, bf[p].y);
+                                bf[p].z = fmaf(dq[p][kx].z, wq[kx].z, bf[p].z);
+                                bf[p].w = fmaf(dq[p][kx].w, wq[kx].w, bf[p].w);
+                            }
+                        if (ky < 2) {
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) {
+                                wq[kx] = wn[kx];
+#pragma unroll
+                                for (int p = 0; p < PG; p++) dq[p][kx] = dn[p][kx];
+                            }
+                        }
+                    }
                     float4 bb = ld4(bdw + h * g.Ch + 4 * j);
 #pragma unroll
                     for (int p = 0; p < PG; p++) { bf[p].x += bb.x; bf[p].y += bb.y; bf[p].z += bb.z; bf[p].w += bb.w; }
@@ -194,87 +276,88 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
                 }
 #pragma unroll
                 for (int m = 0; m < MTG; m++) {
-                    if (mt0 + m < g.MT) {
-                        // A fragment of tile (mt0+m), k-steps 4j..4j+3: packed [mt][j][lane][4]
-                        long ao = (((long)(mt0 + m) * (g.Ch >> 2) + j) * 64 + lane) * 4;
-                        float4 av = g.a_lds ? ld4(aL + ao) : ld4(a.w_pw + ao);
 #pragma unroll
-                        for (int p = 0; p < PG; p++) {
-                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf[p].x, D[p][m], 0, 0, 0);
-                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf[p].y, D[p][m], 0, 0, 0);
-                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf[p].z, D[p][m], 0, 0, 0);
-                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf[p].w, D[p][m], 0, 0, 0);
-                        }
+                    for (int p = 0; p < PG; p++) {
+                        D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bf[p].x, D[p][m], 0, 0, 0);
+                        D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bf[p].y, D[p][m], 0, 0, 0);
+                        D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bf[p].z, D[p][m], 0, 0, 0);
+                        D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf[p].w, D[p][m], 0, 0, 0);
                     }
                 }
             }
+            MI_STAMP(1)
             // ---- epilogue: lane holds pixel pl, output channels (mt*32 + 8*gq + 4*h .. +3) in D[..][4*gq .. 4*gq+3]
+            float* op[PG];
+            const float *rd[PG], *r0[PG], *r1[PG];
 #pragma unroll
             for (int p = 0; p < PG; p++) {
-                if (!valid[p]) continue;
-                float* op = a.out + (long)b * a.out_fs + ((long)oy[p] * a.Wo + ox[p]) * a.Co;
+                op[p] = a.out + (long)b * a.out_fs + ((long)(oys + rp[p]) * a.Wo + ox[p]) * a.Co;
+                rd[p] = tile + wrap(ring0 + rp[p] + a.pt) * g.RS + (ox[p] + 1) * g.PS;                       // RES_DIRECT source pixel
+                r0[p] = tile + wrap(ring0 + (S == 2 ? 2 * rp[p] : 0)) * g.RS + (2 * ox[p] + 1) * g.PS;       // RES_MAXPOOL rows
+                r1[p] = tile + wrap(ring0 + (S == 2 ? 2 * rp[p] + 1 : 0)) * g.RS + (2 * ox[p] + 1) * g.PS;
+            }
 #pragma unroll
-                for (int m = 0; m < MTG; m++) {
+            for (int m = 0; m < MTG; m++) {
 #pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        int ch = (mt0 + m) * 32 + 8 * gq + 4 * h;
-                        if (mt0 + m >= g.MT || ch >= a.Co) continue;
-                        float4 v = make_float4(D[p][m][4 * gq], D[p][m][4 * gq + 1], D[p][m][4 * gq + 2], D[p][m][4 * gq + 3]);
-                        if (a.ep.bias) { float4 bb = ld4(a.ep.bias + ch); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
-                        if (a.ep.res_mode != RES_NONE && ch < a.ep.res_C) {
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = (mt0 + m) * 32 + 8 * gq + 4 * h;
+                    if (mt0 + m >= g.MT || ch >= a.Co) continue;
+                    const float4 bb = ld4(biasL + ch), al = ld4(alphaL + ch);
+                    const bool has_res = rk != 0 && ch < a.ep.res_C;
+#pragma unroll
+                    for (int p = 0; p < PG; p++) {
+                        if (!valid[p]) continue;
+                        float4 v = make_float4(D[p][m][4 * gq] + bb.x, D[p][m][4 * gq + 1] + bb.y, D[p][m][4 * gq + 2] + bb.z, D[p][m][4 * gq + 3] + bb.w);
+                        if (has_res) {
                             float4 rv;
-                            if (g.res_lds) {
-                                if (a.ep.res_mode == RES_DIRECT) {
-                                    int rel = (oy[p] - oy0) + a.pt;
-                                    rv = ld4(tile + (rel % g.NR) * g.RS + (ox[p] + 1) * g.PS + ch);
-                                } else {  // RES_MAXPOOL of the stride-2 block input (pt = pl = 0)
-                                    int rel = (oy[p] - oy0) * 2;
-                                    const float* r0 = tile + (rel % g.NR) * g.RS + (2 * ox[p] + 1) * g.PS + ch;
-                                    const float* r1 = tile + ((rel + 1) % g.NR) * g.RS + (2 * ox[p] + 1) * g.PS + ch;
-                                    float4 x0 = ld4(r0), x1 = ld4(r0 + g.PS), x2 = ld4(r1), x3 = ld4(r1 + g.PS);
-                                    rv = make_float4(fmaxf(fmaxf(x0.x, x1.x), fmaxf(x2.x, x3.x)), fmaxf(fmaxf(x0.y, x1.y), fmaxf(x2.y, x3.y)),
-                                                     fmaxf(fmaxf(x0.z, x1.z), fmaxf(x2.z, x3.z)), fmaxf(fmaxf(x0.w, x1.w), fmaxf(x2.w, x3.w)));
-                                }
-                            } else {
-                                rv = res_from_global(a.ep, b, oy[p], ox[p], a.Wo, ch);
-                            }
+                            if (rk == 1) rv = ld4(rd[p] + ch);
+                            else if (rk == 2) rv = max4(ld4(r0[p] + ch), ld4(r0[p] + g.PS + ch), ld4(r1[p] + ch), ld4(r1[p] + g.PS + ch));
+                            else if (SLOW) rv = res_from_global(a.ep, b, oys + rp[p], ox[p], a.Wo, ch);
+                            else rv = make_float4(0.f, 0.f, 0.f, 0.f);
                             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                         }
-                        if (a.ep.act == ACT_RELU) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        } else if (a.ep.act == ACT_PRELU) {
-                            float4 al = ld4(a.ep.alpha + ch);
-                            v.x = v.x >= 0.f ? v.x : al.x * v.x; v.y = v.y >= 0.f ? v.y : al.y * v.y;
-                            v.z = v.z >= 0.f ? v.z : al.z * v.z; v.w = v.w >= 0.f ? v.w : al.w * v.w;
-                        } else if (a.ep.act == ACT_RELU6) {
-                            v.x = fminf(fmaxf(v.x, 0.f), 6.f); v.y = fminf(fmaxf(v.y, 0.f), 6.f);
-                            v.z = fminf(fmaxf(v.z, 0.f), 6.f); v.w = fminf(fmaxf(v.w, 0.f), 6.f);
-                        }
-                        *reinterpret_cast<float4*>(op + ch) = v;
+                        // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
+                        v.x = fminf(fmaxf(v.x, 0.f) + al.x * fminf(v.x, 0.f), hi);
+                        v.y = fminf(fmaxf(v.y, 0.f) + al.y * fminf(v.y, 0.f), hi);
+                        v.z = fminf(fmaxf(v.z, 0.f) + al.z * fminf(v.z, 0.f), hi);
+                        v.w = fminf(fmaxf(v.w, 0.f) + al.w * fminf(v.w, 0.f), hi);
+                        *reinterpret_cast<float4*>(op[p] + ch) = v;
                     }
                 }
             }
         }
 
         // ---- retire this step's dead rows: write the prefetched rows into their ring slots
+        MI_STAMP(2)
         __syncthreads();
+        MI_STAMP(3)
         if (more) {
+            const int slot_lo = wrap(ring0 + (g.R - 1) * S + KS);  // first dead slot
 #pragma unroll
             for (int k = 0; k < kPrefetch; k++) {
-                int i = tid + k * 256;
-                if (i < new_n * rowf4) {
-                    int r = i / rowf4, e = i - r * rowf4;
-                    int px = e / g.C4, c4 = e - px * g.C4;
-                    *reinterpret_cast<float4*>(tile + ((new_lo + r) % g.NR) * g.RS + (px + 1) * g.PS + 4 * c4) = pf[k];
+                const int r = pf_pack[k] >> 20;
+                if (r < new_n) {
+                    int sl = slot_lo + r;
+                    sl = sl >= g.NR ? sl - g.NR : sl;
+                    *reinterpret_cast<float4*>(tile + sl * g.RS + (pf_pack[k] & 0xFFFFF)) = pf[k];
                 }
             }
         }
+        ring0 = wrap(ring0 + g.R * S);
+        MI_STAMP(4)
         __syncthreads();
+        MI_STAMP(5)
     }
+#ifdef MI_BLOCK_STAMPS
+    if (g.stamps && lane == 0)
+        for (int k = 0; k < 6; k++) g.stamps[((long)blockIdx.x * 4 + wave) * 8 + k] = st_acc[k];
+#endif
 }
 
-bool make_geom(const BlockArgs& a, int PG, BlockGeom* out) {
+bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     BlockGeom g{};
+    g.stamps = nullptr;
+    g.PG = PG;
     const int S = a.sh, KS = a.has_dw ? 3 : 1;
     if (a.C % 4 || a.Co % 4 || a.sh != a.sw || (S != 1 && S != 2)) return false;
     if (!a.has_dw && S != 1) return false;
@@ -286,23 +369,29 @@ bool make_geom(const BlockArgs& a, int PG, BlockGeom* out) {
     g.MT = (a.Co + 31) / 32;
     const long a_bytes = (long)g.MT * 32 * g.Cp * 4;
     g.a_lds = a_bytes <= kALdsMax;
-    const int fixed = (a.has_dw ? 10 * g.Cp * 4 : 0) + (g.a_lds ? (int)a_bytes : 0);
+    const int fixed = (a.has_dw ? 10 * g.Cp * 4 : 0) + (g.a_lds ? (int)a_bytes : 0) + g.MT * 32 * 8 + 64;
     auto lds_for = [&](int R) { return ((R - 1) * S + KS) * g.RS * 4 + fixed; };
+    auto pf_ok = [&](int R) { return (long)R * S * a.W * g.C4 <= (long)kPrefetch * 256; };
     int R = std::max(1, std::min(a.Ho, (128 * PG) / a.Wo));
-    while (R > 1 && (lds_for(R) > kLdsBudget || (long)R * S * a.W * g.C4 > (long)kPrefetch * 256)) R--;
-    if (lds_for(R) > 150 * 1024 || (long)R * S * a.W * g.C4 > (long)kPrefetch * 256) return false;
+    while (R > 1 && (lds_for(R) > lds_budget() || !pf_ok(R))) R--;
+    if (lds_for(R) > 150 * 1024 || !pf_ok(R)) return false;
+    if (g.RS >= (1 << 20)) return false;
     g.R = R;
     g.NR = (R - 1) * S + KS;
-    const int max_bands = (a.Ho + R - 1) / R;
-    int bands = std::min(max_bands, std::max(1, (1536 + a.B - 1) / std::max(1, a.B)));
-    g.band = ((a.Ho + bands - 1) / bands + R - 1) / R * R;
-    g.bands = (a.Ho + g.band - 1) / g.band;
     int off = g.NR * g.RS;
     g.off_wdw = off; off += a.has_dw ? 9 * g.Cp : 0;
     g.off_bdw = off; off += a.has_dw ? g.Cp : 0;
     off = (off + 3) & ~3;
     g.off_a = off; off += g.a_lds ? g.MT * 32 * g.Cp : 0;
+    g.off_bias = off; off += g.MT * 32;
+    g.off_alpha = off; off += g.MT * 32;
     g.lds_bytes = off * 4;
+    // bands: about one resident wave of workgroups over the chip (prologue + halo paid once per band)
+    const int per_cu = std::max(1, std::min(2, (160 * 1024) / g.lds_bytes));
+    const int max_bands = (a.Ho + R - 1) / R;
+    int bands = std::min(max_bands, std::max(1, (kCUs * per_cu + a.B / 2) / std::max(1, a.B)));
+    g.band = ((a.Ho + bands - 1) / bands + R - 1) / R * R;
+    g.bands = (a.Ho + g.band - 1) / g.band;
     // skip connection straight from the ring when it is the block's own input tensor
     g.res_lds = 0;
     if (a.ep.res == a.in && a.ep.res_fs == a.in_fs && a.ep.res_C == a.C) {
@@ -317,10 +406,22 @@ bool make_geom(const BlockArgs& a, int PG, BlockGeom* out) {
     return true;
 }
 
-template <int MTG, int S, int KS, int PG>
-int launch_inst(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
-    auto kern = block_kernel<MTG, S, KS, PG>;
-    static bool configured = false;  // one attribute call per instantiation (process-wide; same for every device here)
+// Two 32-pixel groups per wave halve the depthwise-weight reads per pixel, but only pay when a step has >= 192 pixels.
+bool make_geom(const BlockArgs& a, BlockGeom* out) {
+    static const int forced = getenv("MI_BLOCK_PG") ? atoi(getenv("MI_BLOCK_PG")) : 0;  // tuning aid
+    const int MT = (a.Co + 31) / 32;
+    BlockGeom g2;
+    if (forced != 1 && MT <= 2 && make_geom_pg(a, 2, &g2) && g2.R * a.Wo >= 192) {
+        *out = g2;
+        return true;
+    }
+    return make_geom_pg(a, 1, out);
+}
+
+template <int MTG, int S, int KS, int PG, bool SLOW>
+int launch_inst2(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
+    auto kern = block_kernel<MTG, S, KS, PG, SLOW>;
+    static bool configured = false;  // one attribute call per instantiation (one GPU per process here)
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
@@ -330,14 +431,15 @@ int launch_inst(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-int pick_pg(const BlockArgs& a) {
-    int MT = (a.Co + 31) / 32;
-    return MT <= 2 ? 2 : 1;
+template <int MTG, int S, int KS, int PG>
+int launch_inst(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
+    const bool slow = !g.a_lds || (a.ep.res_mode != RES_NONE && !g.res_lds);
+    return slow ? launch_inst2<MTG, S, KS, PG, true>(a, g, s) : launch_inst2<MTG, S, KS, PG, false>(a, g, s);
 }
 
 }  // namespace
 
-// Pointwise weights are packed on the host straight into MFMA A-fragment order (see pack_block_weights).
+// Pointwise weights are packed on the host straight into MFMA A-fragment order (engine.cpp).
 void block_weight_dims(int C, int Co, int* Cp, int* Cop) {
     *Cp = (C + 7) & ~7;
     *Cop = (Co + 31) / 32 * 32;
@@ -345,21 +447,35 @@ void block_weight_dims(int C, int Co, int* Cp, int* Cop) {
 
 bool block_kernel_supports(const BlockArgs& a) {
     BlockGeom g;
-    return make_geom(a, pick_pg(a), &g);
+    return make_geom(a, &g);
 }
+
+const char* block_kernel_label(const BlockArgs& a, char* buf, size_t cap) {
+    BlockGeom g;
+    if (!make_geom(a, &g)) return "block_kernel<?>";
+    const bool slow = !g.a_lds || (a.ep.res_mode != RES_NONE && !g.res_lds);
+    snprintf(buf, cap, "block_kernel<%d,%d,%d,%d,%d>", std::min(4, g.MT), a.has_dw ? a.sh : 1, a.has_dw ? 3 : 1, g.PG, slow ? 1 : 0);
+    return buf;
+}
+
+#ifdef MI_BLOCK_STAMPS
+unsigned long long* g_stamp_ptr = nullptr;
+#endif
 
 int launch_block(const BlockArgs& a, void* stream) {
     BlockGeom g;
-    const int PG = pick_pg(a);
-    if (!make_geom(a, PG, &g)) return (int)hipErrorInvalidValue;
+    if (!make_geom(a, &g)) return (int)hipErrorInvalidValue;
+#ifdef MI_BLOCK_STAMPS
+    g.stamps = g_stamp_ptr;
+#endif
     hipStream_t s = (hipStream_t)stream;
     const int MTG = std::min(4, g.MT);
-    const int S = a.sh;
-#define MI_BLOCK_CASE(M, SS, K, P) \
-    if (MTG == M && S == SS && (a.has_dw ? 3 : 1) == K && PG == P) return launch_inst<M, SS, K, P>(a, g, s);
-    MI_BLOCK_CASE(1, 1, 3, 2) MI_BLOCK_CASE(2, 1, 3, 2) MI_BLOCK_CASE(3, 1, 3, 1) MI_BLOCK_CASE(4, 1, 3, 1)
-    MI_BLOCK_CASE(1, 2, 3, 2) MI_BLOCK_CASE(2, 2, 3, 2) MI_BLOCK_CASE(3, 2, 3, 1) MI_BLOCK_CASE(4, 2, 3, 1)
-    MI_BLOCK_CASE(1, 1, 1, 2) MI_BLOCK_CASE(2, 1, 1, 2) MI_BLOCK_CASE(3, 1, 1, 1) MI_BLOCK_CASE(4, 1, 1, 1)
+    const int S = a.sh, K = a.has_dw ? 3 : 1, PG = g.PG;
+#define MI_BLOCK_CASE(M, SS, KK, P) \
+    if (MTG == M && S == SS && K == KK && PG == P) return launch_inst<M, SS, KK, P>(a, g, s);
+    MI_BLOCK_CASE(1, 1, 3, 2) MI_BLOCK_CASE(2, 1, 3, 2) MI_BLOCK_CASE(1, 1, 3, 1) MI_BLOCK_CASE(2, 1, 3, 1) MI_BLOCK_CASE(3, 1, 3, 1) MI_BLOCK_CASE(4, 1, 3, 1)
+    MI_BLOCK_CASE(1, 2, 3, 2) MI_BLOCK_CASE(2, 2, 3, 2) MI_BLOCK_CASE(1, 2, 3, 1) MI_BLOCK_CASE(2, 2, 3, 1) MI_BLOCK_CASE(3, 2, 3, 1) MI_BLOCK_CASE(4, 2, 3, 1)
+    MI_BLOCK_CASE(1, 1, 1, 2) MI_BLOCK_CASE(2, 1, 1, 2) MI_BLOCK_CASE(1, 1, 1, 1) MI_BLOCK_CASE(2, 1, 1, 1) MI_BLOCK_CASE(3, 1, 1, 1) MI_BLOCK_CASE(4, 1, 1, 1)
 #undef MI_BLOCK_CASE
     return (int)hipErrorInvalidValue;
 }

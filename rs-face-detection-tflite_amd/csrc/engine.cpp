@@ -223,7 +223,9 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
     std::vector<hipEvent_t> marks;
     for (int r = 0; r < reps; r++) {
         marks.clear();
-        for (int start = 0; start < batch; start += chunk_cap_) enqueue_chunk(in, start, std::min(chunk_cap_, batch - start), s, &marks);
+        std::vector<std::string> labels;
+        for (int start = 0; start < batch; start += chunk_cap_) enqueue_chunk(in, start, std::min(chunk_cap_, batch - start), s, &marks, &labels);
+        for (size_t i = 0; i < nl && i < labels.size(); i++) stats[i].kernel = labels[i];
         hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
         if (marks.size() != static_cast<size_t>(nchunks) * (nl + 1)) throw std::runtime_error("internal: profile marks mismatch");
         for (int c = 0; c < nchunks; c++)
@@ -238,7 +240,8 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
     return stats;
 }
 
-void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s, std::vector<hipEvent_t>* marks) {
+void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s, std::vector<hipEvent_t>* marks,
+                          std::vector<std::string>* labels) {
     const Graph& g = plan_.graph;
     auto mark = [&] {
         if (!marks) return;
@@ -268,6 +271,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         }
         int rc = 0;
         long in_fs = 0, out_fs = 0;
+        if (labels) labels->push_back(node_label(n));
         const float* ip = tensor_ptr(n.in[0], in, chunk_start, &in_fs);
         float* op = tensor_ptr_mut(n.out, chunk_start, &out_fs);
         switch (n.kind) {
@@ -304,6 +308,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.sh = n.sh; a.sw = n.sw;
                 if (a.has_dw && n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
+                if (labels) { char buf[96]; labels->back() = block_kernel_label(a, buf, sizeof buf); }
                 rc = launch_block(a, s);
                 break;
             }

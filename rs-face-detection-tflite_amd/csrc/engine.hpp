@@ -57,7 +57,8 @@ class Model {
    private:
     void rebuild();                       // (re)lower + upload weights for the current options
     void ensure_capacity(int batch);
-    void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s, std::vector<hipEvent_t>* marks = nullptr);
+    void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s, std::vector<hipEvent_t>* marks = nullptr,
+                       std::vector<std::string>* labels = nullptr);
     std::string node_label(const Node& n) const;
     void enqueue_all(const float* in, int batch, hipStream_t s);
     const float* tensor_ptr(int t, const float* in, int chunk_start, long* frame_stride) const;

@@ -109,6 +109,7 @@ int launch_conv(const ConvArgs& a, void* stream);
 int launch_dw(const DwArgs& a, void* stream);
 int launch_block(const BlockArgs& a, void* stream);
 bool block_kernel_supports(const BlockArgs& a);
+const char* block_kernel_label(const BlockArgs& a, char* buf, size_t cap);  // instantiation name as rocprofv3 prints it
 int launch_add(const EltArgs& a, void* stream);
 int launch_act(const EltArgs& a, void* stream);
 int launch_maxpool(const EltArgs& a, void* stream);
