@@ -96,7 +96,92 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ stem convolution
+// First layer of every graph: K x K, stride 2, 3 input channels (RGB) -> CO channels, + bias + ReLU/PReLU.
+// (back/front 5x5 -> 24, full 3x3 -> 32, landmark 3x3 -> 16, iris 3x3 -> 64; SURVEY.md Appendix A.)
+// One thread = one output pixel x all CO channels: the K*K*3 filter taps are wave-uniform, so the weights travel
+// through the scalar cache into SGPR operands of v_fmac and every VALU lane does useful work; the input patch comes
+// from an LDS tile (zero padded, TF SAME), staged with coalesced row-segment loads.  Output 16 B stores.
+template <int K, int CO>
+__global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
+    constexpr int TW = 32, TH = 8;                       // output tile
+    constexpr int IW = 2 * TW + K - 2, IH = 2 * TH + K - 2;  // input tile (stride 2)
+    constexpr int RS = (IW * 3 + 1) & ~1;                // row stride in floats (even: 8-byte aligned float2 reads)
+    __shared__ __attribute__((aligned(16))) float tile[IH * RS];
+    const int tid = threadIdx.x;
+    const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx0 = (t % tiles_x) * TW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * TH;
+    const int b = t / tiles_y;
+    const float* in = a.in + (long)b * a.in_fs;
+    const int ix0 = tx0 * 2 - a.pl, iy0 = ty0 * 2 - a.pt;
+    for (int i = tid; i < IH * IW * 3; i += 256) {
+        int r = i / (IW * 3), e = i - r * (IW * 3);
+        int iy = iy0 + r, ix = ix0 + e / 3;
+        float v = 0.f;
+        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = in[((long)iy * a.W) * 3 + (long)ix0 * 3 + e];
+        tile[r * RS + e] = v;
+    }
+    __syncthreads();
+    const int lx = tid & (TW - 1), ly = tid / TW;
+    const int ox = tx0 + lx, oy = ty0 + ly;
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; o++) acc[o] = 0.f;
+    const float* __restrict__ w = a.w;  // [K][K][3][Cop], uniform -> scalar loads
+    const int Cop = (CO + 3) & ~3;
+    // Not unrolled beyond 3 taps: the weights of a tap are 24..64 SGPRs; letting the compiler hoist all K*K*3 taps'
+    // scalar loads would spill SGPRs into VGPR lanes.  Occupancy (<= 64 VGPRs) hides the scalar-load latency instead.
+#pragma unroll 1
+    for (int ky = 0; ky < K; ky++) {
+        const float* row = tile + (2 * ly + ky) * RS + 2 * lx * 3;
+        const float* wk = w + (long)(ky * K * 3) * Cop;
+#pragma unroll 3
+        for (int e = 0; e < K * 3; e++) {
+            const float xv = row[e];
+            const float* we = wk + (long)e * Cop;
+#pragma unroll
+            for (int o = 0; o < CO; o++) acc[o] = fmaf(xv, we[o], acc[o]);
+        }
+    }
+    if (ox < a.Wo && oy < a.Ho) {
+        float* op = a.out + (long)b * a.out_fs + ((long)oy * a.Wo + ox) * CO;
+#pragma unroll
+        for (int o = 0; o < CO; o += 4) {
+            float4 v;
+            v.x = apply_act(acc[o] + a.ep.bias[o], a.ep.act, a.ep.alpha, o);
+            v.y = apply_act(acc[o + 1] + a.ep.bias[o + 1], a.ep.act, a.ep.alpha, o + 1);
+            v.z = apply_act(acc[o + 2] + a.ep.bias[o + 2], a.ep.act, a.ep.alpha, o + 2);
+            v.w = apply_act(acc[o + 3] + a.ep.bias[o + 3], a.ep.act, a.ep.alpha, o + 3);
+            *reinterpret_cast<float4*>(op + o) = v;
+        }
+    }
+}
+
+template <int K, int CO>
+static int launch_stem(const ConvArgs& a, hipStream_t s) {
+    unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + 7) / 8));
+    hipLaunchKernelGGL((stem_conv_kernel<K, CO>), dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// true when (and how) the specialised stem kernel takes this convolution
+static bool stem_applicable(const ConvArgs& a) {
+    if (a.C != 3 || a.sh != 2 || a.sw != 2 || a.KH != a.KW || !a.ep.bias || a.ep.res_mode != RES_NONE) return false;
+    if ((reinterpret_cast<uintptr_t>(a.out) & 15) || (a.out_fs & 3)) return false;
+    return (a.KH == 5 && a.Co == 24) || (a.KH == 3 && (a.Co == 16 || a.Co == 32 || a.Co == 64));
+}
+
 int launch_conv(const ConvArgs& a, void* stream) {
+    if (stem_applicable(a)) {
+        hipStream_t st = (hipStream_t)stream;
+        if (a.KH == 5) return launch_stem<5, 24>(a, st);
+        if (a.Co == 16) return launch_stem<3, 16>(a, st);
+        if (a.Co == 32) return launch_stem<3, 32>(a, st);
+        return launch_stem<3, 64>(a, st);
+    }
     long total = (long)a.B * a.Ho * a.Wo * (a.Cop >> 2);
     if (total <= 0) return 0;
     unsigned blocks = (unsigned)((total + 255) / 256);
