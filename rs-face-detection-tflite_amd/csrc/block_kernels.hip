@@ -372,8 +372,14 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     const int fixed = (a.has_dw ? 10 * g.Cp * 4 : 0) + (g.a_lds ? (int)a_bytes : 0) + g.MT * 32 * 8 + 64;
     auto lds_for = [&](int R) { return ((R - 1) * S + KS) * g.RS * 4 + fixed; };
     auto pf_ok = [&](int R) { return (long)R * S * a.W * g.C4 <= (long)kPrefetch * 256; };
-    int R = std::max(1, std::min(a.Ho, (128 * PG) / a.Wo));
+    const int Rfull = std::max(1, std::min(a.Ho, (128 * PG) / a.Wo));  // rows that fill every lane of the 4 waves
+    int R = Rfull;
     while (R > 1 && (lds_for(R) > lds_budget() || !pf_ok(R))) R--;
+    if (R * a.Wo * 4 < 128 * PG * 3) {  // step under 75% full: small, channel-heavy layer -> spend the whole LDS of a CU on one workgroup
+        int R2 = Rfull;
+        while (R2 > 1 && (lds_for(R2) > 150 * 1024 || !pf_ok(R2))) R2--;
+        if (R2 > R) R = R2;
+    }
     if (lds_for(R) > 150 * 1024 || !pf_ok(R)) return false;
     if (g.RS >= (1 << 20)) return false;
     g.R = R;

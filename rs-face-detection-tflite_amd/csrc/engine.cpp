@@ -283,6 +283,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.KH = n.KH; a.KW = n.KW; a.sh = n.sh; a.sw = n.sw;
                 if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
+                if (labels) labels->back() = conv_kernel_label(a);
                 rc = launch_conv(a, s);
                 break;
             }

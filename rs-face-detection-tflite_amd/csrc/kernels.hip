@@ -174,6 +174,8 @@ static bool stem_applicable(const ConvArgs& a) {
     return (a.KH == 5 && a.Co == 24) || (a.KH == 3 && (a.Co == 16 || a.Co == 32 || a.Co == 64));
 }
 
+const char* conv_kernel_label(const ConvArgs& a) { return stem_applicable(a) ? "stem_conv_kernel" : "conv_generic_kernel"; }
+
 int launch_conv(const ConvArgs& a, void* stream) {
     if (stem_applicable(a)) {
         hipStream_t st = (hipStream_t)stream;

@@ -106,6 +106,7 @@ struct ProjArgs {  // project_landmarks, one thread per landmark
 
 // ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).
 int launch_conv(const ConvArgs& a, void* stream);
+const char* conv_kernel_label(const ConvArgs& a);
 int launch_dw(const DwArgs& a, void* stream);
 int launch_block(const BlockArgs& a, void* stream);
 bool block_kernel_supports(const BlockArgs& a);
