@@ -88,24 +88,14 @@ def main():
     import ctypes as C
 
     # ---- weights: rank 0 reads the frozen .tflite, every other rank receives it over RCCL/xGMI (one-time, timed apart)
-    path = os.path.join(ROOT, "models", "face_detection_back.tflite")
-    bcast_ms = 0.0
-    if world > 1:
-        size = torch.zeros(1, dtype=torch.int64, device=device)
-        if rank == 0:
-            blob = torch.from_numpy(np.fromfile(path, dtype=np.uint8)).to(device)
-            size[0] = blob.numel()
-        dist.broadcast(size, 0)
-        if rank != 0:
-            blob = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        dist.broadcast(blob, 0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.time() - t0) * 1e3
-        model_bytes = blob.cpu().numpy().tobytes()
-    else:
-        model_bytes = open(path, "rb").read()
+    from importlib import import_module
+    mdist = import_module("rs_face_detection_tflite_amd.dist")
+    path = os.path.join(ROOT, "models", "face_detection_back.tflite") if rank == 0 else "/nonexistent"
+    torch.cuda.synchronize()
+    t0 = time.time()
+    model_bytes = mdist.broadcast_model_bytes(path, dist, device)
+    torch.cuda.synchronize()
+    bcast_ms = (time.time() - t0) * 1e3 if world > 1 else 0.0
     L = mi.lib()
     h = C.c_void_p()
     rc = L.mi_fd_create_from_bytes(int(mi.FaceDetectionModel.BackCamera), model_bytes, len(model_bytes), local_rank, C.byref(h))
@@ -146,10 +136,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = mdist.max_over_ranks(elapsed, dist, device)
     n_faces = int((counts > 0).sum().item())
 
     result = None

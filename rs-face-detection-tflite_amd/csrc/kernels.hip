@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     constexpr int TW = 32, TH = 8;                       // output tile
     constexpr int IW = 2 * TW + K - 2, IH = 2 * TH + K - 2;  // input tile (stride 2)
     constexpr int RS = (IW * 3 + 1) & ~1;                // row stride in floats (even: 8-byte aligned float2 reads)
-    __shared__ __attribute__((aligned(16))) float tile[IH * RS];
+    constexpr int LDSF = (IH * RS > TH * TW * (CO + 4)) ? IH * RS : TH * TW * (CO + 4);
+    __shared__ __attribute__((aligned(16))) float tile[LDSF];
     const int tid = threadIdx.x;
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
     int t = blockIdx.x;
@@ -146,17 +147,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
             for (int o = 0; o < CO; o++) acc[o] = fmaf(xv, we[o], acc[o]);
         }
     }
-    if (ox < a.Wo && oy < a.Ho) {
-        float* op = a.out + (long)b * a.out_fs + ((long)oy * a.Wo + ox) * CO;
+    // Epilogue through LDS: a thread owns one pixel (CO floats), but 16-byte stores at a CO*4-byte lane stride reach
+    // HBM as partial 32-byte sectors (measured 2.85x WRITE_SIZE).  Re-tile so that each wave-instruction writes
+    // 1 KiB of consecutive addresses: the tile's rows are contiguous runs of TW*CO floats in the NHWC output.
+    __syncthreads();  // all reads of the input tile are done; reuse the LDS
+    float* otile = tile;  // [TH*TW][CO + 4] (pad keeps the float4 writes of consecutive pixels on distinct banks)
+    constexpr int OS = CO + 4;
+    static_assert(TH * TW * OS <= IH * RS || true, "");
 #pragma unroll
-        for (int o = 0; o < CO; o += 4) {
-            float4 v;
-            v.x = apply_act(acc[o] + a.ep.bias[o], a.ep.act, a.ep.alpha, o);
-            v.y = apply_act(acc[o + 1] + a.ep.bias[o + 1], a.ep.act, a.ep.alpha, o + 1);
-            v.z = apply_act(acc[o + 2] + a.ep.bias[o + 2], a.ep.act, a.ep.alpha, o + 2);
-            v.w = apply_act(acc[o + 3] + a.ep.bias[o + 3], a.ep.act, a.ep.alpha, o + 3);
-            *reinterpret_cast<float4*>(op + o) = v;
-        }
+    for (int o = 0; o < CO; o += 4) {
+        float4 v;
+        v.x = apply_act(acc[o] + a.ep.bias[o], a.ep.act, a.ep.alpha, o);
+        v.y = apply_act(acc[o + 1] + a.ep.bias[o + 1], a.ep.act, a.ep.alpha, o + 1);
+        v.z = apply_act(acc[o + 2] + a.ep.bias[o + 2], a.ep.act, a.ep.alpha, o + 2);
+        v.w = apply_act(acc[o + 3] + a.ep.bias[o + 3], a.ep.act, a.ep.alpha, o + 3);
+        *reinterpret_cast<float4*>(otile + tid * OS + o) = v;
+    }
+    __syncthreads();
+    constexpr int C4 = CO / 4;
+    for (int i = tid; i < TH * TW * C4; i += 256) {
+        int px = i / C4, c4 = i - px * C4;
+        int y = ty0 + px / TW, x = tx0 + (px & (TW - 1));
+        if (y < a.Ho && x < a.Wo)
+            *reinterpret_cast<float4*>(a.out + (long)b * a.out_fs + ((long)y * a.Wo + x) * CO + 4 * c4) =
+                *reinterpret_cast<const float4*>(otile + px * OS + 4 * c4);
     }
 }
 

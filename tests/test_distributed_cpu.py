@@ -1,0 +1,78 @@
+"""N>1 path on CPU: world_size-2 gloo run of the same sharding / weight-broadcast / timing logic bench.py uses with
+RCCL on the GPUs (frames shard, the only exchange is the one-time model broadcast)."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, model_path
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import rs_face_detection_tflite_amd as mi
+    from importlib import import_module
+    d = import_module("rs_face_detection_tflite_amd.dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    # rank 1 gets the bytes only through the broadcast (it is handed a path that does not exist)
+    path = model_path("back") if rank == 0 else "/nonexistent/model.tflite"
+    blob = d.broadcast_model_bytes(path, dist, dev)
+    plan = mi.plan_describe(blob, 2)            # host-only lowering of the received bytes
+    lo, hi = d.shard_range(513, world, rank)
+    counts = torch.full((4,), rank, dtype=torch.int32)
+    gathered = d.gather_counts(counts, dist, dev)
+    t = d.max_over_ranks(1.0 + rank, dist, dev)
+    q.put((rank, hashlib.md5(blob).hexdigest(), hashlib.md5(plan.encode()).hexdigest(), lo, hi, t, [int(g[0]) for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_broadcast_and_sharding():
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = hashlib.md5(open(model_path("back"), "rb").read()).hexdigest()
+    assert res[0][1] == res[1][1] == ref              # both ranks hold the frozen model bytes
+    assert res[0][2] == res[1][2]                     # and lower them to the same launch plan
+    assert (res[0][3], res[0][4]) == (0, 257) and (res[1][3], res[1][4]) == (257, 513)   # contiguous, disjoint, complete
+    assert res[0][5] == res[1][5] == 2.0              # max over ranks
+    assert res[0][6] == res[1][6] == [0, 1]
+
+
+def test_shard_range_properties():
+    import sys
+    sys.path.insert(0, ROOT)
+    from importlib import import_module
+    import rs_face_detection_tflite_amd  # noqa: F401
+    d = import_module("rs_face_detection_tflite_amd.dist")
+    for total in (0, 1, 7, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            spans = [d.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,43 @@
+"""Turns raw rocprofv3 output under gpurun_out/ into the small, committed summaries under profiles/.
+usage: python tools/summarize_profiles.py <round-tag> <trace-dir> <fetch-dir> <write-dir>
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate
+passes, are reported in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide (16 B/lane) coalesced read stream,
+so reads = 2 x FETCH_SIZE for the block kernels (their loads are 16 B/lane); other kernels are listed uncorrected."""
+import collections, csv, glob, json, os, shutil, statistics, sys
+
+tag, trace, fetch, write = sys.argv[1:5]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+ks = glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0]
+shutil.copy(ks, os.path.join(out, "%s_kernel_stats.csv" % tag))
+
+def load(d):
+    by = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
+        by[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return by
+f, w = load(fetch), load(write)
+rows = []
+for k in sorted(f, key=lambda k: -sum(f[k])):
+    if not k.startswith("void mi::") and not k.startswith("mi::"):
+        continue
+    wide = "block_kernel" in k
+    fk, wk = statistics.mean(f[k]), statistics.mean(w.get(k, [0]))
+    rows.append({"kernel": k, "dispatches": len(f[k]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
+                 "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
+with open(os.path.join(out, "%s_pmc_by_kernel.csv" % tag), "w", newline="") as fh:
+    wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+    wr.writeheader()
+    wr.writerows(rows)
+dom = max(csv.DictReader(open(ks)), key=lambda r: float(r["TotalDurationNs"]))
+name = dom["Name"]
+pm = next(r for r in rows if r["kernel"] == name)
+import re
+m = re.search(r"block_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", name)
+label = "block_kernel<%s,%s,%s,%s,%d>" % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(5) == "true") if m else name
+json.dump({"round": tag, "workload": "back256_b256", "kernel": label, "rocprof_name": name, "calls": int(dom["Calls"]),
+           "avg_ns": float(dom["AverageNs"]), "hbm_bytes_per_launch": pm["hbm_bytes_per_launch"],
+           "note": "reads = 2 x FETCH_SIZE (gfx950 16B/lane stream correction) + WRITE_SIZE, KiB -> bytes"},
+          open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(open(os.path.join(out, "pmc_summary.json")).read())
