@@ -115,7 +115,8 @@ def run(g: tfl3.Graph, x: np.ndarray, keep_all=False, num_threads=None):
             c = op.code
             o = op.outputs[0]
             if c == tfl3.DEQUANTIZE:
-                vals[o] = torch.from_numpy(const(op.inputs[0]).astype(np.float32))
+                src = vals[op.inputs[0]].numpy() if op.inputs[0] in vals else const(op.inputs[0])
+                vals[o] = torch.from_numpy(np.ascontiguousarray(src).astype(np.float32))
             elif c == tfl3.DENSIFY:
                 vals[o] = torch.from_numpy(densify(g.tensors[op.inputs[0]]))
             elif c in (tfl3.CONV_2D, tfl3.DEPTHWISE_CONV_2D):

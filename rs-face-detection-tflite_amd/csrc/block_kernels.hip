@@ -368,7 +368,8 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     g.RS = (a.W + 2) * g.PS;
     g.MT = (a.Co + 31) / 32;
     const long a_bytes = (long)g.MT * 32 * g.Cp * 4;
-    g.a_lds = a_bytes <= kALdsMax;
+    static const int alds_max = getenv("MI_BLOCK_ALDS") ? atoi(getenv("MI_BLOCK_ALDS")) : kALdsMax;  // tuning aid
+    g.a_lds = a_bytes <= alds_max;
     const int fixed = (a.has_dw ? 10 * g.Cp * 4 : 0) + (g.a_lds ? (int)a_bytes : 0) + g.MT * 32 * 8 + 64;
     auto lds_for = [&](int R) { return ((R - 1) * S + KS) * g.RS * 4 + fixed; };
     auto pf_ok = [&](int R) { return (long)R * S * a.W * g.C4 <= (long)kPrefetch * 256; };
@@ -393,7 +394,8 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     g.off_alpha = off; off += g.MT * 32;
     g.lds_bytes = off * 4;
     // bands: about one resident wave of workgroups over the chip (prologue + halo paid once per band)
-    const int per_cu = std::max(1, std::min(2, (160 * 1024) / g.lds_bytes));
+    static const int max_per_cu = getenv("MI_BLOCK_PERCU") ? atoi(getenv("MI_BLOCK_PERCU")) : 2;  // tuning aid
+    const int per_cu = std::max(1, std::min(max_per_cu, (160 * 1024) / g.lds_bytes));
     const int max_bands = (a.Ho + R - 1) / R;
     int bands = std::min(max_bands, std::max(1, (kCUs * per_cu + a.B / 2) / std::max(1, a.B)));
     g.band = ((a.Ho + bands - 1) / bands + R - 1) / R * R;

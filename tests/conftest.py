@@ -16,10 +16,11 @@ MODEL_FILES = {
     "front": "face_detection_front.tflite",
     "short": "face_detection_short_range.tflite",
     "full": "face_detection_full_range.tflite",
+    "sparse": "face_detection_full_range_sparse.tflite",
     "landmark": "face_landmark.tflite",
     "iris": "iris_landmark.tflite",
 }
-INPUT_RANGE = {"back": (-1, 1), "front": (-1, 1), "short": (-1, 1), "full": (-1, 1), "landmark": (0, 1), "iris": (0, 1)}
+INPUT_RANGE = {"back": (-1, 1), "front": (-1, 1), "short": (-1, 1), "full": (-1, 1), "sparse": (-1, 1), "landmark": (0, 1), "iris": (0, 1)}
 
 
 def pytest_configure(config):

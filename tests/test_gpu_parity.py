@@ -141,7 +141,8 @@ def test_postprocess_edge_cases(gpu, oracle):
     fd.close()
 
 
-@pytest.mark.parametrize("kind,name", [("BackCamera", "back"), ("FrontCamera", "front"), ("Short", "short"), ("Full", "full")])
+@pytest.mark.parametrize("kind,name", [("BackCamera", "back"), ("FrontCamera", "front"), ("Short", "short"), ("Full", "full"),
+                                       ("FullSparse", "sparse")])
 def test_detector_tensor_path_vs_oracle(gpu, oracle, gold, kind, name):
     """Config 2 shape at test size: face-bearing + noise frames through net + decode + NMS."""
     fd = gpu.FaceDetection(getattr(gpu.FaceDetectionModel, kind))
@@ -155,7 +156,8 @@ def test_detector_tensor_path_vs_oracle(gpu, oracle, gold, kind, name):
         x[5] = (np.roll(face, (-20, 25), axis=(0, 1)) * 0.9).astype(np.float32)
     out, counts = fd.infer_tensor(x, cap=32)
     rb, rs = om.run(x, nthreads=6)
-    anchors = oracle.ssd_anchors({"back": oracle.FD_BACK, "front": oracle.FD_FRONT, "short": oracle.FD_SHORT, "full": oracle.FD_FULL}[name])
+    anchors = oracle.ssd_anchors({"back": oracle.FD_BACK, "front": oracle.FD_FRONT, "short": oracle.FD_SHORT, "full": oracle.FD_FULL,
+                                  "sparse": oracle.FD_FULL_SPARSE}[name])
     total = 0
     for f in range(6):
         ref = oracle.fd_postprocess(rb[f], rs[f], anchors, float(H))

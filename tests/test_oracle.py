@@ -23,7 +23,7 @@ def test_oracle_matches_golden_noise(oracle, gold, name):
         np.testing.assert_allclose(o.reshape(2, -1), g, rtol=0, atol=1e-4 * max(1.0, float(np.abs(g).max())))
 
 
-@pytest.mark.parametrize("name", ["front", "landmark", "iris", "full"])
+@pytest.mark.parametrize("name", ["front", "landmark", "iris", "full", "sparse"])
 def test_oracle_vs_independent_torch_eval(oracle, name):
     torch = pytest.importorskip("torch")
     from oracle.np import evaluate, tfl3
