@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
+    ap.add_argument("--lanes", type=int, default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,6 +107,8 @@ def main():
         model.set_option("fuse", args.fuse)
     if args.chunk is not None:
         model.set_option("chunk", args.chunk)
+    if args.lanes is not None:
+        model.set_option("lanes", args.lanes)
 
     B, cap = args.batch, 16
     x_host = make_frames(B, seed=rank)

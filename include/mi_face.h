@@ -199,6 +199,26 @@ int mi_iris_infer_image(mi_iris *h, const uint8_t *rgb, int width, int height, i
                         int is_right_eye, mi_landmark *contour71, mi_landmark *iris5);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Batched detector -> mesh -> iris pipeline, every stage on the device (BASELINE config 5)
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct mi_pipeline mi_pipeline;
+
+/* Loads the detector selected by `fd_kind` plus face_landmark.tflite and iris_landmark.tflite from `model_dir`
+ * (NULL = "./models") — the three handles of the README.md:27-46 / lib.rs:18-40 flow. */
+int mi_pipeline_create(int fd_kind, const char *model_dir, int device, mi_pipeline **out);
+void mi_pipeline_free(mi_pipeline *p);
+/* For each of `batch` equally sized RGB frames (8UC3, rows of `stride` bytes, frames `stride*height` bytes apart):
+ *   FaceDetection::infer(frame, None) -> faces[0] -> face_detection_to_roi -> FaceLandmark::infer(frame, roi)
+ *   -> iris_roi_from_face_landmarks -> IrisLandmark::infer(frame, left, false) and (frame, right, true)
+ * (lib.rs:24-40) without any host round trip between the stages: ROIs, rotated-ROI warps and projections stay on the GPU.
+ *   faces        [batch] top-1 detection (zeroed when none)      face_counts [batch] detections found by the detector
+ *   landmarks    f32 [batch][468][3]                             present     [batch] 1 = face found and mesh flag passed
+ *   eyes         f32 [batch][2][76][3]: left eye then right eye, each 71 eye-contour + 5 iris landmarks (zeros when absent)
+ * All pointers follow `mem`. */
+int mi_pipeline_run(mi_pipeline *p, const uint8_t *frames, int batch, int width, int height, int stride, mi_detection *faces,
+                    int *face_counts, float *landmarks, int *present, float *eyes, int mem, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Host-side helpers the reference exports next to the three structs
  * ---------------------------------------------------------------------------------------------------------------- */
 /* face_detection_to_roi(face_detection, image_size, None) — face_landmark.rs:180-198 (SquareLong, scale 1.5). */

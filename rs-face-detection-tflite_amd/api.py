@@ -36,6 +36,7 @@ EXPORTS = [
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
+    "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_run",
     "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_image_to_tensor",
 ]
 
@@ -174,6 +175,10 @@ def lib():
     L.mi_iris_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.mi_iris_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.POINTER(CLandmark),
                                       C.POINTER(CLandmark)]
+    L.mi_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.mi_pipeline_free.argtypes = [vp]
+    L.mi_pipeline_free.restype = None
+    L.mi_pipeline_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
     L.mi_face_detection_to_roi.argtypes = [C.POINTER(CDetection), C.c_int, C.c_int, C.POINTER(Rect)]
     L.mi_iris_roi_from_face_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(Rect)]
     L.mi_image_to_tensor.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.c_int, C.c_int,
@@ -505,6 +510,50 @@ class IrisLandmark:
         _check(self.L.mi_iris_infer_tensor(self.h, p, B, rp, sp, pp, fp_, _ptr(contour)[0], _ptr(iris)[0], mem,
                                            C.c_void_p(stream or 0)))
         return contour, iris
+
+
+class Pipeline:
+    """Batched detector -> mesh -> iris flow of lib.rs:18-40 / README.md:27-46, every stage on the GPU."""
+
+    def __init__(self, model_type=FaceDetectionModel.BackCamera, model_dir=None, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        d = model_dir if model_dir is not None else DEFAULT_MODEL_DIR
+        _check(self.L.mi_pipeline_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_pipeline_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, frames, stream=None):
+        """frames: uint8 [B,H,W,3] RGB (numpy, or a torch CUDA tensor).
+        Returns dict(faces [B,17], face_counts [B], landmarks [B,468,3], present [B], eyes [B,2,76,3])."""
+        B, H, W = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        if _is_torch(frames) and frames.is_cuda:
+            import torch
+            mem, dev = MI_MEM_DEVICE, frames.device
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+            out = dict(faces=z((B, 17), torch.float32), face_counts=z((B,), torch.int32), landmarks=z((B, 468, 3), torch.float32),
+                       present=z((B,), torch.int32), eyes=z((B, 2, 76, 3), torch.float32))
+            p = C.c_void_p(frames.data_ptr())
+            stride = int(frames.stride(1))
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            mem = MI_MEM_HOST
+            out = dict(faces=np.zeros((B, 17), np.float32), face_counts=np.zeros((B,), np.int32), landmarks=np.zeros((B, 468, 3), np.float32),
+                       present=np.zeros((B,), np.int32), eyes=np.zeros((B, 2, 76, 3), np.float32))
+            p = C.c_void_p(frames.ctypes.data)
+            stride = int(frames.strides[1])
+        _check(self.L.mi_pipeline_run(self.h, p, B, W, H, stride, _ptr(out["faces"])[0], _ptr(out["face_counts"])[0],
+                                      _ptr(out["landmarks"])[0], _ptr(out["present"])[0], _ptr(out["eyes"])[0], mem, C.c_void_p(stream or 0)))
+        return out
 
 
 def face_detection_to_roi(face_detection: Detection, image_size, size_mode=None) -> Rect:

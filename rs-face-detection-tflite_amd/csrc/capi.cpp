@@ -103,6 +103,14 @@ struct mi_fl {
     DeviceBuf d_in, d_roi, d_size, d_lm, d_present, d_flag, d_img;
 };
 
+struct mi_pipeline {
+    std::unique_ptr<mi_fd> fd;
+    std::unique_ptr<mi_fl> fl;
+    std::unique_ptr<mi_iris> iris;
+    DeviceBuf frames, geom, pad_det, pad_eye, in_det, dets, counts, roi_face, valid_face, in_lm, lm, present, roi_eye, valid_eye,
+        flip_eye, in_eye, eyes, sizes, faces;
+};
+
 struct mi_iris {
     mi_model model;
     int in_w = 0, in_h = 0;
@@ -684,6 +692,135 @@ int mi_iris_infer_image(mi_iris* h, const uint8_t* rgb, int width, int height, i
         mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
         for (int i = 0; i < MI_NUM_EYE_LANDMARKS; i++) contour71[i] = mi_landmark{c[3 * i], c[3 * i + 1], c[3 * i + 2]};
         for (int i = 0; i < MI_NUM_IRIS_LANDMARKS; i++) iris5[i] = mi_landmark{ir[3 * i], ir[3 * i + 1], ir[3 * i + 2]};
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ batched pipeline
+int mi_pipeline_create(int fd_kind, const char* model_dir, int device, mi_pipeline** out) {
+    return guarded([&] {
+        require(out, "null argument");
+        std::string dir = model_dir ? model_dir : "./models";
+        auto p = std::make_unique<mi_pipeline>();
+        mi_fd* fd = nullptr;
+        mi_fl* fl = nullptr;
+        mi_iris* ir = nullptr;
+        if (int rc = mi_fd_create(fd_kind, dir.c_str(), device, &fd)) throw ApiError(rc, g_error);
+        p->fd.reset(fd);
+        if (int rc = mi_fl_create((dir + "/face_landmark.tflite").c_str(), device, &fl)) throw ApiError(rc, g_error);
+        p->fl.reset(fl);
+        if (int rc = mi_iris_create((dir + "/iris_landmark.tflite").c_str(), device, &ir)) throw ApiError(rc, g_error);
+        p->iris.reset(ir);
+        *out = p.release();
+    });
+}
+
+void mi_pipeline_free(mi_pipeline* p) { delete p; }
+
+int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width, int height, int stride, mi_detection* faces,
+                    int* face_counts, float* landmarks, int* present, float* eyes, int mem, void* stream) {
+    return guarded([&] {
+        require(p && frames && faces && face_counts && landmarks && present && eyes, "null argument");
+        require(batch > 0 && width > 0 && height > 0 && stride >= 3 * width, "bad frame geometry");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        mi::Model& fdm = *p->fd->model.m;
+        mi::Model& flm = *p->fl->model.m;
+        mi::Model& irm = *p->iris->model.m;
+        mi::hip_check(hipSetDevice(fdm.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fdm.stream();
+        const int B = batch, cap = 4;
+        const size_t frame_bytes = static_cast<size_t>(stride) * height;
+        const uint8_t* d_frames = frames;
+        if (mem == MI_MEM_HOST) {
+            d_frames = static_cast<const uint8_t*>(p->frames.get(frame_bytes * B));
+            mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, frame_bytes * B, hipMemcpyHostToDevice, s), "H2D frames");
+        }
+        auto* d_geom = static_cast<mi::PreGeom*>(p->geom.get(sizeof(mi::PreGeom) * 2 * B));
+        // (w, h) of the source image of every ROI, for Rect::scaled in project_landmarks
+        int* d_sizes = static_cast<int*>(p->sizes.get(sizeof(int) * 4 * B));
+        {
+            std::vector<int> hs(4 * static_cast<size_t>(B));
+            for (int i = 0; i < 2 * B; i++) { hs[2 * i] = width; hs[2 * i + 1] = height; }
+            mi::hip_check(hipMemcpyAsync(d_sizes, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D sizes");
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
+        }
+        // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
+        mi::PreItems it{};
+        it.frames = d_frames; it.frame_bytes = static_cast<long>(frame_bytes); it.width = width; it.height = height; it.stride = stride;
+        it.items_per_frame = 1; it.N = B; it.out_w = p->fd->in_w; it.out_h = p->fd->in_h; it.keep_aspect = 1;
+        it.range_min = -1.0; it.range_max = 1.0;
+        double* d_pad_det = static_cast<double*>(p->pad_det.get(sizeof(double) * 4 * B));
+        float* d_in_det = static_cast<float*>(p->in_det.get(fdm.input_elems() * sizeof(float) * B));
+        mi::launch_pre_geom(it, d_geom, d_pad_det, s);
+        mi::launch_pre_tensor(it, d_geom, d_in_det, s);
+        fdm.run_device(d_in_det, B, s);
+        float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
+        mi::hip_check(hipMemsetAsync(d_dets, 0, sizeof(mi_detection) * cap * B, s), "hipMemsetAsync");  // frames without a face report zeros
+        int* d_counts = mem == MI_MEM_DEVICE ? face_counts : static_cast<int*>(p->counts.get(sizeof(int) * B));
+        fd_post(p->fd.get(), fdm.output_device(0), fdm.output_device(1), B, d_pad_det, reinterpret_cast<mi_detection*>(d_dets), cap, d_counts,
+                MI_MEM_DEVICE, s);
+        // ---- 2. faces[0] -> face_detection_to_roi -> image_to_tensor(frame, roi, (192,192), false, (0,1)) -> mesh net
+        auto* d_roi_face = static_cast<mi::RectD*>(p->roi_face.get(sizeof(mi::RectD) * B));
+        int* d_valid_face = static_cast<int*>(p->valid_face.get(sizeof(int) * B));
+        mi::launch_face_rois(d_dets, d_counts, B, cap, width, height, d_roi_face, d_valid_face, s);
+        it.rois = d_roi_face; it.roi_valid = d_valid_face; it.out_w = p->fl->in_w; it.out_h = p->fl->in_h; it.keep_aspect = 0;
+        it.range_min = 0.0; it.range_max = 1.0;
+        float* d_in_lm = static_cast<float*>(p->in_lm.get(flm.input_elems() * sizeof(float) * B));
+        mi::launch_pre_geom(it, d_geom, nullptr, s);
+        mi::launch_pre_tensor(it, d_geom, d_in_lm, s);
+        flm.run_device(d_in_lm, B, s);
+        float* d_lm = mem == MI_MEM_DEVICE ? landmarks : static_cast<float*>(p->lm.get(sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B));
+        int* d_present = mem == MI_MEM_DEVICE ? present : static_cast<int*>(p->present.get(sizeof(int) * B));
+        {
+            mi::ProjArgs a;
+            a.B = B; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = p->fl->in_w; a.tensor_h = p->fl->in_h;
+            a.roi = d_roi_face; a.image_size = d_sizes; a.gate = d_valid_face;
+            a.raw = flm.output_device(0); a.raw_fs = static_cast<long>(flm.output_elems(0));
+            a.flag = flm.output_device(1) + (flm.output_elems(1) - 1); a.flag_fs = static_cast<long>(flm.output_elems(1));
+            a.out = d_lm; a.present = d_present;
+            int rc = mi::launch_project(a, s);
+            if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        }
+        // ---- 3. iris_roi_from_face_landmarks -> image_to_tensor(frame, eye roi, (64,64), true, (0,1), flip = right eye) -> iris net
+        auto* d_roi_eye = static_cast<mi::RectD*>(p->roi_eye.get(sizeof(mi::RectD) * 2 * B));
+        int* d_valid_eye = static_cast<int*>(p->valid_eye.get(sizeof(int) * 2 * B));
+        int* d_flip_eye = static_cast<int*>(p->flip_eye.get(sizeof(int) * 2 * B));
+        mi::launch_iris_rois(d_lm, d_present, B, width, height, d_roi_eye, d_valid_eye, d_flip_eye, s);
+        it.rois = d_roi_eye; it.roi_valid = d_valid_eye; it.flip = d_flip_eye; it.items_per_frame = 2; it.N = 2 * B;
+        it.out_w = p->iris->in_w; it.out_h = p->iris->in_h; it.keep_aspect = 1;
+        double* d_pad_eye = static_cast<double*>(p->pad_eye.get(sizeof(double) * 8 * B));
+        float* d_in_eye = static_cast<float*>(p->in_eye.get(irm.input_elems() * sizeof(float) * 2 * B));
+        mi::launch_pre_geom(it, d_geom, d_pad_eye, s);
+        mi::launch_pre_tensor(it, d_geom, d_in_eye, s);
+        irm.run_device(d_in_eye, 2 * B, s);
+        const long eye_fs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
+        float* d_eyes = mem == MI_MEM_DEVICE ? eyes : static_cast<float*>(p->eyes.get(sizeof(float) * eye_fs * 2 * B));
+        for (int k = 0; k < 2; k++) {
+            mi::ProjArgs a;
+            a.B = 2 * B; a.n = k == 0 ? MI_NUM_EYE_LANDMARKS : MI_NUM_IRIS_LANDMARKS; a.tensor_w = p->iris->in_w; a.tensor_h = p->iris->in_h;
+            a.roi = d_roi_eye; a.image_size = d_sizes; a.padding = d_pad_eye; a.flip = d_flip_eye; a.gate = d_valid_eye;
+            a.raw = irm.output_device(k); a.raw_fs = static_cast<long>(irm.output_elems(k));
+            a.out = d_eyes + (k == 0 ? 0 : 3 * MI_NUM_EYE_LANDMARKS); a.out_fs = eye_fs;
+            int rc = mi::launch_project(a, s);
+            if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        }
+        // ---- top-1 faces out (strided gather [B][cap][17] -> [B][17]) and host copies
+        mi_detection* d_faces = mem == MI_MEM_DEVICE ? faces : static_cast<mi_detection*>(p->faces.get(sizeof(mi_detection) * B));
+        mi::hip_check(hipMemcpy2DAsync(d_faces, sizeof(mi_detection), d_dets, sizeof(mi_detection) * cap, sizeof(mi_detection), B,
+                                       hipMemcpyDeviceToDevice, s), "gather faces");
+        if (mem == MI_MEM_HOST) {
+            mi::hip_check(hipMemcpyAsync(faces, d_faces, sizeof(mi_detection) * B, hipMemcpyDeviceToHost, s), "D2H faces");
+            mi::hip_check(hipMemcpyAsync(face_counts, d_counts, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H counts");
+            mi::hip_check(hipMemcpyAsync(landmarks, d_lm, sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B, hipMemcpyDeviceToHost, s), "D2H landmarks");
+            mi::hip_check(hipMemcpyAsync(present, d_present, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H present");
+            mi::hip_check(hipMemcpyAsync(eyes, d_eyes, sizeof(float) * eye_fs * 2 * B, hipMemcpyDeviceToHost, s), "D2H eyes");
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+            for (int b = 0; b < B; b++) {
+                if (face_counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
+                if (face_counts[b] == 0) std::memset(&faces[b], 0, sizeof(mi_detection));
+            }
+        } else if (!stream) {
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
     });
 }
 

@@ -41,6 +41,8 @@ Model::~Model() {
     if (d_in_stage_) hipFree(d_in_stage_);
     for (float* p : d_out_)
         if (p) hipFree(p);
+    for (hipStream_t st : side_streams_) hipStreamDestroy(st);
+    for (hipEvent_t ev : lane_events_) hipEventDestroy(ev);
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -54,6 +56,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "graph") use_graph_ = value != 0;
     else if (key == "fuse") { fuse_level_ = std::min(2, std::max(0, value)); dirty_ = true; }
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
+    else if (key == "lanes") lanes_ = std::min(4, std::max(1, value));
     else throw std::runtime_error("unknown option '" + key + "'");
     invalidate_graphs();
     chunk_cap_ = 0;  // arena is re-laid out on the next run
@@ -128,11 +131,13 @@ void Model::rebuild() {
 
 void Model::ensure_capacity(int batch) {
     int chunk = chunk_ > 0 ? std::min(chunk_, batch) : batch;
-    if (chunk > chunk_cap_) {
+    if (lanes_ > 1) chunk = std::min(chunk, (batch + lanes_ - 1) / lanes_);  // each lane owns one arena region
+    if (chunk > chunk_cap_ || static_cast<size_t>(plan_.arena_floats_per_frame) * chunk * lanes_ > arena_floats_) {
         invalidate_graphs();
         if (d_arena_) hip_check(hipFree(d_arena_), "hipFree arena");
         d_arena_ = nullptr;
-        arena_floats_ = static_cast<size_t>(plan_.arena_floats_per_frame) * chunk;
+        chunk = std::max(chunk, chunk_cap_);
+        arena_floats_ = static_cast<size_t>(plan_.arena_floats_per_frame) * chunk * lanes_;
         hip_check(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(arena_floats_, 64) * sizeof(float)), "hipMalloc arena");
         chunk_cap_ = chunk;
     }
@@ -164,7 +169,7 @@ float* Model::tensor_ptr_mut(int t, int chunk_start, long* fs) const {
     if (s.root == plan_.storage[g.inputs[0]].root) throw std::runtime_error("plan writes into the graph input");
     long off = plan_.root_offset[s.root];
     if (off < 0) throw std::runtime_error("tensor has no storage");
-    return d_arena_ + off * chunk_cap_ + s.offset;
+    return d_arena_ + static_cast<size_t>(plan_.arena_floats_per_frame) * chunk_cap_ * arena_lane_ + off * chunk_cap_ + s.offset;
 }
 
 std::string Model::node_label(const Node& n) const {
@@ -350,6 +355,34 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
 }
 
 void Model::enqueue_all(const float* in, int batch, hipStream_t s) {
+    if (lanes_ > 1 && batch > chunk_cap_) {
+        // Independent frame ranges on concurrent streams: while one lane is in its small, latency-bound tail layers the
+        // other lanes' large layers keep the CUs busy.  Fork/join with events (captured as parallel graph branches).
+        while (static_cast<int>(side_streams_.size()) < lanes_ - 1) {
+            hipStream_t st;
+            hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+            side_streams_.push_back(st);
+        }
+        while (static_cast<int>(lane_events_.size()) < lanes_) {
+            hipEvent_t ev;
+            hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+            lane_events_.push_back(ev);
+        }
+        hip_check(hipEventRecord(lane_events_[0], s), "hipEventRecord");
+        int lane = 0;
+        for (int start = 0; start < batch; start += chunk_cap_, lane = (lane + 1) % lanes_) {
+            hipStream_t ls = lane == 0 ? s : side_streams_[lane - 1];
+            if (lane > 0 && start < chunk_cap_ * lanes_) hip_check(hipStreamWaitEvent(ls, lane_events_[0], 0), "hipStreamWaitEvent");
+            arena_lane_ = lane;
+            enqueue_chunk(in, start, std::min(chunk_cap_, batch - start), ls);
+        }
+        arena_lane_ = 0;
+        for (int l = 1; l < lanes_; l++) {
+            hip_check(hipEventRecord(lane_events_[l], side_streams_[l - 1]), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(s, lane_events_[l], 0), "hipStreamWaitEvent");
+        }
+        return;
+    }
     int chunk = chunk_cap_;
     for (int start = 0; start < batch; start += chunk) enqueue_chunk(in, start, std::min(chunk, batch - start), s);
 }

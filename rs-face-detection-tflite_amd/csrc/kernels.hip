@@ -571,6 +571,13 @@ __global__ void project_landmarks_kernel(ProjArgs a) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)a.B * a.n) return;
     int b = (int)(idx / a.n), i = (int)(idx % a.n);
+    float* o = a.out + (long)b * (a.out_fs ? a.out_fs : 3L * a.n) + 3 * i;
+    if (a.gate && !a.gate[b]) {
+        o[0] = o[1] = o[2] = 0.f;
+        if (i == 0 && a.present) a.present[b] = 0;
+        if (i == 0 && a.raw_flag_out && a.flag) a.raw_flag_out[b] = a.flag[(long)b * a.flag_fs];
+        return;
+    }
     const float* r = a.raw + (long)b * a.raw_fs + 3 * i;
     float wf = (float)a.tensor_w, hf = (float)a.tensor_h;
     float x = __fdiv_rn(r[0], wf), y = __fdiv_rn(r[1], hf), z = __fdiv_rn(r[2], wf);
@@ -609,7 +616,6 @@ __global__ void project_landmarks_kernel(ProjArgs a) {
         y = (float)((double)y * h + yc);
         z = (float)((double)z * w + 0.);
     }
-    float* o = a.out + ((long)b * a.n + i) * 3;
     o[0] = x; o[1] = y; o[2] = z;
 }
 

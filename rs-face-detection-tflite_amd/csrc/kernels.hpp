@@ -100,7 +100,9 @@ struct ProjArgs {  // project_landmarks, one thread per landmark
     float* raw_flag_out = nullptr;    // [B] or null
     const double* padding = nullptr;  // [B][4] or null
     const int* flip = nullptr;        // [B] or null
-    float* out = nullptr;             // [B][n][3]
+    const int* gate = nullptr;        // [B] or null: 0 = item has no ROI (no face upstream) -> zeros, present = 0
+    float* out = nullptr;             // [B][out_fs] (first n*3 floats written)
+    long out_fs = 0;                  // floats between items (0 = n*3)
     int B = 0, n = 0, tensor_w = 1, tensor_h = 1;
 };
 

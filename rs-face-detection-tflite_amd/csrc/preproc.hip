@@ -1,9 +1,17 @@
 // preproc.hip — transform::image_to_tensor on the GPU (reference: /root/reference/src/face_detection_lite/
-// transform.rs:188-309).  The reference chains OpenCV calls (getPerspectiveTransform, warpPerspective INTER_LINEAR /
-// BORDER_CONSTANT 0, copyMakeBorder, resize INTER_LINEAR, flip) and a per-pixel u8 -> f32 loop on the CPU; here the
-// same stages run as three small kernels that keep OpenCV's generic 8-bit fixed-point arithmetic
-// (1/32-pixel source coordinates + 15-bit weights for the warp, 11-bit coefficient pairs for the resize), so results
-// stay within 1 LSB of the u8 intermediate images of a non-IPP OpenCV build.
+// transform.rs:188-309), plus the ROI maths that links the detector, the mesh and the iris stages
+// (face_landmark.rs:180-198, iris_landmark.rs:268-292, transform.rs:44-109) so that a whole batch can go through
+// detector -> mesh -> iris without leaving the device.
+//
+// The reference chains OpenCV calls on the CPU: getPerspectiveTransform, warpPerspective (INTER_LINEAR, BORDER_CONSTANT 0),
+// copyMakeBorder, resize (INTER_LINEAR), flip, then a per-pixel u8 -> f32 loop.  Every stage rounds to u8, so the
+// stages cannot be merged arithmetically — but they can be merged *structurally*: one thread per output pixel evaluates
+// the chain backwards (output pixel <- 2x2 of the resized image <- 2x2 each of the bordered/resized image <- 2x2 each of
+// the warped image <- 2x2 source pixels), recomputing the small intermediate neighbourhoods instead of materialising
+// variable-sized intermediate images.  Each stage keeps OpenCV's generic 8-bit fixed-point arithmetic (1/32-pixel
+// coordinates + 15-bit weights for the warp, 11-bit coefficient pairs for the resize), so results stay within 1 LSB of
+// a non-IPP OpenCV build.  The geometry (homography, sizes, paddings) is computed per item by the same code on host
+// (single image) or device (batches whose ROIs were produced on the device).
 #include "preproc.hpp"
 
 #include <algorithm>
@@ -16,32 +24,24 @@
 namespace mi {
 namespace {
 
-struct Geom {
-    double roi_w, roi_h;            // absolute ROI size (untruncated)
-    int warp_w, warp_h;             // warpPerspective target size
-    double Minv[9];                 // dst -> src homography
-    bool two_stage;                 // letterbox: pad + resize to (new_w,new_h)
-    int pad_h, pad_v, new_w, new_h;
-    double pad_x, pad_y;
-};
-
-// 8x8 solve for the 4-point homography (Gauss-Jordan with partial pivoting, f64) and 3x3 inverse.
-bool homography(const float src[4][2], const float dst[4][2], double M[9]) {
+// ---------------------------------------------------------------------------------------------- geometry (host + device)
+__host__ __device__ inline bool solve_homography(const float src[4][2], const float dst[4][2], double M[9]) {
+    // 8x8 system of cv::getPerspectiveTransform, Gauss-Jordan with partial pivoting in f64
     double a[8][9];
-    std::memset(a, 0, sizeof a);
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 9; j++) a[i][j] = 0.0;
     for (int i = 0; i < 4; i++) {
         const double X = src[i][0], Y = src[i][1], u = dst[i][0], v = dst[i][1];
-        double r0[9] = {X, Y, 1, 0, 0, 0, -X * u, -Y * u, u};
-        double r1[9] = {0, 0, 0, X, Y, 1, -X * v, -Y * v, v};
-        std::memcpy(a[i], r0, sizeof r0);
-        std::memcpy(a[i + 4], r1, sizeof r1);
+        a[i][0] = X; a[i][1] = Y; a[i][2] = 1; a[i][6] = -X * u; a[i][7] = -Y * u; a[i][8] = u;
+        a[i + 4][3] = X; a[i + 4][4] = Y; a[i + 4][5] = 1; a[i + 4][6] = -X * v; a[i + 4][7] = -Y * v; a[i + 4][8] = v;
     }
     for (int c = 0; c < 8; c++) {
         int p = c;
         for (int r = c + 1; r < 8; r++)
-            if (std::fabs(a[r][c]) > std::fabs(a[p][c])) p = r;
-        if (std::fabs(a[p][c]) < 1e-300) return false;
-        if (p != c) std::swap_ranges(a[c], a[c] + 9, a[p]);
+            if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
+        if (fabs(a[p][c]) < 1e-300) return false;
+        if (p != c)
+            for (int k = 0; k < 9; k++) { double t = a[c][k]; a[c][k] = a[p][k]; a[p][k] = t; }
         for (int r = 0; r < 8; r++) {
             if (r == c) continue;
             const double f = a[r][c] / a[c][c];
@@ -54,7 +54,7 @@ bool homography(const float src[4][2], const float dst[4][2], double M[9]) {
     return true;
 }
 
-bool inverse3(const double m[9], double o[9]) {
+__host__ __device__ inline bool inverse3(const double m[9], double o[9]) {
     const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
     const double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
     if (det == 0.0) return false;
@@ -65,228 +65,298 @@ bool inverse3(const double m[9], double o[9]) {
     return true;
 }
 
-Geom make_geom(int width, int height, const mi_rect* roi_in, int out_w, int out_h, bool keep_aspect) {
-    Geom g{};
-    mi_rect roi = roi_in ? *roi_in : mi_rect{0.5, 0.5, 1.0, 1.0, 0.0, 1};  // transform.rs:190-197
-    if (roi.normalized) {                                                   // Rect::scaled(size, false), types.rs:62-77
-        roi.x_center *= width; roi.y_center *= height; roi.width *= width; roi.height *= height;
-    }
-    g.roi_w = roi.width;
-    g.roi_h = roi.height;
-    g.warp_w = keep_aspect ? static_cast<int>(roi.width) : out_w;   // Rect::size truncates (types.rs:52-59), 203-207
-    g.warp_h = keep_aspect ? static_cast<int>(roi.height) : out_h;
-    if (g.warp_w <= 0 || g.warp_h <= 0) throw std::runtime_error("ROI is empty");
-    // Rect::points (types.rs:80-96), cast to f32 as Point2f (transform.rs:210-213)
-    const double x = roi.x_center, y = roi.y_center, hw = roi.width / 2.0, hh = roi.height / 2.0;
-    double p[4][2] = {{x - hw, y - hh}, {x + hw, y - hh}, {x + hw, y + hh}, {x - hw, y + hh}};
-    if (roi.rotation != 0.0) {
-        const double s = std::sin(roi.rotation), c = std::cos(roi.rotation);
-        for (auto& q : p) {
-            const double dx = q[0] - x, dy = q[1] - y;
-            q[0] = x + dx * c - dy * s;
-            q[1] = y + dx * s + dy * c;
+// transform.rs:190-257 — everything that depends only on (image size, ROI, output size, keep_aspect_ratio)
+__host__ __device__ inline PreGeom compute_geom(int width, int height, const RectD* roi_in, int out_w, int out_h, bool keep_aspect) {
+    PreGeom g;
+    for (int i = 0; i < 9; i++) g.Minv[i] = 0.0;
+    g.pad_x = g.pad_y = 0.0;
+    g.stage1 = 0; g.pad_h = g.pad_v = 0; g.stage2 = 0; g.valid = 0; g.bw0 = 1;
+    double xc = 0.5, yc = 0.5, rw = 1.0, rh = 1.0, rot = 0.0;  // default ROI = whole image, normalised (190-197)
+    bool normalized = true;
+    if (roi_in) { xc = roi_in->x_center; yc = roi_in->y_center; rw = roi_in->width; rh = roi_in->height; rot = roi_in->rotation; normalized = roi_in->normalized != 0; }
+    if (normalized) { xc *= width; yc *= height; rw *= width; rh *= height; }  // Rect::scaled(size, false), types.rs:62-77
+    g.warp_w = keep_aspect ? (int)rw : out_w;   // Rect::size truncates (types.rs:52-59), transform.rs:203-207
+    g.warp_h = keep_aspect ? (int)rh : out_h;
+    g.new_w = (int)rw;
+    g.new_h = (int)rh;
+    if (!(g.warp_w > 0 && g.warp_h > 0 && g.warp_w <= 16384 && g.warp_h <= 16384)) return g;
+    // Rect::points (types.rs:80-96) -> Point2f (transform.rs:210-213)
+    const double hw = rw / 2.0, hh = rh / 2.0;
+    double p[4][2] = {{xc - hw, yc - hh}, {xc + hw, yc - hh}, {xc + hw, yc + hh}, {xc - hw, yc + hh}};
+    if (rot != 0.0) {
+        const double s = sin(rot), c = cos(rot);
+        for (int i = 0; i < 4; i++) {
+            const double dx = p[i][0] - xc, dy = p[i][1] - yc;
+            p[i][0] = xc + dx * c - dy * s;
+            p[i][1] = yc + dx * s + dy * c;
         }
     }
-    float src[4][2], dst[4][2] = {{0, 0}, {static_cast<float>(g.warp_w), 0}, {static_cast<float>(g.warp_w), static_cast<float>(g.warp_h)}, {0, static_cast<float>(g.warp_h)}};
-    for (int i = 0; i < 4; i++) { src[i][0] = static_cast<float>(p[i][0]); src[i][1] = static_cast<float>(p[i][1]); }
+    float src[4][2], dst[4][2] = {{0.f, 0.f}, {(float)g.warp_w, 0.f}, {(float)g.warp_w, (float)g.warp_h}, {0.f, (float)g.warp_h}};
+    for (int i = 0; i < 4; i++) { src[i][0] = (float)p[i][0]; src[i][1] = (float)p[i][1]; }
     double M[9];
-    if (!homography(src, dst, M) || !inverse3(M, g.Minv)) throw std::runtime_error("degenerate ROI (singular perspective transform)");
-    g.new_w = static_cast<int>(roi.width);
-    g.new_h = static_cast<int>(roi.height);
-    if (keep_aspect) {  // transform.rs:239-257
-        const double out_aspect = static_cast<double>(out_h / out_w);  // integer division in the reference
-        const double roi_aspect = roi.height / roi.width;
-        if (out_aspect > roi_aspect) { g.new_h = static_cast<int>(roi.width * out_aspect); g.pad_y = (1.0 - roi_aspect / out_aspect) / 2.0; }
-        else { g.new_w = static_cast<int>(roi.height / out_aspect); g.pad_x = (1.0 - out_aspect / roi_aspect) / 2.0; }
-        if (g.new_w != static_cast<int>(roi.width) || g.new_h != static_cast<int>(roi.height)) {
-            g.two_stage = true;
-            g.pad_h = static_cast<int>(g.pad_x * g.new_w);
-            g.pad_v = static_cast<int>(g.pad_y * g.new_h);
+    if (!solve_homography(src, dst, M) || !inverse3(M, g.Minv)) return g;
+    // OpenCV tile geometry of warpPerspective (BLOCK_SZ = 32): bh0 = min(16, h); bw0 = min(1024 / bh0, w)
+    const int bh0 = g.warp_h < 16 ? g.warp_h : 16;
+    g.bw0 = (1024 / bh0) < g.warp_w ? (1024 / bh0) : g.warp_w;
+    int cw = g.warp_w, ch = g.warp_h;
+    if (keep_aspect) {  // transform.rs:239-280
+        const double out_aspect = (double)(out_h / out_w);  // integer division in the reference
+        const double roi_aspect = rh / rw;
+        if (out_aspect > roi_aspect) { g.new_h = (int)(rw * out_aspect); g.pad_y = (1.0 - roi_aspect / out_aspect) / 2.0; }
+        else { g.new_w = (int)(rh / out_aspect); g.pad_x = (1.0 - out_aspect / roi_aspect) / 2.0; }
+        if (g.new_w != (int)rw || g.new_h != (int)rh) {
+            g.pad_h = (int)(g.pad_x * (double)g.new_w);
+            g.pad_v = (int)(g.pad_y * (double)g.new_h);
+            if (!(g.new_w > 0 && g.new_h > 0 && g.new_w <= 16384 && g.new_h <= 16384)) return g;
+            g.stage1 = (cw + 2 * g.pad_h == g.new_w && ch + 2 * g.pad_v == g.new_h) ? 1 : 2;  // cv::resize to the same size copies
+            cw = g.new_w; ch = g.new_h;
         }
+        g.stage2 = (cw == out_w && ch == out_h) ? 0 : 1;
     }
+    g.valid = 1;
     return g;
+}
+
+// ---------------------------------------------------------------------------------------------- pixel chain (device)
+struct Px { int r, g, b; };
+
+// cv::warpPerspective, INTER_LINEAR, BORDER_CONSTANT(0), 8UC3 (generic fixed-point path), pixel (x, y) of the warped image
+__device__ __forceinline__ Px warp_px(const PreGeom& g, const uint8_t* src, int sw, int sh, int sstride, int y, int x) {
+    // OpenCV evaluates the mapping per tile: X0 at the tile's first column, then + M[0]*x1
+    const int bx = (x / g.bw0) * g.bw0, x1 = x - bx;
+    const double X0 = g.Minv[0] * bx + g.Minv[1] * y + g.Minv[2];
+    const double Y0 = g.Minv[3] * bx + g.Minv[4] * y + g.Minv[5];
+    double W = (g.Minv[6] * bx + g.Minv[7] * y + g.Minv[8]) + g.Minv[6] * x1;
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + g.Minv[0] * x1) * W));
+    const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + g.Minv[3] * x1) * W));
+    const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+    const int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
+    const int ax = X & 31, ay = Y & 31;
+    int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
+    if (ax == 0 && ay == 0) { w00 = 32767; w11 = 1; }  // saturate_cast<short>(32768) + sum fix-up of the weight table
+    Px o = {0, 0, 0};
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return o;
+    const bool x0in = sx >= 0 && sx < sw, x1in = sx + 1 >= 0 && sx + 1 < sw;
+    const bool y0in = sy >= 0 && sy < sh, y1in = sy + 1 >= 0 && sy + 1 < sh;
+    const uint8_t* r0 = src + (long)sy * sstride + (long)sx * 3;
+    const uint8_t* r1 = r0 + sstride;
+    int v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int p00 = (y0in && x0in) ? r0[c] : 0, p01 = (y0in && x1in) ? r0[3 + c] : 0;
+        const int p10 = (y1in && x0in) ? r1[c] : 0, p11 = (y1in && x1in) ? r1[3 + c] : 0;
+        v[c] = min(max((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15, 0), 255);
+    }
+    o.r = v[0]; o.g = v[1]; o.b = v[2];
+    return o;
+}
+
+// cv::resize INTER_LINEAR 8UC3 (11-bit coefficient pairs, int32 horizontal pass, (b*(S>>4))>>16 vertical pass; exact 2x
+// shrink is routed to INTER_AREA) of a virtual image `fetch(y, x)` of size pw x ph.
+template <typename Fetch>
+__device__ __forceinline__ Px resize_px(int pw, int ph, int dw, int dh, int dy, int dx, Fetch fetch) {
+    const double scale_x = 1.0 / ((double)dw / pw), scale_y = 1.0 / ((double)dh / ph);
+    const int isx = __double2int_rn(scale_x), isy = __double2int_rn(scale_y);
+    Px o;
+    if (fabs(scale_x - isx) < 2.220446049250313e-16 && fabs(scale_y - isy) < 2.220446049250313e-16 && isx == 2 && isy == 2) {
+        const Px a = fetch(2 * dy, 2 * dx), b = fetch(2 * dy, 2 * dx + 1), c = fetch(2 * dy + 1, 2 * dx), d = fetch(2 * dy + 1, 2 * dx + 1);
+        o.r = (a.r + b.r + c.r + d.r + 2) >> 2; o.g = (a.g + b.g + c.g + d.g + 2) >> 2; o.b = (a.b + b.b + c.b + d.b + 2) >> 2;
+        return o;
+    }
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= pw - 1) { fx = 0.f; sx = pw - 1; }
+    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int a0 = min(max(__float2int_rn((1.f - fx) * 2048.f), -32768), 32767), a1 = min(max(__float2int_rn(fx * 2048.f), -32768), 32767);
+    const int b0 = min(max(__float2int_rn((1.f - fy) * 2048.f), -32768), 32767), b1 = min(max(__float2int_rn(fy * 2048.f), -32768), 32767);
+    const int sy0 = min(max(sy, 0), ph - 1), sy1 = min(max(sy + 1, 0), ph - 1);
+    const bool edge = sx + 1 >= pw;
+    const Px p00 = fetch(sy0, sx), p10 = fetch(sy1, sx);
+    Px p01 = p00, p11 = p10;
+    if (!edge) { p01 = fetch(sy0, sx + 1); p11 = fetch(sy1, sx + 1); }
+    auto mix = [&](int v00, int v01, int v10, int v11) {
+        const int r0 = edge ? v00 * 2048 : v00 * a0 + v01 * a1;
+        const int r1 = edge ? v10 * 2048 : v10 * a0 + v11 * a1;
+        return min(max((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2, 0), 255);
+    };
+    o.r = mix(p00.r, p01.r, p10.r, p11.r);
+    o.g = mix(p00.g, p01.g, p10.g, p11.g);
+    o.b = mix(p00.b, p01.b, p10.b, p11.b);
+    return o;
+}
+
+__global__ void pre_geom_kernel(PreItems it, PreGeom* geom, double* padding) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= it.N) return;
+    PreGeom g;
+    if (it.roi_valid && !it.roi_valid[i]) {
+        g = compute_geom(it.width, it.height, nullptr, it.out_w, it.out_h, it.keep_aspect != 0);
+        g.valid = 0;
+        g.pad_x = g.pad_y = 0.0;
+    } else {
+        g = compute_geom(it.width, it.height, it.rois ? &it.rois[i] : nullptr, it.out_w, it.out_h, it.keep_aspect != 0);
+    }
+    geom[i] = g;
+    if (padding) { padding[4 * i] = g.pad_x; padding[4 * i + 1] = g.pad_y; padding[4 * i + 2] = g.pad_x; padding[4 * i + 3] = g.pad_y; }
+}
+
+// One thread per output pixel: flip + `(pixel as f64 * (max - min) / 255.0 + min) as f32` (transform.rs:282-301) of the
+// image produced by warp -> [border (+ resize)] -> [resize].
+__global__ __launch_bounds__(256) void pre_tensor_kernel(PreItems it, const PreGeom* __restrict__ geom, float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= it.out_w * it.out_h) return;
+    const int y = idx / it.out_w, x = idx - y * it.out_w;
+    float* o = out + ((long)i * it.out_h * it.out_w + idx) * 3;
+    const PreGeom g = geom[i];
+    if (!g.valid) { o[0] = o[1] = o[2] = 0.f; return; }
+    const uint8_t* src = it.frames + (long)(i / it.items_per_frame) * it.frame_bytes;
+    const int sx_out = (it.flip && it.flip[i]) ? it.out_w - 1 - x : x;   // cv::flip(…, 1) of the final image
+    const int sw = it.width, sh = it.height, ss = it.stride;
+    auto warped = [&](int yy, int xx) { return warp_px(g, src, sw, sh, ss, yy, xx); };
+    auto bordered = [&](int yy, int xx) {  // copyMakeBorder(top = bottom = pad_v, left = right = pad_h, 0)
+        const int wy = yy - g.pad_v, wx = xx - g.pad_h;
+        if (wy < 0 || wy >= g.warp_h || wx < 0 || wx >= g.warp_w) { Px z = {0, 0, 0}; return z; }
+        return warped(wy, wx);
+    };
+    auto stage1 = [&](int yy, int xx) {
+        if (g.stage1 == 0) return warped(yy, xx);
+        if (g.stage1 == 1) return bordered(yy, xx);
+        return resize_px(g.warp_w + 2 * g.pad_h, g.warp_h + 2 * g.pad_v, g.new_w, g.new_h, yy, xx, bordered);
+    };
+    Px p;
+    if (g.stage2) {
+        const int cw = g.stage1 ? g.new_w : g.warp_w, ch = g.stage1 ? g.new_h : g.warp_h;
+        p = resize_px(cw, ch, it.out_w, it.out_h, y, sx_out, stage1);
+    } else {
+        p = stage1(y, sx_out);
+    }
+    const double k = it.range_max - it.range_min;
+    o[0] = (float)((double)p.r * k / 255.0 + it.range_min);
+    o[1] = (float)((double)p.g * k / 255.0 + it.range_min);
+    o[2] = (float)((double)p.b * k / 255.0 + it.range_min);
+}
+
+// ---------------------------------------------------------------------------------------------- ROI maths (device)
+// bbox_to_roi + select_roi_size(SquareLong) (transform.rs:44-109), f64 like the reference
+__device__ inline bool bbox_to_roi_dev(const double bbox[4], int image_w, int image_h, const double kp[4], double scale, RectD* out) {
+    const double xmin = bbox[0], ymin = bbox[1], xmax = bbox[2], ymax = bbox[3];
+    if (!(xmin >= -1.0 && xmax < 2.0 && ymin >= -1.0)) return false;  // BBox::normalized (types.rs:133-135)
+    const double iw = image_w, ih = image_h;
+    const double aw = xmax * iw - xmin * iw, ah = ymax * ih - ymin * ih;
+    const double side = fmax(aw, ah);
+    const double width = side / iw * scale, height = side / ih * scale;
+    const double pi = 3.14159265358979323846;
+    const double angle = -atan2(kp[1] - kp[3], kp[2] - kp[0]);
+    out->x_center = xmin + (xmax - xmin) / 2.0;
+    out->y_center = ymin + (ymax - ymin) / 2.0;
+    out->width = width;
+    out->height = height;
+    out->rotation = angle - 2.0 * pi * floor((angle + pi) / (2.0 * pi));
+    out->normalized = 1;
+    out->pad_ = 0;
+    return true;
+}
+
+__global__ void face_roi_kernel(const float* dets, const int* counts, int B, int cap, int image_w, int image_h, RectD* rois, int* valid) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    RectD r = {0.5, 0.5, 1.0, 1.0, 0.0, 1, 0};
+    int ok = 0;
+    if (counts[b] > 0) {  // faces[0] (lib.rs:29); Detection::scaled_by_image_size multiplies in f32 (types.rs:237-245)
+        const float* d = dets + (long)b * cap * 17;
+        const float w = (float)image_w, h = (float)image_h;
+        const double kp[4] = {(double)__fmul_rn(d[4], w), (double)__fmul_rn(d[5], h), (double)__fmul_rn(d[6], w), (double)__fmul_rn(d[7], h)};
+        const double bbox[4] = {(double)d[0], (double)d[1], (double)d[2], (double)d[3]};
+        ok = bbox_to_roi_dev(bbox, image_w, image_h, kp, 1.5, &r) ? 1 : 0;  // ROI_SCALE, SquareLong (face_landmark.rs:30,189)
+    }
+    rois[b] = r;
+    valid[b] = ok;
+}
+
+__global__ void iris_roi_kernel(const float* lm, const int* present, int B, int image_w, int image_h, RectD* rois, int* valid, int* flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * B) return;
+    const int b = i >> 1, eye = i & 1;  // 0 = left (33,133), 1 = right (362,263) — iris_landmark.rs:29-35
+    RectD r = {0.5, 0.5, 1.0, 1.0, 0.0, 1, 0};
+    int ok = 0;
+    if (present[b]) {
+        const float* p0 = lm + ((long)b * 468 + (eye ? 362 : 33)) * 3;
+        const float* p1 = lm + ((long)b * 468 + (eye ? 263 : 133)) * 3;
+        const double ax = p0[0], ay = p0[1], bx = p1[0], by = p1[1];
+        const double bbox[4] = {fmin(ax, bx), fmin(ay, by), fmax(ax, bx), fmax(ay, by)};  // bbox_from_landmarks, transform.rs:146-165
+        const double kp[4] = {ax, ay, bx, by};
+        ok = bbox_to_roi_dev(bbox, image_w, image_h, kp, 2.3, &r) ? 1 : 0;  // ROI_SCALE (iris_landmark.rs:27)
+    }
+    rois[i] = r;
+    valid[i] = ok;
+    flip[i] = eye;  // right eye is flipped (lib.rs:39)
 }
 
 size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
-// ---------------------------------------------------------------------------------------------- kernels
-struct WarpArgs {
-    const uint8_t* src; int sw, sh, sstride;
-    uint8_t* dst; int dw, dh;
-    double M[9];
-    int bw0, bh0;
-};
-
-// cv::warpPerspective, INTER_LINEAR, BORDER_CONSTANT(0), 8UC3 (generic fixed-point path).
-__global__ void warp_u8_kernel(WarpArgs a) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || y >= a.dh) return;
-    // OpenCV evaluates the mapping per tile: X0 at the tile's first column, then + M[0]*x1
-    int bx = (x / a.bw0) * a.bw0, x1 = x - bx;
-    double X0 = a.M[0] * bx + a.M[1] * y + a.M[2];
-    double Y0 = a.M[3] * bx + a.M[4] * y + a.M[5];
-    double W = (a.M[6] * bx + a.M[7] * y + a.M[8]) + a.M[6] * x1;
-    W = W != 0.0 ? 32.0 / W : 0.0;
-    double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + a.M[0] * x1) * W));
-    double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + a.M[3] * x1) * W));
-    int X = __double2int_rn(fX), Y = __double2int_rn(fY);
-    int sx = min(max(X >> 5, -32768), 32767), sy = min(max(Y >> 5, -32768), 32767);
-    int ax = X & 31, ay = Y & 31;
-    int w00 = (32 - ay) * (32 - ax) * 32, w01 = (32 - ay) * ax * 32, w10 = ay * (32 - ax) * 32, w11 = ay * ax * 32;
-    if (ax == 0 && ay == 0) { w00 = 32767; w11 = 1; }  // saturate_cast<short>(32768) + sum fix-up of the weight table
-    uint8_t* d = a.dst + ((long)y * a.dw + x) * 3;
-    if (sx >= a.sw || sx + 1 < 0 || sy >= a.sh || sy + 1 < 0) { d[0] = d[1] = d[2] = 0; return; }
-    bool x0in = sx >= 0 && sx < a.sw, x1in = sx + 1 >= 0 && sx + 1 < a.sw;
-    bool y0in = sy >= 0 && sy < a.sh, y1in = sy + 1 >= 0 && sy + 1 < a.sh;
-    const uint8_t* r0 = a.src + (long)sy * a.sstride + (long)sx * 3;
-    const uint8_t* r1 = r0 + a.sstride;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int p00 = (y0in && x0in) ? r0[c] : 0, p01 = (y0in && x1in) ? r0[3 + c] : 0;
-        int p10 = (y1in && x0in) ? r1[c] : 0, p11 = (y1in && x1in) ? r1[3 + c] : 0;
-        int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
-        d[c] = (uint8_t)min(max(v, 0), 255);
-    }
-}
-
-struct ResizeArgs {
-    const uint8_t* src; int sw, sh;   // un-padded source image [sh][sw][3]
-    int pad_l, pad_t, pw, ph;         // virtual zero border: padded size pw x ph (copyMakeBorder fused)
-    uint8_t* dst; int dw, dh;
-    double scale_x, scale_y;
-    int area2x;
-};
-
-__device__ __forceinline__ int padded_px(const ResizeArgs& a, int y, int x, int c) {
-    int yy = y - a.pad_t, xx = x - a.pad_l;
-    if (yy < 0 || yy >= a.sh || xx < 0 || xx >= a.sw) return 0;
-    return a.src[((long)yy * a.sw + xx) * 3 + c];
-}
-
-// cv::resize INTER_LINEAR 8UC3: 11-bit coefficient pairs, int32 horizontal pass, (b*(S>>4))>>16 vertical pass.
-__global__ void resize_u8_kernel(ResizeArgs a) {
-    int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
-    if (dx >= a.dw || dy >= a.dh) return;
-    uint8_t* d = a.dst + ((long)dy * a.dw + dx) * 3;
-    if (a.area2x) {  // exact 2x shrink: INTER_LINEAR is routed to INTER_AREA
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-            d[c] = (uint8_t)((padded_px(a, 2 * dy, 2 * dx, c) + padded_px(a, 2 * dy, 2 * dx + 1, c) + padded_px(a, 2 * dy + 1, 2 * dx, c) +
-                              padded_px(a, 2 * dy + 1, 2 * dx + 1, c) + 2) >> 2);
-        return;
-    }
-    float fx = (float)(((double)dx + 0.5) * a.scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx -= (float)sx;
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= a.pw - 1) { fx = 0.f; sx = a.pw - 1; }
-    float fy = (float)(((double)dy + 0.5) * a.scale_y - 0.5);
-    int sy = (int)floorf(fy);
-    fy -= (float)sy;
-    int a0 = min(max(__float2int_rn((1.f - fx) * 2048.f), -32768), 32767), a1 = min(max(__float2int_rn(fx * 2048.f), -32768), 32767);
-    int b0 = min(max(__float2int_rn((1.f - fy) * 2048.f), -32768), 32767), b1 = min(max(__float2int_rn(fy * 2048.f), -32768), 32767);
-    int sy0 = min(max(sy, 0), a.ph - 1), sy1 = min(max(sy + 1, 0), a.ph - 1);
-    bool edge = sx + 1 >= a.pw;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        int r0, r1;
-        if (!edge) {
-            r0 = padded_px(a, sy0, sx, c) * a0 + padded_px(a, sy0, sx + 1, c) * a1;
-            r1 = padded_px(a, sy1, sx, c) * a0 + padded_px(a, sy1, sx + 1, c) * a1;
-        } else {
-            r0 = padded_px(a, sy0, sx, c) * 2048;
-            r1 = padded_px(a, sy1, sx, c) * 2048;
-        }
-        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        d[c] = (uint8_t)min(max(v, 0), 255);
-    }
-}
-
-// flip + `(pixel as f64 * (max - min) / 255.0 + min) as f32` (transform.rs:282-301)
-__global__ void normalize_kernel(const uint8_t* src, int w, int h, int flip, double rmin, double rmax, float* out) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= w || y >= h) return;
-    int sx = flip ? w - 1 - x : x;
-    const uint8_t* s = src + ((long)y * w + sx) * 3;
-    float* o = out + ((long)y * w + x) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; c++) o[c] = (float)((double)s[c] * (rmax - rmin) / 255.0 + rmin);
-}
-
-void launch_resize(const uint8_t* src, int sw, int sh, int pad_l, int pad_t, uint8_t* dst, int dw, int dh, hipStream_t s) {
-    ResizeArgs a{};
-    a.src = src; a.sw = sw; a.sh = sh; a.pad_l = pad_l; a.pad_t = pad_t; a.pw = sw + 2 * pad_l; a.ph = sh + 2 * pad_t;
-    a.dst = dst; a.dw = dw; a.dh = dh;
-    const double inv_x = static_cast<double>(dw) / a.pw, inv_y = static_cast<double>(dh) / a.ph;
-    a.scale_x = 1.0 / inv_x;
-    a.scale_y = 1.0 / inv_y;
-    const int isx = static_cast<int>(std::lrint(a.scale_x)), isy = static_cast<int>(std::lrint(a.scale_y));
-    a.area2x = std::fabs(a.scale_x - isx) < 2.220446049250313e-16 && std::fabs(a.scale_y - isy) < 2.220446049250313e-16 && isx == 2 && isy == 2;
-    dim3 blk(32, 8), grd((dw + 31) / 32, (dh + 7) / 8);
-    hipLaunchKernelGGL(resize_u8_kernel, grd, blk, 0, s, a);
-    hip_check(hipGetLastError(), "resize kernel launch");
-}
-
 }  // namespace
 
-size_t image_to_tensor_scratch_bytes(int width, int height, int stride, const mi_rect* roi, int out_w, int out_h, bool keep_aspect) {
-    Geom g = make_geom(width, height, roi, out_w, out_h, keep_aspect);
-    size_t n = align256(static_cast<size_t>(stride) * height) + align256(static_cast<size_t>(g.warp_w) * g.warp_h * 3);
-    if (keep_aspect) n += align256(static_cast<size_t>(g.new_w) * g.new_h * 3) + align256(static_cast<size_t>(out_w) * out_h * 3);
-    return n + 256;
+void launch_pre_geom(const PreItems& it, PreGeom* d_geom, double* d_padding, hipStream_t s) {
+    if (it.N <= 0) return;
+    hipLaunchKernelGGL(pre_geom_kernel, dim3((it.N + 63) / 64), dim3(64), 0, s, it, d_geom, d_padding);
+    hip_check(hipGetLastError(), "pre_geom kernel launch");
+}
+
+void launch_pre_tensor(const PreItems& it, const PreGeom* d_geom, float* d_out, hipStream_t s) {
+    if (it.N <= 0) return;
+    dim3 grid((it.out_w * it.out_h + 255) / 256, it.N);
+    hipLaunchKernelGGL(pre_tensor_kernel, grid, dim3(256), 0, s, it, d_geom, d_out);
+    hip_check(hipGetLastError(), "pre_tensor kernel launch");
+}
+
+void launch_face_rois(const float* d_dets, const int* d_counts, int B, int cap, int image_w, int image_h, RectD* d_rois, int* d_valid, hipStream_t s) {
+    hipLaunchKernelGGL(face_roi_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d_dets, d_counts, B, cap, image_w, image_h, d_rois, d_valid);
+    hip_check(hipGetLastError(), "face_roi kernel launch");
+}
+
+void launch_iris_rois(const float* d_landmarks, const int* d_present, int B, int image_w, int image_h, RectD* d_rois, int* d_valid, int* d_flip,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(iris_roi_kernel, dim3((2 * B + 63) / 64), dim3(64), 0, s, d_landmarks, d_present, B, image_w, image_h, d_rois, d_valid, d_flip);
+    hip_check(hipGetLastError(), "iris_roi kernel launch");
+}
+
+size_t image_to_tensor_scratch_bytes(int width, int height, int stride, const mi_rect*, int, int, bool) {
+    (void)width;
+    return align256(static_cast<size_t>(stride) * height) + align256(sizeof(PreGeom)) + 256;
 }
 
 void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
                             bool keep_aspect, double range_min, double range_max, bool flip, float* d_out, double padding[4],
                             void* d_scratch, hipStream_t s) {
-    Geom g = make_geom(width, height, roi, out_w, out_h, keep_aspect);
-    uint8_t* base = static_cast<uint8_t*>(d_scratch);
-    uint8_t* d_img = base;
-    uint8_t* d_warp = d_img + align256(static_cast<size_t>(stride) * height);
-    uint8_t* d_mid = d_warp + align256(static_cast<size_t>(g.warp_w) * g.warp_h * 3);
-    uint8_t* d_fin = d_mid + align256(static_cast<size_t>(g.new_w) * g.new_h * 3);
+    static_assert(sizeof(mi_rect) == sizeof(RectD), "mi_rect layout");
+    RectD r;
+    if (roi) std::memcpy(&r, roi, sizeof r);
+    const PreGeom g = compute_geom(width, height, roi ? &r : nullptr, out_w, out_h, keep_aspect);  // same code as the device path
+    if (!g.valid) throw std::runtime_error("ROI is empty or degenerate (singular perspective transform)");
+    uint8_t* d_img = static_cast<uint8_t*>(d_scratch);
+    PreGeom* d_geom = reinterpret_cast<PreGeom*>(d_img + align256(static_cast<size_t>(stride) * height));
     hip_check(hipMemcpyAsync(d_img, rgb_host, static_cast<size_t>(stride) * height, hipMemcpyHostToDevice, s), "H2D image");
-
-    WarpArgs wa{};
-    wa.src = d_img; wa.sw = width; wa.sh = height; wa.sstride = stride;
-    wa.dst = d_warp; wa.dw = g.warp_w; wa.dh = g.warp_h;
-    std::memcpy(wa.M, g.Minv, sizeof wa.M);
-    // OpenCV tile geometry (BLOCK_SZ = 32): bh0 = min(16, h); bw0 = min(1024 / bh0, w); bh0 = min(1024 / bw0, h)
-    wa.bh0 = std::min(16, g.warp_h);
-    wa.bw0 = std::min(1024 / wa.bh0, g.warp_w);
-    wa.bh0 = std::min(1024 / wa.bw0, g.warp_h);
-    {
-        dim3 blk(32, 8), grd((g.warp_w + 31) / 32, (g.warp_h + 7) / 8);
-        hipLaunchKernelGGL(warp_u8_kernel, grd, blk, 0, s, wa);
-        hip_check(hipGetLastError(), "warp kernel launch");
+    hip_check(hipMemcpyAsync(d_geom, &g, sizeof g, hipMemcpyHostToDevice, s), "H2D geometry");
+    PreItems it{};
+    it.frames = d_img; it.frame_bytes = 0; it.width = width; it.height = height; it.stride = stride;
+    it.items_per_frame = 1; it.N = 1; it.out_w = out_w; it.out_h = out_h; it.keep_aspect = keep_aspect;
+    it.range_min = range_min; it.range_max = range_max;
+    int* d_flip = nullptr;
+    if (flip) {  // flip flag lives right after the geometry
+        d_flip = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(d_geom) + sizeof(PreGeom));
+        const int one = 1;
+        hip_check(hipMemcpyAsync(d_flip, &one, sizeof one, hipMemcpyHostToDevice, s), "H2D flip");
     }
-    const uint8_t* cur = d_warp;
-    int cw = g.warp_w, ch = g.warp_h;
-    if (keep_aspect) {
-        if (g.two_stage) {
-            if (cw + 2 * g.pad_h == g.new_w && ch + 2 * g.pad_v == g.new_h) {
-                // same-size resize is a copy in OpenCV: fold the border into the next resize instead of materialising it
-                launch_resize(cur, cw, ch, g.pad_h, g.pad_v, d_fin, out_w, out_h, s);
-                cur = d_fin; cw = out_w; ch = out_h;
-            } else {
-                launch_resize(cur, cw, ch, g.pad_h, g.pad_v, d_mid, g.new_w, g.new_h, s);
-                cur = d_mid; cw = g.new_w; ch = g.new_h;
-            }
-        }
-        if (!(cur == d_fin)) {
-            if (cw == out_w && ch == out_h) {
-                // cv::resize to the same size copies
-            } else {
-                launch_resize(cur, cw, ch, 0, 0, d_fin, out_w, out_h, s);
-                cur = d_fin; cw = out_w; ch = out_h;
-            }
-        }
-    }
-    {
-        dim3 blk(32, 8), grd((cw + 31) / 32, (ch + 7) / 8);
-        hipLaunchKernelGGL(normalize_kernel, grd, blk, 0, s, cur, cw, ch, flip ? 1 : 0, range_min, range_max, d_out);
-        hip_check(hipGetLastError(), "normalize kernel launch");
-    }
+    it.flip = d_flip;
+    launch_pre_tensor(it, d_geom, d_out, s);
+    // the H2D copies above read host stack variables: make sure they are consumed before returning
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
     padding[0] = g.pad_x; padding[1] = g.pad_y; padding[2] = g.pad_x; padding[3] = g.pad_y;
 }
 

@@ -306,3 +306,72 @@ def test_batch256_properties(gpu, gold):
         s = out[b, : min(counts[b], 16), 16]
         assert np.all(np.diff(s) <= 0) and np.all(s > 0.5)
     fd.close()
+
+
+def _oracle_pipeline(oracle, models, img):
+    """lib.rs:18-40 through the oracle, one frame."""
+    fd, fl, ir = models
+    H, W = img.shape[:2]
+    t, pad = oracle.image_to_tensor(img, None, (256, 256), True, (-1., 1.), False)
+    rb, rs = fd.run(t[None])
+    dets = oracle.fd_postprocess(rb[0], rs[0], oracle.ssd_anchors(oracle.FD_BACK), 256.0, pad)
+    res = dict(count=len(dets), face=None, landmarks=None, eyes=None)
+    if not len(dets):
+        return res
+    res["face"] = dets[0]
+    roi = oracle.face_detection_to_roi(dets[0], (W, H))
+    t2, pad2 = oracle.image_to_tensor(img, roi, (192, 192), False, (0., 1.), False)
+    raw, flag = fl.run(t2[None])
+    if not oracle.lib().orc_face_flag_passes(float(flag.reshape(-1)[-1])):
+        return res
+    lms = oracle.project_landmarks(raw[0], (192, 192), (W, H), pad2, roi, False)
+    res["landmarks"] = lms
+    left, right = oracle.iris_rois_from_face_landmarks(lms, (W, H))
+    eyes = []
+    for r, is_right in ((left, False), (right, True)):
+        t3, pad3 = oracle.image_to_tensor(img, r, (64, 64), True, (0., 1.), is_right)
+        c, i5 = ir.run(t3[None])
+        eyes.append(np.concatenate([oracle.project_landmarks(c[0], (64, 64), (W, H), pad3, r, is_right),
+                                    oracle.project_landmarks(i5[0], (64, 64), (W, H), pad3, r, is_right)]))
+    res["eyes"] = np.stack(eyes)
+    return res
+
+
+def test_batched_device_pipeline_vs_oracle(gpu, oracle, man_image):
+    """BASELINE config 5 shape at test size: frames -> detector -> faces[0] ROI -> mesh -> eye ROIs -> iris, all on the GPU."""
+    img = man_image
+    frames = np.stack([
+        img,
+        np.roll(img, (12, -30), axis=(0, 1)),
+        img[:, ::-1].copy(),                                    # mirrored face
+        (img.astype(np.float32) * 0.6).astype(np.uint8),        # darker
+        np.zeros_like(img),                                     # no face
+        np.random.RandomState(3).randint(0, 256, img.shape).astype(np.uint8),  # noise
+    ])
+    pipe = gpu.Pipeline(gpu.FaceDetectionModel.BackCamera)
+    out = pipe.run(frames)
+    models = (oracle.Model(model_path("back")), oracle.Model(model_path("landmark")), oracle.Model(model_path("iris")))
+    n_faces = 0
+    for b in range(len(frames)):
+        ref = _oracle_pipeline(oracle, models, frames[b])
+        assert out["face_counts"][b] == ref["count"], b
+        if ref["face"] is None:
+            assert out["present"][b] == 0 and not out["faces"][b].any() and not out["landmarks"][b].any() and not out["eyes"][b].any()
+            continue
+        n_faces += 1
+        assert _iou(out["faces"][b][:4], ref["face"][:4]) >= 0.999
+        np.testing.assert_allclose(out["faces"][b], ref["face"], atol=2e-3)
+        assert out["present"][b] == (ref["landmarks"] is not None)
+        if ref["landmarks"] is not None:
+            np.testing.assert_allclose(out["landmarks"][b], ref["landmarks"], atol=3e-3)
+            np.testing.assert_allclose(out["eyes"][b], ref["eyes"], atol=5e-3)
+    assert n_faces >= 4
+    # device-resident frames give the same answer
+    torch = pytest.importorskip("torch")
+    fd = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    out2 = pipe.run(fd)
+    torch.cuda.synchronize()
+    for k in out:
+        np.testing.assert_array_equal(out2[k].cpu().numpy(), out[k])
+    pipe.close()
