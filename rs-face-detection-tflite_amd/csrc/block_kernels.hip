@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
                 for (int m = 0; m < MTG; m++)
 #pragma unroll
                     for (int e = 0; e < 16; e++) D[p][m][e] = 0.f;
+            if constexpr (MTG < 2) {
             for (int j = 0; j < (g.Ch >> 2); j++) {
                 // A fragments of tiles mt0.., k-steps 4j..4j+3: packed [mt][j][lane][4]
                 float4 av[MTG];
@@ -284,6 +285,83 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom g) {
                         D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf[p].w, D[p][m], 0, 0, 0);
                     }
                 }
+            }
+            } else {
+            // Two or more output-channel tiles: software pipeline over channel chunks — the MFMAs of chunk j (matrix pipe)
+            // are issued in the same basic block as the depthwise math of chunk j+1 (VALU + LDS) and interleaved with it
+            // (sched_group_barrier), +4..8 % on the 48- and 96-channel layers.  With one tile the extra live registers
+            // cost a resident workgroup, so the single-tile variants keep the simple loop above.
+                const int nch = g.Ch >> 2;
+                auto dw_chunk = [&](int j, float4 (&bf)[PG]) {
+                    if (KS == 3) {
+                        const float* wj = wdw + h * g.Ch + 4 * j;
+#pragma unroll
+                        for (int p = 0; p < PG; p++) bf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) {
+                                const float4 w = ld4(wj + (ky * 3 + kx) * g.Cp);
+#pragma unroll
+                                for (int p = 0; p < PG; p++) {
+                                    const float4 d = ld4(tile + base[p][ky] + kx * g.PS + 4 * j);
+                                    bf[p].x = fmaf(d.x, w.x, bf[p].x);
+                                    bf[p].y = fmaf(d.y, w.y, bf[p].y);
+                                    bf[p].z = fmaf(d.z, w.z, bf[p].z);
+                                    bf[p].w = fmaf(d.w, w.w, bf[p].w);
+                                }
+                            }
+                        const float4 bb = ld4(bdw + h * g.Ch + 4 * j);
+#pragma unroll
+                        for (int p = 0; p < PG; p++) { bf[p].x += bb.x; bf[p].y += bb.y; bf[p].z += bb.z; bf[p].w += bb.w; }
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < PG; p++) bf[p] = ld4(tile + base[p][0] + 4 * j);
+                    }
+                };
+                auto a_frag = [&](int j, float4 (&av)[MTG]) {
+#pragma unroll
+                    for (int m = 0; m < MTG; m++) {
+                        int mt = min(mt0 + m, g.MT - 1);
+                        long ao = (((long)mt * nch + j) * 64 + lane) * 4;
+                        av[m] = (SLOW && !g.a_lds) ? ld4(a.w_pw + ao) : ld4(aL + ao);
+                    }
+                };
+                auto mfma_chunk = [&](const float4 (&av)[MTG], const float4 (&bf)[PG]) {
+#pragma unroll
+                    for (int m = 0; m < MTG; m++)
+#pragma unroll
+                        for (int p = 0; p < PG; p++) {
+                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bf[p].x, D[p][m], 0, 0, 0);
+                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bf[p].y, D[p][m], 0, 0, 0);
+                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bf[p].z, D[p][m], 0, 0, 0);
+                            D[p][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf[p].w, D[p][m], 0, 0, 0);
+                        }
+                };
+                float4 bf[PG], av[MTG];
+                dw_chunk(0, bf);
+                a_frag(0, av);
+                for (int j = 0; j + 1 < nch; j++) {
+                    float4 bn[PG], an[MTG];
+                    mfma_chunk(av, bf);
+                    a_frag(j + 1, an);
+                    dw_chunk(j + 1, bn);
+#pragma unroll
+                    for (int p = 0; p < PG; p++) bf[p] = bn[p];
+#pragma unroll
+                    for (int m = 0; m < MTG; m++) av[m] = an[m];
+                    if (KS == 3) {
+                        // program order: one MFMA (64 cycles of matrix pipe), then a slice of the next chunk's LDS reads + FMAs
+                        constexpr int NM = 4 * MTG * PG, ND = 10 + 9 * PG + MTG, NV = 20 * PG;
+#pragma unroll
+                        for (int k = 0; k < NM; k++) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, (ND + NM - 1) / NM, 0);  // DS read
+                            __builtin_amdgcn_sched_group_barrier(0x002, (NV + NM - 1) / NM, 0);  // VALU
+                        }
+                    }
+                }
+                mfma_chunk(av, bf);
             }
             MI_STAMP(1)
             // ---- epilogue: lane holds pixel pl, output channels (mt*32 + 8*gq + 4*h .. +3) in D[..][4*gq .. 4*gq+3]

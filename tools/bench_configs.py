@@ -1,0 +1,54 @@
+"""Secondary BASELINE configs (parity-test cases, not the bench line): config 3 (FaceLandmark 192x192, batch 512) and
+config 5 (full_range detector -> mesh -> iris pipeline, 128 frames/GPU).  Prints one JSON line per config."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import rs_face_detection_tflite_amd as mi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+gold = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+
+def timeit(fn, n=20, w=5):
+    for _ in range(w): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
+
+# config 3
+fl = mi.FaceLandmark()
+B = 512
+rs = np.random.RandomState(0)
+x = rs.uniform(0, 1, (B, 192, 192, 3)).astype(np.float32)
+x[1::2] = gold["man_face_u8"].astype(np.float32) / 255.0
+xd = torch.from_numpy(x).cuda()
+dt = timeit(lambda: fl.infer_tensor(xd))
+print(json.dumps({"config": "FaceLandmark 192x192 batch 512 (net + projection + face flag)", "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(B / dt)}))
+recs = fl.model.profile(xd, reps=3)
+by = {}
+for r in recs:
+    k = by.setdefault(r["kernel"], [0.0, 0]); k[0] += r["ms"]; k[1] += 1
+print("   ", {k: (round(v[0], 3), v[1]) for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])})
+
+# iris alone
+ir = mi.IrisLandmark()
+xe = torch.rand((1024, 64, 64, 3), device="cuda")
+dt = timeit(lambda: ir.infer_tensor(xe))
+print(json.dumps({"config": "IrisLandmark 64x64 batch 1024", "ms_per_batch": round(dt * 1e3, 3), "eyes_per_s": round(1024 / dt)}))
+recs = ir.model.profile(xe, reps=3)
+by = {}
+for r in recs:
+    k = by.setdefault(r["kernel"], [0.0, 0]); k[0] += r["ms"]; k[1] += 1
+print("   ", {k: (round(v[0], 3), v[1]) for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])})
+
+# config 5
+from PIL import Image
+img = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "man.jpg")).convert("RGB").resize((192, 192)))
+B = 128
+frames = np.stack([np.roll(img, (int(rs.randint(-10, 11)), int(rs.randint(-10, 11))), axis=(0, 1)) if b % 2 else rs.randint(0, 256, img.shape).astype(np.uint8) for b in range(B)])
+fd_ = torch.from_numpy(frames).cuda()
+pipe = mi.Pipeline(mi.FaceDetectionModel.Full)
+out = pipe.run(fd_)
+torch.cuda.synchronize()
+dt = timeit(lambda: pipe.run(fd_))
+print(json.dumps({"config": "full_range 192x192 -> face_landmark -> 2x iris, 128 frames/GPU, all on device", "ms_per_batch": round(dt * 1e3, 3),
+                  "frames_per_s": round(B / dt), "faces_found": int((out["face_counts"] > 0).sum().item()), "meshes": int(out["present"].sum().item())}))
