@@ -1,0 +1,189 @@
+// mi_face.hpp — C++17 host-side mirror of the reference crate's public API over the C ABI (mi_face.h).
+//
+// The reference is compiled (Rust) code; no Rust toolchain exists in this image, so the host side above the C ABI is
+// written in C++ with the reference's names, argument meaning and error behaviour:
+//   FaceDetection::{new, infer}   /root/reference/src/face_detection_lite/face_detection.rs:153,205
+//   FaceLandmark::{new, infer}    face_landmark.rs:208,232        face_detection_to_roi  face_landmark.rs:180
+//   IrisLandmark::{new, infer}    iris_landmark.rs:142,158        iris_roi_from_face_landmarks iris_landmark.rs:268
+//   Detection / Rect / Landmark / BBox / IrisResults             types.rs:24-246, iris_landmark.rs:115-129
+// `anyhow::Error` (and the reference's panics) become `mi_face::Error`; `Option<T>` becomes `std::optional<T>`;
+// `&Mat` (8UC3 RGB, utils.rs:8-21) becomes the non-owning `Image` view.  Header-only; link with -lmiface.
+#pragma once
+
+#include <array>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mi_face.h"
+
+namespace mi_face {
+
+class Error : public std::runtime_error {
+   public:
+    Error(int code, const std::string& msg) : std::runtime_error(msg), code_(code) {}
+    int code() const { return code_; }
+
+   private:
+    int code_;
+};
+
+namespace detail {
+inline void check(int rc) {
+    if (rc != MI_OK) throw Error(rc, mi_last_error());
+}
+}  // namespace detail
+
+// types.rs:24-36
+struct Rect {
+    double x_center = 0.5, y_center = 0.5, width = 1.0, height = 1.0, rotation = 0.0;
+    bool normalized = true;
+    mi_rect c() const { return mi_rect{x_center, y_center, width, height, rotation, normalized ? 1 : 0}; }
+    static Rect from(const mi_rect& r) { return Rect{r.x_center, r.y_center, r.width, r.height, r.rotation, r.normalized != 0}; }
+};
+
+// types.rs:99-174 (the parts callers use)
+struct BBox {
+    double xmin, ymin, xmax, ymax;
+    double width() const { return xmax - xmin; }
+    double height() const { return ymax - ymin; }
+};
+
+// types.rs:176-187
+struct Landmark {
+    double x, y, z;
+};
+
+// types.rs:189-246: data is [8][2] = (xmin,ymin), (xmax,ymax), 6 keypoints
+struct Detection {
+    std::array<float, 16> data{};
+    float score = 0.f;
+    std::size_t keypoint_count() const { return 6; }
+    std::pair<float, float> keypoint(std::size_t k) const { return {data[2 * (k + 2)], data[2 * (k + 2) + 1]}; }
+    BBox bbox() const { return BBox{data[0], data[1], data[2], data[3]}; }
+};
+
+// iris_landmark.rs:115-129
+struct IrisResults {
+    std::vector<Landmark> contour;  // 71
+    std::vector<Landmark> iris;     // 5
+    std::vector<Landmark> eyeball_contour() const { return std::vector<Landmark>(contour.begin(), contour.begin() + 15); }
+};
+
+// face_detection.rs:117-123
+enum class FaceDetectionModel { FrontCamera = 0, BackCamera = 1, Short = 2, Full = 3, FullSparse = 4 };
+
+// Stand-in for `&opencv::core::Mat` holding 8UC3 RGB pixels (utils.rs:8-21); does not own the pixels.
+struct Image {
+    const std::uint8_t* rgb;
+    int width, height;
+    int stride;  // bytes per row
+};
+
+class FaceDetection {
+   public:
+    // FaceDetection::new(model_type, model_path): model_path is a DIRECTORY, default "./models" (face_detection.rs:157-161)
+    explicit FaceDetection(FaceDetectionModel model_type, std::optional<std::string> model_path = std::nullopt, int device = 0) {
+        detail::check(mi_fd_create(static_cast<int>(model_type), model_path ? model_path->c_str() : nullptr, device, &h_));
+    }
+    ~FaceDetection() { mi_fd_free(h_); }
+    FaceDetection(const FaceDetection&) = delete;
+    FaceDetection& operator=(const FaceDetection&) = delete;
+
+    // FaceDetection::infer(&Mat, Option<Rect>) -> Vec<Detection> (face_detection.rs:205-267)
+    std::vector<Detection> infer(const Image& image, std::optional<Rect> roi = std::nullopt) const {
+        std::vector<mi_detection> out(256);
+        int n = 0;
+        mi_rect r{};
+        if (roi) r = roi->c();
+        detail::check(mi_fd_infer_image(h_, image.rgb, image.width, image.height, image.stride, roi ? &r : nullptr, out.data(),
+                                        static_cast<int>(out.size()), &n));
+        std::vector<Detection> dets(static_cast<std::size_t>(n < 256 ? n : 256));
+        for (std::size_t i = 0; i < dets.size(); i++) {
+            for (int k = 0; k < 16; k++) dets[i].data[k] = out[i].data[k];
+            dets[i].score = out[i].score;
+        }
+        return dets;
+    }
+    mi_fd* handle() const { return h_; }
+
+   private:
+    mi_fd* h_ = nullptr;
+};
+
+class FaceLandmark {
+   public:
+    // FaceLandmark::new(model_path): FILE path, default "./models/face_landmark.tflite" (face_landmark.rs:211-215)
+    explicit FaceLandmark(std::optional<std::string> model_path = std::nullopt, int device = 0) {
+        detail::check(mi_fl_create(model_path ? model_path->c_str() : nullptr, device, &h_));
+    }
+    ~FaceLandmark() { mi_fl_free(h_); }
+    FaceLandmark(const FaceLandmark&) = delete;
+    FaceLandmark& operator=(const FaceLandmark&) = delete;
+
+    // FaceLandmark::infer(&Mat, Option<Rect>) -> Vec<Landmark>; empty when the face flag fails (face_landmark.rs:292-296)
+    std::vector<Landmark> infer(const Image& image, std::optional<Rect> roi = std::nullopt) const {
+        std::vector<mi_landmark> out(MI_NUM_FACE_LANDMARKS);
+        int n = 0;
+        mi_rect r{};
+        if (roi) r = roi->c();
+        detail::check(mi_fl_infer_image(h_, image.rgb, image.width, image.height, image.stride, roi ? &r : nullptr, out.data(),
+                                        MI_NUM_FACE_LANDMARKS, &n));
+        std::vector<Landmark> lm(static_cast<std::size_t>(n));
+        for (std::size_t i = 0; i < lm.size(); i++) lm[i] = Landmark{out[i].x, out[i].y, out[i].z};
+        return lm;
+    }
+
+   private:
+    mi_fl* h_ = nullptr;
+};
+
+class IrisLandmark {
+   public:
+    explicit IrisLandmark(std::optional<std::string> model_path = std::nullopt, int device = 0) {
+        detail::check(mi_iris_create(model_path ? model_path->c_str() : nullptr, device, &h_));
+    }
+    ~IrisLandmark() { mi_iris_free(h_); }
+    IrisLandmark(const IrisLandmark&) = delete;
+    IrisLandmark& operator=(const IrisLandmark&) = delete;
+
+    // IrisLandmark::infer(&Mat, Option<Rect>, Option<bool>) -> IrisResults (iris_landmark.rs:158-248)
+    IrisResults infer(const Image& image, std::optional<Rect> roi = std::nullopt, std::optional<bool> is_right_eye = std::nullopt) const {
+        mi_landmark c[MI_NUM_EYE_LANDMARKS], i5[MI_NUM_IRIS_LANDMARKS];
+        mi_rect r{};
+        if (roi) r = roi->c();
+        detail::check(mi_iris_infer_image(h_, image.rgb, image.width, image.height, image.stride, roi ? &r : nullptr,
+                                          is_right_eye.value_or(false) ? 1 : 0, c, i5));
+        IrisResults res;
+        for (const auto& v : c) res.contour.push_back(Landmark{v.x, v.y, v.z});
+        for (const auto& v : i5) res.iris.push_back(Landmark{v.x, v.y, v.z});
+        return res;
+    }
+
+   private:
+    mi_iris* h_ = nullptr;
+};
+
+// face_detection_to_roi(face_detection, image_size, None) (face_landmark.rs:180-198); image_size = (width, height)
+inline Rect face_detection_to_roi(const Detection& d, std::pair<int, int> image_size) {
+    mi_detection c{};
+    for (int k = 0; k < 16; k++) c.data[k] = d.data[k];
+    c.score = d.score;
+    mi_rect r{};
+    detail::check(mi_face_detection_to_roi(&c, image_size.first, image_size.second, &r));
+    return Rect::from(r);
+}
+
+// iris_roi_from_face_landmarks(face_landmarks, image_size) -> (left_eye_roi, right_eye_roi) (iris_landmark.rs:268-292)
+inline std::pair<Rect, Rect> iris_roi_from_face_landmarks(const std::vector<Landmark>& lm, std::pair<int, int> image_size) {
+    if (lm.size() < MI_NUM_FACE_LANDMARKS) throw Error(MI_EINVAL, "expected 468 face landmarks");  // the reference would panic on lm[362]
+    std::vector<mi_landmark> c(MI_NUM_FACE_LANDMARKS);
+    for (int i = 0; i < MI_NUM_FACE_LANDMARKS; i++) c[i] = mi_landmark{lm[i].x, lm[i].y, lm[i].z};
+    mi_rect l{}, r{};
+    detail::check(mi_iris_roi_from_face_landmarks(c.data(), image_size.first, image_size.second, &l, &r));
+    return {Rect::from(l), Rect::from(r)};
+}
+
+}  // namespace mi_face

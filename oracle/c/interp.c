@@ -427,7 +427,12 @@ int orc_model_run(const orc_model *m, const float *in, int batch, float *const *
     if (nthreads < 1) nthreads = 1;
 #pragma omp parallel num_threads(nthreads)
     {
-        float *arena = (float *)malloc((m->arena_elems ? m->arena_elems : 1) * sizeof(float));
+        /* per-thread arena kept across calls: re-faulting ~60 MB per thread per call dominated multi-threaded runs */
+        static __thread float *t_arena = NULL;
+        static __thread size_t t_cap = 0;
+        size_t need = (m->arena_elems ? m->arena_elems : 1);
+        if (need > t_cap) { free(t_arena); t_arena = (float *)malloc(need * sizeof(float)); t_cap = need; }
+        float *arena = t_arena;
         char lerr[256];
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < batch; b++) {
@@ -442,7 +447,6 @@ int orc_model_run(const orc_model *m, const float *in, int batch, float *const *
                 memcpy(outs[k] + (size_t)b * m->elems[ti], src, m->elems[ti] * 4);
             }
         }
-        free(arena);
     }
     if (failed) { snprintf(g_err, sizeof(g_err), "%s", err); return -1; }
     return 0;
