@@ -1,0 +1,231 @@
+// chain_kernels.hip — frame-resident chains of BlazeBlocks for the small-spatial, channel-heavy stages.
+//
+// At 16x16x96 (BackCamera, 7 consecutive blocks), 12x12x128 / 6x6x128 (face mesh) … a whole frame fits in the 160 KB LDS
+// of a CU, while per-block launches are latency-bound (few pixels, 144 dependent MFMAs per 32-pixel group).  Here ONE
+// 512-thread workgroup loads a frame into LDS once, runs every block of the chain on it
+//     x <- act( PW1x1( DW3x3(x) + b_dw ) + b_pw + x )
+// and writes the frame back once: the chain's intermediate activations never touch HBM (6 of 7 round trips removed for
+// the 16x16 stage) and 7 launches become 1.  (Replaces the same TFLite op chains as block_kernels.hip; reference call
+// site /root/reference/src/face_detection_lite/face_detection.rs:235.)
+//
+//   * each of the 8 waves owns one 32-pixel group of the frame for the whole chain (H*W <= 256);
+//   * per block: depthwise 3x3 on the VALU in the MFMA B-operand layout (lane = pixel x k-half, see block_kernels.hip),
+//     v_mfma_f32_32x32x2_f32 over all output-channel tiles, the MFMAs of channel chunk j interleaved with the depthwise
+//     math of chunk j+1; pointwise weights stream from L2 in A-fragment order, one chunk ahead;
+//   * epilogue values stay in registers across a workgroup barrier (all reads of x done), then overwrite x in place.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace mi {
+
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ float4 cld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct ChainGeom {
+    int Cp, Ch, C4, PS, RS, MT;
+    int off_wdw, off_bdw, off_bias, off_alpha;  // LDS offsets (floats)
+    int lds_bytes;
+};
+
+template <int MT>
+__global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tile = lds;  // [(H+2)][(W+2)][PS], zero border
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const int b = blockIdx.x;
+    const float* in = a.in + (long)b * a.in_fs;
+    const int rowf4 = a.W * g.C4;
+    const int nch = g.Ch >> 2;
+
+    // ---- load the frame (coalesced), zero border / pad channels
+    for (int i = tid; i < ((a.H + 2) * g.RS) >> 2; i += 512) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int i = tid; i < a.H * rowf4; i += 512) {
+        int r = i / rowf4, e = i - r * rowf4;
+        int px = e / g.C4, c4 = e - px * g.C4;
+        *reinterpret_cast<float4*>(tile + (r + 1) * g.RS + (px + 1) * g.PS + 4 * c4) = cld4(in + 4 * (long)i);
+    }
+    // this wave's pixel group
+    const int q = wave * 32 + pl;
+    const bool valid = q < a.H * a.W;
+    const int oy = valid ? q / a.W : 0, ox = valid ? q - (q / a.W) * a.W : 0;
+    const bool wave_active = wave * 32 < a.H * a.W;
+    const int base0 = oy * g.RS + ox * g.PS + h * g.Ch;  // tap (ky, kx) = base0 + ky*RS + kx*PS (input row oy-1+ky at slot oy+ky)
+    float* centre = tile + (oy + 1) * g.RS + (ox + 1) * g.PS;
+
+    for (int blk = 0; blk < a.nblocks; blk++) {
+        const ChainBlock& cb = a.blocks[blk];
+        // ---- stage this block's small constants (previous block's readers are past the barrier below)
+        for (int i = tid; i < 9 * g.Cp; i += 512) {
+            int c = i % g.Cp;
+            lds[g.off_wdw + i] = c < a.C ? cb.w_dw[(i / g.Cp) * a.C + c] : 0.f;
+        }
+        for (int i = tid; i < g.Cp; i += 512) lds[g.off_bdw + i] = (i < a.C && cb.b_dw) ? cb.b_dw[i] : 0.f;
+        for (int i = tid; i < MT * 32; i += 512) {
+            lds[g.off_bias + i] = (i < a.C && cb.bias) ? cb.bias[i] : 0.f;
+            lds[g.off_alpha + i] = (i < a.C && cb.act == ACT_PRELU) ? cb.alpha[i] : (cb.act == ACT_NONE ? 1.f : 0.f);
+        }
+        __syncthreads();
+        const float* wdw = lds + g.off_wdw;
+        const float* bdw = lds + g.off_bdw;
+
+        f32x16c D[MT];
+        if (wave_active) {
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) D[m][e] = 0.f;
+            auto dw_chunk = [&](int j, float4& bf) {
+                const float* wj = wdw + h * g.Ch + 4 * j;
+                bf = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float4 w = cld4(wj + (ky * 3 + kx) * g.Cp);
+                        const float4 d = cld4(tile + base0 + ky * g.RS + kx * g.PS + 4 * j);
+                        bf.x = fmaf(d.x, w.x, bf.x);
+                        bf.y = fmaf(d.y, w.y, bf.y);
+                        bf.z = fmaf(d.z, w.z, bf.z);
+                        bf.w = fmaf(d.w, w.w, bf.w);
+                    }
+                const float4 bb = cld4(bdw + h * g.Ch + 4 * j);
+                bf.x += bb.x; bf.y += bb.y; bf.z += bb.z; bf.w += bb.w;
+            };
+            auto a_frag = [&](int j, float4 (&av)[MT]) {  // packed [tile][chunk][lane][4] in global/L2
+#pragma unroll
+                for (int m = 0; m < MT; m++) av[m] = cld4(cb.w_pw + (((long)m * nch + j) * 64 + lane) * 4);
+            };
+            auto mfma_chunk = [&](const float4 (&av)[MT], const float4& bf) {
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bf.x, D[m], 0, 0, 0);
+                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bf.y, D[m], 0, 0, 0);
+                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bf.z, D[m], 0, 0, 0);
+                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf.w, D[m], 0, 0, 0);
+                }
+            };
+            float4 bf, av[MT];
+            dw_chunk(0, bf);
+            a_frag(0, av);
+            for (int j = 0; j + 1 < nch; j++) {
+                float4 bn, an[MT];
+                mfma_chunk(av, bf);
+                a_frag(j + 1, an);
+                dw_chunk(j + 1, bn);
+                bf = bn;
+#pragma unroll
+                for (int m = 0; m < MT; m++) av[m] = an[m];
+                constexpr int NM = 4 * MT;
+#pragma unroll
+                for (int k = 0; k < NM; k++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, (19 + NM - 1) / NM, 0);  // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, (20 + NM - 1) / NM, 0);  // VALU
+                }
+            }
+            mfma_chunk(av, bf);
+            // ---- epilogue into registers (reads x at the centre pixel), written back after the barrier
+            const float hi = cb.act == ACT_RELU6 ? 6.f : INFINITY;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = m * 32 + 8 * gq + 4 * h;
+                    if (ch >= a.C) continue;
+                    const float4 bb = cld4(lds + g.off_bias + ch), al = cld4(lds + g.off_alpha + ch);
+                    float4 v = make_float4(D[m][4 * gq] + bb.x, D[m][4 * gq + 1] + bb.y, D[m][4 * gq + 2] + bb.z, D[m][4 * gq + 3] + bb.w);
+                    if (cb.has_res) {
+                        const float4 rv = cld4(centre + ch);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    D[m][4 * gq] = fminf(fmaxf(v.x, 0.f) + al.x * fminf(v.x, 0.f), hi);
+                    D[m][4 * gq + 1] = fminf(fmaxf(v.y, 0.f) + al.y * fminf(v.y, 0.f), hi);
+                    D[m][4 * gq + 2] = fminf(fmaxf(v.z, 0.f) + al.z * fminf(v.z, 0.f), hi);
+                    D[m][4 * gq + 3] = fminf(fmaxf(v.w, 0.f) + al.w * fminf(v.w, 0.f), hi);
+                }
+        }
+        __syncthreads();  // every wave has read x for this block
+        if (wave_active && valid) {
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = m * 32 + 8 * gq + 4 * h;
+                    if (ch >= a.C) continue;
+                    *reinterpret_cast<float4*>(centre + ch) = make_float4(D[m][4 * gq], D[m][4 * gq + 1], D[m][4 * gq + 2], D[m][4 * gq + 3]);
+                }
+        }
+        __syncthreads();
+    }
+    // ---- write the frame back (coalesced 16 B per lane, consecutive addresses)
+    float* out = a.out + (long)b * a.out_fs;
+    for (int i = tid; i < a.H * rowf4; i += 512) {
+        int r = i / rowf4, e = i - r * rowf4;
+        int px = e / g.C4, c4 = e - px * g.C4;
+        *reinterpret_cast<float4*>(out + 4 * (long)i) = cld4(tile + (r + 1) * g.RS + (px + 1) * g.PS + 4 * c4);
+    }
+}
+
+bool make_chain_geom(const ChainArgs& a, ChainGeom* out) {
+    ChainGeom g{};
+    if (a.C % 8 || a.H * a.W > 256 || a.nblocks < 1 || a.nblocks > kMaxChain) return false;
+    g.Cp = a.C; g.Ch = a.C / 2; g.C4 = a.C / 4; g.PS = a.C + 4; g.RS = (a.W + 2) * g.PS;
+    g.MT = (a.C + 31) / 32;
+    if (g.MT > 4) return false;
+    int off = (a.H + 2) * g.RS;
+    g.off_wdw = off; off += 9 * g.Cp;
+    g.off_bdw = off; off += g.Cp;
+    off = (off + 3) & ~3;
+    g.off_bias = off; off += g.MT * 32;
+    g.off_alpha = off; off += g.MT * 32;
+    g.lds_bytes = off * 4;
+    if (g.lds_bytes > 158 * 1024) return false;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!aligned16(a.in) || !aligned16(a.out) || (a.in_fs & 3) || (a.out_fs & 3)) return false;
+    *out = g;
+    return true;
+}
+
+template <int MT>
+int launch_chain_inst(const ChainArgs& a, const ChainGeom& g, hipStream_t s) {
+    auto kern = chain_kernel<MT>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(512), (size_t)g.lds_bytes, s, a, g);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool chain_kernel_supports(const ChainArgs& a) {
+    ChainGeom g;
+    return make_chain_geom(a, &g);
+}
+
+int launch_chain(const ChainArgs& a, void* stream) {
+    ChainGeom g;
+    if (!make_chain_geom(a, &g)) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch (g.MT) {
+        case 1: return launch_chain_inst<1>(a, g, s);
+        case 2: return launch_chain_inst<2>(a, g, s);
+        case 3: return launch_chain_inst<3>(a, g, s);
+        case 4: return launch_chain_inst<4>(a, g, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace mi

@@ -54,7 +54,7 @@ void Model::invalidate_graphs() {
 void Model::set_option(const std::string& key, int value) {
     if (key == "chunk") chunk_ = std::max(0, value);
     else if (key == "graph") use_graph_ = value != 0;
-    else if (key == "fuse") { fuse_level_ = std::min(2, std::max(0, value)); dirty_ = true; }
+    else if (key == "fuse") { fuse_level_ = std::min(3, std::max(0, value)); dirty_ = true; }
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
     else if (key == "lanes") lanes_ = std::min(4, std::max(1, value));
     else throw std::runtime_error("unknown option '" + key + "'");
@@ -83,8 +83,39 @@ void Model::rebuild() {
     };
     const size_t NN = plan_.nodes.size();
     node_w_.assign(NN, -1); node_b_.assign(NN, -1); node_w2_.assign(NN, -1); node_b2_.assign(NN, -1); node_alpha_.assign(NN, -1);
+    chain_off_.assign(NN, {});
+    // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
+    // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
+    auto pack_pw = [&](int wt) {
+        const auto& ws = g.tensors[wt].shape;
+        const auto& src = g.tensors[wt].f32;
+        int O = ws[0], I = ws[3], Cp, Cop;
+        block_weight_dims(I, O, &Cp, &Cop);
+        const int Ch = Cp / 2, MT = Cop / 32;
+        std::vector<float> r(static_cast<size_t>(Cop) * Cp, 0.f);
+        for (int mt = 0; mt < MT; mt++)
+            for (int j = 0; j < Ch / 4; j++)
+                for (int l = 0; l < 64; l++)
+                    for (int e2 = 0; e2 < 4; e2++) {
+                        int o = mt * 32 + (l & 31), c = (l >> 5) * Ch + 4 * j + e2;
+                        if (o < O && c < I) r[((static_cast<size_t>(mt) * (Ch / 4) + j) * 64 + l) * 4 + e2] = src[static_cast<size_t>(o) * I + c];
+                    }
+        return put(r);
+    };
     for (size_t i = 0; i < NN; i++) {
         const Node& n = plan_.nodes[i];
+        if (n.kind == Node::Chain) {
+            for (const Node& m : n.members) {
+                MemberOff mo;
+                mo.w = put(g.tensors[m.w].f32);
+                if (m.b >= 0) mo.b = put(g.tensors[m.b].f32);
+                mo.w2 = pack_pw(m.w2);
+                if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
+                if (m.alpha >= 0) mo.alpha = put(g.tensors[m.alpha].f32);
+                chain_off_[i].push_back(mo);
+            }
+            continue;
+        }
         if (n.b >= 0) node_b_[i] = put(g.tensors[n.b].f32);
         if (n.b2 >= 0) node_b2_[i] = put(g.tensors[n.b2].f32);
         if (n.alpha >= 0) node_alpha_[i] = put(g.tensors[n.alpha].f32);
@@ -103,22 +134,7 @@ void Model::rebuild() {
             node_w_[i] = put(g.tensors[n.w].f32);
         } else if (n.kind == Node::Block) {
             if (n.w >= 0) node_w_[i] = put(g.tensors[n.w].f32);
-            // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
-            // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
-            const auto& ws = g.tensors[n.w2].shape;
-            const auto& src = g.tensors[n.w2].f32;
-            int O = ws[0], I = ws[3], Cp, Cop;
-            block_weight_dims(I, O, &Cp, &Cop);
-            const int Ch = Cp / 2, MT = Cop / 32;
-            std::vector<float> r(static_cast<size_t>(Cop) * Cp, 0.f);
-            for (int mt = 0; mt < MT; mt++)
-                for (int j = 0; j < Ch / 4; j++)
-                    for (int l = 0; l < 64; l++)
-                        for (int e2 = 0; e2 < 4; e2++) {
-                            int o = mt * 32 + (l & 31), c = (l >> 5) * Ch + 4 * j + e2;
-                            if (o < O && c < I) r[((static_cast<size_t>(mt) * (Ch / 4) + j) * 64 + l) * 4 + e2] = src[static_cast<size_t>(o) * I + c];
-                        }
-            node_w2_[i] = put(r);
+            node_w2_[i] = pack_pw(n.w2);
         }
     }
     if (d_weights_) hip_check(hipFree(d_weights_), "hipFree");
@@ -182,6 +198,7 @@ std::string Model::node_label(const Node& n) const {
             const int MT = (Co + 31) / 32, MTG = std::min(4, MT), PG = MT <= 2 ? 2 : 1;
             return "block_kernel<" + std::to_string(MTG) + "," + std::to_string(n.w >= 0 ? n.sh : 1) + "," + (n.w >= 0 ? "3" : "1") + "," + std::to_string(PG) + ">";
         }
+        case Node::Chain: return "chain_kernel<" + std::to_string((g.tensors[n.out].shape.back() + 31) / 32) + ">";
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -216,6 +233,11 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
         if (n.kind == Node::Conv) st.macs = elems(n.out) * n.KH * n.KW * si.back() * batch;
         if (n.kind == Node::Dw) st.macs = elems(n.out) * n.KH * n.KW * batch;
         if (n.kind == Node::Block) st.macs = elems(n.out) / so.back() * si.back() * ((n.w >= 0 ? 9 : 0) + so.back()) * batch;
+        if (n.kind == Node::Chain) {
+            st.macs = elems(n.out) * (9 + so.back()) * batch * n.members.size();
+            for (const Node& m : n.members)
+                for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) st.bytes += 4 * elems(c);
+        }
         std::string d;
         for (size_t k = 1; k < si.size(); k++) d += (k > 1 ? "x" : "") + std::to_string(si[k]);
         d += "->";
@@ -301,6 +323,24 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
                 rc = launch_dw(a, s);
+                break;
+            }
+            case Node::Chain: {
+                ChainArgs a;
+                a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
+                a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.nblocks = static_cast<int>(n.members.size());
+                for (size_t k = 0; k < n.members.size(); k++) {
+                    const MemberOff& mo = chain_off_[i][k];
+                    ChainBlock& cb = a.blocks[k];
+                    cb.w_dw = d_weights_ + mo.w;
+                    cb.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
+                    cb.w_pw = d_weights_ + mo.w2;
+                    cb.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
+                    cb.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
+                    cb.act = n.members[k].act;
+                    cb.has_res = n.members[k].res >= 0;
+                }
+                rc = launch_chain(a, s);
                 break;
             }
             case Node::Block: {

@@ -68,7 +68,7 @@ class Model {
     int device_ = 0;
     std::vector<uint8_t> blob_;
     Plan plan_;
-    int fuse_level_ = 2, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1;
+    int fuse_level_ = 3, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1;
     int arena_lane_ = 0;                    // arena region the chunk being enqueued writes to
     std::vector<hipStream_t> side_streams_;  // lanes 1.. run on their own streams (forked/joined with events)
     std::vector<hipEvent_t> lane_events_;
@@ -76,6 +76,8 @@ class Model {
 
     float* d_weights_ = nullptr;
     std::vector<long> node_w_, node_b_, node_w2_, node_b2_, node_alpha_;  // float offsets into d_weights_ (-1 none)
+    struct MemberOff { long w = -1, b = -1, w2 = -1, b2 = -1, alpha = -1; };
+    std::vector<std::vector<MemberOff>> chain_off_;  // per node: offsets of each chain member's constants
 
     float* d_arena_ = nullptr;
     size_t arena_floats_ = 0;

@@ -61,6 +61,25 @@ struct BlockArgs {
     Epilogue ep;
 };
 
+// Frame-resident chain of same-shape stride-1 BlazeBlocks (chain_kernels.hip): x <- act(PW(DW(x)) + b + [x]) per block.
+constexpr int kMaxChain = 8;
+struct ChainBlock {
+    const float* w_dw = nullptr;   // [3][3][C]
+    const float* b_dw = nullptr;   // [C] or null
+    const float* w_pw = nullptr;   // A-fragment order (see block_weight_dims)
+    const float* bias = nullptr;   // [C] or null
+    const float* alpha = nullptr;  // PReLU slopes [C]
+    int act = ACT_NONE;
+    int has_res = 0;               // skip connection = the block's own input
+};
+struct ChainArgs {
+    const float* in = nullptr;
+    float* out = nullptr;
+    long in_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, C = 0, nblocks = 0;
+    ChainBlock blocks[kMaxChain];
+};
+
 struct EltArgs {  // ADD / activation / MAX_POOL / channel PAD / RESIZE / DEPTH_TO_SPACE fallbacks (un-fused graphs)
     const float* a = nullptr;
     const float* b = nullptr;
@@ -113,6 +132,8 @@ int launch_dw(const DwArgs& a, void* stream);
 int launch_block(const BlockArgs& a, void* stream);
 bool block_kernel_supports(const BlockArgs& a);
 const char* block_kernel_label(const BlockArgs& a, char* buf, size_t cap);  // instantiation name as rocprofv3 prints it
+int launch_chain(const ChainArgs& a, void* stream);
+bool chain_kernel_supports(const ChainArgs& a);
 int launch_add(const EltArgs& a, void* stream);
 int launch_act(const EltArgs& a, void* stream);
 int launch_maxpool(const EltArgs& a, void* stream);

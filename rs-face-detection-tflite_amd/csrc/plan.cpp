@@ -271,6 +271,60 @@ Plan build_plan(Graph graph, int fuse_level) {
     for (auto& n : nodes)
         if (!n.dead) plan.nodes.push_back(n);
 
+    // ---- level 3: frame-resident chains (consecutive same-shape stride-1 blocks, each feeding only the next one)
+    if (fuse_level >= 3) {
+        auto uses = [&](int t) {
+            int c = 0;
+            for (const Node& n : plan.nodes) {
+                for (int x : n.in) c += x == t;
+                c += n.res == t;
+            }
+            return c;
+        };
+        auto chainable = [&](const Node& n) {
+            if (n.kind != Node::Block || n.w < 0 || n.sh != 1 || n.sw != 1 || n.padding != Padding::Same) return false;
+            const auto& si = g.tensors[n.in[0]].shape;
+            const auto& so = g.tensors[n.out].shape;
+            if (si.size() != 4 || si != so || si[1] * si[2] > 256 || si[3] % 8) return false;
+            if (n.res >= 0 && !(n.res == n.in[0] && n.res_mode == RES_DIRECT)) return false;
+            return true;
+        };
+        std::vector<Node> fusedv;
+        for (size_t i = 0; i < plan.nodes.size();) {
+            size_t j = i;
+            if (chainable(plan.nodes[i])) {
+                while (j + 1 < plan.nodes.size() && j + 1 - i < static_cast<size_t>(kMaxChain) && chainable(plan.nodes[j + 1]) &&
+                       plan.nodes[j + 1].in[0] == plan.nodes[j].out && g.tensors[plan.nodes[j + 1].in[0]].shape == g.tensors[plan.nodes[i].in[0]].shape &&
+                       uses(plan.nodes[j].out) == (plan.nodes[j + 1].res >= 0 ? 2 : 1) &&
+                       std::find(g.outputs.begin(), g.outputs.end(), plan.nodes[j].out) == g.outputs.end())
+                    j++;
+            }
+            if (j > i) {
+                ChainArgs ca;
+                const auto& si = g.tensors[plan.nodes[i].in[0]].shape;
+                ca.in = reinterpret_cast<const float*>(0x1000); ca.out = reinterpret_cast<float*>(0x2000);
+                ca.in_fs = ca.out_fs = static_cast<long>(g.tensors[plan.nodes[i].in[0]].elems());
+                ca.B = 1; ca.H = si[1]; ca.W = si[2]; ca.C = si[3]; ca.nblocks = static_cast<int>(j - i + 1);
+                if (chain_kernel_supports(ca)) {
+                    Node c;
+                    c.kind = Node::Chain;
+                    c.in = {plan.nodes[i].in[0]};
+                    c.out = plan.nodes[j].out;
+                    for (size_t k = i; k <= j; k++) {
+                        c.members.push_back(plan.nodes[k]);
+                        c.src_ops.insert(c.src_ops.end(), plan.nodes[k].src_ops.begin(), plan.nodes[k].src_ops.end());
+                    }
+                    fusedv.push_back(std::move(c));
+                    i = j + 1;
+                    continue;
+                }
+            }
+            fusedv.push_back(plan.nodes[i]);
+            i++;
+        }
+        plan.nodes = std::move(fusedv);
+    }
+
     // ---- storage: RESHAPE = view of its input; CONCATENATION inputs live inside the joined buffer.
     const int NT = static_cast<int>(g.tensors.size());
     plan.storage.resize(NT);
@@ -350,6 +404,14 @@ Plan build_plan(Graph graph, int fuse_level) {
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
         for (int t : n.in) bytes += 4 * elems(t);
         bytes += 4 * elems(n.out);
+        if (n.kind == Node::Chain) {
+            for (const Node& m : n.members) {
+                for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) bytes += 4 * elems(c);
+                const auto& so2 = g.tensors[m.out].shape;
+                macs += static_cast<double>(so2[1]) * so2[2] * so2[3] * (9 + so2[3]);
+            }
+            continue;
+        }
         if (n.res >= 0 && !(n.kind == Node::Block && n.res == n.in[0])) bytes += 4 * elems(n.res);
         for (int c : {n.w, n.b, n.w2, n.b2, n.alpha}) bytes += 4 * elems(c);
         const auto& so = g.tensors[n.out].shape;
@@ -367,7 +429,7 @@ Plan build_plan(Graph graph, int fuse_level) {
 }
 
 std::string Plan::describe() const {
-    static const char* kinds[] = {"conv", "dw", "block", "add", "act", "maxpool", "pad", "reshape", "concat", "resize", "d2s"};
+    static const char* kinds[] = {"conv", "dw", "block", "add", "act", "maxpool", "pad", "reshape", "concat", "resize", "d2s", "chain"};
     static const char* acts[] = {"", "+relu", "+relu6", "+prelu"};
     static const char* res[] = {"", "+skip", "+skip(maxpool)", "+skip(up2x)"};
     std::ostringstream os;
@@ -383,6 +445,7 @@ std::string Plan::describe() const {
         os << "]";
         if (n.kind == Node::Conv || n.kind == Node::Dw || (n.kind == Node::Block && n.w >= 0)) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
+        if (n.kind == Node::Chain) os << " x" << n.members.size() << " blocks, frame resident in LDS";
         os << " ops{";
         for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
         os << "}\n";

@@ -6,6 +6,7 @@
 //   level 1  ADD / RELU / PRELU / MAX_POOL_2D-skip / channel-PAD-skip / RESIZE_BILINEAR-skip folded into the
 //            producing convolution's epilogue
 //   level 2  DEPTHWISE_CONV_2D -> CONV_2D 1x1 (-> skip -> activation) fused into one BlazeBlock kernel
+//   level 3  runs of same-shape stride-1 BlazeBlocks whose frame fits in LDS fused into one frame-resident chain kernel
 #pragma once
 
 #include <string>
@@ -17,7 +18,8 @@
 namespace mi {
 
 struct Node {
-    enum Kind { Conv, Dw, Block, Add, Act, MaxPool, Pad, Reshape, Concat, Resize, DepthToSpace } kind = Conv;
+    enum Kind { Conv, Dw, Block, Add, Act, MaxPool, Pad, Reshape, Concat, Resize, DepthToSpace, Chain } kind = Conv;
+    std::vector<Node> members;  // Chain: the fused BlazeBlocks, in order
     std::vector<int> in;   // activation inputs (tensor ids)
     int out = -1;
     bool dead = false;

@@ -28,6 +28,8 @@ def test_library_exports_every_declared_symbol(mi):
 def test_lowering_without_gpu(mi, name):
     blob = open(model_path(name), "rb").read()
     p0, p1, p2 = (mi.plan_describe(blob, lvl) for lvl in (0, 1, 2))
+    p3 = mi.plan_describe(blob, 3)
+    assert int(re.search(r"launches=(\d+)", p3).group(1)) <= int(re.search(r"launches=(\d+)", p2).group(1))
     n0, n1, n2 = (int(re.search(r"launches=(\d+)", p).group(1)) for p in (p0, p1, p2))
     assert n0 > n1 > n2
     assert "block" in p2 and "block" not in p1

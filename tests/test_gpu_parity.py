@@ -47,7 +47,7 @@ def gpu(mi):
 
 
 @pytest.mark.parametrize("name", list(MODEL_FILES))
-@pytest.mark.parametrize("fuse", [0, 1, 2])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3])
 def test_network_raw_outputs_vs_oracle(gpu, oracle, name, fuse):
     m = gpu.Model(model_path(name))
     m.set_option("fuse", fuse)
