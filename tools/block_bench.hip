@@ -59,7 +59,8 @@ int main(int argc, char** argv) {
         double tot = 0; for (int k = 0; k < 6; k++) tot += acc[k];
         int steps = (g.band + g.R - 1) / g.R;
         for (int k = 0; k < 6; k++) printf("  %-15s %6.1f%%  %8.0f cycles/step\n", nm[k], 100 * acc[k] / tot, acc[k] / nw / steps);
-        printf("  total %.0f cycles/step/wave (memtime ticks, 100MHz? see below)\n", tot / nw / steps);
+        double pro = 0; for (size_t i = 0; i < nw; i++) pro += h[i * 8 + 6];
+        printf("  total %.0f cycles/step/wave; prologue %.0f cycles/wave = %.1f steps; steps/band %d\n", tot / nw / steps, pro / nw, pro / nw / (tot / nw / steps), steps);
     }
 #endif
     return 0;
