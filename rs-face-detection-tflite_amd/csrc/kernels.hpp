@@ -53,6 +53,7 @@ struct BlockArgs {
     const float* w_dw = nullptr;
     const float* b_dw = nullptr;
     const float* w_pw = nullptr;  // [Cop][Cp] row-major (out channel major), zero padded: Cp = C up to 4, Cop = Co up to 16/32
+    const float* w_strip = nullptr;  // strip_pack_consts() blob when the shape qualifies for strip_kernels.hip, else null
     float* out = nullptr;
     long in_fs = 0, out_fs = 0;
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0;
@@ -132,6 +133,13 @@ int launch_dw(const DwArgs& a, void* stream);
 int launch_block(const BlockArgs& a, void* stream);
 bool block_kernel_supports(const BlockArgs& a);
 const char* block_kernel_label(const BlockArgs& a, char* buf, size_t cap);  // instantiation name as rocprofv3 prints it
+// strip_kernels.hip: register-resident variant for stride-1 blocks with C = Co in {16, 24, 32}
+int launch_strip(const BlockArgs& a, void* stream);
+bool strip_kernel_supports(const BlockArgs& a);
+bool strip_shape_ok(int C, int Co);
+int strip_consts_floats(int C);
+void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
+const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
 int launch_chain(const ChainArgs& a, void* stream);
 bool chain_kernel_supports(const ChainArgs& a);
 int launch_add(const EltArgs& a, void* stream);
