@@ -53,16 +53,17 @@ struct StripArgs {
     int strips, bands, band_rows;
     int has_res;
     float hi;              // upper clamp of the activation (6 for ReLU6, +inf otherwise)
+    unsigned long long* stamps;  // diagnostic builds only (MI_STRIP_STAMPS): 8 accumulators per wave
 };
 
 template <int CQ>
 struct SK {
     static constexpr int C = 4 * CQ;          // channels
-    static constexpr int PS = C + 4;          // LDS pixel stride (floats)
     static constexpr int K2 = C / 2;          // MFMA k-steps (2 channels each)
     static constexpr int NF = 66 * CQ;        // float4s of one staged input row (64 pixels + 2 halo pixels)
-    static constexpr int NL = (NF + 63) / 64; // float4s per lane of that row
-    static constexpr int IN_F = 66 * PS, OUT_F = 64 * PS, WAVE_F = IN_F + OUT_F;
+    static constexpr int NL = (NF + 63) / 64; // LDS-DMA instructions per row (the last one partial)
+    static constexpr int BUF_F = (66 * C + 63) / 64 * 64;  // floats per row buffer (pixel-major, unpadded: DMA image is lane-linear)
+    static constexpr int WAVE_F = 3 * BUF_F;  // three row buffers per wave: row r in use, rows r+1 and r+2 in flight
     // constants blob (floats): per channel pair 9 taps x 2 (+2 spare); pointwise bias (+ W b_dw); negative slopes; A fragments
     static constexpr int OFF_DW = 0, OFF_BIAS = CQ * 40, OFF_SLOPE = OFF_BIAS + 32, OFF_A = OFF_SLOPE + 32, TOTAL = OFF_A + K2 * 64;
 };
@@ -77,15 +78,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0], expcnt and lgkmcnt left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
 
 template <int CQ, bool RELU>
 __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
     using K = SK<CQ>;
-    constexpr int C = K::C, PS = K::PS, NL = K::NL;
+    constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* inbuf = lds + wave * K::WAVE_F;
-    float* outbuf = inbuf + K::IN_F;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: everything derived from it (band, rows, branches) stays on the SALU
+    float* wbase = lds + wave * K::WAVE_F;
     int gw = blockIdx.x * 4 + wave;
     const int band = gw % a.bands;
     gw /= a.bands;
@@ -103,66 +107,83 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 #pragma unroll
     for (int j = 0; j < K::K2; j++) A[j] = cst[K::OFF_A + j * 64 + lane];
 
-    // transpose geometry: float4 number f = lane + 64k of a staged row <-> (pixel f / CQ, channel quad f % CQ).
-    // Loads are unconditional: a lane whose pixel lies outside the image (the halo of an edge strip, the tail of a
-    // partial strip) reads a clamped in-image pixel instead, and the one staged pixel column that must be zero (left of
-    // x = 0, right of x = W-1) is cleared in LDS after staging — no per-lane branches around the memory instructions.
-    int loff[NL], goff[NL];
+    // Row image in LDS: [66 pixels][C] floats, filled by LDS-DMA (global_load_lds_dwordx4: LDS destination = M0 + offset +
+    // 16 * lane, source address per lane), so float4 number f = lane + 64k of the image comes from (pixel f / CQ, quad
+    // f % CQ) of the strip.  A lane whose pixel lies outside the image (halo of an edge strip, tail of a partial strip)
+    // reads a clamped in-image pixel instead; the one pixel column that must be zero (left of x = 0, right of x = W-1)
+    // is cleared in LDS after the DMA has landed — no per-lane branches around the memory instructions.
+    // The DMA is issued from inline asm: hipcc would otherwise drain vmcnt(0) before every LDS read that follows a DMA
+    // it can see (it cannot tell the three row buffers apart), which serialises the two-rows-ahead prefetch.
+    int goff[NL];  // byte offset of the lane's float4 from the row start, per DMA instruction
 #pragma unroll
     for (int k = 0; k < NL; k++) {
         const int f = min(lane + 64 * k, K::NF - 1), px = f / CQ, qd = f - px * CQ;
-        loff[k] = px * PS + 4 * qd;
-        goff[k] = min(max(x0 - 1 + px, 0), a.W - 1) * C + 4 * qd;
+        goff[k] = (min(max(x0 - 1 + px, 0), a.W - 1) * C + 4 * qd) * 4;
     }
     const int npx = min(64, a.W - x0);              // valid pixels of this strip
     const bool full = npx == 64;
-    const int zl = x0 == 0 ? 0 : -1;                // staged pixel columns to clear (-1: none)
+    const int zl = x0 == 0 ? 0 : -1;                // image pixel columns to clear (-1: none)
     const int zr = x0 + 64 >= a.W ? npx + 1 : -1;
     const long gout = (long)x0 * C + 4 * lane;
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)wbase);
 
-    float4 pf[NL];
-    auto load_row = [&](int r) {
-        if (r >= 0 && r < a.H) {  // wave-uniform
-            const float* src = in + (long)r * a.W * C;
+    // start the DMA of input row r into row buffer bi (always NL instructions, so that counted vmcnt waits stay valid;
+    // a row outside the image reads a clamped row and is zeroed when it is consumed)
+    auto issue_row = [&](int r, int bi) {
+        const char* src = reinterpret_cast<const char*>(in + (long)min(max(r, 0), a.H - 1) * a.W * C);
+        const unsigned dstb = lds_wave + (unsigned)(bi * BUF_F * 4);
+        constexpr int TAIL = K::NF - 64 * (NL - 1);  // active lanes of the last instruction
 #pragma unroll
-            for (int k = 0; k < NL; k++) pf[k] = sld4(src + goff[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NL; k++) pf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NL; k++) {
+            if (k < NL - 1 || TAIL == 64) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+            } else {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+            }
         }
     };
-    auto stage_row = [&]() {
+    // after the DMA of row r has landed in buffer bi: zero what lies outside the image
+    auto fix_row = [&](int r, int bi) {
+        float* buf = wbase + bi * BUF_F;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 0 || r >= a.H) {  // wave-uniform, only at the top / bottom image edge
 #pragma unroll
-        for (int k = 0; k < NL; k++)
-            if (64 * (k + 1) <= K::NF || lane + 64 * k < K::NF) sst4(inbuf + loff[k], pf[k]);
-        if (lane < CQ) {
-            if (zl >= 0) sst4(inbuf + zl * PS + 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f));
-            if (zr >= 0) sst4(inbuf + zr * PS + 4 * lane, make_float4(0.f, 0.f, 0.f, 0.f));
+            for (int k = 0; k < NL; k++)
+                if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
+        } else if (lane < CQ) {
+            if (zl >= 0) sst4(buf + zl * C + 4 * lane, z);
+            if (zr >= 0) sst4(buf + zr * C + 4 * lane, z);
         }
     };
 
-    // One input row r (staged in inbuf): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aP / aC /
-    // aN).  Work is cut into 2*CQ stages of one channel PAIR each (= one MFMA k-step): stage s waits for its own
-    // operands (20 scalar weights, 3 float4 LDS reads per quad), issues the loads of stage s+1, then finishes the pair of
-    // row r-1 (3 v_pk_fma), swaps it into the two B operands and issues the two MFMAs; the remaining 6 v_pk_fma of the
+    // One input row r (DMA image in buffer bi): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aP /
+    // aC / aN).  Work is cut into 2*CQ stages of one channel PAIR each (= one MFMA k-step): stage s waits for its own
+    // operands (18 scalar weights, 3 float4 LDS reads per quad), issues the loads of stage s+1, then finishes the pair of
+    // row r-1 (3 v_pk_fma), swaps it into the two B operands and issues the two MFMAs; the remaining 6 FMAs of the
     // pair (rows r, r+1) and the next stage's load latency sit in the shadow of those 128 MFMA-pipe cycles.
-    sf32x16 D0, D1;
-    auto row = [&](auto emit_t, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], float4 (&xcur)[CQ]) {
-        constexpr bool EMIT = decltype(emit_t)::value;
-        const float* me = inbuf + lane * PS;
+    // accumulator layout: register 4g + e of lane l holds output channel 8g + e + 4 * (l >> 5) (of pixel l & 31)
+    sf32x16 Dinit;
 #pragma unroll
-        for (int e = 0; e < 16; e++) { D0[e] = 0.f; D1[e] = 0.f; }
-        float wbuf[2][20];
+    for (int e = 0; e < 16; e++) Dinit[e] = cst[K::OFF_BIAS + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
+    sf32x16 D0, D1;
+    auto row = [&](auto emit_t, int bi, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], float4 (&xcur)[CQ]) {
+        constexpr bool EMIT = decltype(emit_t)::value;
+        const float* me = wbase + bi * BUF_F + lane * C;
+        D0 = Dinit;  // pointwise bias (+ W b_dw), already in the accumulator layout
+        D1 = Dinit;
+        float wbuf[2][18];
         float4 xbuf[2][3];
-        auto load_w = [&](int st, float (&w)[20]) {
+        auto load_w = [&](int st, float (&w)[18]) {
             const cfloat* wp = cst + K::OFF_DW + st * 20;
             asm volatile("" : "+s"(wp));  // opaque per use: the scalar loads stay in the row loop, one stage ahead of their use
 #pragma unroll
-            for (int i = 0; i < 20; i++) w[i] = wp[i];
+            for (int i = 0; i < 18; i++) w[i] = wp[i];
         };
         auto load_x = [&](int q, float4 (&x)[3]) {
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me + kx * PS + 4 * q);
+            for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me + kx * C + 4 * q);
         };
         load_w(0, wbuf[0]);
         load_x(0, xbuf[0]);
@@ -171,9 +192,9 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
             const int q = st >> 1, h = st & 1;
             __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's weights and pixels have landed ...
             if (st + 1 < 2 * CQ) load_w(st + 1, wbuf[(st + 1) & 1]);  // ... so the next stage's loads never delay this stage's math
-            if (h == 0 && q + 1 < CQ) load_x(q + 1, xbuf[(q + 1) & 1]);
+            if (h == 1 && q + 1 < CQ) load_x(q + 1, xbuf[(q + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const float (&w)[20] = wbuf[st & 1];
+            const float (&w)[18] = wbuf[st & 1];
             const float4 (&x)[3] = xbuf[q & 1];
             if (h == 0) xcur[q] = x[1];
             v2f t[3];
@@ -181,9 +202,14 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
             for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
             auto wv = [&](int tap) { return v2f{w[2 * tap], w[2 * tap + 1]}; };
             if constexpr (EMIT) {
+                // plain v_fma_f32 on purpose: packed f32 ops do not overlap a running MFMA (hipcc itself unpacks the ones it
+                // finds behind an MFMA), and this chain sits in the shadow of the previous stage's MFMAs
                 v2f pch = aP[q][h];
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++) pch = pkfma(t[kx], wv(6 + kx), pch);
+                for (int kx = 0; kx < 3; kx++) {
+                    pch.x = fmaf(t[kx].x, w[2 * (6 + kx)], pch.x);
+                    pch.y = fmaf(t[kx].y, w[2 * (6 + kx) + 1], pch.y);
+                }
                 const v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(pch.x), __float_as_uint(pch.y), false, false);
                 D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st], __uint_as_float(sw.x), D0, 0, 0, 0);
                 D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st], __uint_as_float(sw.y), D1, 0, 0, 0);
@@ -202,8 +228,10 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // epilogue of output row y: D back to lane = pixel, + bias + skip, activation, transposed store
-    auto epilogue = [&](int y, const float4 (&xres)[CQ]) {
+    // epilogue of output row y: D back to lane = pixel, + bias + skip, activation, transposed through the (now dead)
+    // row buffer bi so that every store instruction writes 1 KiB of consecutive bytes
+    auto epilogue = [&](int y, int bi, const float4 (&xres)[CQ]) {
+        float* obuf = wbase + bi * BUF_F;
 #pragma unroll
         for (int g = 0; g < CQ / 2; g++) {
             float4 v[2];
@@ -217,9 +245,7 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
                 const int q = 2 * g + hh;
-                const cfloat* bq = cst + K::OFF_BIAS + 4 * q;
-                asm volatile("" : "+s"(bq));
-                float4 o = make_float4(v[hh].x + bq[0], v[hh].y + bq[1], v[hh].z + bq[2], v[hh].w + bq[3]);
+                float4 o = v[hh];
                 if (a.has_res) { o.x += xres[q].x; o.y += xres[q].y; o.z += xres[q].z; o.w += xres[q].w; }
                 if (RELU) {
                     o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
@@ -231,18 +257,18 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
                     o.z = fminf(fmaxf(o.z, 0.f) + sq[2] * fminf(o.z, 0.f), a.hi);
                     o.w = fminf(fmaxf(o.w, 0.f) + sq[3] * fminf(o.w, 0.f), a.hi);
                 }
-                sst4(outbuf + lane * PS + 4 * q, o);
+                sst4(obuf + lane * C + 4 * q, o);
             }
         }
         wave_sync();
         float* dst = out + (long)y * a.W * C + gout;
         if (full) {  // wave-uniform
 #pragma unroll
-            for (int k = 0; k < CQ; k++) sst4(dst + 256 * k, sld4(outbuf + loff[k]));
+            for (int k = 0; k < CQ; k++) sst4(dst + 256 * k, sld4(obuf + 4 * lane + 256 * k));
         } else {
 #pragma unroll
             for (int k = 0; k < CQ; k++) {
-                const float4 o = sld4(outbuf + loff[k]);
+                const float4 o = sld4(obuf + 4 * lane + 256 * k);
                 if (lane + 64 * k < npx * CQ) sst4(dst + 256 * k, o);
             }
         }
@@ -255,31 +281,59 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
         acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = acc2[q][0] = acc2[q][1] = v2f{0.f, 0.f};
         xa[q] = xb[q] = xd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    load_row(y0 - 1);
-    stage_row();
-    wave_sync();
+    // Step r consumes input row r from buffer BI (its DMA was started two steps earlier), starts the DMA of row r+2 into
+    // the buffer row r-1 used, and emits output row r-1.  vm operations are retired in issue order, so "row r has landed"
+    // = at most [DMA of row r+1] + [stores of step r-1] still outstanding; the store count is only relied on when it is
+    // exact (full strip, previous step emitted), otherwise the wait also covers those (older) stores.
     // EMIT is a compile-time property of the call site (the two priming rows of a band produce no output): as a run-time
     // branch the compiler sinks a third of the depthwise FMAs into it, across the scheduling fences, and spills SGPRs.
-    auto step = [&](auto emit, int r, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
-        const bool more = r < y1;  // input rows run to y1 inclusive
-        if (more) load_row(r + 1);
-        row(emit, aP, aC, aN, xcur);
-        wave_sync();  // every read of inbuf above is issued before the writes below
-        if (more) stage_row();  // before the epilogue: its stores are then never waited on until a row later, and the
-                                // staging covers the drain of the last MFMAs
-        if constexpr (decltype(emit)::value) epilogue(r - 1, xprev);
+#ifdef MI_STRIP_STAMPS
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#define MI_SSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_SSTAMP(k)
+#endif
+    auto step = [&](auto emit, auto bi_t, int r, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
+        constexpr int BI = decltype(bi_t)::value;
+        if (r + 1 <= y1) {
+            if (full && r >= y0 + 2) wait_vm<NL + CQ>();
+            else wait_vm<NL>();
+        } else {
+            wait_vm<0>();
+        }
+        MI_SSTAMP(0)
+        fix_row(r, BI);
         wave_sync();
+        if (r + 2 <= y1) issue_row(r + 2, (BI + 2) % 3);
+        MI_SSTAMP(1)
+        row(emit, BI, aP, aC, aN, xcur);
+        wave_sync();  // every read of the row image above is issued before the epilogue overwrites it
+        MI_SSTAMP(2)
+        if constexpr (decltype(emit)::value) epilogue(r - 1, BI, xprev);
+        wave_sync();
+        MI_SSTAMP(3)
     };
-    step(std::false_type{}, y0 - 1, acc0, acc1, acc2, xd, xa);
-    step(std::false_type{}, y0, acc1, acc2, acc0, xa, xb);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    issue_row(y0 - 1, 0);
+    issue_row(y0, 1);
+    step(std::false_type{}, I0{}, y0 - 1, acc0, acc1, acc2, xd, xa);
+    step(std::false_type{}, I1{}, y0, acc1, acc2, acc0, xa, xb);
     for (int r = y0 + 1; r <= y1; r += 3) {
-        step(std::true_type{}, r, acc2, acc0, acc1, xb, xd);
+        step(std::true_type{}, I2{}, r, acc2, acc0, acc1, xb, xd);
         if (r + 1 > y1) break;
-        step(std::true_type{}, r + 1, acc0, acc1, acc2, xd, xa);
+        step(std::true_type{}, I0{}, r + 1, acc0, acc1, acc2, xd, xa);
         if (r + 2 > y1) break;
-        step(std::true_type{}, r + 2, acc1, acc2, acc0, xa, xb);
+        step(std::true_type{}, I1{}, r + 2, acc1, acc2, acc0, xa, xb);
     }
+#ifdef MI_STRIP_STAMPS
+    if (a.stamps && lane == 0)
+        for (int k = 0; k < 4; k++) a.stamps[((long)blockIdx.x * 4 + wave) * 8 + k] = st_acc[k];
+#endif
 }
+
+unsigned long long* g_strip_stamps = nullptr;  // set by the development harness (MI_STRIP_STAMPS builds)
 
 int strips_band_rows(const BlockArgs& a, int strips) {
     // about one resident set of waves over the chip (8 per CU), but bands of at least 8 rows (2 halo rows re-read per band)
@@ -304,8 +358,9 @@ int launch_strip_inst(const BlockArgs& a, hipStream_t s) {
     sa.bands = (a.H + sa.band_rows - 1) / sa.band_rows;
     sa.has_res = a.ep.res_mode == RES_DIRECT;
     sa.hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY;
+    sa.stamps = g_strip_stamps;
     const long waves = (long)a.B * sa.strips * sa.bands;
-    const size_t lds_bytes = (size_t)4 * K::WAVE_F * 4;
+    const size_t lds_bytes = (size_t)4 * K::WAVE_F * 4;  // 4 waves x 3 row buffers
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -76,5 +76,22 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
         printf("%s B %d %dx%d C %d : %.4f ms  %.1f GB/s algorithmic\n", which ? "strip" : "block", B, H, W, C, ms, 2.0 * n * 4 / ms / 1e6);
     }
+#ifdef MI_STRIP_STAMPS
+    {
+        int strips = (W + 63) / 64, rows = strips_band_rows(a2, strips), bands = (H + rows - 1) / rows;
+        size_t nw = ((size_t)B * strips * bands + 3) / 4 * 4;
+        unsigned long long* dstp; CK(hipMalloc(&dstp, nw * 64)); CK(hipMemset(dstp, 0, nw * 64));
+        g_strip_stamps = dstp;
+        launch_strip(a2, s); CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nw * 8);
+        CK(hipMemcpy(h.data(), dstp, nw * 64, hipMemcpyDeviceToHost));
+        double acc[4] = {0}, tot = 0;
+        for (size_t i = 0; i < nw; i++) for (int k = 0; k < 4; k++) acc[k] += h[i * 8 + k];
+        for (int k = 0; k < 4; k++) tot += acc[k];
+        const char* nm[4] = {"wait-dma", "fix+issue", "dw+mfma", "epilogue"};
+        for (int k = 0; k < 4; k++) printf("  %-10s %5.1f%%  %8.0f cycles/row\n", nm[k], 100 * acc[k] / tot, acc[k] / ((double)B * strips * bands) / (rows + 2));
+        printf("  total %.0f cycles/row/wave (memtime ticks = 100 MHz? see ratio), band rows %d\n", tot / ((double)B * strips * bands) / (rows + 2), rows);
+    }
+#endif
     return bad ? 2 : 0;
 }
