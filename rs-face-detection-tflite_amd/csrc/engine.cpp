@@ -84,6 +84,7 @@ void Model::rebuild() {
     const size_t NN = plan_.nodes.size();
     node_w_.assign(NN, -1); node_b_.assign(NN, -1); node_w2_.assign(NN, -1); node_b2_.assign(NN, -1); node_alpha_.assign(NN, -1);
     chain_off_.assign(NN, {});
+    node_strip_.assign(NN, -1);
     // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
     // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
     auto pack_pw = [&](int wt) {
@@ -135,6 +136,13 @@ void Model::rebuild() {
         } else if (n.kind == Node::Block) {
             if (n.w >= 0) node_w_[i] = put(g.tensors[n.w].f32);
             node_w2_[i] = pack_pw(n.w2);
+            const auto& ws = g.tensors[n.w2].shape;  // [O][1][1][I]
+            if (n.w >= 0 && n.sh == 1 && n.sw == 1 && n.padding == Padding::Same && strip_shape_ok(ws[3], ws[0])) {
+                std::vector<float> sc(static_cast<size_t>(strip_consts_floats(ws[3])));
+                strip_pack_consts(ws[3], g.tensors[n.w].f32.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, g.tensors[n.w2].f32.data(),
+                                  n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
+                node_strip_[i] = put(sc);
+            }
         }
     }
     if (d_weights_) hip_check(hipFree(d_weights_), "hipFree");
@@ -354,8 +362,10 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.sh = n.sh; a.sw = n.sw;
                 if (a.has_dw && n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
-                if (labels) { char buf[96]; labels->back() = block_kernel_label(a, buf, sizeof buf); }
-                rc = launch_block(a, s);
+                a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
+                const bool strip = strip_kernel_supports(a);
+                if (labels) { char buf[96]; labels->back() = strip ? strip_kernel_label(a, buf, sizeof buf) : block_kernel_label(a, buf, sizeof buf); }
+                rc = strip ? launch_strip(a, s) : launch_block(a, s);
                 break;
             }
             default: {

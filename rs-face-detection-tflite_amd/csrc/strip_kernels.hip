@@ -63,9 +63,11 @@ struct SK {
     static constexpr int NF = 66 * CQ;        // float4s of one staged input row (64 pixels + 2 halo pixels)
     static constexpr int NL = (NF + 63) / 64; // LDS-DMA instructions per row (the last one partial)
     static constexpr int BUF_F = (66 * C + 63) / 64 * 64;  // floats per row buffer (pixel-major, unpadded: DMA image is lane-linear)
-    static constexpr int WAVE_F = 3 * BUF_F;  // three row buffers per wave: row r in use, rows r+1 and r+2 in flight
-    // constants blob (floats): per channel pair 9 taps x 2 (+2 spare); pointwise bias (+ W b_dw); negative slopes; A fragments
-    static constexpr int OFF_DW = 0, OFF_BIAS = CQ * 40, OFF_SLOPE = OFF_BIAS + 32, OFF_A = OFF_SLOPE + 32, TOTAL = OFF_A + K2 * 64;
+    static constexpr int WAVE_F = 2 * BUF_F;  // two row buffers per wave: row r in use, row r+1 in flight
+    // constants blob (floats): per input-channel pair a stage record of ST_F floats = depthwise taps [9][2] at 0, pointwise
+    // columns W[0..C)[2st] at 32 and W[0..C)[2st+1] at 32 + C; then the pointwise bias (+ W b_dw) and the negative slopes
+    static constexpr int ST_F = 32 + 2 * C + (16 - (2 * C) % 16) % 16;
+    static constexpr int OFF_DW = 0, OFF_BIAS = K2 * ST_F, OFF_SLOPE = OFF_BIAS + 32, TOTAL = OFF_SLOPE + 32;
 };
 
 __device__ __forceinline__ float4 sld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -83,7 +85,7 @@ template <int N>
 __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
 
 template <int CQ, bool RELU>
-__global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
+__global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a) {
     using K = SK<CQ>;
     constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -102,10 +104,6 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
     float* out = a.out + (long)b * a.out_fs;
     // constant address space: the blob is never written while kernels run, and wave-uniform loads from it become s_load
     const cfloat* cst = (const cfloat*)a.consts;
-
-    float A[K::K2];
-#pragma unroll
-    for (int j = 0; j < K::K2; j++) A[j] = cst[K::OFF_A + j * 64 + lane];
 
     // Row image in LDS: [66 pixels][C] floats, filled by LDS-DMA (global_load_lds_dwordx4: LDS destination = M0 + offset +
     // 16 * lane, source address per lane), so float4 number f = lane + 64k of the image comes from (pixel f / CQ, quad
@@ -159,64 +157,70 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
     };
 
     // One input row r (DMA image in buffer bi): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aP /
-    // aC / aN).  Work is cut into 2*CQ stages of one channel PAIR each (= one MFMA k-step): stage s waits for its own
-    // operands (18 scalar weights, 3 float4 LDS reads per quad), issues the loads of stage s+1, then finishes the pair of
-    // row r-1 (3 v_pk_fma), swaps it into the two B operands and issues the two MFMAs; the remaining 6 FMAs of the
-    // pair (rows r, r+1) and the next stage's load latency sit in the shadow of those 128 MFMA-pipe cycles.
-    // accumulator layout: register 4g + e of lane l holds output channel 8g + e + 4 * (l >> 5) (of pixel l & 31)
-    sf32x16 Dinit;
-#pragma unroll
-    for (int e = 0; e < 16; e++) Dinit[e] = cst[K::OFF_BIAS + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)];
-    sf32x16 D0, D1;
-    auto row = [&](auto emit_t, int bi, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], float4 (&xcur)[CQ]) {
+    // aC / aN); the finished row r-1 goes straight into the pointwise accumulators.  Everything runs on the VALU as
+    // v_pk_fma_f32 with SGPR-pair weights: on this part the f32 MFMA does not overlap VALU work (measured: 2 x
+    // v_mfma_f32_32x32x2_f32 + n x v_fma_f32 costs 129 + 4.5 n cycles, at one or two waves per SIMD), it runs at the
+    // packed-FMA rate, and M = 32 would waste a quarter of it on 24 output channels.
+    // Work is cut into 2*CQ stages of one input-channel PAIR.  Scalar loads return out of order, so every wait is
+    // lgkmcnt(0); each stage therefore waits twice and issues the NEXT chunk's loads right after each wait:
+    //   wait | load PW weights of the pair's 2nd channel | depthwise (9 pk) + pointwise of the 1st channel (CQ*2 pk)
+    //   wait | load DW + 1st-channel PW weights of the next stage, next quad's pixels | pointwise of the 2nd channel
+    v2f oacc[2 * CQ];
+    auto row = [&](auto emit_t, int bi, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xres)[CQ], float4 (&xcur)[CQ]) {
         constexpr bool EMIT = decltype(emit_t)::value;
         const float* me = wbase + bi * BUF_F + lane * C;
-        D0 = Dinit;  // pointwise bias (+ W b_dw), already in the accumulator layout
-        D1 = Dinit;
-        float wbuf[2][18];
+        float wd[18], wp0[C], wp1[C];
         float4 xbuf[2][3];
-        auto load_w = [&](int st, float (&w)[18]) {
-            const cfloat* wp = cst + K::OFF_DW + st * 20;
-            asm volatile("" : "+s"(wp));  // opaque per use: the scalar loads stay in the row loop, one stage ahead of their use
+        auto load_wd = [&](int st) {
+            const cfloat* p = cst;
+            asm volatile("" : "+s"(p));  // opaque per use: the scalar loads stay in the row loop, just ahead of their use;
+                                         // the record offset stays an immediate of the s_load (no per-stage pointer to keep)
 #pragma unroll
-            for (int i = 0; i < 18; i++) w[i] = wp[i];
+            for (int i = 0; i < 18; i++) wd[i] = p[K::OFF_DW + st * K::ST_F + i];
+        };
+        auto load_wp = [&](int st, int half, float (&w)[C]) {
+            const cfloat* p = cst;
+            asm volatile("" : "+s"(p));
+#pragma unroll
+            for (int i = 0; i < C; i++) w[i] = p[K::OFF_DW + st * K::ST_F + 32 + half * C + i];
         };
         auto load_x = [&](int q, float4 (&x)[3]) {
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me + kx * C + 4 * q);
         };
-        load_w(0, wbuf[0]);
+        if constexpr (EMIT) {  // accumulators start from skip + bias (bias = b_pw + W b_dw)
+            const cfloat* bp = cst + K::OFF_BIAS;
+            asm volatile("" : "+s"(bp));
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                oacc[2 * q] = v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc[2 * q + 1] = v2f{bp[4 * q + 2], bp[4 * q + 3]};
+                if (a.has_res) {
+                    oacc[2 * q] += v2f{xres[q].x, xres[q].y};
+                    oacc[2 * q + 1] += v2f{xres[q].z, xres[q].w};
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        load_wd(0);
+        if (EMIT) load_wp(0, 0, wp0);
         load_x(0, xbuf[0]);
 #pragma unroll
         for (int st = 0; st < 2 * CQ; st++) {
             const int q = st >> 1, h = st & 1;
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's weights and pixels have landed ...
-            if (st + 1 < 2 * CQ) load_w(st + 1, wbuf[(st + 1) & 1]);  // ... so the next stage's loads never delay this stage's math
-            if (h == 1 && q + 1 < CQ) load_x(q + 1, xbuf[(q + 1) & 1]);
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+            if (EMIT) load_wp(st, 1, wp1);
             __builtin_amdgcn_sched_barrier(0);
-            const float (&w)[18] = wbuf[st & 1];
             const float4 (&x)[3] = xbuf[q & 1];
             if (h == 0) xcur[q] = x[1];
             v2f t[3];
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
-            auto wv = [&](int tap) { return v2f{w[2 * tap], w[2 * tap + 1]}; };
-            if constexpr (EMIT) {
-                // plain v_fma_f32 on purpose: packed f32 ops do not overlap a running MFMA (hipcc itself unpacks the ones it
-                // finds behind an MFMA), and this chain sits in the shadow of the previous stage's MFMAs
-                v2f pch = aP[q][h];
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    pch.x = fmaf(t[kx].x, w[2 * (6 + kx)], pch.x);
-                    pch.y = fmaf(t[kx].y, w[2 * (6 + kx) + 1], pch.y);
-                }
-                const v2u sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(pch.x), __float_as_uint(pch.y), false, false);
-                D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st], __uint_as_float(sw.x), D0, 0, 0, 0);
-                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[st], __uint_as_float(sw.y), D1, 0, 0, 0);
-            }
-            v2f n = t[0] * wv(0), c = aC[q][h];  // the depthwise bias is folded into the pointwise bias on the host
+            auto wv = [&](int tap) { return v2f{wd[2 * tap], wd[2 * tap + 1]}; };
+            v2f n = t[0] * wv(0), c = aC[q][h], pch = aP[q][h];  // the depthwise bias is folded into the pointwise bias on the host
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
+                if (EMIT) pch = pkfma(t[kx], wv(6 + kx), pch);
                 if (kx) n = pkfma(t[kx], wv(kx), n);
                 c = pkfma(t[kx], wv(3 + kx), c);
             }
@@ -225,40 +229,44 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
             // pin the partial rows here: left alone, LLVM sinks these updates past the loop-exit test into the next row's
             // block, across the scheduling fences, which keeps every stage's weights alive (SGPR spills)
             asm volatile("" : "+v"(aC[q][h]), "+v"(aN[q][h]));
+            if constexpr (EMIT) {
+#pragma unroll
+                for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.x, pch.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc[o]);
+                asm volatile("" : "+v"(pch));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (st + 1 < 2 * CQ) {
+                load_wd(st + 1);
+                if (EMIT) load_wp(st + 1, 0, wp0);
+                if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EMIT) {
+#pragma unroll
+                for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.y, pch.y}, v2f{wp1[2 * o], wp1[2 * o + 1]}, oacc[o]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // epilogue of output row y: D back to lane = pixel, + bias + skip, activation, transposed through the (now dead)
-    // row buffer bi so that every store instruction writes 1 KiB of consecutive bytes
-    auto epilogue = [&](int y, int bi, const float4 (&xres)[CQ]) {
+    // epilogue of output row y: activation, then transposed through the (now dead) row buffer bi so that every store
+    // instruction writes 1 KiB of consecutive bytes
+    auto epilogue = [&](int y, int bi) {
         float* obuf = wbase + bi * BUF_F;
 #pragma unroll
-        for (int g = 0; g < CQ / 2; g++) {
-            float4 v[2];
-            float* vv = reinterpret_cast<float*>(v);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const v2u s = __builtin_amdgcn_permlane32_swap(__float_as_uint(D0[4 * g + e]), __float_as_uint(D1[4 * g + e]), false, false);
-                vv[e] = __uint_as_float(s.x);      // channel 8g + e     of pixel `lane`
-                vv[4 + e] = __uint_as_float(s.y);  // channel 8g + 4 + e
+        for (int q = 0; q < CQ; q++) {
+            float4 o = make_float4(oacc[2 * q].x, oacc[2 * q].y, oacc[2 * q + 1].x, oacc[2 * q + 1].y);
+            if (RELU) {
+                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+            } else {
+                // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
+                const cfloat* sq = cst + K::OFF_SLOPE + 4 * q;
+                o.x = fminf(fmaxf(o.x, 0.f) + sq[0] * fminf(o.x, 0.f), a.hi);
+                o.y = fminf(fmaxf(o.y, 0.f) + sq[1] * fminf(o.y, 0.f), a.hi);
+                o.z = fminf(fmaxf(o.z, 0.f) + sq[2] * fminf(o.z, 0.f), a.hi);
+                o.w = fminf(fmaxf(o.w, 0.f) + sq[3] * fminf(o.w, 0.f), a.hi);
             }
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                const int q = 2 * g + hh;
-                float4 o = v[hh];
-                if (a.has_res) { o.x += xres[q].x; o.y += xres[q].y; o.z += xres[q].z; o.w += xres[q].w; }
-                if (RELU) {
-                    o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-                } else {
-                    // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
-                    const cfloat* sq = cst + K::OFF_SLOPE + 4 * q;
-                    o.x = fminf(fmaxf(o.x, 0.f) + sq[0] * fminf(o.x, 0.f), a.hi);
-                    o.y = fminf(fmaxf(o.y, 0.f) + sq[1] * fminf(o.y, 0.f), a.hi);
-                    o.z = fminf(fmaxf(o.z, 0.f) + sq[2] * fminf(o.z, 0.f), a.hi);
-                    o.w = fminf(fmaxf(o.w, 0.f) + sq[3] * fminf(o.w, 0.f), a.hi);
-                }
-                sst4(obuf + lane * C + 4 * q, o);
-            }
+            sst4(obuf + lane * C + 4 * q, o);
         }
         wave_sync();
         float* dst = out + (long)y * a.W * C + gout;
@@ -281,10 +289,11 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
         acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = acc2[q][0] = acc2[q][1] = v2f{0.f, 0.f};
         xa[q] = xb[q] = xd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // Step r consumes input row r from buffer BI (its DMA was started two steps earlier), starts the DMA of row r+2 into
-    // the buffer row r-1 used, and emits output row r-1.  vm operations are retired in issue order, so "row r has landed"
-    // = at most [DMA of row r+1] + [stores of step r-1] still outstanding; the store count is only relied on when it is
-    // exact (full strip, previous step emitted), otherwise the wait also covers those (older) stores.
+    // Step r consumes input row r from buffer r & 1 (band-relative), emits output row r-1 through the same buffer and then
+    // starts the DMA of row r+2 into it; row r+1 is in flight in the other buffer meanwhile.  vm operations are retired
+    // in issue order, so "row r has landed" = at most [stores of step r-1] + [DMA of row r+1] still outstanding; the
+    // store count is only relied on when it is exact (full strip, previous step emitted), otherwise the wait also covers
+    // those stores.
     // EMIT is a compile-time property of the call site (the two priming rows of a band produce no output): as a run-time
     // branch the compiler sinks a third of the depthwise FMAs into it, across the scheduling fences, and spills SGPRs.
 #ifdef MI_STRIP_STAMPS
@@ -293,8 +302,8 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 #else
 #define MI_SSTAMP(k)
 #endif
-    auto step = [&](auto emit, auto bi_t, int r, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
-        constexpr int BI = decltype(bi_t)::value;
+    auto step = [&](auto emit, int r, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
+        const int bi = (r - (y0 - 1)) & 1;
         if (r + 1 <= y1) {
             if (full && r >= y0 + 2) wait_vm<NL + CQ>();
             else wait_vm<NL>();
@@ -302,30 +311,27 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
             wait_vm<0>();
         }
         MI_SSTAMP(0)
-        fix_row(r, BI);
+        fix_row(r, bi);
         wave_sync();
-        if (r + 2 <= y1) issue_row(r + 2, (BI + 2) % 3);
         MI_SSTAMP(1)
-        row(emit, BI, aP, aC, aN, xcur);
+        row(emit, bi, aP, aC, aN, xprev, xcur);
         wave_sync();  // every read of the row image above is issued before the epilogue overwrites it
         MI_SSTAMP(2)
-        if constexpr (decltype(emit)::value) epilogue(r - 1, BI, xprev);
+        if constexpr (decltype(emit)::value) epilogue(r - 1, bi);
         wave_sync();
+        if (r + 2 <= y1) issue_row(r + 2, bi);
         MI_SSTAMP(3)
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
     issue_row(y0 - 1, 0);
     issue_row(y0, 1);
-    step(std::false_type{}, I0{}, y0 - 1, acc0, acc1, acc2, xd, xa);
-    step(std::false_type{}, I1{}, y0, acc1, acc2, acc0, xa, xb);
+    step(std::false_type{}, y0 - 1, acc0, acc1, acc2, xd, xa);
+    step(std::false_type{}, y0, acc1, acc2, acc0, xa, xb);
     for (int r = y0 + 1; r <= y1; r += 3) {
-        step(std::true_type{}, I2{}, r, acc2, acc0, acc1, xb, xd);
+        step(std::true_type{}, r, acc2, acc0, acc1, xb, xd);
         if (r + 1 > y1) break;
-        step(std::true_type{}, I0{}, r + 1, acc0, acc1, acc2, xd, xa);
+        step(std::true_type{}, r + 1, acc0, acc1, acc2, xd, xa);
         if (r + 2 > y1) break;
-        step(std::true_type{}, I1{}, r + 2, acc1, acc2, acc0, xa, xb);
+        step(std::true_type{}, r + 2, acc1, acc2, acc0, xa, xb);
     }
 #ifdef MI_STRIP_STAMPS
     if (a.stamps && lane == 0)
@@ -336,11 +342,11 @@ __global__ __launch_bounds__(256, 2) void strip_kernel(StripArgs a) {
 unsigned long long* g_strip_stamps = nullptr;  // set by the development harness (MI_STRIP_STAMPS builds)
 
 int strips_band_rows(const BlockArgs& a, int strips) {
-    // about one resident set of waves over the chip (8 per CU), but bands of at least 8 rows (2 halo rows re-read per band)
+    // about one resident set of waves over the chip (12 per CU), but bands of at least 8 rows (2 halo rows re-read per band)
     static const int forced = getenv("MI_STRIP_BAND") ? atoi(getenv("MI_STRIP_BAND")) : 0;  // tuning aid
     if (forced > 0) return std::min(forced, a.H);
     const long per_row_waves = (long)a.B * strips;
-    long bands = std::max<long>(1, (2048 + per_row_waves / 2) / per_row_waves);
+    long bands = std::max<long>(1, (3072 + per_row_waves / 2) / per_row_waves);
     int rows = (int)((a.H + bands - 1) / bands);
     rows = std::max(rows, std::min(a.H, 8));
     return rows;
@@ -360,7 +366,7 @@ int launch_strip_inst(const BlockArgs& a, hipStream_t s) {
     sa.hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY;
     sa.stamps = g_strip_stamps;
     const long waves = (long)a.B * sa.strips * sa.bands;
-    const size_t lds_bytes = (size_t)4 * K::WAVE_F * 4;  // 4 waves x 3 row buffers
+    const size_t lds_bytes = (size_t)4 * K::WAVE_F * 4;  // 4 waves x 2 row buffers
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -389,18 +395,22 @@ bool strip_kernel_supports(const BlockArgs& a) {
 
 bool strip_shape_ok(int C, int Co) { return C == Co && (C == 16 || C == 24 || C == 32); }
 
-int strip_consts_floats(int C) { return C / 4 * 40 + 64 + C / 2 * 64; }
+static int strip_stage_floats(int C) { return 32 + 2 * C + (16 - (2 * C) % 16) % 16; }
+int strip_consts_floats(int C) { return C / 2 * strip_stage_floats(C) + 64; }
 
 // w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C] (TFLite OHWI with H = W = 1), bias [Co] or null, alpha [Co] or null.
 void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
-    const int CQ = C / 4;
+    const int SF = strip_stage_floats(C);
     std::fill(dst, dst + strip_consts_floats(C), 0.f);
-    for (int st = 0; st < 2 * CQ; st++)  // channel pair (2st, 2st+1): 9 taps x 2 (the last 2 floats of the 20 are spare)
+    for (int st = 0; st < C / 2; st++) {  // input channels (2st, 2st+1)
+        float* rec = dst + (size_t)st * SF;
         for (int t = 0; t < 9; t++)
-            for (int e = 0; e < 2; e++) dst[st * 20 + 2 * t + e] = w_dw[t * C + 2 * st + e];
-    float* pb = dst + CQ * 40;
+            for (int e = 0; e < 2; e++) rec[2 * t + e] = w_dw[t * C + 2 * st + e];
+        for (int half = 0; half < 2; half++)
+            for (int o = 0; o < C; o++) rec[32 + half * C + o] = w_pw[(size_t)o * C + 2 * st + half];
+    }
+    float* pb = dst + (size_t)(C / 2) * SF;
     float* ps = pb + 32;
-    float* pa = ps + 32;
     for (int c = 0; c < C; c++) {
         // PW(dw + b_dw) + b_pw = PW(dw) + (W b_dw + b_pw): the depthwise bias is folded into the pointwise bias
         double acc = bias ? bias[c] : 0.0;
@@ -409,12 +419,6 @@ void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float*
         pb[c] = (float)acc;
         ps[c] = act == ACT_PRELU ? alpha[c] : (act == ACT_NONE ? 1.f : 0.f);
     }
-    // A fragment of k-step j: lane l holds W[out = l & 31][in = 2j + (l >> 5)]
-    for (int j = 0; j < C / 2; j++)
-        for (int l = 0; l < 64; l++) {
-            const int o = l & 31, c = 2 * j + (l >> 5);
-            pa[j * 64 + l] = o < C ? w_pw[(size_t)o * C + c] : 0.f;
-        }
 }
 
 const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap) {
