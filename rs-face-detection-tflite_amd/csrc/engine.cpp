@@ -113,6 +113,13 @@ void Model::rebuild() {
                 mo.w2 = pack_pw(m.w2);
                 if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
                 if (m.alpha >= 0) mo.alpha = put(g.tensors[m.alpha].f32);
+                const auto& ws = g.tensors[m.w2].shape;  // [O][1][1][I]
+                if (strip_shape_ok(ws[3], ws[0])) {
+                    std::vector<float> sc(static_cast<size_t>(strip_consts_floats(ws[3])));
+                    strip_pack_consts(ws[3], g.tensors[m.w].f32.data(), m.b >= 0 ? g.tensors[m.b].f32.data() : nullptr, g.tensors[m.w2].f32.data(),
+                                      m.b2 >= 0 ? g.tensors[m.b2].f32.data() : nullptr, m.alpha >= 0 ? g.tensors[m.alpha].f32.data() : nullptr, m.act, sc.data());
+                    mo.strip = put(sc);
+                }
                 chain_off_[i].push_back(mo);
             }
             continue;
@@ -206,7 +213,11 @@ std::string Model::node_label(const Node& n) const {
             const int MT = (Co + 31) / 32, MTG = std::min(4, MT), PG = MT <= 2 ? 2 : 1;
             return "block_kernel<" + std::to_string(MTG) + "," + std::to_string(n.w >= 0 ? n.sh : 1) + "," + (n.w >= 0 ? "3" : "1") + "," + std::to_string(PG) + ">";
         }
-        case Node::Chain: return "chain_kernel<" + std::to_string((g.tensors[n.out].shape.back() + 31) / 32) + ">";
+        case Node::Chain: {
+            const auto& so = g.tensors[n.out].shape;
+            if (so[1] * so[2] <= 256) return "chain_kernel<" + std::to_string((so.back() + 31) / 32) + ">";
+            return "strip_pipe_kernel<" + std::to_string(so.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + ">";
+        }
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -337,18 +348,43 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 ChainArgs a;
                 a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
                 a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.nblocks = static_cast<int>(n.members.size());
+                if (a.nblocks <= kMaxChain && a.H * a.W <= 256 && chain_kernel_supports(a)) {  // frame-resident in LDS
+                    for (size_t k = 0; k < n.members.size(); k++) {
+                        const MemberOff& mo = chain_off_[i][k];
+                        ChainBlock& cb = a.blocks[k];
+                        cb.w_dw = d_weights_ + mo.w;
+                        cb.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
+                        cb.w_pw = d_weights_ + mo.w2;
+                        cb.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
+                        cb.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
+                        cb.act = n.members[k].act;
+                        cb.has_res = n.members[k].res >= 0;
+                    }
+                    rc = launch_chain(a, s);
+                    break;
+                }
+                // row-pipelined group of strip blocks: only the first input and the last output exist in memory
+                std::vector<BlockArgs> blk(n.members.size());
                 for (size_t k = 0; k < n.members.size(); k++) {
                     const MemberOff& mo = chain_off_[i][k];
-                    ChainBlock& cb = a.blocks[k];
-                    cb.w_dw = d_weights_ + mo.w;
-                    cb.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
-                    cb.w_pw = d_weights_ + mo.w2;
-                    cb.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
-                    cb.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
-                    cb.act = n.members[k].act;
-                    cb.has_res = n.members[k].res >= 0;
+                    const Node& m = n.members[k];
+                    BlockArgs& b = blk[k];
+                    b.in = ip; b.out = op; b.in_fs = in_fs; b.out_fs = out_fs;
+                    b.has_dw = 1;
+                    b.w_dw = d_weights_ + mo.w;
+                    b.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
+                    b.w_pw = d_weights_ + mo.w2;
+                    b.w_strip = mo.strip >= 0 ? d_weights_ + mo.strip : nullptr;
+                    b.B = F; b.H = si[1]; b.W = si[2]; b.C = si[3]; b.Ho = si[1]; b.Wo = si[2]; b.Co = si[3];
+                    b.sh = b.sw = 1; b.pt = b.pl = 1;
+                    b.ep.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
+                    b.ep.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
+                    b.ep.act = m.act;
+                    if (m.res >= 0) { b.ep.res = b.in; b.ep.res_fs = b.in_fs; b.ep.res_C = b.C; b.ep.res_mode = RES_DIRECT; }
                 }
-                rc = launch_chain(a, s);
+                if (!strip_pipe_supports(blk.data(), static_cast<int>(blk.size()))) throw std::runtime_error("chain node without a kernel");
+                if (labels) { char buf[96]; labels->back() = strip_pipe_label(blk.data(), static_cast<int>(blk.size()), buf, sizeof buf); }
+                rc = launch_strip_pipe(blk.data(), static_cast<int>(blk.size()), s);
                 break;
             }
             case Node::Block: {

@@ -140,6 +140,11 @@ bool strip_shape_ok(int C, int Co);
 int strip_consts_floats(int C);
 void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
 const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
+// row-pipelined chain of 2..4 strip-eligible blocks (blocks[k+1].in == blocks[k].out, which never reaches HBM)
+bool strip_pipe_supports(const BlockArgs* blocks, int n);
+bool strip_pipe_shape_ok(int C, int W);  // host-only shape test for the planner
+int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream);
+const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
 int launch_chain(const ChainArgs& a, void* stream);
 bool chain_kernel_supports(const ChainArgs& a);
 int launch_add(const EltArgs& a, void* stream);

@@ -2,6 +2,7 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -281,42 +282,65 @@ Plan build_plan(Graph graph, int fuse_level) {
             }
             return c;
         };
+        // a block that can sit inside a chain: stride 1, same shape in and out, skip = its own input (or none)
         auto chainable = [&](const Node& n) {
             if (n.kind != Node::Block || n.w < 0 || n.sh != 1 || n.sw != 1 || n.padding != Padding::Same) return false;
             const auto& si = g.tensors[n.in[0]].shape;
             const auto& so = g.tensors[n.out].shape;
-            if (si.size() != 4 || si != so || si[1] * si[2] > 256 || si[3] % 8) return false;
+            if (si.size() != 4 || si != so) return false;
             if (n.res >= 0 && !(n.res == n.in[0] && n.res_mode == RES_DIRECT)) return false;
             return true;
         };
+        auto links = [&](size_t j) {  // node j+1 continues the chain that node j is in
+            return j + 1 < plan.nodes.size() && chainable(plan.nodes[j + 1]) && plan.nodes[j + 1].in[0] == plan.nodes[j].out &&
+                   g.tensors[plan.nodes[j + 1].in[0]].shape == g.tensors[plan.nodes[j].in[0]].shape &&
+                   (plan.nodes[j + 1].act == ACT_RELU) == (plan.nodes[j].act == ACT_RELU) &&
+                   uses(plan.nodes[j].out) == (plan.nodes[j + 1].res >= 0 ? 2 : 1) &&
+                   std::find(g.outputs.begin(), g.outputs.end(), plan.nodes[j].out) == g.outputs.end();
+        };
+        auto make_chain = [&](size_t i, size_t j) {
+            Node c;
+            c.kind = Node::Chain;
+            c.in = {plan.nodes[i].in[0]};
+            c.out = plan.nodes[j].out;
+            for (size_t k = i; k <= j; k++) {
+                c.members.push_back(plan.nodes[k]);
+                c.src_ops.insert(c.src_ops.end(), plan.nodes[k].src_ops.begin(), plan.nodes[k].src_ops.end());
+            }
+            return c;
+        };
+        static const int pipe_max = getenv("MI_PIPE_K") ? atoi(getenv("MI_PIPE_K")) : 4;  // tuning aid: blocks per row pipeline
         std::vector<Node> fusedv;
         for (size_t i = 0; i < plan.nodes.size();) {
-            size_t j = i;
             if (chainable(plan.nodes[i])) {
-                while (j + 1 < plan.nodes.size() && j + 1 - i < static_cast<size_t>(kMaxChain) && chainable(plan.nodes[j + 1]) &&
-                       plan.nodes[j + 1].in[0] == plan.nodes[j].out && g.tensors[plan.nodes[j + 1].in[0]].shape == g.tensors[plan.nodes[i].in[0]].shape &&
-                       uses(plan.nodes[j].out) == (plan.nodes[j + 1].res >= 0 ? 2 : 1) &&
-                       std::find(g.outputs.begin(), g.outputs.end(), plan.nodes[j].out) == g.outputs.end())
-                    j++;
-            }
-            if (j > i) {
-                ChainArgs ca;
                 const auto& si = g.tensors[plan.nodes[i].in[0]].shape;
-                ca.in = reinterpret_cast<const float*>(0x1000); ca.out = reinterpret_cast<float*>(0x2000);
-                ca.in_fs = ca.out_fs = static_cast<long>(g.tensors[plan.nodes[i].in[0]].elems());
-                ca.B = 1; ca.H = si[1]; ca.W = si[2]; ca.C = si[3]; ca.nblocks = static_cast<int>(j - i + 1);
-                if (chain_kernel_supports(ca)) {
-                    Node c;
-                    c.kind = Node::Chain;
-                    c.in = {plan.nodes[i].in[0]};
-                    c.out = plan.nodes[j].out;
-                    for (size_t k = i; k <= j; k++) {
-                        c.members.push_back(plan.nodes[k]);
-                        c.src_ops.insert(c.src_ops.end(), plan.nodes[k].src_ops.begin(), plan.nodes[k].src_ops.end());
+                size_t j = i;
+                while (links(j)) j++;
+                const int run = static_cast<int>(j - i + 1);
+                if (run >= 2) {
+                    // (a) the whole frame fits in LDS: frame-resident chain kernel
+                    ChainArgs ca;
+                    ca.in = reinterpret_cast<const float*>(0x1000); ca.out = reinterpret_cast<float*>(0x2000);
+                    ca.in_fs = ca.out_fs = static_cast<long>(g.tensors[plan.nodes[i].in[0]].elems());
+                    ca.B = 1; ca.H = si[1]; ca.W = si[2]; ca.C = si[3];
+                    ca.nblocks = std::min(run, kMaxChain);
+                    if (si[1] * si[2] <= 256 && si[3] % 8 == 0 && chain_kernel_supports(ca)) {
+                        fusedv.push_back(make_chain(i, i + ca.nblocks - 1));
+                        i += ca.nblocks;
+                        continue;
                     }
-                    fusedv.push_back(std::move(c));
-                    i = j + 1;
-                    continue;
+                    // (b) narrow layers: row-pipelined groups of up to 4 blocks, the intermediate rows handed over in LDS
+                    if (pipe_max >= 2 && strip_pipe_shape_ok(si[3], si[2])) {
+                        int left = run;
+                        while (left >= 2) {
+                            int take = std::min(left, std::min(pipe_max, 4));
+                            if (left - take == 1 && take > 2) take--;  // never leave a single block behind a full group
+                            fusedv.push_back(make_chain(i, i + take - 1));
+                            i += take;
+                            left -= take;
+                        }
+                        continue;  // a leftover single block is handled by the next iteration as a plain node
+                    }
                 }
             }
             fusedv.push_back(plan.nodes[i]);
@@ -445,7 +469,8 @@ std::string Plan::describe() const {
         os << "]";
         if (n.kind == Node::Conv || n.kind == Node::Dw || (n.kind == Node::Block && n.w >= 0)) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
-        if (n.kind == Node::Chain) os << " x" << n.members.size() << " blocks, frame resident in LDS";
+        if (n.kind == Node::Chain)
+            os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS");
         os << " ops{";
         for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
         os << "}\n";

@@ -84,6 +84,124 @@ __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_ele
 template <int N>
 __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
 
+// One input row r (pixel-major image in LDS; `me` = this lane's left neighbour in it): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aP /
+// aC / aN); the finished row r-1 goes straight into the pointwise accumulators.  Everything runs on the VALU as
+// v_pk_fma_f32 with SGPR-pair weights: on this part the f32 MFMA does not overlap VALU work (measured: 2 x
+// v_mfma_f32_32x32x2_f32 + n x v_fma_f32 costs 129 + 4.5 n cycles, at one or two waves per SIMD), it runs at the
+// packed-FMA rate, and M = 32 would waste a quarter of it on 24 output channels.
+// Work is cut into 2*CQ stages of one input-channel PAIR.  Scalar loads return out of order, so every wait is
+// lgkmcnt(0); each stage therefore waits twice and issues the NEXT chunk's loads right after each wait:
+//   wait | load PW weights of the pair's 2nd channel | depthwise (9 pk) + pointwise of the 1st channel (CQ*2 pk)
+//   wait | load DW + 1st-channel PW weights of the next stage, next quad's pixels | pointwise of the 2nd channel
+template <int CQ, bool EMIT>
+__device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bool has_res, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2],
+                                          const float4 (&xres)[CQ], float4 (&xcur)[CQ], v2f (&oacc)[2 * CQ]) {
+    using K = SK<CQ>;
+    constexpr int C = K::C;
+    float wd[18], wp0[C], wp1[C];
+    float4 xbuf[2][3];
+    auto load_wd = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));  // opaque per use: the scalar loads stay in the row loop, just ahead of their use;
+                                     // the record offset stays an immediate of the s_load (no per-stage pointer to keep)
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[i] = p[K::OFF_DW + st * K::ST_F + i];
+    };
+    auto load_wp = [&](int st, int half, float (&w)[C]) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < C; i++) w[i] = p[K::OFF_DW + st * K::ST_F + 32 + half * C + i];
+    };
+    auto load_x = [&](int q, float4 (&x)[3]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me + kx * C + 4 * q);
+    };
+    if constexpr (EMIT) {  // accumulators start from skip + bias (bias = b_pw + W b_dw)
+        const cfloat* bp = cst + K::OFF_BIAS;
+        asm volatile("" : "+s"(bp));
+#pragma unroll
+        for (int q = 0; q < CQ; q++) {
+            oacc[2 * q] = v2f{bp[4 * q], bp[4 * q + 1]};
+            oacc[2 * q + 1] = v2f{bp[4 * q + 2], bp[4 * q + 3]};
+            if (has_res) {
+                oacc[2 * q] += v2f{xres[q].x, xres[q].y};
+                oacc[2 * q + 1] += v2f{xres[q].z, xres[q].w};
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    load_wd(0);
+    if (EMIT) load_wp(0, 0, wp0);
+    load_x(0, xbuf[0]);
+#pragma unroll
+    for (int st = 0; st < 2 * CQ; st++) {
+        const int q = st >> 1, h = st & 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        if (EMIT) load_wp(st, 1, wp1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&x)[3] = xbuf[q & 1];
+        if (h == 0) xcur[q] = x[1];
+        v2f t[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
+        auto wv = [&](int tap) { return v2f{wd[2 * tap], wd[2 * tap + 1]}; };
+        v2f n = t[0] * wv(0), c = aC[q][h], pch = aP[q][h];  // the depthwise bias is folded into the pointwise bias on the host
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            if (EMIT) pch = pkfma(t[kx], wv(6 + kx), pch);
+            if (kx) n = pkfma(t[kx], wv(kx), n);
+            c = pkfma(t[kx], wv(3 + kx), c);
+        }
+        aC[q][h] = c;
+        aN[q][h] = n;
+        // pin the partial rows here: left alone, LLVM sinks these updates past the loop-exit test into the next row's
+        // block, across the scheduling fences, which keeps every stage's weights alive (SGPR spills)
+        asm volatile("" : "+v"(aC[q][h]), "+v"(aN[q][h]));
+        if constexpr (EMIT) {
+#pragma unroll
+            for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.x, pch.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc[o]);
+            asm volatile("" : "+v"(pch));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (st + 1 < 2 * CQ) {
+            load_wd(st + 1);
+            if (EMIT) load_wp(st + 1, 0, wp0);
+            if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (EMIT) {
+#pragma unroll
+            for (int o = 0; o < 2 * CQ; o++) {
+                oacc[o] = pkfma(v2f{pch.y, pch.y}, v2f{wp1[2 * o], wp1[2 * o + 1]}, oacc[o]);
+                asm volatile("" : "+v"(oacc[o]));  // same pin as above: a caller that emits conditionally must not pull the pointwise FMAs into its branch
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// activation of a finished output row (lane = pixel, channel quads)
+template <int CQ, bool RELU>
+__device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloat* cst, float hi, float4 (&o)[CQ]) {
+    using K = SK<CQ>;
+#pragma unroll
+    for (int q = 0; q < CQ; q++) {
+        o[q] = make_float4(oacc[2 * q].x, oacc[2 * q].y, oacc[2 * q + 1].x, oacc[2 * q + 1].y);
+        if (RELU) {
+            o[q].x = fmaxf(o[q].x, 0.f); o[q].y = fmaxf(o[q].y, 0.f); o[q].z = fmaxf(o[q].z, 0.f); o[q].w = fmaxf(o[q].w, 0.f);
+        } else {
+            // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
+            const cfloat* sq = cst + K::OFF_SLOPE + 4 * q;
+            o[q].x = fminf(fmaxf(o[q].x, 0.f) + sq[0] * fminf(o[q].x, 0.f), hi);
+            o[q].y = fminf(fmaxf(o[q].y, 0.f) + sq[1] * fminf(o[q].y, 0.f), hi);
+            o[q].z = fminf(fmaxf(o[q].z, 0.f) + sq[2] * fminf(o[q].z, 0.f), hi);
+            o[q].w = fminf(fmaxf(o[q].w, 0.f) + sq[3] * fminf(o[q].w, 0.f), hi);
+        }
+    }
+}
+
 template <int CQ, bool RELU>
 __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a) {
     using K = SK<CQ>;
@@ -156,118 +274,18 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
         }
     };
 
-    // One input row r (DMA image in buffer bi): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aP /
-    // aC / aN); the finished row r-1 goes straight into the pointwise accumulators.  Everything runs on the VALU as
-    // v_pk_fma_f32 with SGPR-pair weights: on this part the f32 MFMA does not overlap VALU work (measured: 2 x
-    // v_mfma_f32_32x32x2_f32 + n x v_fma_f32 costs 129 + 4.5 n cycles, at one or two waves per SIMD), it runs at the
-    // packed-FMA rate, and M = 32 would waste a quarter of it on 24 output channels.
-    // Work is cut into 2*CQ stages of one input-channel PAIR.  Scalar loads return out of order, so every wait is
-    // lgkmcnt(0); each stage therefore waits twice and issues the NEXT chunk's loads right after each wait:
-    //   wait | load PW weights of the pair's 2nd channel | depthwise (9 pk) + pointwise of the 1st channel (CQ*2 pk)
-    //   wait | load DW + 1st-channel PW weights of the next stage, next quad's pixels | pointwise of the 2nd channel
     v2f oacc[2 * CQ];
     auto row = [&](auto emit_t, int bi, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xres)[CQ], float4 (&xcur)[CQ]) {
-        constexpr bool EMIT = decltype(emit_t)::value;
-        const float* me = wbase + bi * BUF_F + lane * C;
-        float wd[18], wp0[C], wp1[C];
-        float4 xbuf[2][3];
-        auto load_wd = [&](int st) {
-            const cfloat* p = cst;
-            asm volatile("" : "+s"(p));  // opaque per use: the scalar loads stay in the row loop, just ahead of their use;
-                                         // the record offset stays an immediate of the s_load (no per-stage pointer to keep)
-#pragma unroll
-            for (int i = 0; i < 18; i++) wd[i] = p[K::OFF_DW + st * K::ST_F + i];
-        };
-        auto load_wp = [&](int st, int half, float (&w)[C]) {
-            const cfloat* p = cst;
-            asm volatile("" : "+s"(p));
-#pragma unroll
-            for (int i = 0; i < C; i++) w[i] = p[K::OFF_DW + st * K::ST_F + 32 + half * C + i];
-        };
-        auto load_x = [&](int q, float4 (&x)[3]) {
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me + kx * C + 4 * q);
-        };
-        if constexpr (EMIT) {  // accumulators start from skip + bias (bias = b_pw + W b_dw)
-            const cfloat* bp = cst + K::OFF_BIAS;
-            asm volatile("" : "+s"(bp));
-#pragma unroll
-            for (int q = 0; q < CQ; q++) {
-                oacc[2 * q] = v2f{bp[4 * q], bp[4 * q + 1]};
-                oacc[2 * q + 1] = v2f{bp[4 * q + 2], bp[4 * q + 3]};
-                if (a.has_res) {
-                    oacc[2 * q] += v2f{xres[q].x, xres[q].y};
-                    oacc[2 * q + 1] += v2f{xres[q].z, xres[q].w};
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
-        load_wd(0);
-        if (EMIT) load_wp(0, 0, wp0);
-        load_x(0, xbuf[0]);
-#pragma unroll
-        for (int st = 0; st < 2 * CQ; st++) {
-            const int q = st >> 1, h = st & 1;
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-            if (EMIT) load_wp(st, 1, wp1);
-            __builtin_amdgcn_sched_barrier(0);
-            const float4 (&x)[3] = xbuf[q & 1];
-            if (h == 0) xcur[q] = x[1];
-            v2f t[3];
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
-            auto wv = [&](int tap) { return v2f{wd[2 * tap], wd[2 * tap + 1]}; };
-            v2f n = t[0] * wv(0), c = aC[q][h], pch = aP[q][h];  // the depthwise bias is folded into the pointwise bias on the host
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                if (EMIT) pch = pkfma(t[kx], wv(6 + kx), pch);
-                if (kx) n = pkfma(t[kx], wv(kx), n);
-                c = pkfma(t[kx], wv(3 + kx), c);
-            }
-            aC[q][h] = c;
-            aN[q][h] = n;
-            // pin the partial rows here: left alone, LLVM sinks these updates past the loop-exit test into the next row's
-            // block, across the scheduling fences, which keeps every stage's weights alive (SGPR spills)
-            asm volatile("" : "+v"(aC[q][h]), "+v"(aN[q][h]));
-            if constexpr (EMIT) {
-#pragma unroll
-                for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.x, pch.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc[o]);
-                asm volatile("" : "+v"(pch));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            if (st + 1 < 2 * CQ) {
-                load_wd(st + 1);
-                if (EMIT) load_wp(st + 1, 0, wp0);
-                if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (EMIT) {
-#pragma unroll
-                for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.y, pch.y}, v2f{wp1[2 * o], wp1[2 * o + 1]}, oacc[o]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        strip_row<CQ, decltype(emit_t)::value>(wbase + bi * BUF_F + lane * C, cst, a.has_res != 0, aP, aC, aN, xres, xcur, oacc);
     };
     // epilogue of output row y: activation, then transposed through the (now dead) row buffer bi so that every store
     // instruction writes 1 KiB of consecutive bytes
     auto epilogue = [&](int y, int bi) {
         float* obuf = wbase + bi * BUF_F;
+        float4 o[CQ];
+        strip_act<CQ, RELU>(oacc, cst, a.hi, o);
 #pragma unroll
-        for (int q = 0; q < CQ; q++) {
-            float4 o = make_float4(oacc[2 * q].x, oacc[2 * q].y, oacc[2 * q + 1].x, oacc[2 * q + 1].y);
-            if (RELU) {
-                o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-            } else {
-                // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
-                const cfloat* sq = cst + K::OFF_SLOPE + 4 * q;
-                o.x = fminf(fmaxf(o.x, 0.f) + sq[0] * fminf(o.x, 0.f), a.hi);
-                o.y = fminf(fmaxf(o.y, 0.f) + sq[1] * fminf(o.y, 0.f), a.hi);
-                o.z = fminf(fmaxf(o.z, 0.f) + sq[2] * fminf(o.z, 0.f), a.hi);
-                o.w = fminf(fmaxf(o.w, 0.f) + sq[3] * fminf(o.w, 0.f), a.hi);
-            }
-            sst4(obuf + lane * C + 4 * q, o);
-        }
+        for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
         wave_sync();
         float* dst = out + (long)y * a.W * C + gout;
         if (full) {  // wave-uniform
@@ -337,6 +355,190 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
     if (a.stamps && lane == 0)
         for (int k = 0; k < 4; k++) a.stamps[((long)blockIdx.x * 4 + wave) * 8 + k] = st_acc[k];
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-pipelined chain of KB same-shape stride-1 blocks (W <= 128): one workgroup = 2 * KB waves.  Waves (2j, 2j+1) run
+// block j of the chain on the two 64-column strips of a band (W <= 64: on two independent bands); block j's finished row
+// goes, activated, into a double-buffered full-width row image in LDS instead of HBM, where block j+1's waves pick it
+// up one step later (they read their strip's 66-pixel window of it, so the halo columns come from the partner wave for
+// free).  Only block 0 reads HBM (LDS-DMA) and only block KB-1 writes it: the HBM traffic of KB layers becomes that of
+// one.  Steps are separated by one s_barrier; block j lags block j-1 by two rows, so a band costs band_rows + 3 KB - 1
+// steps, and block j computes KB-1-j extra rows above and below the band (the halo of the blocks behind it).
+constexpr int kMaxPipe = 4;
+struct PipeArgs {
+    const float* in;
+    float* out;
+    const float* consts[kMaxPipe];  // strip_pack_consts() blobs, one per block
+    long in_fs, out_fs;
+    int B, H, W;
+    int strips, bands, band_rows, units;
+    int has_res[kMaxPipe];
+    float hi[kMaxPipe];
+};
+
+template <int CQ, int KB, bool RELU>
+__global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
+    using K = SK<CQ>;
+    constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
+    constexpr int IMG = 132 * C;                 // floats of one full-width row image (<= 130 pixels used)
+    constexpr int RING_F = (KB - 1) * 2 * IMG;   // KB-1 hand-over rings of two row images
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = w & 1, role = w >> 1;
+    // wave-private scratch: block 0 waves own two DMA row buffers each, block KB-1 waves one transposition buffer each
+    float* scratch = lds + RING_F + (role == 0 ? p * 2 * BUF_F : 4 * BUF_F + p * BUF_F);
+    const int unit = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + p;
+    const bool active = unit < a.units;
+    const int band = unit % a.bands, b = min(unit / a.bands, a.B - 1);
+    const int x0 = a.strips == 2 ? 64 * p : 0;
+    const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
+    const float* in = a.in + (long)b * a.in_fs;
+    float* out = a.out + (long)b * a.out_fs;
+    const cfloat* cst = (const cfloat*)a.consts[role];
+    const bool has_res = a.has_res[role] != 0;
+    const float hi = a.hi[role];
+    const int lo_j = y0 - (KB - 1 - role), hi_j = y1 + (KB - 1 - role);  // this block produces rows [lo_j, hi_j)
+    const int img_p = a.strips == 2 ? 64 * C * p : 66 * C * p;           // this wave's window / sub-image inside a row image
+
+    // clear the hand-over rings once: their border pixel columns (left of x = 0, right of x = W-1) are never written
+    for (int i = threadIdx.x; i < RING_F / 4; i += 128 * KB) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int goff[NL];  // block 0: byte offset of the lane's float4 from the row start, per DMA instruction (see strip_kernel)
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int f = min(lane + 64 * k, K::NF - 1), px = f / CQ, qd = f - px * CQ;
+        goff[k] = (min(max(x0 - 1 + px, 0), a.W - 1) * C + 4 * qd) * 4;
+    }
+    const int npx = min(64, a.W - x0);
+    const bool full = npx == 64;
+    const int zl = x0 == 0 ? 0 : -1;
+    const int zr = x0 + 64 >= a.W ? npx + 1 : -1;
+    const long gout = (long)x0 * C + 4 * lane;
+    const unsigned lds_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)scratch);
+    auto issue_row = [&](int r, int bi) {
+        const char* src = reinterpret_cast<const char*>(in + (long)min(max(r, 0), a.H - 1) * a.W * C);
+        const unsigned dstb = lds_scratch + (unsigned)(bi * BUF_F * 4);
+        constexpr int TAIL = K::NF - 64 * (NL - 1);
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            if (k < NL - 1 || TAIL == 64) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+            } else {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+            }
+        }
+    };
+    auto fix_row = [&](int r, int bi) {
+        float* buf = scratch + bi * BUF_F;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 0 || r >= a.H) {
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
+        } else if (lane < CQ) {
+            if (zl >= 0) sst4(buf + zl * C + 4 * lane, z);
+            if (zr >= 0) sst4(buf + zr * C + 4 * lane, z);
+        }
+    };
+
+    v2f acc0[CQ][2], acc1[CQ][2], acc2[CQ][2], oacc[2 * CQ];
+    float4 xa[CQ], xb[CQ], xd[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; q++) {
+        acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = acc2[q][0] = acc2[q][1] = v2f{0.f, 0.f};
+        xa[q] = xb[q] = xd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int c_first = y0 - KB - 2 * role;  // row this block would consume at step 0 (it starts at step 3 * role)
+    if (role == 0 && active) {
+        issue_row(c_first, 0);
+        issue_row(c_first + 1, 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+
+    auto step = [&](int t, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
+        const int c = c_first + t;  // row consumed in this step; the row it completes is c - 1
+        if (active && c >= lo_j - 1 && c <= hi_j) {
+            const float* me;
+            if (role == 0) {
+                if (c + 1 <= hi_j) wait_vm<NL>();
+                else wait_vm<0>();
+                fix_row(c, t & 1);
+                wave_sync();
+                me = scratch + (t & 1) * BUF_F + lane * C;
+            } else {
+                me = lds + ((role - 1) * 2 + ((t - 1) & 1)) * IMG + img_p + lane * C;
+            }
+            strip_row<CQ, true>(me, cst, has_res, aP, aC, aN, xprev, xcur, oacc);
+            wave_sync();
+            const int e = c - 1;
+            if (e >= lo_j && e < hi_j) {
+                float4 o[CQ];
+                strip_act<CQ, RELU>(oacc, cst, hi, o);
+                if (role < KB - 1) {
+                    // hand the row to the next block; rows outside the image are that block's zero padding
+                    const bool zero = e < 0 || e >= a.H || lane >= npx;
+                    float* dstl = lds + (role * 2 + (t & 1)) * IMG + img_p + (1 + lane) * C;
+#pragma unroll
+                    for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, zero ? make_float4(0.f, 0.f, 0.f, 0.f) : o[q]);
+                } else {
+                    float* obuf = scratch;
+#pragma unroll
+                    for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+                    wave_sync();
+                    float* dst = out + (long)e * a.W * C + gout;
+                    if (full) {
+#pragma unroll
+                        for (int k = 0; k < CQ; k++) sst4(dst + 256 * k, sld4(obuf + 4 * lane + 256 * k));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CQ; k++) {
+                            const float4 v = sld4(obuf + 4 * lane + 256 * k);
+                            if (lane + 64 * k < npx * CQ) sst4(dst + 256 * k, v);
+                        }
+                    }
+                }
+            }
+            if (role == 0 && c + 2 <= hi_j) {
+                wave_sync();
+                issue_row(c + 2, t & 1);
+            }
+        }
+        // one workgroup barrier per step: raw s_barrier with an LDS-only wait, so that the stores of block KB-1 and the
+        // DMA of block 0 stay in flight across it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const int T = a.band_rows + 3 * KB - 1;
+    for (int t = 0; t < T; t += 3) {
+        step(t, acc0, acc1, acc2, xd, xa);
+        if (t + 1 >= T) break;
+        step(t + 1, acc1, acc2, acc0, xa, xb);
+        if (t + 2 >= T) break;
+        step(t + 2, acc2, acc0, acc1, xb, xd);
+    }
+}
+
+template <int CQ, int KB, bool RELU>
+int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
+    using K = SK<CQ>;
+    auto kern = strip_pipe_kernel<CQ, KB, RELU>;
+    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + 6 * K::BUF_F) * 4;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const int wgs = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(128 * KB), lds_bytes, s, pa);
+    return (int)hipGetLastError();
 }
 
 unsigned long long* g_strip_stamps = nullptr;  // set by the development harness (MI_STRIP_STAMPS builds)
@@ -433,6 +635,59 @@ int launch_strip(const BlockArgs& a, void* stream) {
     if (a.C == 4 * Q) return relu ? launch_strip_inst<Q, true>(a, s) : launch_strip_inst<Q, false>(a, s);
     MI_STRIP_CASE(4) MI_STRIP_CASE(6) MI_STRIP_CASE(8)
 #undef MI_STRIP_CASE
+    return (int)hipErrorInvalidValue;
+}
+
+// Row-pipelined chain of n (2..4) strip-eligible blocks: blocks[k+1] consumes blocks[k]'s output, which never reaches HBM.
+bool strip_pipe_supports(const BlockArgs* blocks, int n) {
+    static const bool off = getenv("MI_NO_PIPE") != nullptr;  // tuning aid
+    if (off || n < 2 || n > kMaxPipe) return false;
+    for (int k = 0; k < n; k++) {
+        BlockArgs t = blocks[k];
+        if (k > 0) { t.in = blocks[0].in; t.in_fs = blocks[0].in_fs; if (t.ep.res_mode != RES_NONE) { t.ep.res = t.in; t.ep.res_fs = t.in_fs; } }
+        if (k < n - 1) { t.out = blocks[n - 1].out; t.out_fs = blocks[n - 1].out_fs; }
+        if (!strip_kernel_supports(t)) return false;
+        if (t.C != blocks[0].C || t.H != blocks[0].H || t.W != blocks[0].W) return false;
+        if ((t.ep.act == ACT_RELU) != (blocks[0].ep.act == ACT_RELU)) return false;
+    }
+    return blocks[0].W <= 128 && blocks[0].C <= 24;
+}
+
+bool strip_pipe_shape_ok(int C, int W) { return getenv("MI_NO_PIPE") == nullptr && (C == 16 || C == 24) && W <= 128; }
+
+const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap) {
+    snprintf(buf, cap, "strip_pipe_kernel<%d,%d,%d>", blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0);
+    return buf;
+}
+
+int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
+    const BlockArgs& a = blocks[0];
+    PipeArgs pa{};
+    pa.in = a.in; pa.out = blocks[n - 1].out; pa.in_fs = a.in_fs; pa.out_fs = blocks[n - 1].out_fs;
+    pa.B = a.B; pa.H = a.H; pa.W = a.W;
+    pa.strips = (a.W + 63) / 64;
+    for (int k = 0; k < n; k++) {
+        pa.consts[k] = blocks[k].w_strip;
+        pa.has_res[k] = blocks[k].ep.res_mode == RES_DIRECT;
+        pa.hi[k] = blocks[k].ep.act == ACT_RELU6 ? 6.f : INFINITY;
+    }
+    // bands: about one resident set of workgroups over the chip, but not so short that the 3n-1 pipeline fill steps dominate
+    static const int forced = getenv("MI_PIPE_BAND") ? atoi(getenv("MI_PIPE_BAND")) : 0;  // tuning aid
+    const int per_cu = n <= 2 ? 2 : 1;
+    const long wg_units = pa.strips == 2 ? 1 : 2;
+    long bands = std::max<long>(1, (256L * per_cu * wg_units + a.B / 2) / std::max(1, a.B));
+    int rows = (int)((a.H + bands - 1) / bands);
+    rows = std::max(rows, std::min(a.H, 8 * n));
+    if (forced > 0) rows = std::min(forced, a.H);
+    pa.band_rows = rows;
+    pa.bands = (a.H + rows - 1) / rows;
+    pa.units = a.B * pa.bands;
+    hipStream_t s = (hipStream_t)stream;
+    const bool relu = a.ep.act == ACT_RELU;
+#define MI_PIPE_CASE(Q, KBV) \
+    if (a.C == 4 * Q && n == KBV) return relu ? launch_pipe_inst<Q, KBV, true>(pa, s) : launch_pipe_inst<Q, KBV, false>(pa, s);
+    MI_PIPE_CASE(4, 2) MI_PIPE_CASE(4, 3) MI_PIPE_CASE(4, 4) MI_PIPE_CASE(6, 2) MI_PIPE_CASE(6, 3) MI_PIPE_CASE(6, 4)
+#undef MI_PIPE_CASE
     return (int)hipErrorInvalidValue;
 }
 

@@ -76,6 +76,49 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
         printf("%s B %d %dx%d C %d : %.4f ms  %.1f GB/s algorithmic\n", which ? "strip" : "block", B, H, W, C, ms, 2.0 * n * 4 / ms / 1e6);
     }
+    int nb = argc > 7 ? atoi(argv[7]) : 1;
+    if (nb > 1) {  // row-pipelined chain of nb blocks vs nb strip launches
+        std::vector<BlockArgs> blk(nb);
+        float *t0, *t1, *dpipe; CK(hipMalloc(&t0, n * 4)); CK(hipMalloc(&t1, n * 4)); CK(hipMalloc(&dpipe, n * 4));
+        for (int k = 0; k < nb; k++) {
+            std::vector<float> w2(9 * C), bdw2(C), bias2(C), pw2((size_t)C * C), sc2(strip_consts_floats(C));
+            for (auto& v : w2) v = 0.3f * rnd(seed);
+            for (auto& v : bdw2) v = 0.1f * rnd(seed);
+            for (auto& v : bias2) v = 0.1f * rnd(seed);
+            for (auto& v : pw2) v = 0.2f * rnd(seed);
+            strip_pack_consts(C, w2.data(), bdw2.data(), pw2.data(), bias2.data(), alpha.data(), act, sc2.data());
+            float* dsc; up(&dsc, sc2);
+            blk[k] = a2; blk[k].w_strip = dsc;
+            blk[k].in = k == 0 ? din : (k % 2 ? t0 : t1);
+            blk[k].out = k == nb - 1 ? dout : (k % 2 ? t1 : t0);
+            if (has_res) blk[k].ep.res = blk[k].in;
+        }
+        for (int k = 0; k < nb; k++) if (launch_strip(blk[k], s)) { printf("strip launch failed\n"); return 1; }
+        CK(hipStreamSynchronize(s));
+        if (!strip_pipe_supports(blk.data(), nb)) { printf("pipe: unsupported\n"); return 1; }
+        std::vector<BlockArgs> pb = blk; pb[nb - 1].out = dpipe;
+        CK(hipMemset(dpipe, 0xff, n * 4));
+        int rc = launch_strip_pipe(pb.data(), nb, s);
+        if (rc) { printf("pipe launch failed %d\n", rc); return 1; }
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(r0.data(), dout, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), dpipe, n * 4, hipMemcpyDeviceToHost));
+        double md = 0; size_t nbad = 0, fi = (size_t)-1;
+        for (size_t i = 0; i < n; i++) { double d = std::fabs((double)r0[i] - r1[i]); if (!(d <= 1e-5 * std::max(1.0, std::fabs((double)r0[i])))) { if (!nbad) fi = i; nbad++; } if (d > md || d != d) md = d; }
+        printf("pipe x%d check: max |diff| %.3g, %zu of %zu outside 1e-5", nb, md, nbad, n);
+        if (nbad) { size_t px = fi / C; printf("  first at frame %zu y %zu x %zu c %zu: ref %g got %g", px / ((size_t)H * W), px / W % H, px % W, fi % C, r0[fi], r1[fi]); }
+        printf("\n");
+        for (int which = 0; which < 2; which++) {
+            const int it = 20;
+            auto run = [&] { if (which) launch_strip_pipe(pb.data(), nb, s); else for (int k = 0; k < nb; k++) launch_strip(blk[k], s); };
+            for (int i = 0; i < 3; i++) run();
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < it; i++) run();
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+            printf("%s x%d B %d %dx%d C %d : %.4f ms (%.4f per block)\n", which ? "pipe " : "strips", nb, B, H, W, C, ms, ms / nb);
+        }
+        return nbad ? 2 : 0;
+    }
 #ifdef MI_STRIP_STAMPS
     {
         int strips = (W + 63) / 64, rows = strips_band_rows(a2, strips), bands = (H + rows - 1) / rows;
