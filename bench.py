@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+F32_PEAK_TFLOPS = 157.3  # dense f32 (MFMA = packed VALU FMA), /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -163,14 +164,22 @@ def main():
                     traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "launches_per_step": d["calls"],
-                    "avg_launch_ms": round(d["ms"] / d["calls"], 5),
-                    "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]),
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "net_event_ms": round(sum(r["ms"] for r in recs), 4),
-                    "kernels": {k: {"ms": round(v["ms"], 4), "calls": v["calls"], "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                                    "TFLOPs": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in by.items()}}
+        # Which roof binds the dominant kernel: its algorithmic bytes against HBM, or its algorithmic FLOPs against the dense
+        # f32 rate (157.3 TFLOP/s: v_mfma_f32_* and v_pk_fma_f32 have the same peak on gfx950; the row-pipelined chain
+        # kernels keep the intermediate rows of up to 4 layers in LDS, so their launches are FLOP-bound, not HBM-bound).
+        tflops = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+        hbm_frac, flop_frac = achieved / HBM_PEAK_GBS, tflops / F32_PEAK_TFLOPS
+        common = {"kernel": dom, "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 5),
+                  "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]), "algorithmic_flops_per_launch": round(2 * d["macs"] / d["calls"]),
+                  "hbm_GBps": round(achieved, 1), "hbm_frac": round(hbm_frac, 4), "f32_TFLOPs": round(tflops, 2), "f32_frac": round(flop_frac, 4)}
+        if hbm_frac >= flop_frac:
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic}
+        else:
+            roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic}
+        roofline.update(common)
+        roofline["net_event_ms"] = round(sum(r["ms"] for r in recs), 4)
+        roofline["kernels"] = {k: {"ms": round(v["ms"], 4), "calls": v["calls"], "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                                   "TFLOPs": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in by.items()}
         value = world * B * args.steps / elapsed
         result = {
             "metric": "faces/sec at batch=256 (256x256 back-camera) per GPU", "value": round(value, 1), "unit": "faces/s",

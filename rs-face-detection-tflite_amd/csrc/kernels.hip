@@ -118,19 +118,31 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     const int b = t / tiles_y;
     const float* in = a.in + (long)b * a.in_fs;
     const int ix0 = tx0 * 2 - a.pl, iy0 = ty0 * 2 - a.pt;
-    for (int i = tid; i < IH * IW * 3; i += 256) {
-        int r = i / (IW * 3), e = i - r * (IW * 3);
-        int iy = iy0 + r, ix = ix0 + e / 3;
-        float v = 0.f;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = in[((long)iy * a.W) * 3 + (long)ix0 * 3 + e];
-        tile[r * RS + e] = v;
+    // all loads of the tile are issued before the first LDS write (a load -> wait -> write loop pays one HBM round trip per
+    // iteration: 15 of them in a row made this kernel latency-bound at 2.1 TB/s)
+    constexpr int NLD = (IH * IW * 3 + 255) / 256;
+    float stage[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int i = tid + 256 * k;
+        const int r = i / (IW * 3), e = i - r * (IW * 3);
+        const int iy = iy0 + r, ix = ix0 + e / 3;
+        stage[k] = 0.f;
+        if (i < IH * IW * 3 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) stage[k] = in[((long)iy * a.W) * 3 + (long)ix0 * 3 + e];
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int i = tid + 256 * k;
+        const int r = i / (IW * 3), e = i - r * (IW * 3);
+        if (i < IH * IW * 3) tile[r * RS + e] = stage[k];
     }
     __syncthreads();
     const int lx = tid & (TW - 1), ly = tid / TW;
     const int ox = tx0 + lx, oy = ty0 + ly;
-    float acc[CO];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f acc2[CO / 2];  // two output channels per v_pk_fma_f32 (the weight pair is an SGPR-pair operand)
 #pragma unroll
-    for (int o = 0; o < CO; o++) acc[o] = 0.f;
+    for (int o = 0; o < CO / 2; o++) acc2[o] = v2f{0.f, 0.f};
     const float* __restrict__ w = a.w;  // [K][K][3][Cop], uniform -> scalar loads
     const int Cop = (CO + 3) & ~3;
     // Not unrolled beyond 3 taps: the weights of a tap are 24..64 SGPRs; letting the compiler hoist all K*K*3 taps'
@@ -144,9 +156,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
             const float xv = row[e];
             const float* we = wk + (long)e * Cop;
 #pragma unroll
-            for (int o = 0; o < CO; o++) acc[o] = fmaf(xv, we[o], acc[o]);
+            for (int o = 0; o < CO / 2; o++) acc2[o] = __builtin_elementwise_fma(v2f{xv, xv}, v2f{we[2 * o], we[2 * o + 1]}, acc2[o]);
         }
     }
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO / 2; o++) { acc[2 * o] = acc2[o].x; acc[2 * o + 1] = acc2[o].y; }
     // Epilogue through LDS: a thread owns one pixel (CO floats), but 16-byte stores at a CO*4-byte lane stride reach
     // HBM as partial 32-byte sectors (measured 2.85x WRITE_SIZE).  Re-tile so that each wave-instruction writes
     // 1 KiB of consecutive addresses: the tile's rows are contiguous runs of TW*CO floats in the NHWC output.
@@ -154,14 +169,23 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     float* otile = tile;  // [TH*TW][CO + 4] (pad keeps the float4 writes of consecutive pixels on distinct banks)
     constexpr int OS = CO + 4;
     static_assert(TH * TW * OS <= IH * RS || true, "");
+    // branch-free activation: act(v) = min(max(v,0) + slope * min(v,0), hi) with slope 0 (ReLU / ReLU6), alpha (PReLU) or 1
+    // (none).  A switch per element costs a scalar load + wait + branches for each of the CO channels of every wave,
+    // which took longer than the 900 packed FMAs of the 5x5 stem.
+    const bool prelu = a.ep.act == ACT_PRELU;
+    const float base_slope = a.ep.act == ACT_NONE ? 1.f : 0.f, hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY;
+    const float* __restrict__ bias = a.ep.bias;
+    const float* __restrict__ al = prelu ? a.ep.alpha : a.ep.bias;  // always a readable array: no branch around the loads
 #pragma unroll
     for (int o = 0; o < CO; o += 4) {
-        float4 v;
-        v.x = apply_act(acc[o] + a.ep.bias[o], a.ep.act, a.ep.alpha, o);
-        v.y = apply_act(acc[o + 1] + a.ep.bias[o + 1], a.ep.act, a.ep.alpha, o + 1);
-        v.z = apply_act(acc[o + 2] + a.ep.bias[o + 2], a.ep.act, a.ep.alpha, o + 2);
-        v.w = apply_act(acc[o + 3] + a.ep.bias[o + 3], a.ep.act, a.ep.alpha, o + 3);
-        *reinterpret_cast<float4*>(otile + tid * OS + o) = v;
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float v = acc[o + e] + bias[o + e];
+            const float sl = prelu ? al[o + e] : base_slope;
+            r[e] = fminf(fmaxf(v, 0.f) + sl * fminf(v, 0.f), hi);
+        }
+        *reinterpret_cast<float4*>(otile + tid * OS + o) = make_float4(r[0], r[1], r[2], r[3]);
     }
     __syncthreads();
     constexpr int C4 = CO / 4;

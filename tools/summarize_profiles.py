@@ -2,7 +2,8 @@
 usage: python tools/summarize_profiles.py <round-tag> <trace-dir> <fetch-dir> <write-dir>
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate
 passes, are reported in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide (16 B/lane) coalesced read stream,
-so reads = 2 x FETCH_SIZE for the block kernels (their loads are 16 B/lane); other kernels are listed uncorrected."""
+so reads = 2 x FETCH_SIZE for the block / strip / chain kernels (their loads are 16 B/lane, plain or LDS-DMA); other kernels are
+listed uncorrected."""
 import collections, csv, glob, json, os, shutil, statistics, sys
 
 tag, trace, fetch, write = sys.argv[1:5]
@@ -22,7 +23,7 @@ rows = []
 for k in sorted(f, key=lambda k: -sum(f[k])):
     if not k.startswith("void mi::") and not k.startswith("mi::"):
         continue
-    wide = "block_kernel" in k
+    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "chain_kernel"))
     fk, wk = statistics.mean(f[k]), statistics.mean(w.get(k, [0]))
     rows.append({"kernel": k, "dispatches": len(f[k]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
                  "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
@@ -34,8 +35,14 @@ dom = max(csv.DictReader(open(ks)), key=lambda r: float(r["TotalDurationNs"]))
 name = dom["Name"]
 pm = next(r for r in rows if r["kernel"] == name)
 import re
-m = re.search(r"block_kernel<(\d+), (\d+), (\d+), (\d+), (true|false)", name)
-label = "block_kernel<%s,%s,%s,%s,%d>" % (m.group(1), m.group(2), m.group(3), m.group(4), m.group(5) == "true") if m else name
+def label(name):
+    # rocprofv3 symbol -> the label mi_model_profile / bench.py use: template arguments as integers, SLOW / CPT dropped for block kernels
+    m = re.search(r"(\w+)<([^>]*)>", name.replace("(anonymous namespace)::", ""))
+    if not m: return name
+    args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2).split(",")]
+    if m.group(1) == "block_kernel": args = args[:5]
+    return "%s<%s>" % (m.group(1), ",".join(args))
+label = label(name)
 json.dump({"round": tag, "workload": "back256_b256", "kernel": label, "rocprof_name": name, "calls": int(dom["Calls"]),
            "avg_ns": float(dom["AverageNs"]), "hbm_bytes_per_launch": pm["hbm_bytes_per_launch"],
            "note": "reads = 2 x FETCH_SIZE (gfx950 16B/lane stream correction) + WRITE_SIZE, KiB -> bytes"},
