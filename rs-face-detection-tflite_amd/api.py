@@ -196,7 +196,7 @@ def device_count():
     return lib().mi_device_count()
 
 
-def plan_describe(tflite_bytes: bytes, fuse_level=2) -> str:
+def plan_describe(tflite_bytes: bytes, fuse_level=4) -> str:
     """Host-only lowering of a .tflite blob (no GPU needed)."""
     L = lib()
     n = L.mi_plan_describe(tflite_bytes, len(tflite_bytes), fuse_level, None, 0)

@@ -54,7 +54,9 @@ void Model::invalidate_graphs() {
 void Model::set_option(const std::string& key, int value) {
     if (key == "chunk") chunk_ = std::max(0, value);
     else if (key == "graph") use_graph_ = value != 0;
-    else if (key == "fuse") { fuse_level_ = std::min(3, std::max(0, value)); dirty_ = true; }
+    else if (key == "fuse") { fuse_level_ = std::min(4, std::max(0, value)); dirty_ = true; }
+    else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
+    else if (key == "strip") { strip_ = value != 0; }                                          // 0: LDS-ring block kernel for every block
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
     else if (key == "lanes") lanes_ = std::min(4, std::max(1, value));
     else throw std::runtime_error("unknown option '" + key + "'");
@@ -65,7 +67,7 @@ void Model::set_option(const std::string& key, int value) {
 void Model::rebuild() {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     invalidate_graphs();
-    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_);
+    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_, pipe_max_);
     const Graph& g = plan_.graph;
     if (!reuse_) {  // debugging layout: every tensor keeps its own slot
         long off = 0;
@@ -399,7 +401,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 if (a.has_dw && n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
                 a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
-                const bool strip = strip_kernel_supports(a);
+                const bool strip = strip_ && strip_kernel_supports(a);
                 if (labels) { char buf[96]; labels->back() = strip ? strip_kernel_label(a, buf, sizeof buf) : block_kernel_label(a, buf, sizeof buf); }
                 rc = strip ? launch_strip(a, s) : launch_block(a, s);
                 break;

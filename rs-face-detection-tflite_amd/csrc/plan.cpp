@@ -184,7 +184,7 @@ void same_pad(int in, int k, int stride, int& before, int& out) {
 
 }  // namespace
 
-Plan build_plan(Graph graph, int fuse_level) {
+Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
     Plan plan;
     plan.graph = std::move(graph);
     plan.fuse_level = fuse_level;
@@ -309,7 +309,7 @@ Plan build_plan(Graph graph, int fuse_level) {
             }
             return c;
         };
-        static const int pipe_max = getenv("MI_PIPE_K") ? atoi(getenv("MI_PIPE_K")) : 4;  // tuning aid: blocks per row pipeline
+        const int pipe_max = fuse_level >= 4 ? pipe_max_opt : 0;
         std::vector<Node> fusedv;
         for (size_t i = 0; i < plan.nodes.size();) {
             if (chainable(plan.nodes[i])) {

@@ -7,6 +7,8 @@
 //            producing convolution's epilogue
 //   level 2  DEPTHWISE_CONV_2D -> CONV_2D 1x1 (-> skip -> activation) fused into one BlazeBlock kernel
 //   level 3  runs of same-shape stride-1 BlazeBlocks whose frame fits in LDS fused into one frame-resident chain kernel
+//   level 4  runs of narrow (C <= 24, W <= 128) stride-1 BlazeBlocks cut into row-pipelined chains of up to 4 blocks: one
+//            launch, the intermediate rows handed from block to block through LDS (strip_kernels.hip)
 #pragma once
 
 #include <string>
@@ -56,11 +58,12 @@ struct Plan {
     std::vector<long> root_offset;      // per tensor (valid for roots): float offset inside the arena, per frame-slot
     std::vector<long> root_elems;       // per root: floats per frame
     long arena_floats_per_frame = 0;
-    int fuse_level = 2;
+    int fuse_level = 4;
     double bytes_per_frame = 0, macs_per_frame = 0;
     std::string describe() const;
 };
 
-Plan build_plan(Graph g, int fuse_level);
+// pipe_max: most blocks one row-pipelined chain may hold (level 4; 2..4, below 2 disables them)
+Plan build_plan(Graph g, int fuse_level, int pipe_max = 4);
 
 }  // namespace mi

@@ -84,8 +84,9 @@ __device__ __forceinline__ v2f pkfma(v2f a, v2f b, v2f c) { return __builtin_ele
 template <int N>
 __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
 
-// One input row r (pixel-major image in LDS; `me` = this lane's left neighbour in it): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aP /
-// aC / aN); the finished row r-1 goes straight into the pointwise accumulators.  Everything runs on the VALU as
+// One input row r (pixel-major image in LDS; `me` = this lane's left neighbour in it): its ky = 2 / 1 / 0 taps go to the partial output rows r-1 / r / r+1 (aPN on
+// entry / aC / aPN on exit: the slot of the row that finishes here is re-used for the row that starts here); the finished
+// row r-1 goes straight into the pointwise accumulators.  Everything runs on the VALU as
 // v_pk_fma_f32 with SGPR-pair weights: on this part the f32 MFMA does not overlap VALU work (measured: 2 x
 // v_mfma_f32_32x32x2_f32 + n x v_fma_f32 costs 129 + 4.5 n cycles, at one or two waves per SIMD), it runs at the
 // packed-FMA rate, and M = 32 would waste a quarter of it on 24 output channels.
@@ -94,51 +95,60 @@ __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) 
 //   wait | load PW weights of the pair's 2nd channel | depthwise (9 pk) + pointwise of the 1st channel (CQ*2 pk)
 //   wait | load DW + 1st-channel PW weights of the next stage, next quad's pixels | pointwise of the 2nd channel
 template <int CQ, bool EMIT>
-__device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bool has_res, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2],
+__device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bool has_res, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2],
                                           const float4 (&xres)[CQ], float4 (&xcur)[CQ], v2f (&oacc)[2 * CQ]) {
     using K = SK<CQ>;
     constexpr int C = K::C;
     float wd[18], wp0[C], wp1[C];
     float4 xbuf[2][3];
-    auto load_wd = [&](int st) {
-        const cfloat* p = cst;
-        asm volatile("" : "+s"(p));  // opaque per use: the scalar loads stay in the row loop, just ahead of their use;
-                                     // the record offset stays an immediate of the s_load (no per-stage pointer to keep)
-#pragma unroll
-        for (int i = 0; i < 18; i++) wd[i] = p[K::OFF_DW + st * K::ST_F + i];
-    };
-    auto load_wp = [&](int st, int half, float (&w)[C]) {
+    // scalar loads of one group share one opaque copy of the blob pointer: opaque so that the loads stay inside the row
+    // loop, just ahead of their use (hoisted, they spill SGPRs); the record offsets stay immediates of the s_load
+    auto load_first = [&](int st) {  // what a stage needs at its first wait: depthwise taps + pointwise column of channel 2st
         const cfloat* p = cst;
         asm volatile("" : "+s"(p));
 #pragma unroll
-        for (int i = 0; i < C; i++) w[i] = p[K::OFF_DW + st * K::ST_F + 32 + half * C + i];
+        for (int i = 0; i < 18; i++) wd[i] = p[K::OFF_DW + st * K::ST_F + i];
+        if (EMIT) {
+#pragma unroll
+            for (int i = 0; i < C; i++) wp0[i] = p[K::OFF_DW + st * K::ST_F + 32 + i];
+        }
+    };
+    auto load_second = [&](int st) {  // pointwise column of channel 2st + 1
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < C; i++) wp1[i] = p[K::OFF_DW + st * K::ST_F + 32 + C + i];
     };
     auto load_x = [&](int q, float4 (&x)[3]) {
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me + kx * C + 4 * q);
     };
-    if constexpr (EMIT) {  // accumulators start from skip + bias (bias = b_pw + W b_dw)
+    if constexpr (EMIT) {  // accumulators start from skip + bias (bias = b_pw + W b_dw): one v_pk_add_f32 with an SGPR-pair operand each
         const cfloat* bp = cst + K::OFF_BIAS;
         asm volatile("" : "+s"(bp));
+        if (has_res) {  // wave-uniform branch
 #pragma unroll
-        for (int q = 0; q < CQ; q++) {
-            oacc[2 * q] = v2f{bp[4 * q], bp[4 * q + 1]};
-            oacc[2 * q + 1] = v2f{bp[4 * q + 2], bp[4 * q + 3]};
-            if (has_res) {
-                oacc[2 * q] += v2f{xres[q].x, xres[q].y};
-                oacc[2 * q + 1] += v2f{xres[q].z, xres[q].w};
+            for (int q = 0; q < CQ; q++) {
+                oacc[2 * q] = v2f{xres[q].x, xres[q].y} + v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc[2 * q + 1] = v2f{xres[q].z, xres[q].w} + v2f{bp[4 * q + 2], bp[4 * q + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                oacc[2 * q] = v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc[2 * q + 1] = v2f{bp[4 * q + 2], bp[4 * q + 3]};
             }
         }
-        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int o = 0; o < 2 * CQ; o++) asm volatile("" : "+v"(oacc[o]));  // keeps the two arms from being merged into selects
     }
-    load_wd(0);
-    if (EMIT) load_wp(0, 0, wp0);
+    load_first(0);
     load_x(0, xbuf[0]);
 #pragma unroll
     for (int st = 0; st < 2 * CQ; st++) {
         const int q = st >> 1, h = st & 1;
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        if (EMIT) load_wp(st, 1, wp1);
+        if (EMIT) load_second(st);
         __builtin_amdgcn_sched_barrier(0);
         const float4 (&x)[3] = xbuf[q & 1];
         if (h == 0) xcur[q] = x[1];
@@ -146,7 +156,7 @@ __device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bo
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
         auto wv = [&](int tap) { return v2f{wd[2 * tap], wd[2 * tap + 1]}; };
-        v2f n = t[0] * wv(0), c = aC[q][h], pch = aP[q][h];  // the depthwise bias is folded into the pointwise bias on the host
+        v2f n = t[0] * wv(0), c = aC[q][h], pch = aPN[q][h];  // the depthwise bias is folded into the pointwise bias on the host
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
             if (EMIT) pch = pkfma(t[kx], wv(6 + kx), pch);
@@ -154,10 +164,10 @@ __device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bo
             c = pkfma(t[kx], wv(3 + kx), c);
         }
         aC[q][h] = c;
-        aN[q][h] = n;
+        aPN[q][h] = n;  // the slot of the row just finished now starts the row after next
         // pin the partial rows here: left alone, LLVM sinks these updates past the loop-exit test into the next row's
         // block, across the scheduling fences, which keeps every stage's weights alive (SGPR spills)
-        asm volatile("" : "+v"(aC[q][h]), "+v"(aN[q][h]));
+        asm volatile("" : "+v"(aC[q][h]), "+v"(aPN[q][h]));
         if constexpr (EMIT) {
 #pragma unroll
             for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.x, pch.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc[o]);
@@ -166,8 +176,7 @@ __device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bo
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);
         if (st + 1 < 2 * CQ) {
-            load_wd(st + 1);
-            if (EMIT) load_wp(st + 1, 0, wp0);
+            load_first(st + 1);
             if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -260,7 +269,9 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
             }
         }
     };
-    // after the DMA of row r has landed in buffer bi: zero what lies outside the image
+    // after the DMA of row r has landed in buffer bi: zero what lies outside the image (zfix: this lane's float offset in
+    // the row image of the border-column float4 it clears, -1 for the lanes that clear nothing)
+    const int zfix = lane < CQ ? (zl >= 0 ? zl * C + 4 * lane : -1) : (lane < 2 * CQ ? (zr >= 0 ? zr * C + 4 * (lane - CQ) : -1) : -1);
     auto fix_row = [&](int r, int bi) {
         float* buf = wbase + bi * BUF_F;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,15 +279,14 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
 #pragma unroll
             for (int k = 0; k < NL; k++)
                 if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
-        } else if (lane < CQ) {
-            if (zl >= 0) sst4(buf + zl * C + 4 * lane, z);
-            if (zr >= 0) sst4(buf + zr * C + 4 * lane, z);
+        } else if (zfix >= 0) {
+            sst4(buf + zfix, z);
         }
     };
 
     v2f oacc[2 * CQ];
-    auto row = [&](auto emit_t, int bi, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xres)[CQ], float4 (&xcur)[CQ]) {
-        strip_row<CQ, decltype(emit_t)::value>(wbase + bi * BUF_F + lane * C, cst, a.has_res != 0, aP, aC, aN, xres, xcur, oacc);
+    auto row = [&](auto emit_t, int bi, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2], const float4 (&xres)[CQ], float4 (&xcur)[CQ]) {
+        strip_row<CQ, decltype(emit_t)::value>(wbase + bi * BUF_F + lane * C, cst, a.has_res != 0, aPN, aC, xres, xcur, oacc);
     };
     // epilogue of output row y: activation, then transposed through the (now dead) row buffer bi so that every store
     // instruction writes 1 KiB of consecutive bytes
@@ -300,12 +310,13 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
         }
     };
 
-    v2f acc0[CQ][2], acc1[CQ][2], acc2[CQ][2];
-    float4 xa[CQ], xb[CQ], xd[CQ];
+    // two partial-row sets and two centre rows alternate roles from one row to the next (the loop is unrolled by two)
+    v2f acc0[CQ][2], acc1[CQ][2];
+    float4 xa[CQ], xb[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; q++) {
-        acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = acc2[q][0] = acc2[q][1] = v2f{0.f, 0.f};
-        xa[q] = xb[q] = xd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = v2f{0.f, 0.f};
+        xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // Step r consumes input row r from buffer r & 1 (band-relative), emits output row r-1 through the same buffer and then
     // starts the DMA of row r+2 into it; row r+1 is in flight in the other buffer meanwhile.  vm operations are retired
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
 #else
 #define MI_SSTAMP(k)
 #endif
-    auto step = [&](auto emit, int r, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
+    auto step = [&](auto emit, int r, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
         const int bi = (r - (y0 - 1)) & 1;
         if (r + 1 <= y1) {
             if (full && r >= y0 + 2) wait_vm<NL + CQ>();
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
         fix_row(r, bi);
         wave_sync();
         MI_SSTAMP(1)
-        row(emit, bi, aP, aC, aN, xprev, xcur);
+        row(emit, bi, aPN, aC, xprev, xcur);
         wave_sync();  // every read of the row image above is issued before the epilogue overwrites it
         MI_SSTAMP(2)
         if constexpr (decltype(emit)::value) epilogue(r - 1, bi);
@@ -342,14 +353,12 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
     };
     issue_row(y0 - 1, 0);
     issue_row(y0, 1);
-    step(std::false_type{}, y0 - 1, acc0, acc1, acc2, xd, xa);
-    step(std::false_type{}, y0, acc1, acc2, acc0, xa, xb);
-    for (int r = y0 + 1; r <= y1; r += 3) {
-        step(std::true_type{}, r, acc2, acc0, acc1, xb, xd);
+    step(std::false_type{}, y0 - 1, acc0, acc1, xb, xa);
+    step(std::false_type{}, y0, acc1, acc0, xa, xb);
+    for (int r = y0 + 1; r <= y1; r += 2) {
+        step(std::true_type{}, r, acc0, acc1, xb, xa);
         if (r + 1 > y1) break;
-        step(std::true_type{}, r + 1, acc0, acc1, acc2, xd, xa);
-        if (r + 2 > y1) break;
-        step(std::true_type{}, r + 2, acc1, acc2, acc0, xa, xb);
+        step(std::true_type{}, r + 1, acc1, acc0, xa, xb);
     }
 #ifdef MI_STRIP_STAMPS
     if (a.stamps && lane == 0)
@@ -377,12 +386,12 @@ struct PipeArgs {
     float hi[kMaxPipe];
 };
 
-template <int CQ, int KB, bool RELU>
-__global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
+template <int CQ, int KB, bool RELU, int SLOTS>
+__global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kernel(PipeArgs a) {
     using K = SK<CQ>;
     constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
     constexpr int IMG = 132 * C;                 // floats of one full-width row image (<= 130 pixels used)
-    constexpr int RING_F = (KB - 1) * 2 * IMG;   // KB-1 hand-over rings of two row images
+    constexpr int RING_F = (KB - 1) * SLOTS * IMG;   // KB-1 hand-over rings of SLOTS row images (1: two barriers per step, less LDS)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -432,6 +441,7 @@ __global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
             }
         }
     };
+    const int zfix = lane < CQ ? (zl >= 0 ? zl * C + 4 * lane : -1) : (lane < 2 * CQ ? (zr >= 0 ? zr * C + 4 * (lane - CQ) : -1) : -1);
     auto fix_row = [&](int r, int bi) {
         float* buf = scratch + bi * BUF_F;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -439,18 +449,17 @@ __global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
 #pragma unroll
             for (int k = 0; k < NL; k++)
                 if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
-        } else if (lane < CQ) {
-            if (zl >= 0) sst4(buf + zl * C + 4 * lane, z);
-            if (zr >= 0) sst4(buf + zr * C + 4 * lane, z);
+        } else if (zfix >= 0) {
+            sst4(buf + zfix, z);
         }
     };
 
-    v2f acc0[CQ][2], acc1[CQ][2], acc2[CQ][2], oacc[2 * CQ];
-    float4 xa[CQ], xb[CQ], xd[CQ];
+    v2f acc0[CQ][2], acc1[CQ][2], oacc[2 * CQ];
+    float4 xa[CQ], xb[CQ];
 #pragma unroll
     for (int q = 0; q < CQ; q++) {
-        acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = acc2[q][0] = acc2[q][1] = v2f{0.f, 0.f};
-        xa[q] = xb[q] = xd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = v2f{0.f, 0.f};
+        xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int c_first = y0 - KB - 2 * role;  // row this block would consume at step 0 (it starts at step 3 * role)
     if (role == 0 && active) {
@@ -460,8 +469,18 @@ __global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
 
-    auto step = [&](int t, v2f (&aP)[CQ][2], v2f (&aC)[CQ][2], v2f (&aN)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
+    auto wg_barrier = [&]() {
+        // raw s_barrier with an LDS-only wait, so that the stores of block KB-1 and the DMA of block 0 stay in flight across it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto step = [&](int t, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
         const int c = c_first + t;  // row consumed in this step; the row it completes is c - 1
+        const int e = c - 1;
+        bool hand_over = false;     // this wave has a finished row for the next block
+        float4 o[CQ];
         if (active && c >= lo_j - 1 && c <= hi_j) {
             const float* me;
             if (role == 0) {
@@ -471,20 +490,14 @@ __global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
                 wave_sync();
                 me = scratch + (t & 1) * BUF_F + lane * C;
             } else {
-                me = lds + ((role - 1) * 2 + ((t - 1) & 1)) * IMG + img_p + lane * C;
+                me = lds + ((role - 1) * SLOTS + (SLOTS == 2 ? ((t - 1) & 1) : 0)) * IMG + img_p + lane * C;
             }
-            strip_row<CQ, true>(me, cst, has_res, aP, aC, aN, xprev, xcur, oacc);
+            strip_row<CQ, true>(me, cst, has_res, aPN, aC, xprev, xcur, oacc);
             wave_sync();
-            const int e = c - 1;
             if (e >= lo_j && e < hi_j) {
-                float4 o[CQ];
                 strip_act<CQ, RELU>(oacc, cst, hi, o);
                 if (role < KB - 1) {
-                    // hand the row to the next block; rows outside the image are that block's zero padding
-                    const bool zero = e < 0 || e >= a.H || lane >= npx;
-                    float* dstl = lds + (role * 2 + (t & 1)) * IMG + img_p + (1 + lane) * C;
-#pragma unroll
-                    for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, zero ? make_float4(0.f, 0.f, 0.f, 0.f) : o[q]);
+                    hand_over = true;
                 } else {
                     float* obuf = scratch;
 #pragma unroll
@@ -508,28 +521,38 @@ __global__ __launch_bounds__(128 * KB) void strip_pipe_kernel(PipeArgs a) {
                 issue_row(c + 2, t & 1);
             }
         }
-        // one workgroup barrier per step: raw s_barrier with an LDS-only wait, so that the stores of block KB-1 and the
-        // DMA of block 0 stay in flight across it
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        // with one row image per ring the row may only be written once every reader of the previous one is done
+        if (SLOTS == 1) wg_barrier();
+        if (hand_over) {
+            // hand the row to the next block; rows outside the image are that block's zero padding
+            float* dstl = lds + (role * SLOTS + (SLOTS == 2 ? (t & 1) : 0)) * IMG + img_p + (1 + lane) * C;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 0 || e >= a.H) {  // wave-uniform
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, z);
+            } else if (full) {
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, o[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, lane >= npx ? z : o[q]);
+            }
+        }
+        wg_barrier();
     };
     const int T = a.band_rows + 3 * KB - 1;
-    for (int t = 0; t < T; t += 3) {
-        step(t, acc0, acc1, acc2, xd, xa);
+    for (int t = 0; t < T; t += 2) {
+        step(t, acc0, acc1, xb, xa);
         if (t + 1 >= T) break;
-        step(t + 1, acc1, acc2, acc0, xa, xb);
-        if (t + 2 >= T) break;
-        step(t + 2, acc2, acc0, acc1, xb, xd);
+        step(t + 1, acc1, acc0, xa, xb);
     }
 }
 
-template <int CQ, int KB, bool RELU>
+template <int CQ, int KB, bool RELU, int SLOTS>
 int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
     using K = SK<CQ>;
-    auto kern = strip_pipe_kernel<CQ, KB, RELU>;
-    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + 6 * K::BUF_F) * 4;
+    auto kern = strip_pipe_kernel<CQ, KB, RELU, SLOTS>;
+    const size_t lds_bytes = (size_t)((KB - 1) * SLOTS * 132 * K::C + 6 * K::BUF_F) * 4;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -673,7 +696,8 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     }
     // bands: about one resident set of workgroups over the chip, but not so short that the 3n-1 pipeline fill steps dominate
     static const int forced = getenv("MI_PIPE_BAND") ? atoi(getenv("MI_PIPE_BAND")) : 0;  // tuning aid
-    const int per_cu = n <= 2 ? 2 : 1;
+    static const int per_cu_forced = getenv("MI_PIPE_PERCU") ? atoi(getenv("MI_PIPE_PERCU")) : 0;  // tuning aid
+    const int per_cu = per_cu_forced > 0 ? per_cu_forced : (n <= 2 ? 2 : 1);
     const long wg_units = pa.strips == 2 ? 1 : 2;
     long bands = std::max<long>(1, (256L * per_cu * wg_units + a.B / 2) / std::max(1, a.B));
     int rows = (int)((a.H + bands - 1) / bands);
@@ -684,8 +708,12 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     pa.units = a.B * pa.bands;
     hipStream_t s = (hipStream_t)stream;
     const bool relu = a.ep.act == ACT_RELU;
+    static const int slots = getenv("MI_PIPE_SLOTS") ? atoi(getenv("MI_PIPE_SLOTS")) : 2;  // tuning aid
 #define MI_PIPE_CASE(Q, KBV) \
-    if (a.C == 4 * Q && n == KBV) return relu ? launch_pipe_inst<Q, KBV, true>(pa, s) : launch_pipe_inst<Q, KBV, false>(pa, s);
+    if (a.C == 4 * Q && n == KBV) { \
+        if (slots == 1) return relu ? launch_pipe_inst<Q, KBV, true, 1>(pa, s) : launch_pipe_inst<Q, KBV, false, 1>(pa, s); \
+        return relu ? launch_pipe_inst<Q, KBV, true, 2>(pa, s) : launch_pipe_inst<Q, KBV, false, 2>(pa, s); \
+    }
     MI_PIPE_CASE(4, 2) MI_PIPE_CASE(4, 3) MI_PIPE_CASE(4, 4) MI_PIPE_CASE(6, 2) MI_PIPE_CASE(6, 3) MI_PIPE_CASE(6, 4)
 #undef MI_PIPE_CASE
     return (int)hipErrorInvalidValue;

@@ -30,6 +30,8 @@ def test_lowering_without_gpu(mi, name):
     p0, p1, p2 = (mi.plan_describe(blob, lvl) for lvl in (0, 1, 2))
     p3 = mi.plan_describe(blob, 3)
     assert int(re.search(r"launches=(\d+)", p3).group(1)) <= int(re.search(r"launches=(\d+)", p2).group(1))
+    p4 = mi.plan_describe(blob, 4)
+    assert int(re.search(r"launches=(\d+)", p4).group(1)) <= int(re.search(r"launches=(\d+)", p3).group(1))
     n0, n1, n2 = (int(re.search(r"launches=(\d+)", p).group(1)) for p in (p0, p1, p2))
     assert n0 > n1 > n2
     assert "block" in p2 and "block" not in p1
