@@ -116,7 +116,12 @@ void Model::rebuild() {
                 if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
                 if (m.alpha >= 0) mo.alpha = put(g.tensors[m.alpha].f32);
                 const auto& ws = g.tensors[m.w2].shape;  // [O][1][1][I]
-                if (strip_shape_ok(ws[3], ws[0])) {
+                if (m.sh == 2) {  // stride-2 tail of a row pipeline
+                    std::vector<float> sc(static_cast<size_t>(strip_consts_s2_floats(ws[3], ws[0])));
+                    strip_pack_consts_s2(ws[3], ws[0], g.tensors[m.w].f32.data(), m.b >= 0 ? g.tensors[m.b].f32.data() : nullptr, g.tensors[m.w2].f32.data(),
+                                         m.b2 >= 0 ? g.tensors[m.b2].f32.data() : nullptr, m.alpha >= 0 ? g.tensors[m.alpha].f32.data() : nullptr, m.act, sc.data());
+                    mo.strip = put(sc);
+                } else if (strip_shape_ok(ws[3], ws[0])) {
                     std::vector<float> sc(static_cast<size_t>(strip_consts_floats(ws[3])));
                     strip_pack_consts(ws[3], g.tensors[m.w].f32.data(), m.b >= 0 ? g.tensors[m.b].f32.data() : nullptr, g.tensors[m.w2].f32.data(),
                                       m.b2 >= 0 ? g.tensors[m.b2].f32.data() : nullptr, m.alpha >= 0 ? g.tensors[m.alpha].f32.data() : nullptr, m.act, sc.data());
@@ -217,8 +222,10 @@ std::string Model::node_label(const Node& n) const {
         }
         case Node::Chain: {
             const auto& so = g.tensors[n.out].shape;
-            if (so[1] * so[2] <= 256) return "chain_kernel<" + std::to_string((so.back() + 31) / 32) + ">";
-            return "strip_pipe_kernel<" + std::to_string(so.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + ">";
+            if (g.tensors[n.in[0]].shape[1] * g.tensors[n.in[0]].shape[2] <= 256) return "chain_kernel<" + std::to_string((so.back() + 31) / 32) + ">";
+            const auto& sin = g.tensors[n.in[0]].shape;
+            const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
+            return "strip_pipe_kernel<" + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
@@ -255,7 +262,11 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
         if (n.kind == Node::Dw) st.macs = elems(n.out) * n.KH * n.KW * batch;
         if (n.kind == Node::Block) st.macs = elems(n.out) / so.back() * si.back() * ((n.w >= 0 ? 9 : 0) + so.back()) * batch;
         if (n.kind == Node::Chain) {
-            st.macs = elems(n.out) * (9 + so.back()) * batch * n.members.size();
+            st.macs = 0;
+            for (const Node& m : n.members) {
+                const auto& mo = g.tensors[m.out].shape;
+                st.macs += static_cast<double>(mo[1]) * mo[2] * g.tensors[m.in[0]].shape[3] * (9 + mo[3]) * batch;
+            }
             for (const Node& m : n.members)
                 for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) st.bytes += 4 * elems(c);
         }
@@ -383,6 +394,11 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     b.ep.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
                     b.ep.act = m.act;
                     if (m.res >= 0) { b.ep.res = b.in; b.ep.res_fs = b.in_fs; b.ep.res_C = b.C; b.ep.res_mode = RES_DIRECT; }
+                    if (m.sh == 2) {  // stride-2 tail: halves the resolution, 2x2 max-pool skip from its (never materialised) input
+                        b.sh = b.sw = 2; b.pt = b.pl = 0;
+                        b.Ho = so[1]; b.Wo = so[2]; b.Co = so[3];
+                        if (m.res >= 0) { b.ep.res_mode = RES_MAXPOOL; b.ep.res_H = b.H; b.ep.res_W = b.W; }
+                    }
                 }
                 if (!strip_pipe_supports(blk.data(), static_cast<int>(blk.size()))) throw std::runtime_error("chain node without a kernel");
                 if (labels) { char buf[96]; labels->back() = strip_pipe_label(blk.data(), static_cast<int>(blk.size()), buf, sizeof buf); }

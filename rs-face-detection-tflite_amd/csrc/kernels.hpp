@@ -142,7 +142,10 @@ void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float*
 const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
 // row-pipelined chain of 2..4 strip-eligible blocks (blocks[k+1].in == blocks[k].out, which never reaches HBM)
 bool strip_pipe_supports(const BlockArgs* blocks, int n);
-bool strip_pipe_shape_ok(int C, int W);  // host-only shape test for the planner
+bool strip_pipe_shape_ok(int C, int W);  // host-only shape tests for the planner
+bool strip_tail_shape_ok(int C, int Co, int H, int W);
+int strip_consts_s2_floats(int C, int Co);
+void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
 int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream);
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
 int launch_chain(const ChainArgs& a, void* stream);

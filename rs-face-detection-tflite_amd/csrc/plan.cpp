@@ -329,9 +329,20 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
                         i += ca.nblocks;
                         continue;
                     }
-                    // (b) narrow layers: row-pipelined groups of up to 4 blocks, the intermediate rows handed over in LDS
-                    if (pipe_max >= 2 && strip_pipe_shape_ok(si[3], si[2])) {
-                        int left = run;
+                }
+                // (b) narrow layers: row-pipelined groups of up to 4 blocks, the intermediate rows handed over in LDS; the
+                // stride-2 block that follows the run (max-pool skip from its own input) can be the last stage of the last group
+                if (pipe_max >= 2 && strip_pipe_shape_ok(si[3], si[2])) {
+                    bool tail = false;
+                    if (j + 1 < plan.nodes.size()) {
+                        const Node& t = plan.nodes[j + 1];
+                        tail = t.kind == Node::Block && t.w >= 0 && t.sh == 2 && t.sw == 2 && t.padding == Padding::Same && t.in[0] == plan.nodes[j].out &&
+                               t.res == t.in[0] && t.res_mode == RES_MAXPOOL && t.act == ACT_RELU && plan.nodes[i].act == ACT_RELU &&
+                               uses(plan.nodes[j].out) == 2 && std::find(g.outputs.begin(), g.outputs.end(), plan.nodes[j].out) == g.outputs.end() &&
+                               strip_tail_shape_ok(si[3], g.tensors[t.out].shape[3], si[1], si[2]);
+                    }
+                    int left = run + (tail ? 1 : 0);
+                    if (left >= 2) {
                         while (left >= 2) {
                             int take = std::min(left, std::min(pipe_max, 4));
                             if (left - take == 1 && take > 2) take--;  // never leave a single block behind a full group
@@ -432,7 +443,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
             for (const Node& m : n.members) {
                 for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) bytes += 4 * elems(c);
                 const auto& so2 = g.tensors[m.out].shape;
-                macs += static_cast<double>(so2[1]) * so2[2] * so2[3] * (9 + so2[3]);
+                macs += static_cast<double>(so2[1]) * so2[2] * g.tensors[m.in[0]].shape[3] * (9 + so2[3]);
             }
             continue;
         }
@@ -470,7 +481,8 @@ std::string Plan::describe() const {
         if (n.kind == Node::Conv || n.kind == Node::Dw || (n.kind == Node::Block && n.w >= 0)) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
         if (n.kind == Node::Chain)
-            os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS");
+            os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
+               << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
         os << " ops{";
         for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
         os << "}\n";

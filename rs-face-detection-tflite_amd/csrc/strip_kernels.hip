@@ -193,8 +193,7 @@ __device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bo
 
 // activation of a finished output row (lane = pixel, channel quads)
 template <int CQ, bool RELU>
-__device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloat* cst, float hi, float4 (&o)[CQ]) {
-    using K = SK<CQ>;
+__device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloat* slopes, float hi, float4 (&o)[CQ]) {
 #pragma unroll
     for (int q = 0; q < CQ; q++) {
         o[q] = make_float4(oacc[2 * q].x, oacc[2 * q].y, oacc[2 * q + 1].x, oacc[2 * q + 1].y);
@@ -202,12 +201,123 @@ __device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloa
             o[q].x = fmaxf(o[q].x, 0.f); o[q].y = fmaxf(o[q].y, 0.f); o[q].z = fmaxf(o[q].z, 0.f); o[q].w = fmaxf(o[q].w, 0.f);
         } else {
             // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
-            const cfloat* sq = cst + K::OFF_SLOPE + 4 * q;
+            const cfloat* sq = slopes + 4 * q;
             o[q].x = fminf(fmaxf(o[q].x, 0.f) + sq[0] * fminf(o[q].x, 0.f), hi);
             o[q].y = fminf(fmaxf(o[q].y, 0.f) + sq[1] * fminf(o[q].y, 0.f), hi);
             o[q].z = fminf(fmaxf(o[q].z, 0.f) + sq[2] * fminf(o[q].z, 0.f), hi);
             o[q].w = fminf(fmaxf(o[q].w, 0.f) + sq[3] * fminf(o[q].w, 0.f), hi);
         }
+    }
+}
+
+// Stride-2 tail of a row pipeline (the BlazeBlock that halves the resolution: DW3x3 s2 (TF SAME on an even size = taps at
+// rows 2oy..2oy+2, columns 2ox..2ox+2) -> PW1x1 C -> NH*C -> + [2x2 max-pool of the input, zero channel-pad] -> act).
+// lane = OUTPUT pixel; `me2` = this lane's first tap column in the full-width row image the last stride-1 block wrote.
+// Rows arrive one per step: an even row 2k finishes output row k-1 (its ky = 2 taps, then the pointwise conv of this
+// wave's C output channels) and starts output row k (ky = 0); an odd row adds the ky = 1 taps.  The max-pool runs beside
+// it (max over the kx = 0, 1 taps of rows 2k, 2k+1).  MODE 0: odd row, 1: even row that only starts, 2: even row that
+// finishes and starts.  Constants record per channel pair: depthwise taps [9][2] at 0, pointwise columns of the two
+// channels at 32 and 32 + NH*C (this wave reads entries [hf*C, hf*C + C) of them).
+template <int CQ, int NH, int MODE>
+__device__ __forceinline__ void strip_row_s2(const float* me2, const cfloat* cst, int hf, bool has_skip, v2f (&acc)[CQ][2], float4 (&mx)[CQ],
+                                             v2f (&oacc)[2 * CQ]) {
+    constexpr int C = 4 * CQ, Co = NH * C;
+    constexpr int ST2 = (32 + 2 * Co + 15) / 16 * 16, OFF_BIAS2 = (C / 2) * ST2;
+    float wd[18], wp0[C], wp1[C];
+    float4 xbuf[2][3];
+    auto load_first = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[i] = p[st * ST2 + i];
+        if (MODE == 2) {
+            const cfloat* pc = p + hf * C;  // wave-uniform offset
+#pragma unroll
+            for (int i = 0; i < C; i++) wp0[i] = pc[st * ST2 + 32 + i];
+        }
+    };
+    auto load_second = [&](int st) {
+        const cfloat* p = cst + hf * C;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < C; i++) wp1[i] = p[st * ST2 + 32 + Co + i];
+    };
+    auto load_x = [&](int q, float4 (&x)[3]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me2 + kx * C + 4 * q);
+    };
+    if constexpr (MODE == 2) {  // accumulators start from bias (+ the finished max-pool of rows 2k-2, 2k-1 for channels < C)
+        const cfloat* bp = cst + OFF_BIAS2 + hf * C;
+        asm volatile("" : "+s"(bp));
+        if (has_skip) {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                oacc[2 * q] = v2f{mx[q].x, mx[q].y} + v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc[2 * q + 1] = v2f{mx[q].z, mx[q].w} + v2f{bp[4 * q + 2], bp[4 * q + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                oacc[2 * q] = v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc[2 * q + 1] = v2f{bp[4 * q + 2], bp[4 * q + 3]};
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2 * CQ; o++) asm volatile("" : "+v"(oacc[o]));
+    }
+    load_first(0);
+    load_x(0, xbuf[0]);
+#pragma unroll
+    for (int st = 0; st < 2 * CQ; st++) {
+        const int q = st >> 1, h = st & 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (MODE == 2) load_second(st);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&x)[3] = xbuf[q & 1];
+        if (h == 0) {  // running 2x2 max-pool of this quad (columns 2ox, 2ox+1 = taps 0, 1)
+            float4 m = make_float4(fmaxf(x[0].x, x[1].x), fmaxf(x[0].y, x[1].y), fmaxf(x[0].z, x[1].z), fmaxf(x[0].w, x[1].w));
+            if (MODE == 0) m = make_float4(fmaxf(m.x, mx[q].x), fmaxf(m.y, mx[q].y), fmaxf(m.z, mx[q].z), fmaxf(m.w, mx[q].w));
+            mx[q] = m;
+        }
+        v2f t[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
+        auto wv = [&](int tap) { return v2f{wd[2 * tap], wd[2 * tap + 1]}; };
+        v2f pch = acc[q][h], n;
+        if (MODE == 0) {
+            n = pch;
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) n = pkfma(t[kx], wv(3 + kx), n);
+        } else {
+            n = t[0] * wv(0);
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                if (MODE == 2) pch = pkfma(t[kx], wv(6 + kx), pch);
+                if (kx) n = pkfma(t[kx], wv(kx), n);
+            }
+        }
+        acc[q][h] = n;
+        asm volatile("" : "+v"(acc[q][h]));
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int o = 0; o < 2 * CQ; o++) oacc[o] = pkfma(v2f{pch.x, pch.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc[o]);
+            asm volatile("" : "+v"(pch));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (st + 1 < 2 * CQ) {
+            load_first(st + 1);
+            if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int o = 0; o < 2 * CQ; o++) {
+                oacc[o] = pkfma(v2f{pch.y, pch.y}, v2f{wp1[2 * o], wp1[2 * o + 1]}, oacc[o]);
+                asm volatile("" : "+v"(oacc[o]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -293,7 +403,7 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
     auto epilogue = [&](int y, int bi) {
         float* obuf = wbase + bi * BUF_F;
         float4 o[CQ];
-        strip_act<CQ, RELU>(oacc, cst, a.hi, o);
+        strip_act<CQ, RELU>(oacc, cst + K::OFF_SLOPE, a.hi, o);
 #pragma unroll
         for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
         wave_sync();
@@ -386,18 +496,25 @@ struct PipeArgs {
     float hi[kMaxPipe];
 };
 
-template <int CQ, int KB, bool RELU, int SLOTS>
-__global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kernel(PipeArgs a) {
+// NH2 > 0: the chain ends in a stride-2 block (see strip_row_s2) run by NH2 extra waves (one per C output channels); KB
+// counts that block too.
+template <int CQ, int KB, bool RELU, int NH2>
+__global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void strip_pipe_kernel(PipeArgs a) {
     using K = SK<CQ>;
     constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
+    constexpr int S = NH2 ? KB - 1 : KB;         // stride-1 blocks
+    constexpr int NT = 128 * S + 64 * NH2;       // threads
+    constexpr int SLOTS = 2;
     constexpr int IMG = 132 * C;                 // floats of one full-width row image (<= 130 pixels used)
-    constexpr int RING_F = (KB - 1) * SLOTS * IMG;   // KB-1 hand-over rings of SLOTS row images (1: two barriers per step, less LDS)
+    constexpr int RING_F = (KB - 1) * SLOTS * IMG;   // KB-1 hand-over rings of two row images
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = w & 1, role = w >> 1;
-    // wave-private scratch: block 0 waves own two DMA row buffers each, block KB-1 waves one transposition buffer each
-    float* scratch = lds + RING_F + (role == 0 ? p * 2 * BUF_F : 4 * BUF_F + p * BUF_F);
+    const bool tail = NH2 && w >= 2 * S;         // wave of the stride-2 block
+    const int p = tail ? 0 : (w & 1), role = tail ? S : (w >> 1);
+    const int hf = tail ? w - 2 * S : 0;         // which C output channels a tail wave computes
+    // wave-private scratch: block 0 waves own two DMA row buffers each, the waves that store one transposition buffer each
+    float* scratch = lds + RING_F + (role == 0 ? p * 2 * BUF_F : 4 * BUF_F + (tail ? hf : p) * BUF_F);
     const int unit = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + p;
     const bool active = unit < a.units;
     const int band = unit % a.bands, b = min(unit / a.bands, a.B - 1);
@@ -408,11 +525,13 @@ __global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kerne
     const cfloat* cst = (const cfloat*)a.consts[role];
     const bool has_res = a.has_res[role] != 0;
     const float hi = a.hi[role];
-    const int lo_j = y0 - (KB - 1 - role), hi_j = y1 + (KB - 1 - role);  // this block produces rows [lo_j, hi_j)
+    // the last stride-1 block produces rows [y0, hi_last): one more row when a stride-2 tail follows (its third tap row)
+    const int hi_last = NH2 ? y1 + 1 : y1;
+    const int lo_j = y0 - (S - 1 - role), hi_j = hi_last + (S - 1 - role);  // this (stride-1) block produces rows [lo_j, hi_j)
     const int img_p = a.strips == 2 ? 64 * C * p : 66 * C * p;           // this wave's window / sub-image inside a row image
 
     // clear the hand-over rings once: their border pixel columns (left of x = 0, right of x = W-1) are never written
-    for (int i = threadIdx.x; i < RING_F / 4; i += 128 * KB) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < RING_F / 4; i += NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     int goff[NL];  // block 0: byte offset of the lane's float4 from the row start, per DMA instruction (see strip_kernel)
 #pragma unroll
@@ -461,7 +580,7 @@ __global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kerne
         acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = v2f{0.f, 0.f};
         xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const int c_first = y0 - KB - 2 * role;  // row this block would consume at step 0 (it starts at step 3 * role)
+    const int c_first = y0 - S - 2 * role;  // row this block would consume at step 0 (it starts at step 3 * role)
     if (role == 0 && active) {
         issue_row(c_first, 0);
         issue_row(c_first + 1, 1);
@@ -476,12 +595,56 @@ __global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kerne
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    auto step = [&](int t, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ]) {
+    // ---- stride-2 tail: one wave serves both strips (W > 64: lane = output column) or both units (W <= 64: 32 lanes each).
+    // Its state (partial depthwise row, running max-pool) lives in the registers the stride-1 waves use for acc0 / xa.
+    auto tail_step = [&](int t, v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
+        if constexpr (NH2 > 0) {
+            const int k = t - 3 * S;  // band-relative index of the row the last stride-1 block handed over in step t-1
+            if (k < 0 || k > a.band_rows) return;
+            constexpr int Co = NH2 * C;
+            constexpr int ST2 = (32 + 2 * Co + 15) / 16 * 16, OFF_SLOPE2 = (C / 2) * ST2 + 64;
+            const cfloat* cst2 = (const cfloat*)a.consts[S];
+            const float* img = lds + ((S - 1) * SLOTS + ((t - 1) & 1)) * IMG;
+            const int tu = a.strips == 2 ? 0 : lane >> 5, tox = a.strips == 2 ? lane : lane & 31;
+            const float* me2 = img + tu * 66 * C + (2 * tox + 1) * C;
+            const bool skip = hf == 0 && a.has_res[S] != 0;
+            if (k & 1) {
+                strip_row_s2<CQ, NH2, 0>(me2, cst2, hf, skip, tacc, tmx, oacc);
+            } else if (k < 2) {
+                strip_row_s2<CQ, NH2, 1>(me2, cst2, hf, skip, tacc, tmx, oacc);
+            } else {
+                strip_row_s2<CQ, NH2, 2>(me2, cst2, hf, skip, tacc, tmx, oacc);
+                float4 o[CQ];
+                strip_act<CQ, RELU>(oacc, cst2 + OFF_SLOPE2 + hf * C, a.hi[S], o);
+                float* obuf = scratch;
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+                wave_sync();
+                // coalesced read-back: float4 f = lane + 64 j of the [64 pixels][C] image -> pixel f / CQ (unit, column)
+                const int Wo = a.W >> 1;
+#pragma unroll
+                for (int j = 0; j < CQ; j++) {
+                    const int f = lane + 64 * j, px = f / CQ, qd = f - px * CQ;
+                    const int u = a.strips == 2 ? 0 : px >> 5, ox = a.strips == 2 ? px : px & 31;
+                    const int un = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + u;
+                    const int ub = un % a.bands, bb = min(un / a.bands, a.B - 1);
+                    const int uy0 = ub * a.band_rows, uy1 = min(uy0 + a.band_rows, a.H);
+                    const float4 v = sld4(obuf + 4 * f);
+                    if (un < a.units && uy0 + k <= uy1 && ox < Wo) {
+                        const int oy = (uy0 + k - 2) >> 1;
+                        sst4(a.out + (long)bb * a.out_fs + ((long)oy * Wo + ox) * Co + hf * C + 4 * qd, v);
+                    }
+                }
+                wave_sync();
+            }
+        }
+    };
+    auto step = [&](int t, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2], const float4 (&xprev)[CQ], float4 (&xcur)[CQ], v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
         const int c = c_first + t;  // row consumed in this step; the row it completes is c - 1
         const int e = c - 1;
         bool hand_over = false;     // this wave has a finished row for the next block
         float4 o[CQ];
-        if (active && c >= lo_j - 1 && c <= hi_j) {
+        if (!tail && active && c >= lo_j - 1 && c <= hi_j) {
             const float* me;
             if (role == 0) {
                 if (c + 1 <= hi_j) wait_vm<NL>();
@@ -490,13 +653,13 @@ __global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kerne
                 wave_sync();
                 me = scratch + (t & 1) * BUF_F + lane * C;
             } else {
-                me = lds + ((role - 1) * SLOTS + (SLOTS == 2 ? ((t - 1) & 1) : 0)) * IMG + img_p + lane * C;
+                me = lds + ((role - 1) * SLOTS + ((t - 1) & 1)) * IMG + img_p + lane * C;
             }
             strip_row<CQ, true>(me, cst, has_res, aPN, aC, xprev, xcur, oacc);
             wave_sync();
             if (e >= lo_j && e < hi_j) {
-                strip_act<CQ, RELU>(oacc, cst, hi, o);
-                if (role < KB - 1) {
+                strip_act<CQ, RELU>(oacc, cst + K::OFF_SLOPE, hi, o);
+                if (NH2 || role < S - 1) {
                     hand_over = true;
                 } else {
                     float* obuf = scratch;
@@ -521,11 +684,12 @@ __global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kerne
                 issue_row(c + 2, t & 1);
             }
         }
-        // with one row image per ring the row may only be written once every reader of the previous one is done
-        if (SLOTS == 1) wg_barrier();
+        if constexpr (NH2 > 0) {
+            if (tail) tail_step(t, tacc, tmx);
+        }
         if (hand_over) {
             // hand the row to the next block; rows outside the image are that block's zero padding
-            float* dstl = lds + (role * SLOTS + (SLOTS == 2 ? (t & 1) : 0)) * IMG + img_p + (1 + lane) * C;
+            float* dstl = lds + (role * SLOTS + (t & 1)) * IMG + img_p + (1 + lane) * C;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e < 0 || e >= a.H) {  // wave-uniform
 #pragma unroll
@@ -540,19 +704,19 @@ __global__ __launch_bounds__(128 * KB, SLOTS == 1 ? 3 : 2) void strip_pipe_kerne
         }
         wg_barrier();
     };
-    const int T = a.band_rows + 3 * KB - 1;
+    const int T = NH2 ? a.band_rows + 3 * S + 1 : a.band_rows + 3 * S - 1;
     for (int t = 0; t < T; t += 2) {
-        step(t, acc0, acc1, xb, xa);
+        step(t, acc0, acc1, xb, xa, acc0, xa);
         if (t + 1 >= T) break;
-        step(t + 1, acc1, acc0, xa, xb);
+        step(t + 1, acc1, acc0, xa, xb, acc0, xa);
     }
 }
 
-template <int CQ, int KB, bool RELU, int SLOTS>
+template <int CQ, int KB, bool RELU, int NH2>
 int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
     using K = SK<CQ>;
-    auto kern = strip_pipe_kernel<CQ, KB, RELU, SLOTS>;
-    const size_t lds_bytes = (size_t)((KB - 1) * SLOTS * 132 * K::C + 6 * K::BUF_F) * 4;
+    auto kern = strip_pipe_kernel<CQ, KB, RELU, NH2>;
+    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + 6 * K::BUF_F) * 4;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -560,7 +724,7 @@ int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
         configured = true;
     }
     const int wgs = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(128 * KB), lds_bytes, s, pa);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds_bytes, s, pa);
     return (int)hipGetLastError();
 }
 
@@ -661,40 +825,86 @@ int launch_strip(const BlockArgs& a, void* stream) {
     return (int)hipErrorInvalidValue;
 }
 
-// Row-pipelined chain of n (2..4) strip-eligible blocks: blocks[k+1] consumes blocks[k]'s output, which never reaches HBM.
+// Stride-2 block that may end a row pipeline: DW3x3 s2 (SAME on an even size) -> PW C -> Co in {C, 2C} -> + 2x2 max-pool of
+// its input (zero channel-padded) -> act; constants packed by strip_pack_consts_s2().
+static bool strip_tail_supports(const BlockArgs& t, const BlockArgs& first) {
+    if (!t.w_strip || !t.has_dw || t.sh != 2 || t.sw != 2 || t.pt != 0 || t.pl != 0) return false;
+    if (t.C != first.C || t.H != first.H || t.W != first.W || (t.H & 1) || (t.W & 1) || t.Ho * 2 != t.H || t.Wo * 2 != t.W) return false;
+    if (t.Co != t.C && t.Co != 2 * t.C) return false;
+    if (t.ep.res_mode != RES_NONE && (t.ep.res_mode != RES_MAXPOOL || t.ep.res_C != t.C || t.ep.res_H != t.H || t.ep.res_W != t.W)) return false;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return aligned16(t.out) && !(t.out_fs & 3);
+}
+
+// Row-pipelined chain of n (2..4) blocks: blocks[k+1] consumes blocks[k]'s output, which never reaches HBM.  All but the
+// last are strip-eligible stride-1 blocks; the last may be a stride-2 block (strip_tail_supports).
 bool strip_pipe_supports(const BlockArgs* blocks, int n) {
     static const bool off = getenv("MI_NO_PIPE") != nullptr;  // tuning aid
     if (off || n < 2 || n > kMaxPipe) return false;
-    for (int k = 0; k < n; k++) {
+    const bool tail = blocks[n - 1].sh == 2;
+    for (int k = 0; k < n - (tail ? 1 : 0); k++) {
         BlockArgs t = blocks[k];
         if (k > 0) { t.in = blocks[0].in; t.in_fs = blocks[0].in_fs; if (t.ep.res_mode != RES_NONE) { t.ep.res = t.in; t.ep.res_fs = t.in_fs; } }
-        if (k < n - 1) { t.out = blocks[n - 1].out; t.out_fs = blocks[n - 1].out_fs; }
+        if (k < n - 1) { t.out = blocks[0].in == blocks[n - 1].out ? t.out : const_cast<float*>(blocks[0].in); t.out_fs = blocks[0].in_fs; }
         if (!strip_kernel_supports(t)) return false;
         if (t.C != blocks[0].C || t.H != blocks[0].H || t.W != blocks[0].W) return false;
         if ((t.ep.act == ACT_RELU) != (blocks[0].ep.act == ACT_RELU)) return false;
+    }
+    if (tail) {
+        if (!strip_tail_supports(blocks[n - 1], blocks[0])) return false;
+        if ((blocks[n - 1].ep.act == ACT_RELU) != (blocks[0].ep.act == ACT_RELU)) return false;
+        if (blocks[0].ep.act != ACT_RELU) return false;  // only the ReLU tails are instantiated
+        if (blocks[0].C != 24) return false;
     }
     return blocks[0].W <= 128 && blocks[0].C <= 24;
 }
 
 bool strip_pipe_shape_ok(int C, int W) { return getenv("MI_NO_PIPE") == nullptr && (C == 16 || C == 24) && W <= 128; }
+bool strip_tail_shape_ok(int C, int Co, int H, int W) { return C == 24 && (Co == C || Co == 2 * C) && !(H & 1) && !(W & 1) && W <= 128; }
+
+int strip_consts_s2_floats(int C, int Co) { return C / 2 * ((32 + 2 * Co + 15) / 16 * 16) + 128; }
+
+// constants of a stride-2 tail block: w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C], bias [Co] or null, alpha [Co] or null
+void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
+    const int SF = (32 + 2 * Co + 15) / 16 * 16;
+    std::fill(dst, dst + strip_consts_s2_floats(C, Co), 0.f);
+    for (int st = 0; st < C / 2; st++) {
+        float* rec = dst + (size_t)st * SF;
+        for (int t = 0; t < 9; t++)
+            for (int e = 0; e < 2; e++) rec[2 * t + e] = w_dw[t * C + 2 * st + e];
+        for (int half = 0; half < 2; half++)
+            for (int o = 0; o < Co; o++) rec[32 + half * Co + o] = w_pw[(size_t)o * C + 2 * st + half];
+    }
+    float* pb = dst + (size_t)(C / 2) * SF;
+    float* ps = pb + 64;
+    for (int c = 0; c < Co; c++) {
+        double acc = bias ? bias[c] : 0.0;
+        if (b_dw)
+            for (int k = 0; k < C; k++) acc += (double)w_pw[(size_t)c * C + k] * b_dw[k];
+        pb[c] = (float)acc;
+        ps[c] = act == ACT_PRELU ? alpha[c] : (act == ACT_NONE ? 1.f : 0.f);
+    }
+}
 
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap) {
-    snprintf(buf, cap, "strip_pipe_kernel<%d,%d,%d>", blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0);
+    const int nh2 = blocks[n - 1].sh == 2 ? blocks[n - 1].Co / blocks[n - 1].C : 0;
+    snprintf(buf, cap, "strip_pipe_kernel<%d,%d,%d,%d>", blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
     return buf;
 }
 
 int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     const BlockArgs& a = blocks[0];
+    const int nh2 = blocks[n - 1].sh == 2 ? blocks[n - 1].Co / blocks[n - 1].C : 0;
     PipeArgs pa{};
     pa.in = a.in; pa.out = blocks[n - 1].out; pa.in_fs = a.in_fs; pa.out_fs = blocks[n - 1].out_fs;
     pa.B = a.B; pa.H = a.H; pa.W = a.W;
     pa.strips = (a.W + 63) / 64;
     for (int k = 0; k < n; k++) {
         pa.consts[k] = blocks[k].w_strip;
-        pa.has_res[k] = blocks[k].ep.res_mode == RES_DIRECT;
+        pa.has_res[k] = blocks[k].ep.res_mode != RES_NONE;
         pa.hi[k] = blocks[k].ep.act == ACT_RELU6 ? 6.f : INFINITY;
     }
-    // bands: about one resident set of workgroups over the chip, but not so short that the 3n-1 pipeline fill steps dominate
+    // bands: about one resident set of workgroups over the chip, but not so short that the pipeline fill steps dominate
     static const int forced = getenv("MI_PIPE_BAND") ? atoi(getenv("MI_PIPE_BAND")) : 0;  // tuning aid
     static const int per_cu_forced = getenv("MI_PIPE_PERCU") ? atoi(getenv("MI_PIPE_PERCU")) : 0;  // tuning aid
     const int per_cu = per_cu_forced > 0 ? per_cu_forced : (n <= 2 ? 2 : 1);
@@ -703,19 +913,20 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     int rows = (int)((a.H + bands - 1) / bands);
     rows = std::max(rows, std::min(a.H, 8 * n));
     if (forced > 0) rows = std::min(forced, a.H);
+    if (nh2) rows = std::min(a.H, (rows + 1) & ~1);  // a stride-2 tail needs bands that start on even rows
     pa.band_rows = rows;
     pa.bands = (a.H + rows - 1) / rows;
     pa.units = a.B * pa.bands;
     hipStream_t s = (hipStream_t)stream;
     const bool relu = a.ep.act == ACT_RELU;
-    static const int slots = getenv("MI_PIPE_SLOTS") ? atoi(getenv("MI_PIPE_SLOTS")) : 2;  // tuning aid
 #define MI_PIPE_CASE(Q, KBV) \
-    if (a.C == 4 * Q && n == KBV) { \
-        if (slots == 1) return relu ? launch_pipe_inst<Q, KBV, true, 1>(pa, s) : launch_pipe_inst<Q, KBV, false, 1>(pa, s); \
-        return relu ? launch_pipe_inst<Q, KBV, true, 2>(pa, s) : launch_pipe_inst<Q, KBV, false, 2>(pa, s); \
-    }
+    if (a.C == 4 * Q && n == KBV && nh2 == 0) return relu ? launch_pipe_inst<Q, KBV, true, 0>(pa, s) : launch_pipe_inst<Q, KBV, false, 0>(pa, s);
     MI_PIPE_CASE(4, 2) MI_PIPE_CASE(4, 3) MI_PIPE_CASE(4, 4) MI_PIPE_CASE(6, 2) MI_PIPE_CASE(6, 3) MI_PIPE_CASE(6, 4)
 #undef MI_PIPE_CASE
+#define MI_TAIL_CASE(KBV, NH) \
+    if (a.C == 24 && n == KBV && nh2 == NH && relu) return launch_pipe_inst<6, KBV, true, NH>(pa, s);
+    MI_TAIL_CASE(2, 1) MI_TAIL_CASE(3, 1) MI_TAIL_CASE(4, 1) MI_TAIL_CASE(2, 2) MI_TAIL_CASE(3, 2) MI_TAIL_CASE(4, 2)
+#undef MI_TAIL_CASE
     return (int)hipErrorInvalidValue;
 }
 

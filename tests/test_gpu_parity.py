@@ -62,27 +62,30 @@ def test_network_raw_outputs_vs_oracle(gpu, oracle, name, fuse):
 
 @pytest.mark.parametrize("name", ["back", "front", "landmark"])
 def test_strip_and_pipeline_kernels_agree(gpu, name):
-    """The three kernels that can run a stride-1 BlazeBlock are interchangeable: row-pipelined chains (fuse 4) give the
-    same bits as one strip-kernel launch per block (they execute the same operations in the same order), and the strip
-    kernel agrees with the LDS-ring block kernel up to the order of the 3x3 sum / the folded depthwise bias (raw-output
-    tolerance of the oracle comparison)."""
+    """The kernels that can run a BlazeBlock are interchangeable.  However a run of blocks is cut into row-pipelined
+    chains (fuse 4, "pipe" = 2 / 3 / 4 blocks per launch) the bits are the same: the chains execute the same operations
+    in the same order.  One strip-kernel launch per block (fuse 3) and the LDS-ring block kernel ("strip" = 0) agree with
+    them up to the order of the 3x3 sum / the depthwise bias folded into the pointwise bias (the stride-2 block that ends
+    a chain is computed that way, the stand-alone block kernel adds the bias first): raw-output tolerance of the oracle
+    comparison."""
     m = gpu.Model(model_path(name))
     x = seeded_input(name, 6, 99, m.input_dims[1:3])
     m.set_option("fuse", 4)
     chained = [o.copy() for o in m.run(x)]
     if name != "front":  # the front model has no run of equal-shape narrow blocks
         assert "row-pipelined" in m.describe()
+    if name == "back":
+        assert "stride-2 tail" in m.describe()
     for pipe in (2, 3):
         m.set_option("pipe", pipe)
         for o, r in zip(m.run(x), chained):
             np.testing.assert_array_equal(o, r)
     m.set_option("fuse", 3)
-    per_block = [o.copy() for o in m.run(x)]
-    for o, r in zip(per_block, chained):
-        np.testing.assert_array_equal(o, r)
+    for o, r in zip(m.run(x), chained):
+        _raw_close(o, r)
     m.set_option("strip", 0)
     for o, r in zip(m.run(x), chained):
-        _raw_close(o, r)  # whole-network tolerance: the reordered sums compound over ~30 layers
+        _raw_close(o, r)
     m.close()
 
 

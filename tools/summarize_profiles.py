@@ -41,7 +41,6 @@ def label(name):
     if not m: return name
     args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2).split(",")]
     if m.group(1) == "block_kernel": args = args[:5]
-    if m.group(1) == "strip_pipe_kernel": args = args[:3]  # ring depth is a tuning parameter, not part of the label
     return "%s<%s>" % (m.group(1), ",".join(args))
 label = label(name)
 json.dump({"round": tag, "workload": "back256_b256", "kernel": label, "rocprof_name": name, "calls": int(dom["Calls"]),
