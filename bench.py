@@ -191,7 +191,7 @@ def main():
                        "weight_broadcast_ms": round(bcast_ms, 3), "plan": model.describe().splitlines()[0]},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N = 1 only
             threads = min(os.cpu_count() or 1, 64)
             result["cpu_baseline"] = cpu_baseline(x_host, threads)
     L.mi_fd_free(h)
