@@ -105,10 +105,13 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
 // from an LDS tile (zero padded, TF SAME), staged with coalesced row-segment loads.  Output 16 B stores.
 template <int K, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
-    constexpr int TW = 32, TH = 8;                       // output tile
+    // PP output pixels per thread (rows ly and ly + 8): every scalar-loaded weight pair then feeds PP packed FMAs, which
+    // halves the scalar-cache round trips per FMA (they, not the VALU, set the pace at one pixel per thread)
+    constexpr int PP = CO <= 32 ? 2 : 1;
+    constexpr int TW = 32, TH = 8 * PP;                  // output tile
     constexpr int IW = 2 * TW + K - 2, IH = 2 * TH + K - 2;  // input tile (stride 2)
     constexpr int RS = (IW * 3 + 1) & ~1;                // row stride in floats (even: 8-byte aligned float2 reads)
-    constexpr int LDSF = (IH * RS > TH * TW * (CO + 4)) ? IH * RS : TH * TW * (CO + 4);
+    constexpr int LDSF = (IH * RS > 8 * TW * (CO + 4)) ? IH * RS : 8 * TW * (CO + 4);
     __shared__ __attribute__((aligned(16))) float tile[LDSF];
     const int tid = threadIdx.x;
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
@@ -138,11 +141,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     }
     __syncthreads();
     const int lx = tid & (TW - 1), ly = tid / TW;
-    const int ox = tx0 + lx, oy = ty0 + ly;
     typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f acc2[CO / 2];  // two output channels per v_pk_fma_f32 (the weight pair is an SGPR-pair operand)
+    v2f acc2[PP][CO / 2];  // two output channels per v_pk_fma_f32 (the weight pair is an SGPR-pair operand)
 #pragma unroll
-    for (int o = 0; o < CO / 2; o++) acc2[o] = v2f{0.f, 0.f};
+    for (int p = 0; p < PP; p++)
+#pragma unroll
+        for (int o = 0; o < CO / 2; o++) acc2[p][o] = v2f{0.f, 0.f};
     const float* __restrict__ w = a.w;  // [K][K][3][Cop], uniform -> scalar loads
     const int Cop = (CO + 3) & ~3;
     // Not unrolled beyond 3 taps: the weights of a tap are 24..64 SGPRs; letting the compiler hoist all K*K*3 taps'
@@ -153,22 +157,21 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
         const float* wk = w + (long)(ky * K * 3) * Cop;
 #pragma unroll 3
         for (int e = 0; e < K * 3; e++) {
-            const float xv = row[e];
+            float xv[PP];
+#pragma unroll
+            for (int p = 0; p < PP; p++) xv[p] = row[p * 16 * RS + e];
             const float* we = wk + (long)e * Cop;
 #pragma unroll
-            for (int o = 0; o < CO / 2; o++) acc2[o] = __builtin_elementwise_fma(v2f{xv, xv}, v2f{we[2 * o], we[2 * o + 1]}, acc2[o]);
+            for (int o = 0; o < CO / 2; o++)
+#pragma unroll
+                for (int p = 0; p < PP; p++) acc2[p][o] = __builtin_elementwise_fma(v2f{xv[p], xv[p]}, v2f{we[2 * o], we[2 * o + 1]}, acc2[p][o]);
         }
     }
-    float acc[CO];
-#pragma unroll
-    for (int o = 0; o < CO / 2; o++) { acc[2 * o] = acc2[o].x; acc[2 * o + 1] = acc2[o].y; }
     // Epilogue through LDS: a thread owns one pixel (CO floats), but 16-byte stores at a CO*4-byte lane stride reach
     // HBM as partial 32-byte sectors (measured 2.85x WRITE_SIZE).  Re-tile so that each wave-instruction writes
     // 1 KiB of consecutive addresses: the tile's rows are contiguous runs of TW*CO floats in the NHWC output.
-    __syncthreads();  // all reads of the input tile are done; reuse the LDS
-    float* otile = tile;  // [TH*TW][CO + 4] (pad keeps the float4 writes of consecutive pixels on distinct banks)
+    float* otile = tile;  // [8*TW][CO + 4] (pad keeps the float4 writes of consecutive pixels on distinct banks)
     constexpr int OS = CO + 4;
-    static_assert(TH * TW * OS <= IH * RS || true, "");
     // branch-free activation: act(v) = min(max(v,0) + slope * min(v,0), hi) with slope 0 (ReLU / ReLU6), alpha (PReLU) or 1
     // (none).  A switch per element costs a scalar load + wait + branches for each of the CO channels of every wave,
     // which took longer than the 900 packed FMAs of the 5x5 stem.
@@ -176,31 +179,37 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     const float base_slope = a.ep.act == ACT_NONE ? 1.f : 0.f, hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY;
     const float* __restrict__ bias = a.ep.bias;
     const float* __restrict__ al = prelu ? a.ep.alpha : a.ep.bias;  // always a readable array: no branch around the loads
-#pragma unroll
-    for (int o = 0; o < CO; o += 4) {
-        float r[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float v = acc[o + e] + bias[o + e];
-            const float sl = prelu ? al[o + e] : base_slope;
-            r[e] = fminf(fmaxf(v, 0.f) + sl * fminf(v, 0.f), hi);
-        }
-        *reinterpret_cast<float4*>(otile + tid * OS + o) = make_float4(r[0], r[1], r[2], r[3]);
-    }
-    __syncthreads();
     constexpr int C4 = CO / 4;
-    for (int i = tid; i < TH * TW * C4; i += 256) {
-        int px = i / C4, c4 = i - px * C4;
-        int y = ty0 + px / TW, x = tx0 + (px & (TW - 1));
-        if (y < a.Ho && x < a.Wo)
-            *reinterpret_cast<float4*>(a.out + (long)b * a.out_fs + ((long)y * a.Wo + x) * CO + 4 * c4) =
-                *reinterpret_cast<const float4*>(otile + px * OS + 4 * c4);
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+        __syncthreads();  // all reads of the input tile (p = 0) / of the previous half's output image are done; reuse the LDS
+#pragma unroll
+        for (int o = 0; o < CO; o += 4) {
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float acc = (e & 1) ? acc2[p][(o + e) >> 1].y : acc2[p][(o + e) >> 1].x;
+                const float v = acc + bias[o + e];
+                const float sl = prelu ? al[o + e] : base_slope;
+                r[e] = fminf(fmaxf(v, 0.f) + sl * fminf(v, 0.f), hi);
+            }
+            *reinterpret_cast<float4*>(otile + tid * OS + o) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        __syncthreads();
+        for (int i = tid; i < 8 * TW * C4; i += 256) {
+            int px = i / C4, c4 = i - px * C4;
+            int y = ty0 + 8 * p + px / TW, x = tx0 + (px & (TW - 1));
+            if (y < a.Ho && x < a.Wo)
+                *reinterpret_cast<float4*>(a.out + (long)b * a.out_fs + ((long)y * a.Wo + x) * CO + 4 * c4) =
+                    *reinterpret_cast<const float4*>(otile + px * OS + 4 * c4);
+        }
     }
 }
 
 template <int K, int CO>
 static int launch_stem(const ConvArgs& a, hipStream_t s) {
-    unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + 7) / 8));
+    constexpr int TH = CO <= 32 ? 16 : 8;  // rows of a tile (two output pixels per thread up to 32 channels)
+    unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + TH - 1) / TH));
     hipLaunchKernelGGL((stem_conv_kernel<K, CO>), dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
