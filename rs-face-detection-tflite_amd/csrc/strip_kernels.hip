@@ -1,30 +1,28 @@
-// strip_kernels.hip — register-resident fused BlazeBlock for the narrow, stride-1 layers (C = Co in {16, 24, 32}).
+// strip_kernels.hip — register-resident fused BlazeBlocks for the narrow layers (C in {16, 24, 32}), one block per launch
+// (strip_kernel) or a run of 2..4 blocks per launch with the rows handed from block to block through LDS
+// (strip_pipe_kernel), optionally ended by the stride-2 block that halves the resolution.
 //
 //   out = act( PW1x1( DW3x3(in) + b_dw ) + b_pw + in )
 //
 // Same operator chain as block_kernels.hip (DEPTHWISE_CONV_2D -> CONV_2D 1x1 -> ADD -> RELU/PRELU behind
 // `interpreter.invoke()`, /root/reference/src/face_detection_lite/face_detection.rs:235; the 24-channel blocks at 128^2
-// and 64^2 are 14 of BackCamera's 37 launches and two thirds of its time), different mapping to the machine.  The
-// block kernel keeps rows in a workgroup-shared LDS ring and re-reads the 3x3 window and the depthwise weights from
+// and 64^2 are 16 of BackCamera's 41 block-fused launches and two thirds of its time), different mapping to the machine.
+// The block kernel keeps rows in a workgroup-shared LDS ring and re-reads the 3x3 window and the depthwise weights from
 // LDS per lane: ~100 ds_read_b128 per 64 pixels, which keeps the CU's LDS pipe ~60 % busy at 2 waves/SIMD — its wall.
 // Here:
-//   * one WAVE owns a strip of 64 pixel columns and walks down a band of rows on its own: no workgroup barrier at all.
-//   * lane = pixel.  A row of the strip (64 + 2 halo pixels, all channels) is fetched with fully coalesced 16 B/lane
-//     loads (1 KiB contiguous per instruction), transposed through a small wave-private LDS buffer (pixel stride C+4
-//     floats: conflict-free b128 accesses), after which the lane holds its pixel's channels and reads its left / right
-//     neighbours from the same buffer: 3 ds_read_b128 per channel quad and row — each input element is read from LDS
-//     three times instead of nine, and vertical reuse is in registers: the three partial output rows a new input row
-//     contributes to (ky = 2, 1, 0) stay in VGPR accumulators.
-//   * depthwise weights / biases are wave-uniform in this layout: they arrive through the scalar cache as SGPR-pair
-//     operands of v_pk_fma_f32 (two channels per VALU lane-op), no LDS or VGPR cost.
-//   * the finished depthwise row (lane = pixel) becomes the B operand of v_mfma_f32_32x32x2_f32 (B[k = lane>>5][n =
-//     lane&31]) with one v_permlane32_swap per channel pair: swap(ch 2j, ch 2j+1) yields the operands of both 32-pixel
-//     halves.  The pointwise weights sit in C/2 VGPRs for the whole kernel (A[i = lane&31][k = lane>>5]).
-//   * D comes back to lane = pixel with one swap per register pair; + bias (SGPR) + skip (the centre input row, still
-//     in VGPRs) -> activation -> transposed back through LDS so that every store instruction writes 1 KiB of
-//     consecutive bytes (full 128-byte lines instead of 16-byte pieces that have to meet in L2).
-//   * the next input row is loaded into registers before the current row's math and staged to LDS after it.
-// Exact f32 throughout (MFMA f32 = fmaf chain); results match the block kernel to reassociation of the 3x3 sum.
+//   * one WAVE owns a strip of 64 pixel columns and walks down a band of rows; lane = pixel.
+//   * a row of the strip (64 + 2 halo pixels, all channels) arrives by LDS-DMA (1 KiB contiguous per instruction) in a
+//     wave-private buffer; the lane reads its own pixel and its left / right neighbours from it: 3 ds_read_b128 per
+//     channel quad and row — each input element is read from LDS three times instead of nine — and vertical reuse is in
+//     registers: the partial output rows an input row contributes to (ky = 2, 1, 0) stay in VGPR accumulators.
+//   * depthwise AND pointwise weights are wave-uniform in this layout: they arrive through the scalar cache as SGPR-pair
+//     operands of v_pk_fma_f32 (two channels per VALU lane-op), no LDS or VGPR cost.  The 1x1 conv is NOT on the matrix
+//     cores: on gfx950 the f32 MFMA has the packed-FMA peak, does not overlap VALU work, and M = 32 wastes a quarter of it
+//     on 24 channels (the MFMA variant of this kernel, with v_permlane32_swap layout changes, is in the git history).
+//   * + bias (folded W b_dw + b_pw) + skip (the centre input row, still in VGPRs) -> activation -> transposed back
+//     through LDS so that every store instruction writes 1 KiB of consecutive bytes (full 128-byte lines instead of
+//     16-byte pieces that have to meet in L2).
+// Exact f32 throughout; results match the block kernel to reassociation of the 3x3 sum and the folded depthwise bias.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
