@@ -56,6 +56,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "graph") use_graph_ = value != 0;
     else if (key == "fuse") { fuse_level_ = std::min(4, std::max(0, value)); dirty_ = true; }
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
+    else if (key == "pipe_rows") { pipe_rows_ = value == 1 ? 1 : 0; }                         // 1: one row per pipeline step (strip_pipe_kernel)
     else if (key == "strip") { strip_ = value != 0; }                                          // 0: LDS-ring block kernel for every block
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
     else if (key == "lanes") lanes_ = std::min(4, std::max(1, value));
@@ -225,7 +226,7 @@ std::string Model::node_label(const Node& n) const {
             if (g.tensors[n.in[0]].shape[1] * g.tensors[n.in[0]].shape[2] <= 256) return "chain_kernel<" + std::to_string((so.back() + 31) / 32) + ">";
             const auto& sin = g.tensors[n.in[0]].shape;
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
-            return "strip_pipe_kernel<" + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
+            return std::string(strip_pipe_rows_per_step(sin[1], pipe_rows_) == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<") + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
@@ -384,6 +385,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     BlockArgs& b = blk[k];
                     b.in = ip; b.out = op; b.in_fs = in_fs; b.out_fs = out_fs;
                     b.has_dw = 1;
+                    b.pipe_rows = pipe_rows_;
                     b.w_dw = d_weights_ + mo.w;
                     b.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
                     b.w_pw = d_weights_ + mo.w2;

@@ -59,6 +59,7 @@ struct BlockArgs {
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0;
     int sh = 1, sw = 1, pt = 0, pl = 0;
     int has_dw = 1;               // 0: plain pointwise conv (no depthwise stage)
+    int pipe_rows = 0;            // row pipelines: rows per step (0 = automatic: 2 when the height is even; 1 forces strip_pipe_kernel)
     Epilogue ep;
 };
 
@@ -148,6 +149,7 @@ int strip_consts_s2_floats(int C, int Co);
 void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
 int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream);
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
+int strip_pipe_rows_per_step(int H, int hint = 0);
 int launch_chain(const ChainArgs& a, void* stream);
 bool chain_kernel_supports(const ChainArgs& a);
 int launch_add(const EltArgs& a, void* stream);

@@ -189,6 +189,123 @@ __device__ __forceinline__ void strip_row(const float* me, const cfloat* cst, bo
     }
 }
 
+// Two input rows r, r+1 per call (images me0, me1): every scalar-loaded weight then feeds two rows' worth of packed
+// FMAs, which halves the scalar-cache round trips, waits and LDS hand-overs per FMA (with one row per call the waits are
+// only half covered: doubling the FMA work per stage costs 1.58x, not 2x).  Entering: aA = partial row r-1 (rows r-2,
+// r-1 in), aB = partial row r (row r-1 in).  The call finishes rows r-1 and r (into oacc0 / oacc1, which start from
+// bias + skip: xres0 = centre pixels of row r-1; row r's are added at the end), and leaves aA = partial row r+1, aB =
+// partial row r+2, xnext = centre pixels of row r+1.
+template <int CQ>
+__device__ __forceinline__ void strip_row2(const float* me0, const float* me1, const cfloat* cst, bool has_res, v2f (&aA)[CQ][2], v2f (&aB)[CQ][2],
+                                           const float4 (&xres0)[CQ], float4 (&xnext)[CQ], v2f (&oacc0)[2 * CQ], v2f (&oacc1)[2 * CQ]) {
+    using K = SK<CQ>;
+    constexpr int C = K::C;
+    float wd[18], wp0[C], wp1[C];
+    float4 xbuf[2][2][3];
+    auto load_first = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[i] = p[K::OFF_DW + st * K::ST_F + i];
+#pragma unroll
+        for (int i = 0; i < C; i++) wp0[i] = p[K::OFF_DW + st * K::ST_F + 32 + i];
+    };
+    auto load_second = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < C; i++) wp1[i] = p[K::OFF_DW + st * K::ST_F + 32 + C + i];
+    };
+    auto load_x = [&](int q, float4 (&x)[2][3]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            x[0][kx] = sld4(me0 + kx * C + 4 * q);
+            x[1][kx] = sld4(me1 + kx * C + 4 * q);
+        }
+    };
+    {   // both rows start from skip + bias, in that order (the same arithmetic as strip_row whichever row of a pair a row is)
+        const cfloat* bp = cst + K::OFF_BIAS;
+        asm volatile("" : "+s"(bp));
+        float4 xm[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; q++) xm[q] = has_res ? sld4(me0 + C + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);  // centre pixels of row r
+        if (has_res) {  // wave-uniform branch
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                oacc0[2 * q] = v2f{xres0[q].x, xres0[q].y} + v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc0[2 * q + 1] = v2f{xres0[q].z, xres0[q].w} + v2f{bp[4 * q + 2], bp[4 * q + 3]};
+                oacc1[2 * q] = v2f{xm[q].x, xm[q].y} + v2f{bp[4 * q], bp[4 * q + 1]};
+                oacc1[2 * q + 1] = v2f{xm[q].z, xm[q].w} + v2f{bp[4 * q + 2], bp[4 * q + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) {
+                const v2f b0 = v2f{bp[4 * q], bp[4 * q + 1]}, b1 = v2f{bp[4 * q + 2], bp[4 * q + 3]};
+                oacc0[2 * q] = b0;
+                oacc1[2 * q] = b0;
+                oacc0[2 * q + 1] = b1;
+                oacc1[2 * q + 1] = b1;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 2 * CQ; o++) asm volatile("" : "+v"(oacc0[o]), "+v"(oacc1[o]));
+    }
+    load_first(0);
+    load_x(0, xbuf[0]);
+#pragma unroll
+    for (int st = 0; st < 2 * CQ; st++) {
+        const int q = st >> 1, h = st & 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        load_second(st);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&x)[2][3] = xbuf[q & 1];
+        if (h == 0) xnext[q] = x[1][1];
+        v2f t0[3], t1[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            t0[kx] = h == 0 ? v2f{x[0][kx].x, x[0][kx].y} : v2f{x[0][kx].z, x[0][kx].w};
+            t1[kx] = h == 0 ? v2f{x[1][kx].x, x[1][kx].y} : v2f{x[1][kx].z, x[1][kx].w};
+        }
+        auto wv = [&](int tap) { return v2f{wd[2 * tap], wd[2 * tap + 1]}; };
+        v2f p0 = aA[q][h], p1 = aB[q][h], nA = t0[0] * wv(0), nB = t1[0] * wv(0);
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            p0 = pkfma(t0[kx], wv(6 + kx), p0);
+            p1 = pkfma(t0[kx], wv(3 + kx), p1);
+            if (kx) nA = pkfma(t0[kx], wv(kx), nA);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            p1 = pkfma(t1[kx], wv(6 + kx), p1);
+            nA = pkfma(t1[kx], wv(3 + kx), nA);
+            if (kx) nB = pkfma(t1[kx], wv(kx), nB);
+        }
+        aA[q][h] = nA;
+        aB[q][h] = nB;
+        asm volatile("" : "+v"(aA[q][h]), "+v"(aB[q][h]));
+#pragma unroll
+        for (int o = 0; o < 2 * CQ; o++) {
+            oacc0[o] = pkfma(v2f{p0.x, p0.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc0[o]);
+            oacc1[o] = pkfma(v2f{p1.x, p1.x}, v2f{wp0[2 * o], wp0[2 * o + 1]}, oacc1[o]);
+        }
+        asm volatile("" : "+v"(p0), "+v"(p1));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (st + 1 < 2 * CQ) {
+            load_first(st + 1);
+            if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int o = 0; o < 2 * CQ; o++) {
+            oacc0[o] = pkfma(v2f{p0.y, p0.y}, v2f{wp1[2 * o], wp1[2 * o + 1]}, oacc0[o]);
+            oacc1[o] = pkfma(v2f{p1.y, p1.y}, v2f{wp1[2 * o], wp1[2 * o + 1]}, oacc1[o]);
+            asm volatile("" : "+v"(oacc0[o]), "+v"(oacc1[o]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // activation of a finished output row (lane = pixel, channel quads)
 template <int CQ, bool RELU>
 __device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloat* slopes, float hi, float4 (&o)[CQ]) {
@@ -490,6 +607,7 @@ struct PipeArgs {
     long in_fs, out_fs;
     int B, H, W;
     int strips, bands, band_rows, units;
+    int rows_per_step;              // 1: strip_pipe_kernel, 2: strip_pipe2_kernel (even band starts / lengths)
     int has_res[kMaxPipe];
     float hi[kMaxPipe];
 };
@@ -710,16 +828,249 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     }
 }
 
+// Same pipeline with TWO rows per step (strip_row2): block j consumes the row pair its predecessor finished in the previous
+// step.  The rings hold one pair of row images each (single-buffered: a step is compute | barrier | hand over | barrier),
+// block 0 keeps two pairs of DMA buffers per wave.  Needs even band starts / lengths.
+template <int CQ, int KB, bool RELU, int NH2>
+__global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void strip_pipe2_kernel(PipeArgs a) {
+    using K = SK<CQ>;
+    constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
+    constexpr int S = NH2 ? KB - 1 : KB;         // stride-1 blocks
+    constexpr int NT = 128 * S + 64 * NH2;       // threads
+    constexpr int IMG = 132 * C;                 // floats of one full-width row image (<= 130 pixels used)
+    constexpr int RING_F = (KB - 1) * 2 * IMG;   // KB-1 hand-over rings of one pair of row images
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool tail = NH2 && w >= 2 * S;
+    const int p = tail ? 0 : (w & 1), role = tail ? S : (w >> 1);
+    const int hf = tail ? w - 2 * S : 0;
+    // wave-private scratch: block 0 waves own two pairs of DMA row buffers each, the waves that store one transposition buffer
+    float* scratch = lds + RING_F + (role == 0 ? p * 4 * BUF_F : 8 * BUF_F + (tail ? hf : p) * BUF_F);
+    const int unit = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + p;
+    const bool active = unit < a.units;
+    const int band = unit % a.bands, b = min(unit / a.bands, a.B - 1);
+    const int x0 = a.strips == 2 ? 64 * p : 0;
+    const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
+    const float* in = a.in + (long)b * a.in_fs;
+    float* out = a.out + (long)b * a.out_fs;
+    const cfloat* cst = (const cfloat*)a.consts[role];
+    const bool has_res = a.has_res[role] != 0;
+    const float hi = a.hi[role];
+    // the last stride-1 block produces rows [y0, hi_last): two more rows when a stride-2 tail follows (its third tap row,
+    // and one to keep the count even)
+    const int hi_last = NH2 ? y1 + 2 : y1;
+    const int lo_j = y0 - (S - 1 - role), hi_j = hi_last + (S - 1 - role);  // this (stride-1) block produces rows [lo_j, hi_j)
+    const int P = (hi_j - lo_j + 2) >> 1;                                   // row pairs it consumes: (lo_j - 1 + 2m, lo_j + 2m)
+    const int img_p = a.strips == 2 ? 64 * C * p : 66 * C * p;
+
+    for (int i = threadIdx.x; i < RING_F / 4; i += NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int goff[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int f = min(lane + 64 * k, K::NF - 1), px = f / CQ, qd = f - px * CQ;
+        goff[k] = (min(max(x0 - 1 + px, 0), a.W - 1) * C + 4 * qd) * 4;
+    }
+    const int npx = min(64, a.W - x0);
+    const bool full = npx == 64;
+    const int zl = x0 == 0 ? 0 : -1;
+    const int zr = x0 + 64 >= a.W ? npx + 1 : -1;
+    const long gout = (long)x0 * C + 4 * lane;
+    const unsigned lds_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)scratch);
+    auto issue_row = [&](int r, int bi) {
+        const char* src = reinterpret_cast<const char*>(in + (long)min(max(r, 0), a.H - 1) * a.W * C);
+        const unsigned dstb = lds_scratch + (unsigned)(bi * BUF_F * 4);
+        constexpr int TAIL = K::NF - 64 * (NL - 1);
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            if (k < NL - 1 || TAIL == 64) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+            } else {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+            }
+        }
+    };
+    const int zfix = lane < CQ ? (zl >= 0 ? zl * C + 4 * lane : -1) : (lane < 2 * CQ ? (zr >= 0 ? zr * C + 4 * (lane - CQ) : -1) : -1);
+    auto fix_row = [&](int r, int bi) {
+        float* buf = scratch + bi * BUF_F;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 0 || r >= a.H) {
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
+        } else if (zfix >= 0) {
+            sst4(buf + zfix, z);
+        }
+    };
+
+    v2f aA[CQ][2], aB[CQ][2], oacc0[2 * CQ], oacc1[2 * CQ];
+    float4 xa[CQ], xb[CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; q++) {
+        aA[q][0] = aA[q][1] = aB[q][0] = aB[q][1] = v2f{0.f, 0.f};
+        xa[q] = xb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (role == 0 && active) {
+        issue_row(lo_j - 1, 0);
+        issue_row(lo_j, 1);
+        if (P > 1) {
+            issue_row(lo_j + 1, 2);
+            issue_row(lo_j + 2, 3);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+
+    auto wg_barrier = [&]() {
+        // raw s_barrier with an LDS-only wait, so that the stores of the last block and the DMA of block 0 stay in flight across it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    auto store_row = [&](int e, const float4 (&o)[CQ]) {  // transposed through LDS: 1 KiB of consecutive bytes per store instruction
+        float* obuf = scratch;
+#pragma unroll
+        for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+        wave_sync();
+        float* dst = out + (long)e * a.W * C + gout;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < CQ; k++) sst4(dst + 256 * k, sld4(obuf + 4 * lane + 256 * k));
+        } else {
+#pragma unroll
+            for (int k = 0; k < CQ; k++) {
+                const float4 v = sld4(obuf + 4 * lane + 256 * k);
+                if (lane + 64 * k < npx * CQ) sst4(dst + 256 * k, v);
+            }
+        }
+        wave_sync();
+    };
+    auto hand_row = [&](int e, int which, const float4 (&o)[CQ]) {  // rows outside the image are the next block's zero padding
+        float* dstl = lds + (role * 2 + which) * IMG + img_p + (1 + lane) * C;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < 0 || e >= a.H) {  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, z);
+        } else if (full) {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, o[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, lane >= npx ? z : o[q]);
+        }
+    };
+    // ---- stride-2 tail: consumes the pair (even row, odd row) the last stride-1 block handed over in the previous step
+    auto tail_step = [&](int t, v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
+        if constexpr (NH2 > 0) {
+            const int mt = t - 2 * S;
+            if (mt < 0 || 2 * mt > a.band_rows) return;
+            const int k = 2 * mt;  // band-relative index of the even row
+            constexpr int Co = NH2 * C;
+            constexpr int ST2 = (32 + 2 * Co + 15) / 16 * 16, OFF_SLOPE2 = (C / 2) * ST2 + 64;
+            const cfloat* cst2 = (const cfloat*)a.consts[S];
+            const float* img = lds + ((S - 1) * 2) * IMG;
+            const int tu = a.strips == 2 ? 0 : lane >> 5, tox = a.strips == 2 ? lane : lane & 31;
+            const float* me2 = img + tu * 66 * C + (2 * tox + 1) * C;
+            const bool skip = hf == 0 && a.has_res[S] != 0;
+            if (mt == 0) {
+                strip_row_s2<CQ, NH2, 1>(me2, cst2, hf, skip, tacc, tmx, oacc0);
+            } else {
+                strip_row_s2<CQ, NH2, 2>(me2, cst2, hf, skip, tacc, tmx, oacc0);
+                float4 o[CQ];
+                strip_act<CQ, RELU>(oacc0, cst2 + OFF_SLOPE2 + hf * C, a.hi[S], o);
+                float* obuf = scratch;
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+                wave_sync();
+                const int Wo = a.W >> 1;
+#pragma unroll
+                for (int j = 0; j < CQ; j++) {
+                    const int f = lane + 64 * j, px = f / CQ, qd = f - px * CQ;
+                    const int u = a.strips == 2 ? 0 : px >> 5, ox = a.strips == 2 ? px : px & 31;
+                    const int un = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + u;
+                    const int ub = un % a.bands, bb = min(un / a.bands, a.B - 1);
+                    const int uy0 = ub * a.band_rows, uy1 = min(uy0 + a.band_rows, a.H);
+                    const float4 v = sld4(obuf + 4 * f);
+                    if (un < a.units && uy0 + k <= uy1 && ox < Wo) {
+                        const int oy = (uy0 + k - 2) >> 1;
+                        sst4(a.out + (long)bb * a.out_fs + ((long)oy * Wo + ox) * Co + hf * C + 4 * qd, v);
+                    }
+                }
+                wave_sync();
+            }
+            if (k + 1 < a.band_rows) strip_row_s2<CQ, NH2, 0>(me2 + IMG, cst2, hf, skip, tacc, tmx, oacc0);
+        }
+    };
+    auto step = [&](int t, const float4 (&xin)[CQ], float4 (&xout)[CQ], v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
+        const int m = t - 2 * role;  // pair index of this block in this step
+        const int c0 = lo_j - 1 + 2 * m;
+        bool hand_over = false;
+        float4 o0[CQ], o1[CQ];
+        if (!tail && active && m >= 0 && m < P) {
+            const float *me0, *me1;
+            if (role == 0) {
+                if (m + 1 < P) wait_vm<2 * NL>();
+                else wait_vm<0>();
+                fix_row(c0, (m & 1) * 2);
+                fix_row(c0 + 1, (m & 1) * 2 + 1);
+                wave_sync();
+                me0 = scratch + ((m & 1) * 2) * BUF_F + lane * C;
+                me1 = me0 + BUF_F;
+            } else {
+                me0 = lds + ((role - 1) * 2) * IMG + img_p + lane * C;
+                me1 = me0 + IMG;
+            }
+            strip_row2<CQ>(me0, me1, cst, has_res, aA, aB, xin, xout, oacc0, oacc1);
+            wave_sync();
+            if (m >= 1) {  // rows c0 - 1 and c0 are finished
+                strip_act<CQ, RELU>(oacc0, cst + K::OFF_SLOPE, hi, o0);
+                strip_act<CQ, RELU>(oacc1, cst + K::OFF_SLOPE, hi, o1);
+                if (NH2 || role < S - 1) {
+                    hand_over = true;
+                } else {
+                    store_row(c0 - 1, o0);
+                    store_row(c0, o1);
+                }
+            }
+            if (role == 0 && m + 2 < P) {
+                wave_sync();
+                issue_row(c0 + 4, (m & 1) * 2);
+                issue_row(c0 + 5, (m & 1) * 2 + 1);
+            }
+        }
+        if constexpr (NH2 > 0) {
+            if (tail) tail_step(t, tacc, tmx);
+        }
+        wg_barrier();  // every reader of the previous pair is done
+        if (hand_over) {
+            hand_row(c0 - 1, 0, o0);
+            hand_row(c0, 1, o1);
+        }
+        wg_barrier();
+    };
+    const int T = NH2 ? 2 * S + a.band_rows / 2 + 1 : 2 * S - 1 + a.band_rows / 2;
+    for (int t = 0; t < T; t += 2) {
+        step(t, xa, xb, aA, xa);
+        if (t + 1 >= T) break;
+        step(t + 1, xb, xa, aA, xa);
+    }
+}
+
 template <int CQ, int KB, bool RELU, int NH2>
 int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
     using K = SK<CQ>;
-    auto kern = strip_pipe_kernel<CQ, KB, RELU, NH2>;
-    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + 6 * K::BUF_F) * 4;
-    static bool configured = false;
-    if (!configured) {
+    const bool two = pa.rows_per_step == 2;
+    auto kern = two ? strip_pipe2_kernel<CQ, KB, RELU, NH2> : strip_pipe_kernel<CQ, KB, RELU, NH2>;
+    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + (two ? 10 : 6) * K::BUF_F) * 4;
+    static bool configured[2] = {false, false};
+    if (!configured[two]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        configured = true;
+        configured[two] = true;
     }
     const int wgs = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds_bytes, s, pa);
@@ -884,9 +1235,16 @@ void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, c
     }
 }
 
+// rows a pipeline step handles: two (strip_pipe2_kernel) whenever the height is even
+int strip_pipe_rows_per_step(int H, int hint) {
+    static const int rows_forced = getenv("MI_PIPE_ROWS") ? atoi(getenv("MI_PIPE_ROWS")) : 0;  // tuning aid
+    return (rows_forced == 1 || hint == 1 || (H & 1)) ? 1 : 2;
+}
+
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap) {
     const int nh2 = blocks[n - 1].sh == 2 ? blocks[n - 1].Co / blocks[n - 1].C : 0;
-    snprintf(buf, cap, "strip_pipe_kernel<%d,%d,%d,%d>", blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
+    snprintf(buf, cap, "strip_pipe%s_kernel<%d,%d,%d,%d>", strip_pipe_rows_per_step(blocks[0].H, blocks[0].pipe_rows) == 2 ? "2" : "", blocks[0].C / 4, n,
+             blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
     return buf;
 }
 
@@ -911,7 +1269,8 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     int rows = (int)((a.H + bands - 1) / bands);
     rows = std::max(rows, std::min(a.H, 8 * n));
     if (forced > 0) rows = std::min(forced, a.H);
-    if (nh2) rows = std::min(a.H, (rows + 1) & ~1);  // a stride-2 tail needs bands that start on even rows
+    pa.rows_per_step = strip_pipe_rows_per_step(a.H, a.pipe_rows);
+    if (nh2 || pa.rows_per_step == 2) rows = std::min(a.H, (rows + 1) & ~1);  // bands that start on even rows
     pa.band_rows = rows;
     pa.bands = (a.H + rows - 1) / rows;
     pa.units = a.B * pa.bands;

@@ -64,7 +64,7 @@ def test_network_raw_outputs_vs_oracle(gpu, oracle, name, fuse):
 def test_strip_and_pipeline_kernels_agree(gpu, name):
     """The kernels that can run a BlazeBlock are interchangeable.  However a run of blocks is cut into row-pipelined
     chains (fuse 4, "pipe" = 2 / 3 / 4 blocks per launch) the bits are the same: the chains execute the same operations
-    in the same order.  One strip-kernel launch per block (fuse 3) and the LDS-ring block kernel ("strip" = 0) agree with
+    in the same order, one or two rows per pipeline step.  One strip-kernel launch per block (fuse 3) and the LDS-ring block kernel ("strip" = 0) agree with
     them up to the order of the 3x3 sum / the depthwise bias folded into the pointwise bias (the stride-2 block that ends
     a chain is computed that way, the stand-alone block kernel adds the bias first): raw-output tolerance of the oracle
     comparison."""
@@ -80,6 +80,10 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
         m.set_option("pipe", pipe)
         for o, r in zip(m.run(x), chained):
             np.testing.assert_array_equal(o, r)
+    m.set_option("pipe_rows", 1)  # one row per pipeline step (the kernel used for odd heights)
+    for o, r in zip(m.run(x), chained):
+        np.testing.assert_array_equal(o, r)
+    m.set_option("pipe_rows", 0)
     m.set_option("fuse", 3)
     for o, r in zip(m.run(x), chained):
         _raw_close(o, r)

@@ -23,7 +23,7 @@ rows = []
 for k in sorted(f, key=lambda k: -sum(f[k])):
     if not k.startswith("void mi::") and not k.startswith("mi::"):
         continue
-    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "chain_kernel"))
+    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel"))
     fk, wk = statistics.mean(f[k]), statistics.mean(w.get(k, [0]))
     rows.append({"kernel": k, "dispatches": len(f[k]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
                  "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
