@@ -473,6 +473,15 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     }
     if (lds_for(R) > 150 * 1024 || !pf_ok(R)) return false;
     if (g.RS >= (1 << 20)) return false;
+    // Small, channel-heavy layers (16x16x96 -> 8x8, 32x32x48 -> 16x16): the prefetch registers cap R at 2 rows, i.e. 16-32
+    // of the 128 pixel slots of a step.  A band that is finished in ONE step needs no prefetch at all, so take as many rows
+    // as the LDS holds and make each band exactly one such step.
+    bool single_step = false;
+    {
+        int R1 = Rfull;
+        while (R1 > 1 && lds_for(R1) > 150 * 1024) R1--;
+        if (a.Ho * a.Wo <= 256 && R1 >= 2 * R && lds_for(R1) <= 150 * 1024) { R = R1; single_step = true; }
+    }
     g.R = R;
     g.NR = (R - 1) * S + KS;
     int off = g.NR * g.RS;
@@ -488,7 +497,7 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     const int per_cu = std::max(1, std::min(max_per_cu, (160 * 1024) / g.lds_bytes));
     const int max_bands = (a.Ho + R - 1) / R;
     int bands = std::min(max_bands, std::max(1, (kCUs * per_cu + a.B / 2) / std::max(1, a.B)));
-    g.band = ((a.Ho + bands - 1) / bands + R - 1) / R * R;
+    g.band = single_step ? R : ((a.Ho + bands - 1) / bands + R - 1) / R * R;
     g.bands = (a.Ho + g.band - 1) / g.band;
     // skip connection straight from the ring when it is the block's own input tensor
     g.res_lds = 0;
