@@ -43,6 +43,8 @@ Model::~Model() {
         if (p) hipFree(p);
     for (hipStream_t st : side_streams_) hipStreamDestroy(st);
     for (hipEvent_t ev : lane_events_) hipEventDestroy(ev);
+    for (hipStream_t st : head_streams_) hipStreamDestroy(st);
+    for (hipEvent_t ev : head_events_) if (ev) hipEventDestroy(ev);
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -57,7 +59,8 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "fuse") { fuse_level_ = std::min(4, std::max(0, value)); dirty_ = true; }
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
     else if (key == "pipe_rows") { pipe_rows_ = value == 1 ? 1 : 0; }                         // 1: one row per pipeline step (strip_pipe_kernel)
-    else if (key == "strip") { strip_ = value != 0; }                                          // 0: LDS-ring block kernel for every block
+    else if (key == "strip") { strip_ = value != 0; }
+    else if (key == "fork") { fork_ = value != 0; }                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
     else if (key == "lanes") lanes_ = std::min(4, std::max(1, value));
     else throw std::runtime_error("unknown option '" + key + "'");
@@ -164,6 +167,47 @@ void Model::rebuild() {
     d_weights_ = nullptr;
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(host.size(), 64) * sizeof(float)), "hipMalloc weights");
     hip_check(hipMemcpy(d_weights_, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice), "upload weights");
+    // ---- output heads that may run beside the trunk: compute nodes whose output lives in a graph-output buffer and is
+    // read by no other launch, and that come after the last trunk node in plan order (so no later trunk launch can
+    // re-use arena memory they still read: the arena's liveness analysis follows plan order)
+    {
+        const size_t N = plan_.nodes.size();
+        head_slot_.assign(N, -1); head_wait_.assign(N, -1); event_after_.assign(N, 0);
+        auto is_view = [&](const Node& n) { return n.kind == Node::Reshape || n.kind == Node::Concat; };
+        auto root = [&](int t) { return plan_.storage[t].root; };
+        std::vector<int> out_roots;
+        for (int o : g.outputs) out_roots.push_back(root(o));
+        std::vector<char> head(N, 0);
+        int last_trunk = -1;
+        for (size_t i = 0; i < N; i++) {
+            const Node& n = plan_.nodes[i];
+            if (is_view(n)) continue;
+            bool feeds_output = std::find(out_roots.begin(), out_roots.end(), root(n.out)) != out_roots.end();
+            for (size_t j = 0; j < N && feeds_output; j++) {
+                const Node& m = plan_.nodes[j];
+                if (is_view(m)) continue;
+                for (int x : m.in) if (x == n.out) feeds_output = false;
+                if (m.res == n.out) feeds_output = false;
+            }
+            head[i] = feeds_output;
+            if (!feeds_output) last_trunk = static_cast<int>(i);
+        }
+        std::vector<int> slot_of_producer(N + 1, -1);
+        int slots = 0;
+        for (size_t i = 0; i < N; i++) {
+            const Node& n = plan_.nodes[i];
+            if (!head[i] || static_cast<int>(i) < last_trunk || is_view(n)) continue;
+            int prod = -1;  // the launch that produces (the buffer of) its input
+            for (size_t j = 0; j < i; j++)
+                if (!is_view(plan_.nodes[j]) && root(plan_.nodes[j].out) == root(n.in[0])) prod = static_cast<int>(j);
+            if (n.res >= 0 && n.res != n.in[0]) continue;  // two producers: keep it on the trunk
+            int& sl = slot_of_producer[prod + 1];
+            if (sl < 0) sl = slots++ % 3;
+            head_slot_[i] = sl;
+            head_wait_[i] = prod;
+            if (prod >= 0) event_after_[prod] = 1;
+        }
+    }
     dirty_ = false;
     chunk_cap_ = 0;
 }
@@ -311,9 +355,34 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         marks->push_back(ev);
     };
     mark();
+    // heads beside the trunk (not while profiling: the per-launch events there assume one stream)
+    const bool fork = fork_ && !marks;
+    hipStream_t const trunk = s;
+    unsigned used_heads = 0;
+    auto node_event = [&](size_t k) {
+        if (head_events_.size() < plan_.nodes.size() + 4) head_events_.resize(plan_.nodes.size() + 4, nullptr);
+        if (!head_events_[k]) hip_check(hipEventCreateWithFlags(&head_events_[k], hipEventDisableTiming), "hipEventCreate");
+        return head_events_[k];
+    };
     for (size_t i = 0; i < plan_.nodes.size(); i++) {
         const Node& n = plan_.nodes[i];
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;  // views
+        s = trunk;
+        if (fork && head_slot_[i] >= 0) {
+            while (static_cast<int>(head_streams_.size()) <= head_slot_[i]) {
+                hipStream_t st;
+                hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+                head_streams_.push_back(st);
+            }
+            s = head_streams_[head_slot_[i]];
+            if (head_wait_[i] >= 0) {
+                hip_check(hipStreamWaitEvent(s, node_event(static_cast<size_t>(head_wait_[i])), 0), "hipStreamWaitEvent");
+            } else {  // reads the graph input: order it behind whatever the trunk stream was doing before this plan
+                hip_check(hipEventRecord(node_event(plan_.nodes.size()), trunk), "hipEventRecord");
+                hip_check(hipStreamWaitEvent(s, node_event(plan_.nodes.size()), 0), "hipStreamWaitEvent");
+            }
+            used_heads |= 1u << head_slot_[i];
+        }
         const auto& si = g.tensors[n.in[0]].shape;
         const auto& so = g.tensors[n.out].shape;
         auto dim = [](const std::vector<int>& v, size_t d) { return d < v.size() ? v[d] : 1; };
@@ -455,8 +524,15 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             }
         }
         if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (fork && event_after_[i]) hip_check(hipEventRecord(node_event(i), s), "hipEventRecord");
         mark();
     }
+    s = trunk;
+    for (int k = 0; k < 3; k++)  // join: the trunk stream continues (post-processing, the next chunk) after every head
+        if (used_heads & (1u << k)) {
+            hip_check(hipEventRecord(node_event(plan_.nodes.size() + 1 + k), head_streams_[static_cast<size_t>(k)]), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(trunk, node_event(plan_.nodes.size() + 1 + k), 0), "hipStreamWaitEvent");
+        }
     last_chunk_frames_ = F;
 }
 

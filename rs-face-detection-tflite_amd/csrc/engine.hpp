@@ -68,10 +68,16 @@ class Model {
     int device_ = 0;
     std::vector<uint8_t> blob_;
     Plan plan_;
-    int fuse_level_ = 4, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0;
+    int fuse_level_ = 4, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, fork_ = 1;
     int arena_lane_ = 0;                    // arena region the chunk being enqueued writes to
     std::vector<hipStream_t> side_streams_;  // lanes 1.. run on their own streams (forked/joined with events)
     std::vector<hipEvent_t> lane_events_;
+    // output heads (nodes that only feed graph outputs, after the last trunk node) run on side streams beside the trunk
+    std::vector<int> head_slot_;          // per node: side stream of a forked head, -1 otherwise
+    std::vector<int> head_wait_;          // per forked head: node whose completion it waits for (-1: start of the plan)
+    std::vector<char> event_after_;       // per node: a forked head waits for it
+    std::vector<hipStream_t> head_streams_;
+    std::vector<hipEvent_t> head_events_; // one per node (lazily created) + one per side stream for the join
     bool dirty_ = true;
 
     float* d_weights_ = nullptr;

@@ -84,6 +84,10 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
     for o, r in zip(m.run(x), chained):
         np.testing.assert_array_equal(o, r)
     m.set_option("pipe_rows", 0)
+    m.set_option("fork", 0)  # output heads on the trunk's stream instead of side streams
+    for o, r in zip(m.run(x), chained):
+        np.testing.assert_array_equal(o, r)
+    m.set_option("fork", 1)
     m.set_option("fuse", 3)
     for o, r in zip(m.run(x), chained):
         _raw_close(o, r)
