@@ -37,6 +37,7 @@ Model::~Model() {
     hipSetDevice(device_);
     invalidate_graphs();
     if (d_weights_) hipFree(d_weights_);
+    if (d_programs_) hipFree(d_programs_);
     if (d_arena_) hipFree(d_arena_);
     if (d_in_stage_) hipFree(d_in_stage_);
     for (float* p : d_out_)
@@ -56,7 +57,8 @@ void Model::invalidate_graphs() {
 void Model::set_option(const std::string& key, int value) {
     if (key == "chunk") chunk_ = std::max(0, value);
     else if (key == "graph") use_graph_ = value != 0;
-    else if (key == "fuse") { fuse_level_ = std::min(4, std::max(0, value)); dirty_ = true; }
+    else if (key == "fuse") { fuse_level_ = std::min(5, std::max(0, value)); dirty_ = true; }
+    else if (key == "res_budget") { res_budget_ = std::min(156, std::max(16, value)) * 1024; dirty_ = true; }  // LDS (KiB) a stage program may use
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
     else if (key == "pipe_rows") { pipe_rows_ = value == 1 ? 1 : 0; }                         // 1: one row per pipeline step (strip_pipe_kernel)
     else if (key == "strip") { strip_ = value != 0; }
@@ -71,7 +73,7 @@ void Model::set_option(const std::string& key, int value) {
 void Model::rebuild() {
     hip_check(hipSetDevice(device_), "hipSetDevice");
     invalidate_graphs();
-    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_, pipe_max_);
+    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_, pipe_max_, res_budget_);
     const Graph& g = plan_.graph;
     if (!reuse_) {  // debugging layout: every tensor keeps its own slot
         long off = 0;
@@ -96,7 +98,9 @@ void Model::rebuild() {
     auto pack_pw = [&](int wt) {
         const auto& ws = g.tensors[wt].shape;
         const auto& src = g.tensors[wt].f32;
-        int O = ws[0], I = ws[3], Cp, Cop;
+        // [O][KH][KW][I] read as [O][KH*KW*I]: the k x k stride-k convolutions of the stage programs contract over the
+        // "virtual channels" (tap, channel) in exactly this order
+        int O = ws[0], I = ws[1] * ws[2] * ws[3], Cp, Cop;
         block_weight_dims(I, O, &Cp, &Cop);
         const int Ch = Cp / 2, MT = Cop / 32;
         std::vector<float> r(static_cast<size_t>(Cop) * Cp, 0.f);
@@ -135,6 +139,23 @@ void Model::rebuild() {
             }
             continue;
         }
+        if (n.kind == Node::Resident) {
+            for (const Node& m : n.members) {
+                MemberOff mo;
+                if (m.kind == Node::Conv) {  // k x k stride-k convolution: weights in A-fragment order over the virtual channels
+                    mo.w2 = pack_pw(m.w);
+                    if (m.b >= 0) mo.b2 = put(g.tensors[m.b].f32);
+                } else {
+                    if (m.w >= 0) mo.w = put(g.tensors[m.w].f32);
+                    if (m.b >= 0) mo.b = put(g.tensors[m.b].f32);
+                    mo.w2 = pack_pw(m.w2);
+                    if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
+                }
+                if (m.alpha >= 0) mo.alpha = put(g.tensors[m.alpha].f32);
+                chain_off_[i].push_back(mo);
+            }
+            continue;
+        }
         if (n.b >= 0) node_b_[i] = put(g.tensors[n.b].f32);
         if (n.b2 >= 0) node_b2_[i] = put(g.tensors[n.b2].f32);
         if (n.alpha >= 0) node_alpha_[i] = put(g.tensors[n.alpha].f32);
@@ -167,6 +188,50 @@ void Model::rebuild() {
     d_weights_ = nullptr;
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(host.size(), 64) * sizeof(float)), "hipMalloc weights");
     hip_check(hipMemcpy(d_weights_, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice), "upload weights");
+    // ---- stage programs of the resident launches: pointer-free descriptors, resolved against ResBases at launch
+    {
+        std::vector<ResStage> progs;
+        node_prog_.assign(NN, -1);
+        auto ref = [&](int t) {
+            ResRef r;
+            const Storage& st = plan_.storage[t];
+            r.inner = st.offset;
+            r.fs = st.frame_stride;
+            if (st.root == plan_.storage[g.inputs[0]].root) { r.base = 1; return r; }
+            for (size_t k = 0; k < g.outputs.size(); k++)
+                if (plan_.storage[g.outputs[k]].root == st.root) {
+                    if (2 + k >= static_cast<size_t>(kResBases)) throw std::runtime_error("stage program: too many graph outputs");
+                    r.base = 2 + static_cast<int>(k);
+                    return r;
+                }
+            if (plan_.root_offset[st.root] < 0) throw std::runtime_error("stage program: tensor has no storage");
+            r.base = 0;
+            r.root_off = plan_.root_offset[st.root];
+            return r;
+        };
+        for (size_t i = 0; i < NN; i++) {
+            const Node& n = plan_.nodes[i];
+            if (n.kind != Node::Resident) continue;
+            node_prog_[i] = static_cast<long>(progs.size());
+            for (const Node::Stage& sg : n.stages) {
+                ResStage st = sg.st;
+                if (sg.src_t >= 0) st.src_g = ref(sg.src_t);
+                if (st.kind != RES_STAGE_LOAD) {
+                    if (sg.dst_t >= 0) st.dst_g = ref(sg.dst_t);
+                    if (sg.res_t >= 0) st.res_g = ref(sg.res_t);
+                    const MemberOff& mo = chain_off_[i][static_cast<size_t>(sg.member)];
+                    st.w_dw = mo.w; st.b_dw = mo.b; st.w_pw = mo.w2; st.bias = mo.b2; st.alpha = mo.alpha;
+                }
+                progs.push_back(st);
+            }
+        }
+        if (d_programs_) hip_check(hipFree(d_programs_), "hipFree");
+        d_programs_ = nullptr;
+        if (!progs.empty()) {
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d_programs_), progs.size() * sizeof(ResStage)), "hipMalloc programs");
+            hip_check(hipMemcpy(d_programs_, progs.data(), progs.size() * sizeof(ResStage), hipMemcpyHostToDevice), "upload programs");
+        }
+    }
     // ---- output heads that may run beside the trunk: compute nodes whose output lives in a graph-output buffer and is
     // read by no other launch, and that come after the last trunk node in plan order (so no later trunk launch can
     // re-use arena memory they still read: the arena's liveness analysis follows plan order)
@@ -189,6 +254,7 @@ void Model::rebuild() {
                 for (int x : m.in) if (x == n.out) feeds_output = false;
                 if (m.res == n.out) feeds_output = false;
             }
+            if (n.kind == Node::Resident && (n.in.size() != 1 || !n.extra_out.empty())) feeds_output = false;  // several inputs / outputs: stays on the trunk
             head[i] = feeds_output;
             if (!feeds_output) last_trunk = static_cast<int>(i);
         }
@@ -198,8 +264,12 @@ void Model::rebuild() {
             const Node& n = plan_.nodes[i];
             if (!head[i] || static_cast<int>(i) < last_trunk || is_view(n)) continue;
             int prod = -1;  // the launch that produces (the buffer of) its input
-            for (size_t j = 0; j < i; j++)
-                if (!is_view(plan_.nodes[j]) && root(plan_.nodes[j].out) == root(n.in[0])) prod = static_cast<int>(j);
+            for (size_t j = 0; j < i; j++) {
+                if (is_view(plan_.nodes[j])) continue;
+                bool makes = root(plan_.nodes[j].out) == root(n.in[0]);
+                for (int t : plan_.nodes[j].extra_out) makes |= root(t) == root(n.in[0]);
+                if (makes) prod = static_cast<int>(j);
+            }
             if (n.res >= 0 && n.res != n.in[0]) continue;  // two producers: keep it on the trunk
             int& sl = slot_of_producer[prod + 1];
             if (sl < 0) sl = slots++ % 3;
@@ -272,6 +342,7 @@ std::string Model::node_label(const Node& n) const {
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
             return std::string(strip_pipe_rows_per_step(sin[1], pipe_rows_) == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<") + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
+        case Node::Resident: return "resident_kernel";
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -306,6 +377,17 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
         if (n.kind == Node::Conv) st.macs = elems(n.out) * n.KH * n.KW * si.back() * batch;
         if (n.kind == Node::Dw) st.macs = elems(n.out) * n.KH * n.KW * batch;
         if (n.kind == Node::Block) st.macs = elems(n.out) / so.back() * si.back() * ((n.w >= 0 ? 9 : 0) + so.back()) * batch;
+        if (n.kind == Node::Resident) {
+            st.macs = 0;
+            for (int t : n.extra_out) st.bytes += 4 * elems(t) * batch;
+            for (const Node& m : n.members) {
+                const auto& mo = g.tensors[m.out].shape;
+                const int Cm = g.tensors[m.in[0]].shape[3];
+                if (m.kind == Node::Conv) st.macs += elems(m.out) * m.KH * m.KW * Cm * batch;
+                else st.macs += static_cast<double>(mo[1]) * mo[2] * Cm * ((m.w >= 0 ? 9 : 0) + mo[3]) * batch;
+                for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) st.bytes += 4 * elems(c);
+            }
+        }
         if (n.kind == Node::Chain) {
             st.macs = 0;
             for (const Node& m : n.members) {
@@ -425,6 +507,23 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
                 a.ep = ep;
                 rc = launch_dw(a, s);
+                break;
+            }
+            case Node::Resident: {
+                ResLaunch a;
+                a.prog = d_programs_ + node_prog_[i];
+                a.nstages = static_cast<int>(n.stages.size());
+                a.B = F;
+                a.const_off = n.res_const_off;
+                a.lds_bytes = n.res_lds_bytes;
+                for (int k = 0; k < kResBases; k++) { a.bases.p[k] = nullptr; a.bases.scale[k] = 0; a.bases.frame0[k] = 0; }
+                a.bases.p[0] = d_arena_ + static_cast<size_t>(plan_.arena_floats_per_frame) * chunk_cap_ * arena_lane_;
+                a.bases.scale[0] = chunk_cap_;
+                a.bases.p[1] = const_cast<float*>(in);
+                a.bases.frame0[1] = chunk_start;
+                for (int k = 0; k < num_outputs() && 2 + k < kResBases; k++) { a.bases.p[2 + k] = d_out_[k]; a.bases.frame0[2 + k] = chunk_start; }
+                a.bases.weights = d_weights_;
+                rc = launch_resident(a, s);
                 break;
             }
             case Node::Chain: {

@@ -68,7 +68,7 @@ class Model {
     int device_ = 0;
     std::vector<uint8_t> blob_;
     Plan plan_;
-    int fuse_level_ = 4, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, fork_ = 1;
+    int fuse_level_ = 5, res_budget_ = 156 * 1024, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, fork_ = 1;
     int arena_lane_ = 0;                    // arena region the chunk being enqueued writes to
     std::vector<hipStream_t> side_streams_;  // lanes 1.. run on their own streams (forked/joined with events)
     std::vector<hipEvent_t> lane_events_;
@@ -86,6 +86,8 @@ class Model {
     struct MemberOff { long w = -1, b = -1, w2 = -1, b2 = -1, alpha = -1, strip = -1; };
     std::vector<std::vector<MemberOff>> chain_off_;  // per node: offsets of each chain member's constants
 
+    ResStage* d_programs_ = nullptr;        // stage programs of the Resident nodes (device memory)
+    std::vector<long> node_prog_;           // per node: first stage in d_programs_ (-1 none)
     float* d_arena_ = nullptr;
     size_t arena_floats_ = 0;
     int chunk_cap_ = 0;      // frames per chunk the arena is laid out for

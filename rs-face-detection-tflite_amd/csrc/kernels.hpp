@@ -127,6 +127,54 @@ struct ProjArgs {  // project_landmarks, one thread per landmark
     int B = 0, n = 0, tensor_w = 1, tensor_h = 1;
 };
 
+
+// Frame-resident stage programs (resident_kernels.hip, fuse level 5): ONE workgroup per frame runs a list of fused stages
+// with the activations kept in LDS.  Descriptors are pointer-free (they live in device memory, written once per plan):
+// a global tensor is named by (base index, offsets) and resolved against the ResBases passed with each launch.
+struct ResRef {
+    int base = -1;        // index into ResBases (-1: unused)
+    int pad_ = 0;
+    long root_off = 0;    // floats, multiplied by ResBases::scale[base] (arena tensors are laid out per chunk capacity)
+    long inner = 0;       // floats
+    long fs = 0;          // frame stride (floats)
+};
+enum ResKind : int { RES_STAGE_LOAD = 0, RES_STAGE_GATHER = 1, RES_STAGE_DW = 2 };
+struct ResStage {
+    int kind = RES_STAGE_GATHER;
+    int mtg = 1;                       // output-channel tiles per unit (1 or 2)
+    // source: LDS tensor (src_off >= 0; pixel (y,x) at src_off + ((y+b)*(W+2b) + x+b)*PS) or dense NHWC in global memory
+    int src_off = -1, src_H = 0, src_W = 0, src_C = 0, src_PS = 0, src_b = 0;
+    ResRef src_g;
+    int KH = 1, KW = 1, S = 1, pt = 0, pl = 0;
+    int Kv = 0;                        // contraction length: KH*KW*C (GATHER) or C (DW)
+    int Ho = 0, Wo = 0, Co = 0;
+    int dst_off = -1, dst_PS = 0, dst_b = 0;
+    int zero_dst = 0;                  // floats to clear at dst_off before the stage runs
+    ResRef dst_g;                      // optional global copy of the output, dense [Ho][Wo][Co]
+    int res_mode = RES_NONE, res_C = 0, res_H = 0, res_W = 0;
+    int res_off = -1, res_PS = 0, res_b = 0;   // skip source in LDS, else res_g
+    ResRef res_g;
+    int act = ACT_NONE;
+    int pad_ = 0;
+    long w_dw = -1, b_dw = -1, w_pw = -1, bias = -1, alpha = -1;  // float offsets into the weights blob
+};
+constexpr int kResBases = 8;
+struct ResBases {
+    float* p[kResBases];
+    long scale[kResBases];   // multiplier of ResRef::root_off
+    int frame0[kResBases];   // first frame of this launch inside the tensor
+    const float* weights;
+};
+struct ResLaunch {
+    const ResStage* prog = nullptr;  // device memory
+    int nstages = 0, B = 0;
+    int const_off = 0;               // LDS floats: start of the per-stage constants area
+    int lds_bytes = 0;
+    ResBases bases;
+};
+int launch_resident(const ResLaunch& a, void* stream);
+int resident_const_floats(const ResStage& st);  // LDS floats the stage's constants need
+
 // ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).
 int launch_conv(const ConvArgs& a, void* stream);
 const char* conv_kernel_label(const ConvArgs& a);

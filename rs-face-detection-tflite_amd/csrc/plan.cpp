@@ -182,9 +182,281 @@ void same_pad(int in, int k, int stride, int& before, int& out) {
     before = total / 2;
 }
 
+
+// Level 5, step 1: make independent branches contiguous.  TFLite serialises the two heads of the face-mesh / iris graphs
+// op by op in alternation; following each producer by its (ready) consumer keeps a branch together so that it can become one
+// stage program.  Only the order among independent nodes changes.
+void reorder_branches(std::vector<Node>& ns) {
+    const int N = static_cast<int>(ns.size());
+    std::map<int, int> producer;
+    for (int i = 0; i < N; i++) producer[ns[i].out] = i;
+    std::vector<char> emitted(N, 0);
+    std::vector<int> order;
+    auto ready = [&](int k) {
+        auto ok = [&](int t) {
+            auto it = producer.find(t);
+            return t < 0 || it == producer.end() || emitted[it->second];
+        };
+        for (int t : ns[k].in)
+            if (!ok(t)) return false;
+        return ok(ns[k].res);
+    };
+    auto reads = [&](const Node& n, int t) { return std::find(n.in.begin(), n.in.end(), t) != n.in.end() || n.res == t; };
+    for (int i = 0; i < N; i++) {
+        if (emitted[i]) continue;
+        int cur = i;
+        emitted[cur] = 1;
+        order.push_back(cur);
+        for (;;) {
+            int next = -1;
+            for (int k = cur + 1; k < N && next < 0; k++)
+                if (!emitted[k] && reads(ns[k], ns[cur].out) && ready(k)) next = k;
+            if (next < 0) break;
+            emitted[next] = 1;
+            order.push_back(next);
+            cur = next;
+        }
+    }
+    std::vector<Node> out;
+    out.reserve(ns.size());
+    for (int k : order) out.push_back(std::move(ns[k]));
+    ns = std::move(out);
+}
+
+// Level 5, step 2: one candidate group = plan nodes [i, j].  Builds the stage list and places the in-group activations in
+// LDS (first fit by liveness; a block whose skip is its own LDS-resident, now dead, same-shape input tensor is updated in
+// place).  Returns false when a node has no stage form or the program does not fit in `budget` bytes of LDS.
+bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_t j, int budget, Node* out) {
+    std::vector<Node> M;
+    for (size_t k = i; k <= j; k++) {
+        const Node& n = ns[k];
+        if (n.kind == Node::Chain) {
+            const auto& si = g.tensors[n.in[0]].shape;
+            if (si[1] * si[2] > 256) return false;  // row-pipelined chains stay what they are
+            for (const Node& m : n.members) M.push_back(m);
+        } else if (n.kind == Node::Block || n.kind == Node::Conv) {
+            M.push_back(n);
+        } else {
+            return false;
+        }
+    }
+    auto shp = [&](int t) -> const std::vector<int>& { return g.tensors[t].shape; };
+    std::map<int, int> made;  // tensor -> member that produces it
+    for (size_t m = 0; m < M.size(); m++) made[M[m].out] = static_cast<int>(m);
+    auto external = [&](int t) {
+        if (std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end()) return true;
+        for (size_t k = 0; k < ns.size(); k++) {
+            if (k >= i && k <= j) continue;
+            if (std::find(ns[k].in.begin(), ns[k].in.end(), t) != ns[k].in.end() || ns[k].res == t) return true;
+        }
+        return false;
+    };
+    struct Lt { int H, W, C, b = 0, def = -1, last = -1, off = -1; bool in_lds = false; };
+    std::map<int, Lt> lt;
+    auto geom = [&](int t) -> Lt& {
+        auto it = lt.find(t);
+        if (it == lt.end()) {
+            Lt x;
+            x.H = shp(t)[1]; x.W = shp(t)[2]; x.C = shp(t)[3];
+            it = lt.emplace(t, x).first;
+        }
+        return it->second;
+    };
+    // ---- pass 1: stages with tensor ids
+    std::vector<Node::Stage> S;
+    std::vector<int> ext_in, ext_out;
+    auto add_ext_in = [&](int t) { if (std::find(ext_in.begin(), ext_in.end(), t) == ext_in.end()) ext_in.push_back(t); };
+    for (size_t m = 0; m < M.size(); m++) {
+        const Node& n = M[m];
+        if (n.in.size() != 1) return false;
+        const int src = n.in[0];
+        if (shp(src).size() != 4 || shp(n.out).size() != 4) return false;
+        const int H = shp(src)[1], W = shp(src)[2], C = shp(src)[3];
+        const int Ho = shp(n.out)[1], Wo = shp(n.out)[2], Co = shp(n.out)[3];
+        if (C % 4 || Ho * Wo > 256 || H * W > 1024) return false;
+        Node::Stage sg;
+        ResStage& st = sg.st;
+        sg.member = static_cast<int>(m);
+        st.src_H = H; st.src_W = W; st.src_C = C;
+        st.Ho = Ho; st.Wo = Wo; st.Co = Co;
+        st.act = n.act;
+        const bool src_inside = made.count(src) && made[src] < static_cast<int>(m);
+        if (n.kind == Node::Block && n.w >= 0) {
+            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) return false;
+            st.kind = RES_STAGE_DW;
+            st.KH = st.KW = 3; st.S = n.sh; st.Kv = C;
+            st.pt = std::max(0, (Ho - 1) * n.sh + 3 - H) / 2;
+            st.pl = std::max(0, (Wo - 1) * n.sw + 3 - W) / 2;
+            if ((Ho - 1) * n.sh + 2 - st.pt > H || (Wo - 1) * n.sw + 2 - st.pl > W) return false;  // one border pixel covers the overhang
+            if (!src_inside && !lt.count(src)) {  // bring the frame into LDS first
+                Node::Stage ld;
+                ld.st.kind = RES_STAGE_LOAD;
+                ld.st.src_H = H; ld.st.src_W = W; ld.st.src_C = C;
+                ld.src_t = src;
+                ld.dst_t = src;
+                Lt& x = geom(src);
+                x.in_lds = true; x.def = static_cast<int>(S.size());
+                S.push_back(ld);
+                add_ext_in(src);
+            }
+            Lt& x = geom(src);
+            if (!x.in_lds) return false;
+            x.b = 1;
+        } else {
+            int K = 1, sh = 1;
+            if (n.kind == Node::Conv) {
+                if (n.KH != n.KW || n.res >= 0) return false;
+                K = n.KH; sh = n.sh;
+                const bool whole = H == K && W == K;  // the window is the frame: one output pixel whatever the stride
+                if (!whole && (n.sh != K || n.sw != K || H % K || W % K)) return false;
+                if (Ho != H / K || Wo != W / K) return false;
+                (void)sh;
+            } else if (n.kind != Node::Block) {
+                return false;
+            }
+            st.kind = RES_STAGE_GATHER;
+            st.KH = st.KW = K; st.S = K; st.Kv = K * K * C;
+            if (src_inside || lt.count(src)) {
+                if (!geom(src).in_lds) return false;
+            } else {
+                sg.src_t = src;  // gathered straight from global memory
+                add_ext_in(src);
+            }
+        }
+        if (lt.count(src) && lt[src].in_lds) lt[src].last = static_cast<int>(S.size());
+        if (n.res >= 0) {
+            const auto& sr = shp(n.res);
+            if (sr.size() != 4 || sr[3] % 4 || sr[3] > Co) return false;
+            if (n.res_mode == RES_DIRECT) { if (sr[1] != Ho || sr[2] != Wo) return false; }
+            else if (n.res_mode == RES_MAXPOOL) { if (sr[1] != 2 * Ho || sr[2] != 2 * Wo) return false; }
+            else return false;
+            st.res_mode = n.res_mode; st.res_C = sr[3]; st.res_H = sr[1]; st.res_W = sr[2];
+            if (lt.count(n.res) && lt[n.res].in_lds) {
+                lt[n.res].last = static_cast<int>(S.size());
+            } else if (made.count(n.res) && made[n.res] < static_cast<int>(m)) {
+                return false;  // produced inside but not kept: cannot happen (marked below), defensive
+            } else {
+                sg.res_t = n.res;
+                add_ext_in(n.res);
+            }
+        }
+        // where the output goes
+        bool used_inside = false;
+        for (size_t m2 = m + 1; m2 < M.size(); m2++)
+            used_inside |= std::find(M[m2].in.begin(), M[m2].in.end(), n.out) != M[m2].in.end() || M[m2].res == n.out;
+        const bool ext = external(n.out);
+        if (!used_inside && !ext) return false;
+        if (used_inside) {
+            if (Co % 4) return false;
+            Lt& y = geom(n.out);
+            y.in_lds = true; y.def = static_cast<int>(S.size());
+        }
+        if (ext) { sg.dst_t = n.out; ext_out.push_back(n.out); }
+        S.push_back(sg);
+    }
+    if (ext_out.empty() || ext_in.size() + ext_out.size() > 12) return false;
+    // ---- pass 2: LDS placement in stage order
+    struct Live { int off, size, t; };
+    std::vector<Live> live;
+    struct Clean { int off, size, H, W, C, b; };
+    std::vector<Clean> clean;
+    int high = 0, const_max = 0;
+    auto size_of = [&](const Lt& x) { return (x.H + 2 * x.b) * (x.W + 2 * x.b) * (x.C + 4); };
+    for (size_t k = 0; k < S.size(); k++) {
+        Node::Stage& sg = S[k];
+        ResStage& st = sg.st;
+        const int src = sg.member >= 0 ? M[sg.member].in[0] : sg.src_t;
+        const int dst = sg.member >= 0 ? M[sg.member].out : sg.dst_t;
+        const int res = sg.member >= 0 ? M[sg.member].res : -1;
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return lt[l.t].last < static_cast<int>(k); }), live.end());
+        if (st.kind != RES_STAGE_LOAD && lt.count(src) && lt[src].in_lds) {
+            const Lt& x = lt[src];
+            st.src_off = x.off; st.src_PS = x.C + 4; st.src_b = x.b;
+        }
+        if (res >= 0 && lt.count(res) && lt[res].in_lds) {
+            const Lt& x = lt[res];
+            st.res_off = x.off; st.res_PS = x.C + 4; st.res_b = x.b;
+        }
+        if (lt.count(dst) && lt[dst].in_lds && lt[dst].def == static_cast<int>(k)) {
+            Lt& y = lt[dst];
+            if (y.last < static_cast<int>(k)) y.last = static_cast<int>(k);
+            const int size = size_of(y);
+            bool placed = false;
+            if (st.kind != RES_STAGE_LOAD && res >= 0 && res != src && st.res_off >= 0 && st.res_mode == RES_DIRECT) {
+                const Lt& r = lt[res];
+                if (r.last == static_cast<int>(k) && r.H == y.H && r.W == y.W && r.C == y.C && r.b == y.b) {  // in place on the skip tensor
+                    y.off = r.off;
+                    for (Live& l : live) if (l.t == res) l.t = dst;
+                    placed = true;
+                }
+            }
+            if (!placed) {
+                std::sort(live.begin(), live.end(), [](const Live& a, const Live& b) { return a.off < b.off; });
+                int off = 0;
+                for (const Live& l : live) {
+                    if (off + size <= l.off) break;
+                    off = std::max(off, l.off + l.size);
+                }
+                y.off = off;
+                live.push_back({off, size, dst});
+                high = std::max(high, off + size);
+                bool same = false;
+                for (const Clean& c : clean) same |= c.off == off && c.size == size && c.H == y.H && c.W == y.W && c.C == y.C && c.b == y.b;
+                if (!same) {
+                    clean.erase(std::remove_if(clean.begin(), clean.end(), [&](const Clean& c) { return c.off < off + size && off < c.off + c.size; }), clean.end());
+                    clean.push_back({off, size, y.H, y.W, y.C, y.b});
+                    st.zero_dst = size;
+                }
+            }
+            st.dst_off = y.off; st.dst_PS = y.C + 4; st.dst_b = y.b;
+        }
+        const_max = std::max(const_max, resident_const_floats(st));
+    }
+    Node r;
+    r.kind = Node::Resident;
+    r.res_const_off = (high + 3) & ~3;
+    r.res_lds_bytes = (r.res_const_off + const_max) * 4;
+    if (r.res_lds_bytes > budget) return false;
+    r.members = std::move(M);
+    r.stages = std::move(S);
+    r.in = ext_in;
+    r.out = ext_out.back();
+    ext_out.pop_back();
+    r.extra_out = ext_out;
+    for (size_t k = i; k <= j; k++) r.src_ops.insert(r.src_ops.end(), ns[k].src_ops.begin(), ns[k].src_ops.end());
+    *out = std::move(r);
+    return true;
+}
+
+std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget) {
+    std::vector<Node> outv;
+    for (size_t i = 0; i < ns.size();) {
+        Node best;
+        size_t best_j = 0;
+        bool have = false;
+        for (size_t j = i; j < ns.size(); j++) {
+            Node cand;
+            if (!build_resident(g, ns, i, j, budget, &cand)) break;  // a longer run only needs more
+            best = std::move(cand);
+            best_j = j;
+            have = true;
+        }
+        // worth a launch of its own: at least two fused nodes, or a k x k convolution (otherwise the generic direct conv)
+        bool take = have && (best.members.size() >= 2 || (best.members[0].kind == Node::Conv && best.members[0].KH > 1));
+        if (take) {
+            outv.push_back(std::move(best));
+            i = best_j + 1;
+        } else {
+            outv.push_back(ns[i]);
+            i++;
+        }
+    }
+    return outv;
+}
+
 }  // namespace
 
-Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
+Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes) {
     Plan plan;
     plan.graph = std::move(graph);
     plan.fuse_level = fuse_level;
@@ -360,6 +632,12 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
         plan.nodes = std::move(fusedv);
     }
 
+    // ---- level 5: frame-resident stage programs
+    if (fuse_level >= 5) {
+        reorder_branches(plan.nodes);
+        plan.nodes = group_resident(g, plan.nodes, res_budget_bytes);
+    }
+
     // ---- storage: RESHAPE = view of its input; CONCATENATION inputs live inside the joined buffer.
     const int NT = static_cast<int>(g.tensors.size());
     plan.storage.resize(NT);
@@ -404,6 +682,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
         for (int t : plan.nodes[i].in) touch(t, i);
         touch(plan.nodes[i].res, i);
         touch(plan.nodes[i].out, i);
+        for (int t : plan.nodes[i].extra_out) touch(t, i);
     }
     for (int t : g.outputs) touch(t, NN);
     plan.root_offset.assign(NT, -1);
@@ -439,6 +718,17 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
         for (int t : n.in) bytes += 4 * elems(t);
         bytes += 4 * elems(n.out);
+        for (int t : n.extra_out) bytes += 4 * elems(t);
+        if (n.kind == Node::Resident) {
+            for (const Node& m : n.members) {
+                for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) bytes += 4 * elems(c);
+                const auto& so2 = g.tensors[m.out].shape;
+                const int Cm = g.tensors[m.in[0]].shape[3];
+                if (m.kind == Node::Conv) macs += elems(m.out) * m.KH * m.KW * Cm;
+                else macs += static_cast<double>(so2[1]) * so2[2] * Cm * ((m.w >= 0 ? 9 : 0) + so2[3]);
+            }
+            continue;
+        }
         if (n.kind == Node::Chain) {
             for (const Node& m : n.members) {
                 for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) bytes += 4 * elems(c);
@@ -464,7 +754,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt) {
 }
 
 std::string Plan::describe() const {
-    static const char* kinds[] = {"conv", "dw", "block", "add", "act", "maxpool", "pad", "reshape", "concat", "resize", "d2s", "chain"};
+    static const char* kinds[] = {"conv", "dw", "block", "add", "act", "maxpool", "pad", "reshape", "concat", "resize", "d2s", "chain", "resident"};
     static const char* acts[] = {"", "+relu", "+relu6", "+prelu"};
     static const char* res[] = {"", "+skip", "+skip(maxpool)", "+skip(up2x)"};
     std::ostringstream os;
@@ -483,6 +773,10 @@ std::string Plan::describe() const {
         if (n.kind == Node::Chain)
             os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
                << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
+        if (n.kind == Node::Resident) {
+            os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, frame resident, " << n.res_lds_bytes << " B LDS";
+            for (int t : n.extra_out) os << " +t" << t;
+        }
         os << " ops{";
         for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
         os << "}\n";

@@ -9,6 +9,9 @@
 //   level 3  runs of same-shape stride-1 BlazeBlocks whose frame fits in LDS fused into one frame-resident chain kernel
 //   level 4  runs of narrow (C <= 24, W <= 128) stride-1 BlazeBlocks cut into row-pipelined chains of up to 4 blocks: one
 //            launch, the intermediate rows handed from block to block through LDS (strip_kernels.hip)
+//   level 5  the small-spatial parts (outputs of <= 256 pixels) become frame-resident stage programs: independent branches are
+//            made contiguous, then maximal runs of blocks / pointwise convs / k x k stride-k convs whose live activations
+//            fit in LDS are one launch each (resident_kernels.hip)
 #pragma once
 
 #include <string>
@@ -20,8 +23,18 @@
 namespace mi {
 
 struct Node {
-    enum Kind { Conv, Dw, Block, Add, Act, MaxPool, Pad, Reshape, Concat, Resize, DepthToSpace, Chain } kind = Conv;
-    std::vector<Node> members;  // Chain: the fused BlazeBlocks, in order
+    enum Kind { Conv, Dw, Block, Add, Act, MaxPool, Pad, Reshape, Concat, Resize, DepthToSpace, Chain, Resident } kind = Conv;
+    std::vector<Node> members;  // Chain: the fused BlazeBlocks, in order; Resident: the fused nodes (chains expanded), in order
+    // Resident: the stage program.  ResStage geometry / LDS placement is final; global references and weight offsets are
+    // filled in by the engine from (src_t, dst_t, res_t) and the member's constants.
+    struct Stage {
+        ResStage st;
+        int member = -1;                       // index into members (-1: LOAD stage)
+        int src_t = -1, dst_t = -1, res_t = -1;  // tensors behind the global references (-1: none)
+    };
+    std::vector<Stage> stages;
+    int res_const_off = 0, res_lds_bytes = 0;
+    std::vector<int> extra_out;  // Resident: further tensors the launch writes to global memory (besides `out`)
     std::vector<int> in;   // activation inputs (tensor ids)
     int out = -1;
     bool dead = false;
@@ -58,12 +71,13 @@ struct Plan {
     std::vector<long> root_offset;      // per tensor (valid for roots): float offset inside the arena, per frame-slot
     std::vector<long> root_elems;       // per root: floats per frame
     long arena_floats_per_frame = 0;
-    int fuse_level = 4;
+    int fuse_level = 5;
     double bytes_per_frame = 0, macs_per_frame = 0;
     std::string describe() const;
 };
 
 // pipe_max: most blocks one row-pipelined chain may hold (level 4; 2..4, below 2 disables them)
-Plan build_plan(Graph g, int fuse_level, int pipe_max = 4);
+// res_budget_bytes: LDS a frame-resident stage program may use (level 5)
+Plan build_plan(Graph g, int fuse_level, int pipe_max = 4, int res_budget_bytes = 156 * 1024);
 
 }  // namespace mi
