@@ -93,6 +93,7 @@ void Model::rebuild() {
     node_w_.assign(NN, -1); node_b_.assign(NN, -1); node_w2_.assign(NN, -1); node_b2_.assign(NN, -1); node_alpha_.assign(NN, -1);
     chain_off_.assign(NN, {});
     node_strip_.assign(NN, -1);
+    res_cblob_.assign(NN, {});
     // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
     // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
     auto pack_pw = [&](int wt) {
@@ -142,17 +143,34 @@ void Model::rebuild() {
         if (n.kind == Node::Resident) {
             for (const Node& m : n.members) {
                 MemberOff mo;
-                if (m.kind == Node::Conv) {  // k x k stride-k convolution: weights in A-fragment order over the virtual channels
-                    mo.w2 = pack_pw(m.w);
-                    if (m.b >= 0) mo.b2 = put(g.tensors[m.b].f32);
-                } else {
-                    if (m.w >= 0) mo.w = put(g.tensors[m.w].f32);
-                    if (m.b >= 0) mo.b = put(g.tensors[m.b].f32);
-                    mo.w2 = pack_pw(m.w2);
-                    if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
-                }
-                if (m.alpha >= 0) mo.alpha = put(g.tensors[m.alpha].f32);
+                // pointwise / k x k stride-k weights in A-fragment order (the k x k ones over the virtual channels)
+                mo.w2 = pack_pw(m.kind == Node::Conv ? m.w : m.w2);
                 chain_off_[i].push_back(mo);
+            }
+            // per stage: the small constants, padded the way the kernel copies them to LDS
+            res_cblob_[i].assign(n.stages.size(), -1);
+            for (size_t k = 0; k < n.stages.size(); k++) {
+                const Node::Stage& sg = n.stages[k];
+                if (sg.st.kind == RES_STAGE_LOAD) continue;
+                const Node& m = n.members[static_cast<size_t>(sg.member)];
+                const ResStage& st = sg.st;
+                const int Cp = (st.Kv + 7) & ~7, Cop = (st.Co + 31) / 32 * 32;
+                std::vector<float> cb(static_cast<size_t>(resident_const_floats(st)), 0.f);
+                size_t o = 0;
+                const int bias_t = m.kind == Node::Conv ? m.b : m.b2;
+                if (st.kind == RES_STAGE_DW) {
+                    const auto& wd = g.tensors[m.w].f32;  // [3][3][C]
+                    for (int tap = 0; tap < 9; tap++)
+                        for (int c = 0; c < st.Kv; c++) cb[static_cast<size_t>(tap) * Cp + c] = wd[static_cast<size_t>(tap) * st.Kv + c];
+                    if (m.b >= 0)
+                        for (int c = 0; c < st.Kv; c++) cb[static_cast<size_t>(9) * Cp + c] = g.tensors[m.b].f32[c];
+                    o = static_cast<size_t>(10) * Cp;
+                }
+                for (int c = 0; c < st.Co; c++) {
+                    cb[o + c] = bias_t >= 0 ? g.tensors[bias_t].f32[c] : 0.f;
+                    cb[o + Cop + c] = m.act == ACT_PRELU ? g.tensors[m.alpha].f32[c] : (m.act == ACT_NONE ? 1.f : 0.f);
+                }
+                res_cblob_[i][k] = put(cb);
             }
             continue;
         }
@@ -184,6 +202,7 @@ void Model::rebuild() {
             }
         }
     }
+    host.resize(host.size() + 4096, 0.f);  // slack: the stage programs' A-fragment prefetch walks up to 8 KiB past a tile's last chunk
     if (d_weights_) hip_check(hipFree(d_weights_), "hipFree");
     d_weights_ = nullptr;
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_weights_), std::max<size_t>(host.size(), 64) * sizeof(float)), "hipMalloc weights");
@@ -219,8 +238,8 @@ void Model::rebuild() {
                 if (st.kind != RES_STAGE_LOAD) {
                     if (sg.dst_t >= 0) st.dst_g = ref(sg.dst_t);
                     if (sg.res_t >= 0) st.res_g = ref(sg.res_t);
-                    const MemberOff& mo = chain_off_[i][static_cast<size_t>(sg.member)];
-                    st.w_dw = mo.w; st.b_dw = mo.b; st.w_pw = mo.w2; st.bias = mo.b2; st.alpha = mo.alpha;
+                    st.w_pw = chain_off_[i][static_cast<size_t>(sg.member)].w2;
+                    st.cblob = res_cblob_[i][static_cast<size_t>(&sg - n.stages.data())];
                 }
                 progs.push_back(st);
             }
@@ -515,6 +534,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.nstages = static_cast<int>(n.stages.size());
                 a.B = F;
                 a.const_off = n.res_const_off;
+                a.const_floats = n.res_const_floats;
                 a.lds_bytes = n.res_lds_bytes;
                 for (int k = 0; k < kResBases; k++) { a.bases.p[k] = nullptr; a.bases.scale[k] = 0; a.bases.frame0[k] = 0; }
                 a.bases.p[0] = d_arena_ + static_cast<size_t>(plan_.arena_floats_per_frame) * chunk_cap_ * arena_lane_;

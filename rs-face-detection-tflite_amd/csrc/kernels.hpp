@@ -141,7 +141,7 @@ struct ResRef {
 enum ResKind : int { RES_STAGE_LOAD = 0, RES_STAGE_GATHER = 1, RES_STAGE_DW = 2 };
 struct ResStage {
     int kind = RES_STAGE_GATHER;
-    int mtg = 1;                       // output-channel tiles per unit (1 or 2)
+    int dw_pg = 0;                     // DW: 32-pixel groups per batch (depthwise result of a batch -> LDS scratch -> pointwise)
     // source: LDS tensor (src_off >= 0; pixel (y,x) at src_off + ((y+b)*(W+2b) + x+b)*PS) or dense NHWC in global memory
     int src_off = -1, src_H = 0, src_W = 0, src_C = 0, src_PS = 0, src_b = 0;
     ResRef src_g;
@@ -155,8 +155,10 @@ struct ResStage {
     int res_off = -1, res_PS = 0, res_b = 0;   // skip source in LDS, else res_g
     ResRef res_g;
     int act = ACT_NONE;
-    int pad_ = 0;
-    long w_dw = -1, b_dw = -1, w_pw = -1, bias = -1, alpha = -1;  // float offsets into the weights blob
+    int dw_off = -1;                   // DW: LDS floats, scratch [dw_pg*32][roundup8(C) + 4]
+    // float offsets into the weights blob: pointwise / k x k weights in A-fragment order; the stage's small constants, padded and
+    // ready to be copied to LDS: [9][Cp] depthwise taps + [Cp] depthwise bias (DW only), [Cop] bias, [Cop] negative-side slopes
+    long w_pw = -1, cblob = -1;
 };
 constexpr int kResBases = 8;
 struct ResBases {
@@ -168,12 +170,14 @@ struct ResBases {
 struct ResLaunch {
     const ResStage* prog = nullptr;  // device memory
     int nstages = 0, B = 0;
-    int const_off = 0;               // LDS floats: start of the per-stage constants area
+    int const_off = 0;               // LDS floats: start of the per-stage constants area (two halves of const_floats each)
+    int const_floats = 0;
     int lds_bytes = 0;
     ResBases bases;
 };
 int launch_resident(const ResLaunch& a, void* stream);
 int resident_const_floats(const ResStage& st);  // LDS floats the stage's constants need
+constexpr int kResConstMax = 5120;               // most constants a stage may have (10 per thread, prefetched in registers)
 
 // ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).
 int launch_conv(const ConvArgs& a, void* stream);

@@ -412,10 +412,34 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
         }
         const_max = std::max(const_max, resident_const_floats(st));
     }
+    // LDS layout: [activations | constants, two halves (stage s computes from one while s+1's land in the other) | depthwise scratch]
+    if (const_max > kResConstMax) return false;
+    // Depthwise batches: enough pixel groups per batch to give each of the 8 waves a unit — unless smaller batches let two
+    // workgroups share a CU (half of its 160 KB each), which hides more latency than full batches do.
+    const int base_floats = ((high + 3) & ~3) + 2 * const_max;
+    auto scratch_for = [&](int cap_pg) {
+        int mx = 0;
+        for (Node::Stage& sg : S) {
+            ResStage& st = sg.st;
+            if (st.kind != RES_STAGE_DW) continue;
+            const int MT = (st.Co + 31) / 32, PGn = (st.Ho * st.Wo + 31) / 32, Cp = (st.Kv + 7) & ~7;
+            st.dw_pg = std::max(1, std::min(std::min(PGn, cap_pg), (8 + MT - 1) / MT));
+            mx = std::max(mx, st.dw_pg * 32 * (Cp + 4));
+        }
+        return mx;
+    };
+    const int half_cu = 80 * 1024 / 4;
+    int scratch_max = scratch_for(8);
+    for (int cap = 4; cap >= 1 && base_floats + scratch_max > half_cu && base_floats + scratch_for(1) <= half_cu; cap /= 2) scratch_max = scratch_for(cap);
+    if (base_floats + scratch_max > half_cu) scratch_max = scratch_for(8);
     Node r;
     r.kind = Node::Resident;
     r.res_const_off = (high + 3) & ~3;
-    r.res_lds_bytes = (r.res_const_off + const_max) * 4;
+    r.res_const_floats = const_max;
+    const int dw_off = r.res_const_off + 2 * const_max;
+    for (Node::Stage& sg : S)
+        if (sg.st.kind == RES_STAGE_DW) sg.st.dw_off = dw_off;
+    r.res_lds_bytes = (dw_off + scratch_max) * 4;
     if (r.res_lds_bytes > budget) return false;
     r.members = std::move(M);
     r.stages = std::move(S);

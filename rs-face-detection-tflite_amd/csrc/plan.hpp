@@ -33,7 +33,7 @@ struct Node {
         int src_t = -1, dst_t = -1, res_t = -1;  // tensors behind the global references (-1: none)
     };
     std::vector<Stage> stages;
-    int res_const_off = 0, res_lds_bytes = 0;
+    int res_const_off = 0, res_const_floats = 0, res_lds_bytes = 0;
     std::vector<int> extra_out;  // Resident: further tensors the launch writes to global memory (besides `out`)
     std::vector<int> in;   // activation inputs (tensor ids)
     int out = -1;

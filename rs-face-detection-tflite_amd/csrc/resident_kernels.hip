@@ -15,12 +15,16 @@
 // PAD on the skip path, CONV_2D k x k; `interpreter.invoke()` at /root/reference/src/face_detection_lite/
 // iris_landmark.rs:203, face_landmark.rs:265, face_detection.rs:235.)
 //
-// Mapping: a stage is cut into units of 32 output pixels x MTG 32-channel tiles; the 8 waves take units round-robin.  A unit
-// is the block kernel's inner loop: lane = (pixel l & 31, k-half l >> 5) builds the B operand of v_mfma_f32_32x32x2_f32 for 4
-// channels of its k-half (depthwise 3x3 on the VALU from LDS, or a 16-byte gather), the pointwise weights arrive from L2 in
-// A-fragment order through a register ring that runs 8 k-chunks ahead (a stage is a chain of dependent MFMAs fed by L2
-// latency; nothing else hides it here), D gives each lane 4 consecutive output channels per register quad for the float4
-// epilogue (+ bias + skip [direct | 2x2 max-pool, zero channel-padded] -> activation -> LDS and/or global).
+// Mapping: the contraction of a stage is cut into units of 32 output pixels x one 32-channel tile; the 8 waves take units
+// round-robin.  A unit is the block kernel's inner loop: lane = (pixel l & 31, k-half l >> 5) reads the B operand of
+// v_mfma_f32_32x32x2_f32 for 4 channels of its k-half (one 16-byte gather), the weights arrive from L2 in A-fragment order
+// through a register ring that runs 8 k-chunks ahead (a stage is a chain of dependent MFMAs fed by L2 latency; the ring
+// loop has no control flow inside, so that the compiler's vmcnt waits stay partial), D gives each lane 4 consecutive
+// output channels per register quad for the float4 epilogue (+ bias + skip [direct | 2x2 max-pool, zero channel-padded]
+// -> activation -> LDS and/or global).  A DW stage first runs the depthwise 3x3 for a batch of pixel groups with all 512
+// threads (each result computed once) into an LDS scratch, which the units then contract like a pointwise source.
+// The small per-stage constants (depthwise taps, biases, slopes) of stage s+1 are fetched into registers while stage s
+// computes and land in the other half of a double-buffered LDS area behind the stage's closing barrier.
 // Exact f32 (MFMA f32 = fmaf chain); results match block_kernels.hip to reassociation.
 #include <hip/hip_runtime.h>
 
@@ -44,225 +48,330 @@ __device__ __forceinline__ float* resolve(const ResBases& bs, const ResRef& r, i
     return bs.p[r.base] + r.root_off * bs.scale[r.base] + r.inner + (long)(frame + bs.frame0[r.base]) * r.fs;
 }
 
-constexpr int kPFtot = 8;  // A fragments (float4) in flight per lane: 8 k-chunks ahead with one tile per unit, 4 with two
+#ifdef MI_RES_STAMPS
+unsigned long long* g_res_stamps = nullptr;  // [workgroup][stage][8]: stage start, constants issued, units done, stage end; wave 0's first unit: start, ring issued, MFMA loop done, epilogue done (s_memtime)
+#define MI_RES_STAMP(k) if (stamps && tid == 0) stamps[((long)blockIdx.x * nstages + s) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#define MI_RES_USTAMP(k) if (ustamps && threadIdx.x == 0 && u == 0) { __builtin_amdgcn_sched_barrier(0); ustamps[k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_RES_STAMP(k)
+#define MI_RES_USTAMP(k)
+#endif
 
-// MODE 0: GATHER from LDS, 1: GATHER from global memory, 2: DW from LDS
-template <int MTG, int MODE>
-__device__ __forceinline__ void run_units(const ResStage& st, const ResBases& bs, int frame, float* lds, const float* cst) {
+constexpr int kPF = 8;       // k-chunks of A fragments in flight per lane (LDS sources)
+constexpr int kPFG = 4;      // ... when the B fragments come from global memory too (they ride the same ring)
+constexpr int kNPre = (kResConstMax / 4 + 511) / 512;  // float4s per thread
+
+// Where a unit reads its B operand.  linear: the depthwise scratch, indexed by (pixel - px_base); otherwise a tensor
+// (LDS: off/row/PS/b; global: base pointer, row = W, PS = C, b = 0) gathered over KW x KW taps with stride S.
+struct SrcView {
+    const float* g;   // global base (MODE 1)
+    int off, row, PS, b, C, KW, S, Kv, px_base;
+    bool linear;
+};
+
+// Everything the epilogue needs, read from the descriptor ONCE per stage: the descriptor lives in global memory, and a
+// field read after a store has to be loaded again (the compiler cannot rule out aliasing) — scalar-load round trips in the
+// middle of the epilogue were a third of a stage's time.
+struct EpiView {
+    int Ho, Wo, Co, MT;
+    int dst_off, dst_row, dst_PS, dst_b;
+    float* dstg;
+    int res_mode, res_C, res_off, res_row, res_PS, res_b, res_W;
+    const float* resg;
+    float hi;
+    const float* wpw;
+};
+__device__ __forceinline__ EpiView make_epi(const ResStage& st, const ResBases& bs, int frame) {
+    EpiView e;
+    e.Ho = st.Ho; e.Wo = st.Wo; e.Co = st.Co; e.MT = (st.Co + 31) >> 5;
+    e.dst_off = st.dst_off; e.dst_b = st.dst_b; e.dst_row = st.Wo + 2 * st.dst_b; e.dst_PS = st.dst_PS;
+    e.dstg = st.dst_g.base >= 0 ? resolve(bs, st.dst_g, frame) : nullptr;
+    e.res_mode = st.res_mode; e.res_C = st.res_C; e.res_off = st.res_off; e.res_b = st.res_b; e.res_W = st.res_W;
+    e.res_row = st.res_W + 2 * st.res_b; e.res_PS = st.res_PS;
+    e.resg = (st.res_mode != RES_NONE && st.res_off < 0) ? resolve(bs, st.res_g, frame) : nullptr;
+    e.hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
+    e.wpw = bs.weights + st.w_pw;
+    return e;
+}
+
+// MODE 0: B from LDS, 1: B from global memory, 2: B from LDS with the lane's virtual channels contiguous (pointwise sources
+// and the depthwise scratch: a plain pointer walk, no tap bookkeeping — VALU work does not overlap a wave's own dependent
+// MFMAs on this part, so every VALU op in the k-loop is paid in full).  Units: pixel groups [pg0, pg1) x all channel tiles.
+template <int MODE>
+__device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, float* lds, const float* cst_ep, int pg0, int pg1,
+                                          unsigned long long* ustamps = nullptr) {
+    constexpr int PF = MODE == 1 ? kPFG : kPF;
+    constexpr bool CONTIG = MODE == 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
-    const int npix = st.Ho * st.Wo, PGn = (npix + 31) >> 5, MT = (st.Co + 31) >> 5, MGn = (MT + MTG - 1) / MTG;
-    const int nunits = PGn * MGn;
-    const int Cp = (st.Kv + 7) & ~7, Ch = Cp >> 1, nch = Ch >> 2;
-    const int Cop = MT * 32;
-    const float* wdw = cst;                    // [9][Cp] (DW only)
-    const float* bdw = cst + 9 * Cp;           // [Cp]
-    const float* biasL = cst + (MODE == 2 ? 10 * Cp : 0);
-    const float* alphaL = biasL + Cop;
-    const float* wpw = bs.weights + st.w_pw;
-    const float* srcg = MODE == 1 ? resolve(bs, st.src_g, frame) : nullptr;
-    const float* resg = (st.res_mode != RES_NONE && st.res_off < 0) ? resolve(bs, st.res_g, frame) : nullptr;
-    float* dstg = st.dst_g.base >= 0 ? resolve(bs, st.dst_g, frame) : nullptr;
-    const float hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
-    const int srow = st.src_W + 2 * st.src_b;  // LDS row length of the source in pixels
+    const int npix = ep.Ho * ep.Wo, PGn = pg1 - pg0;
+    const int nunits = PGn * ep.MT;
+    const int Cp = (sv.Kv + 7) & ~7, Ch = Cp >> 1, nch = Ch >> 2;
+    const int Cop = ep.MT * 32;
+    const float* biasL = cst_ep;
+    const float* alphaL = cst_ep + Cop;
+    const int ngroups = nch / PF, rem = nch - ngroups * PF;
+    // this lane's first (virtual) channel: tap and channel within the tap (the only divisions, once per stage)
+    const int v_first = h * Ch;
+    const int tap0 = v_first / sv.C, c_first = v_first - tap0 * sv.C;
+    const int ky0 = tap0 / sv.KW, kx0 = tap0 - ky0 * sv.KW;
 
     for (int u = wave; u < nunits; u += 8) {
-        const int pg = u % PGn, mt0 = (u / PGn) * MTG;
+        const int pg = pg0 + u % PGn, mt = u / PGn;
         const int q = pg * 32 + pl;
         const bool valid = q < npix;
         const int qq = valid ? q : 0;
-        const int oy = qq / st.Wo, ox = qq - oy * st.Wo;
+        const int oy = qq / ep.Wo, ox = qq - oy * ep.Wo;
+        MI_RES_USTAMP(4)
+        rf32x16 D;
+#pragma unroll
+        for (int e = 0; e < 16; e++) D[e] = 0.f;
 
-        rf32x16 D[MTG];
-#pragma unroll
-        for (int m = 0; m < MTG; m++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) D[m][e] = 0.f;
-
-        auto a_load = [&](int j, float4 (&av)[MTG]) {
-#pragma unroll
-            for (int m = 0; m < MTG; m++) {
-                const int mt = min(mt0 + m, MT - 1);
-                av[m] = rld4(wpw + (((long)mt * nch + j) * 64 + lane) * 4);
-            }
-        };
-        // B fragment of k-chunk j: 4 consecutive (virtual) channels of this lane's k-half at its pixel
-        auto gather_addr = [&](int j, bool& ok) -> long {
-            const int v0 = h * Ch + 4 * j;
-            ok = v0 < st.Kv;
-            const int vv = ok ? v0 : 0;
-            const int tap = vv / st.src_C, c = vv - tap * st.src_C;
-            const int ky = tap / st.KW, kx = tap - ky * st.KW;
-            const int iy = oy * st.S + ky, ix = ox * st.S + kx;
-            if (MODE == 1) return ((long)iy * st.src_W + ix) * st.src_C + c;
-            return (long)st.src_off + ((iy + st.src_b) * srow + ix + st.src_b) * st.src_PS + c;
-        };
-        auto b_lds = [&](int j) -> float4 {
-            if (MODE == 0) {
-                bool ok;
-                const long a = gather_addr(j, ok);
-                const float4 v = rld4(lds + a);
-                return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            // depthwise 3x3: channels h*Ch + 4j .. +3 (weights and the LDS pad lanes are zero above the real channel count)
-            const int c0 = h * Ch + 4 * j;
-            const float* p = lds + st.src_off + ((oy * st.S - st.pt + st.src_b) * srow + ox * st.S - st.pl + st.src_b) * st.src_PS + c0;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    const float4 w = rld4(wdw + (ky * 3 + kx) * Cp + c0);
-                    const float4 d = rld4(p + (ky * srow + kx) * st.src_PS);
-                    acc.x = fmaf(d.x, w.x, acc.x);
-                    acc.y = fmaf(d.y, w.y, acc.y);
-                    acc.z = fmaf(d.z, w.z, acc.z);
-                    acc.w = fmaf(d.w, w.w, acc.w);
-                }
-            const float4 bb = rld4(bdw + c0);
-            acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w;
-            return acc;
-        };
-        auto b_glb = [&](int j) -> float4 {
-            bool ok;
-            const long a = gather_addr(j, ok);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = rld4(srcg + a);
+        const float* wa = ep.wpw + ((long)mt * nch * 64 + lane) * 4;
+        // A fragments: a plain pointer walk; past the tile's last chunk it runs into the next tile / the next constant of the
+        // weights blob (never used; the blob ends with slack for it)
+        auto a_next = [&]() -> float4 {
+            const float4 v = rld4(wa);
+            wa += 256;
             return v;
         };
-        auto mfma4 = [&](const float4 (&av)[MTG], const float4& bf) {
-#pragma unroll
-            for (int m = 0; m < MTG; m++) {
-                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bf.x, D[m], 0, 0, 0);
-                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bf.y, D[m], 0, 0, 0);
-                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bf.z, D[m], 0, 0, 0);
-                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf.w, D[m], 0, 0, 0);
+        // B operand: 4 consecutive virtual channels of this lane's k-half per chunk, walked tap by tap without divisions
+        const long pix_base = sv.linear ? (long)sv.off + (long)(qq - sv.px_base) * sv.PS
+                                        : (long)sv.off + ((long)(oy * sv.S + sv.b) * sv.row + ox * sv.S + sv.b) * sv.PS;
+        int bv = v_first, bc = c_first, bkx = kx0;
+        long btap = ((long)ky0 * sv.row + kx0) * sv.PS;
+        const float* bp = lds + pix_base + v_first;  // CONTIG: weights of padded channels are zero and so are the LDS pad lanes
+        auto b_next = [&]() -> float4 {
+            if (CONTIG) {
+                const float4 v = rld4(bp);
+                bp += 4;
+                return v;
             }
+            const bool ok = bv < sv.Kv;
+            const long a = pix_base + (ok ? btap + bc : 0);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 1) { if (ok) v = rld4(sv.g + a); }
+            else { v = rld4(lds + a); if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f); }
+            bv += 4; bc += 4;
+            if (bc >= sv.C) {
+                bc = 0; bkx++; btap += sv.PS;
+                if (bkx == sv.KW) { bkx = 0; btap += (long)(sv.row - sv.KW) * sv.PS; }
+            }
+            return v;
+        };
+        auto mfma4 = [&](const float4& av, const float4& bf) {
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf.x, D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf.y, D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf.z, D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf.w, D, 0, 0, 0);
         };
 
-        constexpr int kPF = (MODE == 1 ? kPFtot / 2 : kPFtot) / MTG;
-        float4 ringA[kPF][MTG];
-        float4 ringB[MODE == 1 ? kPF : 1];
+        float4 ringA[PF], ringB[MODE == 1 ? PF : 1];
 #pragma unroll
-        for (int r = 0; r < kPF; r++)
-            if (r < nch) {
-                a_load(r, ringA[r]);
-                if (MODE == 1) ringB[r] = b_glb(r);
-            }
-        for (int j0 = 0; j0 < nch; j0 += kPF) {
+        for (int r = 0; r < PF; r++) {
+            ringA[r] = a_next();
+            if (MODE == 1) ringB[MODE == 1 ? r : 0] = b_next();
+        }
+        MI_RES_USTAMP(5)
+        // LDS sources: the B fragment of chunk j+1 is read before the MFMAs of chunk j (a dependent ds_read per chunk would add
+        // its ~130 cycles of latency to every 256 cycles of MFMA); global sources ride the ring
+        float4 bcur = MODE == 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : b_next();  // (CONTIG reads one chunk past the pixel at the end: inside the scratch / tensor slack)
+        for (int g = 0; g < ngroups; g++) {
 #pragma unroll
-            for (int r = 0; r < kPF; r++) {
-                const int j = j0 + r;
-                if (j < nch) {
-                    const float4 bf = MODE == 1 ? ringB[MODE == 1 ? r : 0] : b_lds(j);
-                    mfma4(ringA[r], bf);
-                    if (j + kPF < nch) {
-                        a_load(j + kPF, ringA[r]);
-                        if (MODE == 1) ringB[MODE == 1 ? r : 0] = b_glb(j + kPF);
-                    }
+            for (int r = 0; r < PF; r++) {  // no control flow around the loads: slot r is consumed, then refilled PF chunks ahead
+                if (MODE == 1) {
+                    mfma4(ringA[r], ringB[MODE == 1 ? r : 0]);
+                    ringB[MODE == 1 ? r : 0] = b_next();
+                } else {
+                    const float4 bn = b_next();
+                    mfma4(ringA[r], bcur);
+                    bcur = bn;
                 }
+                ringA[r] = a_next();
             }
         }
-
-        // ---- epilogue: lane holds pixel q, output channels mt*32 + 8*gq + 4*h .. +3 in D[m][4*gq .. 4*gq+3]
+#pragma unroll
+        for (int r = 0; r < PF - 1; r++)
+            if (r < rem) {
+                if (MODE == 1) {
+                    mfma4(ringA[r], ringB[MODE == 1 ? r : 0]);
+                } else {
+                    const float4 bn = b_next();
+                    mfma4(ringA[r], bcur);
+                    bcur = bn;
+                }
+            }
+        MI_RES_USTAMP(6)
+        // ---- epilogue: lane holds pixel q, output channels mt*32 + 8*gq + 4*h .. +3 in D[4*gq .. 4*gq+3]
         if (valid) {
-            float* dl = st.dst_off >= 0 ? lds + st.dst_off + ((oy + st.dst_b) * (st.Wo + 2 * st.dst_b) + ox + st.dst_b) * st.dst_PS : nullptr;
-            float* dg = dstg ? dstg + ((long)oy * st.Wo + ox) * st.Co : nullptr;
+            float* dl = ep.dst_off >= 0 ? lds + ep.dst_off + ((oy + ep.dst_b) * ep.dst_row + ox + ep.dst_b) * ep.dst_PS : nullptr;
+            float* dg = ep.dstg ? ep.dstg + ((long)oy * ep.Wo + ox) * ep.Co : nullptr;
+            const float* rl = lds + ep.res_off + (ep.res_mode == RES_DIRECT ? ((oy + ep.res_b) * ep.res_row + ox + ep.res_b) * ep.res_PS
+                                                                            : ((2 * oy + ep.res_b) * ep.res_row + 2 * ox + ep.res_b) * ep.res_PS);
+            const float* rg = ep.resg ? ep.resg + (ep.res_mode == RES_DIRECT ? ((long)oy * ep.Wo + ox) * ep.res_C : ((long)(2 * oy) * ep.res_W + 2 * ox) * ep.res_C) : nullptr;
+            float4 outv[4];
+            bool on[4];
 #pragma unroll
-            for (int m = 0; m < MTG; m++) {
-                if (mt0 + m >= MT) continue;
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int ch = (mt0 + m) * 32 + 8 * gq + 4 * h;
-                    if (ch >= st.Co) continue;
-                    const float4 bb = rld4(biasL + ch), al = rld4(alphaL + ch);
-                    float4 v = make_float4(D[m][4 * gq] + bb.x, D[m][4 * gq + 1] + bb.y, D[m][4 * gq + 2] + bb.z, D[m][4 * gq + 3] + bb.w);
-                    if (st.res_mode != RES_NONE && ch < st.res_C) {
-                        float4 rv;
-                        if (st.res_off >= 0) {
-                            const int rrow = st.res_W + 2 * st.res_b;
-                            if (st.res_mode == RES_DIRECT) {
-                                rv = rld4(lds + st.res_off + ((oy + st.res_b) * rrow + ox + st.res_b) * st.res_PS + ch);
-                            } else {
-                                const float* p = lds + st.res_off + ((2 * oy + st.res_b) * rrow + 2 * ox + st.res_b) * st.res_PS + ch;
-                                rv = rmax4(rld4(p), rld4(p + st.res_PS), rld4(p + rrow * st.res_PS), rld4(p + (rrow + 1) * st.res_PS));
-                            }
-                        } else {
-                            if (st.res_mode == RES_DIRECT) {
-                                rv = rld4(resg + ((long)oy * st.Wo + ox) * st.res_C + ch);
-                            } else {
-                                const float* p = resg + ((long)(2 * oy) * st.res_W + 2 * ox) * st.res_C + ch;
-                                rv = rmax4(rld4(p), rld4(p + st.res_C), rld4(p + (long)st.res_W * st.res_C), rld4(p + (long)(st.res_W + 1) * st.res_C));
-                            }
-                        }
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            for (int gq = 0; gq < 4; gq++) {  // all reads first ...
+                const int ch = mt * 32 + 8 * gq + 4 * h;
+                on[gq] = ch < ep.Co;
+                const int chc = on[gq] ? ch : 0;
+                const float4 bb = rld4(biasL + chc), al = rld4(alphaL + chc);
+                float4 v = make_float4(D[4 * gq] + bb.x, D[4 * gq + 1] + bb.y, D[4 * gq + 2] + bb.z, D[4 * gq + 3] + bb.w);
+                if (ep.res_mode != RES_NONE && chc < ep.res_C) {
+                    float4 rv;
+                    if (ep.res_off >= 0) {
+                        if (ep.res_mode == RES_DIRECT) rv = rld4(rl + chc);
+                        else rv = rmax4(rld4(rl + chc), rld4(rl + ep.res_PS + chc), rld4(rl + ep.res_row * ep.res_PS + chc), rld4(rl + (ep.res_row + 1) * ep.res_PS + chc));
+                    } else {
+                        if (ep.res_mode == RES_DIRECT) rv = rld4(rg + chc);
+                        else rv = rmax4(rld4(rg + chc), rld4(rg + ep.res_C + chc), rld4(rg + (long)ep.res_W * ep.res_C + chc), rld4(rg + (long)(ep.res_W + 1) * ep.res_C + chc));
                     }
-                    v.x = fminf(fmaxf(v.x, 0.f) + al.x * fminf(v.x, 0.f), hi);
-                    v.y = fminf(fmaxf(v.y, 0.f) + al.y * fminf(v.y, 0.f), hi);
-                    v.z = fminf(fmaxf(v.z, 0.f) + al.z * fminf(v.z, 0.f), hi);
-                    v.w = fminf(fmaxf(v.w, 0.f) + al.w * fminf(v.w, 0.f), hi);
-                    if (dl) *reinterpret_cast<float4*>(dl + ch) = v;   // Co % 4 == 0 whenever the output stays in LDS (planner)
-                    if (dg) {
-                        if ((st.Co & 3) == 0) {
-                            *reinterpret_cast<float4*>(dg + ch) = v;
-                        } else {  // ragged output heads (213, 15, 1 channels)
-                            dg[ch] = v.x;
-                            if (ch + 1 < st.Co) dg[ch + 1] = v.y;
-                            if (ch + 2 < st.Co) dg[ch + 2] = v.z;
-                            if (ch + 3 < st.Co) dg[ch + 3] = v.w;
-                        }
+                    v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                }
+                v.x = fminf(fmaxf(v.x, 0.f) + al.x * fminf(v.x, 0.f), ep.hi);
+                v.y = fminf(fmaxf(v.y, 0.f) + al.y * fminf(v.y, 0.f), ep.hi);
+                v.z = fminf(fmaxf(v.z, 0.f) + al.z * fminf(v.z, 0.f), ep.hi);
+                v.w = fminf(fmaxf(v.w, 0.f) + al.w * fminf(v.w, 0.f), ep.hi);
+                outv[gq] = v;
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {  // ... then the stores
+                if (!on[gq]) continue;
+                const int ch = mt * 32 + 8 * gq + 4 * h;
+                const float4 v = outv[gq];
+                if (dl) *reinterpret_cast<float4*>(dl + ch) = v;   // Co % 4 == 0 whenever the output stays in LDS (planner)
+                if (dg) {
+                    if ((ep.Co & 3) == 0) {
+                        *reinterpret_cast<float4*>(dg + ch) = v;
+                    } else {  // ragged output heads (213, 15, 1 channels)
+                        dg[ch] = v.x;
+                        if (ch + 1 < ep.Co) dg[ch + 1] = v.y;
+                        if (ch + 2 < ep.Co) dg[ch + 2] = v.z;
+                        if (ch + 3 < ep.Co) dg[ch + 3] = v.w;
                     }
                 }
             }
         }
+        MI_RES_USTAMP(7)
     }
 }
 
-__global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __restrict__ prog, int nstages, int const_off, ResBases bs) {
+__device__ __forceinline__ int const_count(const ResStage& st) {  // floats, a multiple of 4
+    if (st.kind == RES_STAGE_LOAD) return 0;
+    const int Cp = (st.Kv + 7) & ~7, Cop = ((st.Co + 31) >> 5) * 32;
+    return (st.kind == RES_STAGE_DW ? 10 * Cp : 0) + 2 * Cop;
+}
+
+__global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __restrict__ prog, int nstages, int const_off, int const_floats, ResBases bs,
+                                                          unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
     const int frame = blockIdx.x;
-    float* cst = lds + const_off;
+    auto zero_dst = [&](const ResStage& st) {
+        const int n4 = st.zero_dst >> 2, off = st.dst_off;
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(lds + off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    {   // stage 0: constants straight into the first half, destination cleared
+        const ResStage& st = prog[0];
+        const int n4 = const_count(st) >> 2;
+        const float* cb = bs.weights + (n4 > 0 ? st.cblob : 0);
+        for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(lds + const_off)[i] = rld4(cb + 4 * (long)i);
+        zero_dst(st);
+    }
+    __syncthreads();
     for (int s = 0; s < nstages; s++) {
         const ResStage& st = prog[s];
-        // ---- phase 0: clear the destination (zero border / zero pad lanes), stage the small constants
-        for (int i = tid; i < (st.zero_dst >> 2); i += 512) reinterpret_cast<float4*>(lds + st.dst_off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st.kind != RES_STAGE_LOAD) {
-            const int Cp = (st.Kv + 7) & ~7, Cop = ((st.Co + 31) >> 5) * 32;
-            int o = 0;
-            if (st.kind == RES_STAGE_DW) {
-                const float* w = bs.weights + st.w_dw;
-                for (int i = tid; i < 9 * Cp; i += 512) {
-                    const int c = i % Cp;
-                    cst[i] = c < st.Kv ? w[(i / Cp) * st.Kv + c] : 0.f;
-                }
-                for (int i = tid; i < Cp; i += 512) cst[9 * Cp + i] = (i < st.Kv && st.b_dw >= 0) ? bs.weights[st.b_dw + i] : 0.f;
-                o = 10 * Cp;
-            }
-            for (int i = tid; i < Cop; i += 512) {
-                cst[o + i] = (i < st.Co && st.bias >= 0) ? bs.weights[st.bias + i] : 0.f;
-                cst[o + Cop + i] = (i < st.Co && st.act == ACT_PRELU) ? bs.weights[st.alpha + i] : (st.act == ACT_NONE ? 1.f : 0.f);
-            }
+        unsigned long long* ust = nullptr;
+#ifdef MI_RES_STAMPS
+        if (stamps) ust = stamps + ((long)blockIdx.x * nstages + s) * 8;
+#endif
+        MI_RES_STAMP(0)
+        const float* cst = lds + const_off + (s & 1) * const_floats;
+        // ---- the next stage's constants: loads issued now, consumed (written to the other half) after this stage's work
+        float4 pre[kNPre];
+        const bool more = s + 1 < nstages;
+        const int npre = more ? const_count(prog[s + 1]) >> 2 : 0;
+        const float* cnext = bs.weights + (npre > 0 ? prog[s + 1].cblob : 0);
+#pragma unroll
+        for (int k = 0; k < kNPre; k++) {
+            const int i = tid + 512 * k;
+            pre[k] = rld4(cnext + 4 * (long)min(i, max(npre - 1, 0)));
         }
-        __syncthreads();
-        // ---- phase 1
+        MI_RES_STAMP(1)
         if (st.kind == RES_STAGE_LOAD) {
             const float* src = resolve(bs, st.src_g, frame);
-            const int C4 = st.src_C >> 2, n = st.src_H * st.src_W * C4;
-            const int drow = st.src_W + 2 * st.dst_b;
+            const int sW = st.src_W, C4 = st.src_C >> 2, n = st.src_H * sW * C4;
+            const int db = st.dst_b, drow = sW + 2 * db, dPS = st.dst_PS, doff = st.dst_off;
             for (int i = tid; i < n; i += 512) {
                 const int px = i / C4, c4 = i - px * C4;
-                const int y = px / st.src_W, x = px - y * st.src_W;
-                *reinterpret_cast<float4*>(lds + st.dst_off + ((y + st.dst_b) * drow + x + st.dst_b) * st.dst_PS + 4 * c4) = rld4(src + 4 * (long)i);
+                const int y = px / sW, x = px - y * sW;
+                *reinterpret_cast<float4*>(lds + doff + ((y + db) * drow + x + db) * dPS + 4 * c4) = rld4(src + 4 * (long)i);
             }
         } else if (st.kind == RES_STAGE_DW) {
-            run_units<1, 2>(st, bs, frame, lds, cst);
-        } else if (st.src_off >= 0) {
-            run_units<1, 0>(st, bs, frame, lds, cst);
+            const EpiView ep = make_epi(st, bs, frame);
+            const int Kv = st.Kv, Cp = (Kv + 7) & ~7, C4p = Cp >> 2, PSs = Cp + 4;
+            const int Wo = st.Wo, npix = st.Ho * Wo, PGn = (npix + 31) >> 5, dw_pg = st.dw_pg, dw_off = st.dw_off;
+            const int srow = st.src_W + 2 * st.src_b, sPS = st.src_PS, S = st.S;
+            const int src0 = st.src_off + ((st.src_b - st.pt) * srow + st.src_b - st.pl) * sPS;  // tap (0,0) of output pixel (0,0)
+            SrcView sv;
+            sv.g = nullptr; sv.off = dw_off; sv.row = 0; sv.PS = PSs; sv.b = 0; sv.C = Cp; sv.KW = 1; sv.S = 1; sv.Kv = Kv; sv.linear = true;
+            for (int pg0 = 0; pg0 < PGn; pg0 += dw_pg) {
+                const int pg1 = min(PGn, pg0 + dw_pg);
+                const int px0 = pg0 * 32, px1 = min(npix, pg1 * 32);
+                // depthwise 3x3 (+ bias) of pixels [px0, px1), every channel quad once: (pixel, quad) items over all threads
+                for (int it = tid; it < (px1 - px0) * C4p; it += 512) {
+                    const int pxl = it / C4p, c0 = 4 * (it - pxl * C4p);
+                    const int q = px0 + pxl, oy = q / Wo, ox = q - oy * Wo;
+                    const float* p = lds + src0 + (oy * S * srow + ox * S) * sPS + c0;
+                    float4 acc = rld4(cst + 9 * Cp + c0);  // weights and the LDS pad lanes are zero above the real channel count
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const float4 w = rld4(cst + (ky * 3 + kx) * Cp + c0);
+                            const float4 d = rld4(p + (ky * srow + kx) * sPS);
+                            acc.x = fmaf(d.x, w.x, acc.x);
+                            acc.y = fmaf(d.y, w.y, acc.y);
+                            acc.z = fmaf(d.z, w.z, acc.z);
+                            acc.w = fmaf(d.w, w.w, acc.w);
+                        }
+                    *reinterpret_cast<float4*>(lds + dw_off + pxl * PSs + c0) = acc;
+                }
+                __syncthreads();
+                sv.px_base = px0;
+                run_units<2>(ep, sv, lds, cst + 10 * Cp, pg0, pg1, ust);
+                if (pg1 < PGn) __syncthreads();  // the scratch is rewritten by the next batch
+            }
         } else {
-            run_units<1, 1>(st, bs, frame, lds, cst);
+            const EpiView ep = make_epi(st, bs, frame);
+            SrcView sv;
+            sv.linear = false; sv.px_base = 0; sv.C = st.src_C; sv.KW = st.KW; sv.S = st.S; sv.Kv = st.Kv;
+            const int PGn = (st.Ho * st.Wo + 31) >> 5;
+            if (st.src_off >= 0) {
+                sv.g = nullptr; sv.off = st.src_off; sv.row = st.src_W + 2 * st.src_b; sv.PS = st.src_PS; sv.b = st.src_b;
+                if (sv.KW == 1) run_units<2>(ep, sv, lds, cst, 0, PGn, ust);
+                else run_units<0>(ep, sv, lds, cst, 0, PGn, ust);
+            } else {
+                sv.g = resolve(bs, st.src_g, frame); sv.off = 0; sv.row = st.src_W; sv.PS = st.src_C; sv.b = 0;
+                run_units<1>(ep, sv, lds, cst, 0, PGn, ust);
+            }
+        }
+        MI_RES_STAMP(2)
+        if (more) {
+            float* nxt = lds + const_off + ((s + 1) & 1) * const_floats;
+#pragma unroll
+            for (int k = 0; k < kNPre; k++) {
+                const int i = tid + 512 * k;
+                if (i < npre) reinterpret_cast<float4*>(nxt)[i] = pre[k];
+            }
         }
         __syncthreads();
+        if (more && prog[s + 1].zero_dst) {  // uniform
+            zero_dst(prog[s + 1]);
+            __syncthreads();
+        }
+        MI_RES_STAMP(3)
     }
 }
 
@@ -275,14 +384,21 @@ int resident_const_floats(const ResStage& st) {
 }
 
 int launch_resident(const ResLaunch& a, void* stream) {
-    if (!a.prog || a.nstages < 1 || a.B < 1 || a.lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (!a.prog || a.nstages < 1 || a.B < 1 || a.lds_bytes > 160 * 1024 || a.const_floats > kResConstMax) return (int)hipErrorInvalidValue;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(resident_kernel, dim3((unsigned)a.B), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages, a.const_off, a.bases);
+    hipLaunchKernelGGL(resident_kernel, dim3((unsigned)a.B), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages, a.const_off, a.const_floats,
+                       a.bases,
+#ifdef MI_RES_STAMPS
+                       g_res_stamps
+#else
+                       nullptr
+#endif
+    );
     return (int)hipGetLastError();
 }
 

@@ -39,6 +39,25 @@ def test_lowering_without_gpu(mi, name):
     assert macs[0] == macs[1] == macs[2]
 
 
+@pytest.mark.parametrize("name", list(MODEL_FILES))
+def test_stage_program_lowering_covers_every_operator_once(mi, name):
+    """Level 5 reorders independent branches and regroups nodes into frame-resident stage programs: every .tflite operator
+    must still be executed exactly once, the arithmetic (MACs) must not change, and the launch count must not grow."""
+    blob = open(model_path(name), "rb").read()
+    p4, p5 = mi.plan_describe(blob, 4), mi.plan_describe(blob, 5)
+    ops = lambda p: sorted(int(x) for grp in re.findall(r"ops\{([0-9,]*)\}", p) for x in grp.split(",") if x)
+    assert ops(p4) == ops(p5)
+    assert len(set(ops(p5))) == len(ops(p5))
+    get = lambda p, key: int(re.search(key + r"=(\d+)", p).group(1))
+    assert get(p5, "macs_per_frame") == get(p4, "macs_per_frame")
+    assert get(p5, "launches") <= get(p4, "launches")
+    for lds in re.findall(r"frame resident, (\d+) B LDS", p5):
+        assert int(lds) <= 160 * 1024
+    if name in ("iris", "landmark"):
+        assert get(p5, "launches") + 8 <= get(p4, "launches")   # the small-spatial tails collapse
+        assert "resident" in p5
+
+
 def test_back_plan_matches_survey_numbers(mi):
     p = mi.plan_describe(open(model_path("back"), "rb").read(), 0)
     assert "macs_per_frame=188749824" in p        # SURVEY.md §8d, back 256^2
