@@ -229,6 +229,11 @@ int mi_face_detection_to_roi(const mi_detection *det, int image_w, int image_h, 
 /* iris_roi_from_face_landmarks(face_landmarks, image_size) — iris_landmark.rs:268-292 (scale 2.3). */
 int mi_iris_roi_from_face_landmarks(const mi_landmark *landmarks468, int image_w, int image_h, mi_rect *left_eye,
                                     mi_rect *right_eye);
+/* update_face_landmarks_with_iris_results(face_landmarks, iris_data_left, iris_data_right) — iris_landmark.rs:380-398:
+ * the 71 eye-contour/brow landmarks of each eye replace the face-mesh points they refine (index maps iris_landmark.rs:64-95).
+ * out468 may alias face468. */
+int mi_update_face_landmarks_with_iris_results(const mi_landmark *face468, const mi_landmark *left_contour71,
+                                               const mi_landmark *right_contour71, mi_landmark *out468);
 /* transform::image_to_tensor — transform.rs:188-309, on the GPU (rotated-ROI warp, letterbox, resize, flip,
  * normalise).  out = f32 [out_h][out_w][3] (follows `mem`); padding_out[4] = (left, top, right, bottom). */
 int mi_image_to_tensor(int device, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,

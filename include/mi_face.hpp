@@ -186,4 +186,21 @@ inline std::pair<Rect, Rect> iris_roi_from_face_landmarks(const std::vector<Land
     return {Rect::from(l), Rect::from(r)};
 }
 
+// update_face_landmarks_with_iris_results(face_landmarks, iris_data_left, iris_data_right) (iris_landmark.rs:380-398)
+inline std::vector<Landmark> update_face_landmarks_with_iris_results(const std::vector<Landmark>& face_landmarks, const IrisResults& left,
+                                                                     const IrisResults& right) {
+    if (face_landmarks.size() != MI_NUM_FACE_LANDMARKS) throw Error(MI_EINVAL, "unexpected number of items in face_landmarks");  // the reference's Err
+    if (left.contour.size() != MI_NUM_EYE_LANDMARKS || right.contour.size() != MI_NUM_EYE_LANDMARKS) throw Error(MI_EINVAL, "expected 71 contour landmarks per eye");
+    auto pack = [](const std::vector<Landmark>& v) {
+        std::vector<mi_landmark> c(v.size());
+        for (size_t i = 0; i < v.size(); i++) c[i] = mi_landmark{v[i].x, v[i].y, v[i].z};
+        return c;
+    };
+    std::vector<mi_landmark> f = pack(face_landmarks), l = pack(left.contour), r = pack(right.contour);
+    detail::check(mi_update_face_landmarks_with_iris_results(f.data(), l.data(), r.data(), f.data()));
+    std::vector<Landmark> out(f.size());
+    for (size_t i = 0; i < f.size(); i++) out[i] = Landmark{f[i].x, f[i].y, f[i].z};
+    return out;
+}
+
 }  // namespace mi_face

@@ -215,3 +215,22 @@ def iris_rois_from_face_landmarks(landmarks, image_size):
     if L.orc_iris_rois_from_face_landmarks(_dp(lm), image_size[0], image_size[1], C.byref(a), C.byref(b)) != 0:
         raise RuntimeError("bbox must be normalized")
     return a, b
+
+
+# iris_landmark.rs:64-95: eye-contour landmark n refines face-mesh landmark EYE_TO_FACE[eye][n] (0 = left, 1 = right)
+EYE_TO_FACE = (
+    (33, 7, 163, 144, 145, 153, 154, 155, 133, 246, 161, 160, 159, 158, 157, 173, 130, 25, 110, 24, 23, 22, 26, 112, 243, 247, 30, 29, 27, 28, 56, 190, 226, 31, 228, 229, 230, 231, 232, 233, 244, 113, 225, 224, 223, 222, 221, 189, 35, 124, 46, 53, 52, 65, 143, 111, 117, 118, 119, 120, 121, 128, 245, 156, 70, 63, 105, 66, 107, 55, 193),
+    (263, 249, 390, 373, 374, 380, 381, 382, 362, 466, 388, 387, 386, 385, 384, 398, 359, 255, 339, 254, 253, 252, 256, 341, 463, 467, 260, 259, 257, 258, 286, 414, 446, 261, 448, 449, 450, 451, 452, 453, 464, 342, 445, 444, 443, 442, 441, 413, 265, 353, 276, 283, 282, 295, 372, 340, 346, 347, 348, 349, 350, 357, 465, 383, 300, 293, 334, 296, 336, 285, 417),
+)
+
+
+def update_face_landmarks_with_iris_results(face, left_contour, right_contour):
+    """iris_landmark.rs:380-398 restated on arrays: face [468,3], contours [71,3] -> refined [468,3] (left loop, then right)."""
+    face = np.asarray(face, np.float64)
+    if face.shape[0] != 468:
+        raise ValueError("unexpected number of items in face_landmarks")
+    out = face.copy()
+    for eye, contour in enumerate((left_contour, right_contour)):
+        for n, point in enumerate(np.asarray(contour, np.float64)):
+            out[EYE_TO_FACE[eye][n]] = point
+    return out

@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
     "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_run",
-    "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_image_to_tensor",
+    "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor",
 ]
 
 
@@ -181,6 +181,7 @@ def lib():
     L.mi_pipeline_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
     L.mi_face_detection_to_roi.argtypes = [C.POINTER(CDetection), C.c_int, C.c_int, C.POINTER(Rect)]
     L.mi_iris_roi_from_face_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(Rect)]
+    L.mi_update_face_landmarks_with_iris_results.argtypes = [C.POINTER(CLandmark)] * 4
     L.mi_image_to_tensor.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_int, vp, dp, C.c_int, vp]
     _lib = L
@@ -576,6 +577,18 @@ def iris_roi_from_face_landmarks(face_landmarks, image_size):
     a, b = Rect(), Rect()
     _check(lib().mi_iris_roi_from_face_landmarks(arr, int(image_size[0]), int(image_size[1]), C.byref(a), C.byref(b)))
     return a, b
+
+
+def update_face_landmarks_with_iris_results(face_landmarks, iris_data_left, iris_data_right):
+    """iris_landmark.rs:380-398: the eye-contour landmarks of both eyes replace the face-mesh points they refine."""
+    if len(face_landmarks) != NUM_FACE_LANDMARKS:
+        raise MiError(-1, "unexpected number of items in face_landmarks")
+    pack = lambda v: (CLandmark * len(v))(*[CLandmark(l.x, l.y, l.z) for l in v])
+    if len(iris_data_left.contour) != NUM_EYE_LANDMARKS or len(iris_data_right.contour) != NUM_EYE_LANDMARKS:
+        raise MiError(-1, "expected 71 contour landmarks per eye")
+    f, l, r = pack(face_landmarks), pack(iris_data_left.contour), pack(iris_data_right.contour)
+    _check(lib().mi_update_face_landmarks_with_iris_results(f, l, r, f))
+    return [Landmark(x.x, x.y, x.z) for x in f]
 
 
 def image_to_tensor(image, roi=None, output_size=None, keep_aspect_ratio=False, output_range=(0., 1.), flip_horizontal=False,

@@ -851,6 +851,34 @@ int mi_iris_roi_from_face_landmarks(const mi_landmark* lm, int image_w, int imag
     });
 }
 
+namespace {
+// eye-contour landmark n of the iris model refines face-mesh landmark kEyeToFace[eye][n] (iris_landmark.rs:64-95)
+const int kEyeToFace[2][MI_NUM_EYE_LANDMARKS] = {
+    {
+        33, 7, 163, 144, 145, 153, 154, 155, 133, 246, 161, 160, 159, 158, 157, 173, 130, 25, 110, 24, 23,
+        22, 26, 112, 243, 247, 30, 29, 27, 28, 56, 190, 226, 31, 228, 229, 230, 231, 232, 233, 244, 113, 225,
+        224, 223, 222, 221, 189, 35, 124, 46, 53, 52, 65, 143, 111, 117, 118, 119, 120, 121, 128, 245, 156,
+        70, 63, 105, 66, 107, 55, 193,
+    },
+    {
+        263, 249, 390, 373, 374, 380, 381, 382, 362, 466, 388, 387, 386, 385, 384, 398, 359, 255, 339, 254,
+        253, 252, 256, 341, 463, 467, 260, 259, 257, 258, 286, 414, 446, 261, 448, 449, 450, 451, 452, 453,
+        464, 342, 445, 444, 443, 442, 441, 413, 265, 353, 276, 283, 282, 295, 372, 340, 346, 347, 348, 349,
+        350, 357, 465, 383, 300, 293, 334, 296, 336, 285, 417,
+    },
+};
+}  // namespace
+
+int mi_update_face_landmarks_with_iris_results(const mi_landmark* face, const mi_landmark* left, const mi_landmark* right, mi_landmark* out) {
+    return guarded([&] {
+        require(face && left && right && out, "null argument");
+        if (out != face) std::memmove(out, face, sizeof(mi_landmark) * MI_NUM_FACE_LANDMARKS);
+        const mi_landmark* eyes[2] = {left, right};  // left first, then right, as the reference's two loops
+        for (int e = 0; e < 2; e++)
+            for (int n = 0; n < MI_NUM_EYE_LANDMARKS; n++) out[kEyeToFace[e][n]] = eyes[e][n];
+    });
+}
+
 int mi_image_to_tensor(int device, const uint8_t* rgb, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
                        int keep_aspect_ratio, double range_min, double range_max, int flip_horizontal, float* out,
                        double padding_out[4], int mem, void* stream) {

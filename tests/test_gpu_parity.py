@@ -318,6 +318,10 @@ def test_full_pipeline_on_man_jpg(gpu, oracle, gold, man_image):
     assert len(r.contour) == 71 and len(r.iris) == 5 and len(l.eyeball_contour()) == 15
     np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in r.contour]), gold["man_eye_right_contour"], atol=5e-3)
     np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in l.iris]), gold["man_eye_left_iris"], atol=5e-3)
+    # iris_landmark.rs:380-398: the eye contours refine the mesh; checked against the oracle's restatement on the same inputs
+    refined = gpu.update_face_landmarks_with_iris_results(lms, l, r)
+    want = oracle.update_face_landmarks_with_iris_results(arr, [[p.x, p.y, p.z] for p in l.contour], [[p.x, p.y, p.z] for p in r.contour])
+    np.testing.assert_array_equal(np.array([[p.x, p.y, p.z] for p in refined]), want)
     # a frame without a face: empty Vec, like the reference
     assert fd.infer(np.zeros((240, 320, 3), np.uint8), None) == []
     assert gpu.FaceLandmark().infer(np.zeros((240, 320, 3), np.uint8), None) == []

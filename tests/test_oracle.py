@@ -116,3 +116,22 @@ def test_roi_helpers(oracle, gold):
     l, r = oracle.iris_rois_from_face_landmarks(gold["man_face_landmarks"], (540, 360))
     np.testing.assert_allclose([l.x_center, l.y_center, l.width, l.height, l.rotation], gold["man_eye_left_roi"][:5], rtol=1e-12)
     np.testing.assert_allclose([r.x_center, r.y_center, r.width, r.height, r.rotation], gold["man_eye_right_roi"][:5], rtol=1e-12)
+
+
+def test_update_face_landmarks_with_iris_results(mi, oracle):
+    """iris_landmark.rs:380-398 through the C ABI (host-only entry point: runs without a GPU) against the oracle's
+    restatement, plus the properties the index maps (iris_landmark.rs:64-95) guarantee."""
+    rs = np.random.RandomState(3)
+    face, left, right = rs.rand(468, 3), rs.rand(71, 3) + 2.0, rs.rand(71, 3) + 4.0
+    lm = lambda a: [mi.Landmark(*map(float, p)) for p in a]
+    got = mi.update_face_landmarks_with_iris_results(lm(face), mi.IrisResults(lm(left), lm(np.zeros((5, 3)))), mi.IrisResults(lm(right), lm(np.zeros((5, 3)))))
+    got = np.array([[p.x, p.y, p.z] for p in got])
+    want = oracle.update_face_landmarks_with_iris_results(face, left, right)
+    np.testing.assert_array_equal(got, want)
+    changed = np.where((got != face).any(axis=1))[0]
+    assert len(changed) == 142                                   # 71 + 71 distinct mesh points, nothing else touched
+    assert set(changed) == set(oracle.EYE_TO_FACE[0]) | set(oracle.EYE_TO_FACE[1])
+    assert (got[list(oracle.EYE_TO_FACE[0])] >= 2.0).all() and (got[list(oracle.EYE_TO_FACE[0])] < 3.0).all()
+    assert (got[33] == left[0]).all() and (got[263] == right[0]).all()   # eye corners: first entries of the maps
+    with pytest.raises(mi.MiError):                              # the reference returns Err for a wrong landmark count
+        mi.update_face_landmarks_with_iris_results(lm(face[:100]), mi.IrisResults(lm(left), []), mi.IrisResults(lm(right), []))
