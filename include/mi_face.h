@@ -229,6 +229,14 @@ int mi_face_detection_to_roi(const mi_detection *det, int image_w, int image_h, 
 /* iris_roi_from_face_landmarks(face_landmarks, image_size) — iris_landmark.rs:268-292 (scale 2.3). */
 int mi_iris_roi_from_face_landmarks(const mi_landmark *landmarks468, int image_w, int image_h, mi_rect *left_eye,
                                     mi_rect *right_eye);
+/* utils::convert_image_to_mat(im_bytes) — utils.rs:8-21 (cv::imdecode(IMREAD_COLOR) + cvtColor(BGR2RGB)) for JPEG streams:
+ * entropy decoding on the host, dequantisation / IDCT / chroma upsampling / colour conversion on the GPU (the arithmetic
+ * of libjpeg-turbo's default decoder, bit for bit).  Baseline and extended-sequential Huffman JPEG, 8 bit, grey or YCbCr with
+ * h1v1 / h2v1 / h2v2 sampling; anything else (progressive, arithmetic, CMYK, other containers) is MI_EINVAL with a message.
+ * rgb = [height][width][3] u8, at least cap_bytes >= 3*width*height (ask mi_jpeg_info first); follows `mem`. */
+int mi_jpeg_info(const uint8_t *bytes, size_t nbytes, int *width, int *height);
+int mi_jpeg_decode_rgb(int device, const uint8_t *bytes, size_t nbytes, uint8_t *rgb, size_t cap_bytes, int *width,
+                       int *height, int mem, void *stream);
 /* update_face_landmarks_with_iris_results(face_landmarks, iris_data_left, iris_data_right) — iris_landmark.rs:380-398:
  * the 71 eye-contour/brow landmarks of each eye replace the face-mesh points they refine (index maps iris_landmark.rs:64-95).
  * out468 may alias face468. */

@@ -186,6 +186,20 @@ inline std::pair<Rect, Rect> iris_roi_from_face_landmarks(const std::vector<Land
     return {Rect::from(l), Rect::from(r)};
 }
 
+// convert_image_to_mat(im_bytes) (utils.rs:8-21): an owning RGB picture; `.image()` is the borrowed view the infer() calls take
+struct OwnedImage {
+    std::vector<std::uint8_t> rgb;
+    int width = 0, height = 0;
+    Image image() const { return Image{rgb.data(), width, height, 3 * width}; }
+};
+inline OwnedImage convert_image_to_mat(const std::uint8_t* im_bytes, std::size_t n, int device = 0) {
+    OwnedImage o;
+    detail::check(mi_jpeg_info(im_bytes, n, &o.width, &o.height));
+    o.rgb.resize(static_cast<std::size_t>(3) * o.width * o.height);
+    detail::check(mi_jpeg_decode_rgb(device, im_bytes, n, o.rgb.data(), o.rgb.size(), &o.width, &o.height, MI_MEM_HOST, nullptr));
+    return o;
+}
+
 // update_face_landmarks_with_iris_results(face_landmarks, iris_data_left, iris_data_right) (iris_landmark.rs:380-398)
 inline std::vector<Landmark> update_face_landmarks_with_iris_results(const std::vector<Landmark>& face_landmarks, const IrisResults& left,
                                                                      const IrisResults& right) {

@@ -114,6 +114,12 @@ int orc_image_to_tensor(const uint8_t *image, int image_w, int image_h, const or
                         int keep_aspect_ratio, double range_min, double range_max, int flip_horizontal, float *out,
                         double padding_out[4]);
 
+/* ---------------------------------------------------------------- JPEG -> RGB (jpeg.c) */
+/* convert_image_to_mat (utils.rs:8-21) = imdecode(IMREAD_COLOR) + BGR2RGB: baseline Huffman JPEG -> rgb [H][W][3].
+ * 0 on success, -1 malformed, -2 outside the restated subset (progressive, arithmetic, 12-bit, CMYK, odd samplings). */
+int orc_jpeg_info(const uint8_t *data, size_t n, int *width, int *height);
+int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, int cap_h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,3 +234,18 @@ def update_face_landmarks_with_iris_results(face, left_contour, right_contour):
         for n, point in enumerate(np.asarray(contour, np.float64)):
             out[EYE_TO_FACE[eye][n]] = point
     return out
+
+
+def jpeg_decode_rgb(data: bytes):
+    """convert_image_to_mat (utils.rs:8-21): JPEG bytes -> [H, W, 3] u8 RGB, by the C restatement (oracle/c/jpeg.c)."""
+    L = lib()
+    L.orc_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_jpeg_decode_rgb.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+    w, h = C.c_int(), C.c_int()
+    if L.orc_jpeg_info(data, len(data), C.byref(w), C.byref(h)) != 0:
+        raise ValueError("not a JPEG with a frame header")
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    rc = L.orc_jpeg_decode_rgb(data, len(data), out.ctypes.data, w.value, h.value)
+    if rc != 0:
+        raise ValueError("jpeg decode failed (%d)" % rc)
+    return out

@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
     "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_run",
-    "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor",
+    "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor", "mi_jpeg_info", "mi_jpeg_decode_rgb",
 ]
 
 
@@ -182,6 +182,8 @@ def lib():
     L.mi_face_detection_to_roi.argtypes = [C.POINTER(CDetection), C.c_int, C.c_int, C.POINTER(Rect)]
     L.mi_iris_roi_from_face_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(Rect)]
     L.mi_update_face_landmarks_with_iris_results.argtypes = [C.POINTER(CLandmark)] * 4
+    L.mi_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mi_jpeg_decode_rgb.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]
     L.mi_image_to_tensor.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_int, vp, dp, C.c_int, vp]
     _lib = L
@@ -577,6 +579,28 @@ def iris_roi_from_face_landmarks(face_landmarks, image_size):
     a, b = Rect(), Rect()
     _check(lib().mi_iris_roi_from_face_landmarks(arr, int(image_size[0]), int(image_size[1]), C.byref(a), C.byref(b)))
     return a, b
+
+
+def jpeg_info(im_bytes: bytes):
+    """(width, height) of a JPEG stream (headers only; works without a GPU)."""
+    w, h = C.c_int(), C.c_int()
+    _check(lib().mi_jpeg_info(im_bytes, len(im_bytes), C.byref(w), C.byref(h)))
+    return w.value, h.value
+
+
+def convert_image_to_mat(im_bytes: bytes, device=0, to_device=False):
+    """utils.rs:8-21: encoded JPEG bytes -> 8UC3 RGB image [H, W, 3] u8 (numpy; a torch CUDA tensor with to_device=True,
+    in which case the pixels never visit the host: Huffman decoding on the CPU, everything after it on the GPU)."""
+    w, h = jpeg_info(im_bytes)
+    ow, oh = C.c_int(), C.c_int()
+    if to_device:
+        import torch
+        out = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda:%d" % device)
+        _check(lib().mi_jpeg_decode_rgb(device, im_bytes, len(im_bytes), C.c_void_p(out.data_ptr()), out.numel(), C.byref(ow), C.byref(oh), MI_MEM_DEVICE, None))
+        return out
+    out = np.empty((h, w, 3), np.uint8)
+    _check(lib().mi_jpeg_decode_rgb(device, im_bytes, len(im_bytes), C.c_void_p(out.ctypes.data), out.size, C.byref(ow), C.byref(oh), MI_MEM_HOST, None))
+    return out
 
 
 def update_face_landmarks_with_iris_results(face_landmarks, iris_data_left, iris_data_right):

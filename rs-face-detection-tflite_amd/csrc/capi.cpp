@@ -14,6 +14,7 @@
 #include "engine.hpp"
 #include "host_glue.hpp"
 #include "kernels.hpp"
+#include "jpeg.hpp"
 #include "preproc.hpp"
 
 namespace {
@@ -848,6 +849,51 @@ int mi_iris_roi_from_face_landmarks(const mi_landmark* lm, int image_w, int imag
             const double kp[4] = {a.x, a.y, b.x, b.y};
             if (!mi::bbox_to_roi(bbox, image_w, image_h, kp, 2.3, 2.3, 1, outs[e])) throw ApiError(MI_EINVAL, "bbox must be normalized");
         }
+    });
+}
+
+int mi_jpeg_info(const uint8_t* bytes, size_t nbytes, int* width, int* height) {
+    return guarded([&] {
+        require(bytes && width && height, "null argument");
+        try {
+            mi::jpeg_parse_size(bytes, nbytes, width, height);
+        } catch (const std::runtime_error& e) {
+            throw ApiError(MI_EINVAL, e.what());
+        }
+    });
+}
+
+int mi_jpeg_decode_rgb(int device, const uint8_t* bytes, size_t nbytes, uint8_t* rgb, size_t cap_bytes, int* width, int* height, int mem, void* stream) {
+    return guarded([&] {
+        require(bytes && rgb && width && height, "null argument");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        mi::JpegFrame f;
+        try {
+            mi::jpeg_entropy_decode(bytes, nbytes, &f);  // host: the serial part
+        } catch (const std::runtime_error& e) {
+            throw ApiError(MI_EINVAL, e.what());
+        }
+        const size_t out_bytes = static_cast<size_t>(3) * f.width * f.height;
+        if (cap_bytes < out_bytes) throw ApiError(MI_EINVAL, "rgb buffer too small for the decoded picture");
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) throw ApiError(MI_EDEVICE, "no such HIP device (the JPEG sample arithmetic runs on the GPU; no CPU fallback exists)");
+        mi::hip_check(hipSetDevice(device), "hipSetDevice");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        DeviceBuf coef, qt, planes, out;
+        const size_t coef_bytes = f.coef.size() * sizeof(int16_t);
+        auto* d_coef = static_cast<int16_t*>(coef.get(coef_bytes));
+        auto* d_qt = static_cast<uint16_t*>(qt.get(sizeof f.qt));
+        auto* d_planes = static_cast<uint8_t*>(planes.get(mi::jpeg_plane_bytes(f)));
+        uint8_t* d_rgb = mem == MI_MEM_DEVICE ? rgb : static_cast<uint8_t*>(out.get(out_bytes));
+        mi::hip_check(hipMemcpyAsync(d_coef, f.coef.data(), coef_bytes, hipMemcpyHostToDevice, s), "H2D coefficients");
+        mi::hip_check(hipMemcpyAsync(d_qt, f.qt, sizeof f.qt, hipMemcpyHostToDevice, s), "H2D quantisation tables");
+        int rc = mi::launch_jpeg_idct(f, d_coef, d_qt, d_planes, s);
+        if (rc == 0) rc = mi::launch_jpeg_color(f, d_planes, d_rgb, s);
+        if (rc) throw std::runtime_error(std::string("jpeg kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (mem == MI_MEM_HOST) mi::hip_check(hipMemcpyAsync(rgb, d_rgb, out_bytes, hipMemcpyDeviceToHost, s), "D2H rgb");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // the scratch buffers and the host coefficients die with this call
+        *width = f.width;
+        *height = f.height;
     });
 }
 

@@ -1,0 +1,244 @@
+// jpeg.cpp — host half of the JPEG path (see jpeg.hpp): marker parsing and Huffman decoding (ITU-T T.81 Annex F.2).
+// Entropy-coded data is one serial bit stream per restart interval; it stays on the CPU.  Everything after it — the
+// per-block and per-pixel arithmetic — runs on the GPU (jpeg_kernels.hip).
+#include "jpeg.hpp"
+
+#include <cstring>
+#include <stdexcept>
+
+namespace mi {
+namespace {
+
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+constexpr int kLook = 9;  // codes up to 9 bits resolve with one table read
+
+struct Huff {
+    bool present = false;
+    uint8_t symbols[256] = {};
+    uint16_t look[1 << kLook] = {};  // (length << 8) | symbol, 0 = longer code
+    int maxcode[18] = {}, valoff[17] = {};
+    void build(const uint8_t counts[17]) {
+        int code = 0, k = 0;
+        std::memset(look, 0, sizeof look);
+        for (int l = 1; l <= 16; l++) {
+            valoff[l] = k - code;
+            for (int i = 0; i < counts[l]; i++, code++, k++)
+                if (l <= kLook)
+                    for (int fill = 0; fill < (1 << (kLook - l)); fill++) look[(code << (kLook - l)) | fill] = static_cast<uint16_t>((l << 8) | symbols[k]);
+            maxcode[l] = counts[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        present = true;
+    }
+};
+
+struct Bits {
+    const uint8_t *p, *end;
+    uint64_t buf = 0;
+    int n = 0;
+    bool hit_marker = false;
+    void fill() {  // keep at least 32 bits; past a marker (or the end) the stream reads as zeros, like libjpeg
+        while (n <= 56) {
+            unsigned byte = 0;
+            if (!hit_marker && p < end) {
+                byte = *p++;
+                if (byte == 0xFF) {
+                    unsigned nx = p < end ? *p : 0xD9u;
+                    if (nx == 0) p++;
+                    else { hit_marker = true; byte = 0; p--; }
+                }
+            }
+            buf |= static_cast<uint64_t>(byte) << (56 - n);
+            n += 8;
+        }
+    }
+    unsigned peek(int k) { return static_cast<unsigned>(buf >> (64 - k)); }
+    void skip(int k) { buf <<= k; n -= k; }
+    int get(int k) {
+        if (k == 0) return 0;
+        if (n < k) fill();
+        unsigned v = peek(k);
+        skip(k);
+        return static_cast<int>(v);
+    }
+    int symbol(const Huff& h) {
+        if (n < 16) fill();
+        unsigned e = h.look[peek(kLook)];
+        if (e) { skip(static_cast<int>(e >> 8)); return static_cast<int>(e & 255); }
+        int code = static_cast<int>(peek(kLook));
+        for (int l = kLook + 1; l <= 16; l++) {
+            code = static_cast<int>(peek(l));
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l]) { skip(l); return h.symbols[code + h.valoff[l]]; }
+        }
+        skip(16);
+        return 0;  // corrupt stream: libjpeg warns and substitutes 0
+    }
+    void restart() {  // byte-align and step over RSTn
+        n = 0; buf = 0;
+        if (hit_marker) { if (p + 1 < end && p[1] >= 0xD0 && p[1] <= 0xD7) { p += 2; hit_marker = false; } }
+        else if (p + 1 < end && p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) p += 2;
+    }
+};
+
+inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+[[noreturn]] void bad(const char* what) { throw std::runtime_error(std::string("jpeg: ") + what); }
+
+struct Parser {
+    const uint8_t* d;
+    size_t n;
+    JpegFrame* f;
+    Huff dc[4], ac[4];
+    int restart_interval = 0;
+    bool have_frame = false;
+
+    // walks the markers up to SOS; returns the offset of the entropy-coded data (0 when stop_at_frame and a frame header was found)
+    size_t headers(bool stop_at_frame) {
+        if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) bad("not a JPEG stream (no SOI)");
+        size_t i = 2;
+        while (i + 4 <= n) {
+            if (d[i] != 0xFF) { i++; continue; }
+            const int m = d[i + 1];
+            if (m == 0xFF) { i++; continue; }
+            if (m == 0xD9) break;
+            const size_t len = (static_cast<size_t>(d[i + 2]) << 8) | d[i + 3];
+            if (len < 2 || i + 2 + len > n) bad("truncated segment");
+            const uint8_t* seg = d + i + 4;
+            const size_t body = len - 2;
+            if (m == 0xDB) {
+                for (size_t k = 0; k < body;) {
+                    const int pq = seg[k] >> 4, tq = seg[k] & 15;
+                    k++;
+                    if (tq > 3 || k + (pq ? 128u : 64u) > body) bad("bad quantisation table");
+                    for (int z = 0; z < 64; z++) {
+                        f->qt[tq][kZigzag[z]] = pq ? static_cast<uint16_t>((seg[k] << 8) | seg[k + 1]) : seg[k];
+                        k += pq ? 2 : 1;
+                    }
+                }
+            } else if (m == 0xC4) {
+                for (size_t k = 0; k + 17 <= body;) {
+                    const int tc = seg[k] >> 4, th = seg[k] & 15;
+                    if (th > 3 || tc > 1) bad("bad Huffman table id");
+                    uint8_t counts[17] = {};
+                    int total = 0;
+                    for (int l = 1; l <= 16; l++) { counts[l] = seg[k + l]; total += counts[l]; }
+                    if (total > 256 || k + 17 + static_cast<size_t>(total) > body) bad("bad Huffman table");
+                    Huff& h = tc ? ac[th] : dc[th];
+                    std::memcpy(h.symbols, seg + k + 17, static_cast<size_t>(total));
+                    h.build(counts);
+                    k += 17 + static_cast<size_t>(total);
+                }
+            } else if (m == 0xC0 || m == 0xC1) {
+                if (body < 6 || seg[0] != 8) bad("unsupported sample precision (8-bit only)");
+                f->height = (seg[1] << 8) | seg[2];
+                f->width = (seg[3] << 8) | seg[4];
+                f->ncomp = seg[5];
+                if (f->width <= 0 || f->height <= 0) bad("empty frame");
+                if ((f->ncomp != 1 && f->ncomp != 3) || body < 6 + 3 * static_cast<size_t>(f->ncomp)) bad("unsupported component count (1 or 3)");
+                f->hmax = f->vmax = 1;
+                for (int c = 0; c < f->ncomp; c++) {
+                    JpegComponent& cp = f->comp[c];
+                    cp.id = seg[6 + 3 * c]; cp.h = seg[7 + 3 * c] >> 4; cp.v = seg[7 + 3 * c] & 15; cp.tq = seg[8 + 3 * c];
+                    if (cp.tq > 3 || cp.h < 1 || cp.v < 1) bad("bad component");
+                    f->hmax = cp.h > f->hmax ? cp.h : f->hmax;
+                    f->vmax = cp.v > f->vmax ? cp.v : f->vmax;
+                }
+                if (f->ncomp == 1) f->comp[0].h = f->comp[0].v = f->hmax = f->vmax = 1;
+                else {
+                    const JpegComponent* c = f->comp;
+                    const bool ok = c[1].h == 1 && c[1].v == 1 && c[2].h == 1 && c[2].v == 1 && ((c[0].h == 1 && c[0].v == 1) || (c[0].h == 2 && c[0].v <= 2));
+                    if (!ok) bad("unsupported chroma sampling (h1v1, h2v1, h2v2)");
+                }
+                have_frame = true;
+                if (stop_at_frame) return 0;
+            } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+                bad("unsupported coding process (baseline / extended sequential Huffman only)");
+            } else if (m == 0xDD) {
+                if (body < 2) bad("bad DRI");
+                restart_interval = (seg[0] << 8) | seg[1];
+            } else if (m == 0xDA) {
+                if (!have_frame) bad("scan before frame header");
+                if (body < 1 || seg[0] != f->ncomp || body < 1 + 2 * static_cast<size_t>(f->ncomp)) bad("unsupported scan layout (one interleaved scan)");
+                for (int s = 0; s < f->ncomp; s++) {
+                    int c = 0;
+                    while (c < f->ncomp && f->comp[c].id != seg[1 + 2 * s]) c++;
+                    if (c == f->ncomp) bad("scan names an unknown component");
+                    f->comp[c].td = seg[2 + 2 * s] >> 4;
+                    f->comp[c].ta = seg[2 + 2 * s] & 15;
+                    if (f->comp[c].td > 3 || f->comp[c].ta > 3 || !dc[f->comp[c].td].present || !ac[f->comp[c].ta].present) bad("scan uses an undefined Huffman table");
+                }
+                return i + 2 + len;
+            }
+            i += 2 + len;
+        }
+        bad(stop_at_frame ? "no frame header" : "no scan");
+    }
+};
+
+}  // namespace
+
+void jpeg_parse_size(const uint8_t* data, size_t n, int* width, int* height) {
+    JpegFrame f;
+    Parser p{data, n, &f};
+    p.headers(true);
+    *width = f.width;
+    *height = f.height;
+}
+
+void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
+    JpegFrame& f = *out;
+    f = JpegFrame();
+    Parser p{data, n, &f};
+    const size_t ecs = p.headers(false);
+    const int mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax), mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
+    size_t total = 0;
+    for (int c = 0; c < f.ncomp; c++) {
+        JpegComponent& cp = f.comp[c];
+        cp.bw = mcux * cp.h; cp.bh = mcuy * cp.v;
+        cp.dw = (f.width * cp.h + f.hmax - 1) / f.hmax;
+        cp.dh = (f.height * cp.v + f.vmax - 1) / f.vmax;
+        cp.coef_off = total;
+        total += static_cast<size_t>(cp.bw) * cp.bh * 64;
+    }
+    f.coef.assign(total, 0);
+    Bits br{data + ecs, data + n};
+    int pred[3] = {0, 0, 0};
+    int mcus = 0;
+    for (int my = 0; my < mcuy; my++)
+        for (int mx = 0; mx < mcux; mx++) {
+            if (p.restart_interval && mcus > 0 && mcus % p.restart_interval == 0) {
+                br.restart();
+                pred[0] = pred[1] = pred[2] = 0;
+            }
+            mcus++;
+            for (int c = 0; c < f.ncomp; c++) {
+                const JpegComponent& cp = f.comp[c];
+                const Huff &hd = p.dc[cp.td], &ha = p.ac[cp.ta];
+                for (int by = 0; by < cp.v; by++)
+                    for (int bx = 0; bx < cp.h; bx++) {
+                        int16_t* blk = f.coef.data() + cp.coef_off + (static_cast<size_t>(my * cp.v + by) * cp.bw + mx * cp.h + bx) * 64;
+                        const int t = br.symbol(hd) & 15;
+                        if (t) pred[c] += extend(br.get(t), t);
+                        blk[0] = static_cast<int16_t>(pred[c]);
+                        for (int k = 1; k < 64;) {
+                            const int rs = br.symbol(ha), r = rs >> 4, s = rs & 15;
+                            if (s == 0) {
+                                if (r != 15) break;
+                                k += 16;
+                                continue;
+                            }
+                            k += r;
+                            if (k > 63) break;
+                            blk[kZigzag[k]] = static_cast<int16_t>(extend(br.get(s), s));
+                            k++;
+                        }
+                    }
+            }
+        }
+}
+
+}  // namespace mi

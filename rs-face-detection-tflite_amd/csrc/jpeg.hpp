@@ -1,0 +1,41 @@
+// jpeg.hpp — `convert_image_to_mat` (/root/reference/src/face_detection_lite/utils.rs:8-21: cv::imdecode(IMREAD_COLOR) +
+// cvtColor(BGR2RGB)) for baseline / extended-sequential Huffman JPEGs: the serial part (marker parsing, entropy decoding)
+// on the host, the sample arithmetic (dequantise + ISLOW IDCT, fancy chroma upsampling, YCbCr -> RGB: libjpeg-turbo's
+// algorithms, which is what OpenCV's imdecode runs) on the GPU, leaving RGB u8 in HBM for image_to_tensor / the pipeline.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace mi {
+
+struct JpegComponent {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int bw = 0, bh = 0;   // blocks per row / column (whole MCUs)
+    int dw = 0, dh = 0;   // real downsampled size
+    size_t coef_off = 0;  // first coefficient of this component in JpegFrame::coef
+};
+
+struct JpegFrame {             // host-side result of the entropy decoder
+    int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1;
+    JpegComponent comp[3];
+    uint16_t qt[4][64] = {};   // natural order
+    std::vector<int16_t> coef; // per component [bh][bw][64], natural order, quantised
+};
+
+// Parses the headers only. Throws std::runtime_error("unsupported ...") for streams outside the subset.
+void jpeg_parse_size(const uint8_t* data, size_t n, int* width, int* height);
+// Headers + Huffman decoding of the (single, interleaved) scan.
+void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out);
+
+// Device side. d_coef: the frame's coefficients (int16), d_qt: uint16 [4][64], d_planes: scratch of jpeg_plane_bytes(f),
+// d_rgb: [height][width][3].
+size_t jpeg_plane_bytes(const JpegFrame& f);
+int launch_jpeg_idct(const JpegFrame& f, const int16_t* d_coef, const uint16_t* d_qt, uint8_t* d_planes, hipStream_t s);
+int launch_jpeg_color(const JpegFrame& f, const uint8_t* d_planes, uint8_t* d_rgb, hipStream_t s);
+
+}  // namespace mi

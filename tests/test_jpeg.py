@@ -1,0 +1,72 @@
+"""JPEG -> RGB (`convert_image_to_mat`, /root/reference/src/face_detection_lite/utils.rs:8-21).
+
+CPU part: the oracle (oracle/c/jpeg.c) is pinned bit-exactly against libjpeg-turbo's own decode — the committed SHA-256 pins
+of tests/golden/jpeg_pins.json, and Pillow live when it is importable — on the reference's three test JPEGs and on fixtures
+covering the sampling modes, restart intervals, greyscale and odd sizes.  GPU part: the product (host entropy decoding +
+HIP sample arithmetic, through the C ABI) against the oracle, bit-exact."""
+import hashlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+PINS = json.load(open(os.path.join(GOLDEN, "jpeg_pins.json")))
+FILES = sorted(k for k in PINS if not k.startswith("_"))
+
+
+def _bytes(rel):
+    return open(os.path.join(GOLDEN, rel), "rb").read()
+
+
+@pytest.mark.parametrize("rel", FILES)
+def test_oracle_matches_libjpeg_turbo(oracle, rel):
+    data = _bytes(rel)
+    rgb = oracle.jpeg_decode_rgb(data)
+    assert list(rgb.shape) == PINS[rel]["shape"]
+    assert hashlib.sha256(rgb.tobytes()).hexdigest() == PINS[rel]["sha256"]
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    np.testing.assert_array_equal(rgb, np.asarray(Image.open(io.BytesIO(data)).convert("RGB")))
+
+
+def test_headers_and_refusals_without_gpu(mi, oracle):
+    assert mi.jpeg_info(_bytes("man.jpg")) == (540, 360)          # the reference's test image (lib.rs:23)
+    assert mi.jpeg_info(_bytes("russ_cox_2.jpg")) == (200, 225)
+    for bad in (b"", b"\x89PNG\r\n\x1a\n" + b"\0" * 64, _bytes("man.jpg")[:300], _bytes("jpeg/progressive_unsupported.jpg")):
+        with pytest.raises(mi.MiError):
+            mi.convert_image_to_mat(bad)                           # refused before any device work
+    with pytest.raises(ValueError):
+        oracle.jpeg_decode_rgb(_bytes("jpeg/progressive_unsupported.jpg"))
+    if mi.device_count() == 0:
+        with pytest.raises(mi.MiError) as e:                       # the sample arithmetic has no CPU fallback
+            mi.convert_image_to_mat(_bytes("man.jpg"))
+        assert e.value.code == -4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rel", FILES)
+def test_gpu_decode_is_bit_exact(mi, oracle, rel):
+    data = _bytes(rel)
+    want = oracle.jpeg_decode_rgb(data)
+    got = mi.convert_image_to_mat(data)
+    np.testing.assert_array_equal(got, want)
+    assert hashlib.sha256(got.tobytes()).hexdigest() == PINS[rel]["sha256"]
+    dev = mi.convert_image_to_mat(data, to_device=True)            # pixels stay in HBM
+    np.testing.assert_array_equal(dev.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_bytes_to_detections_like_the_reference_test(mi):
+    """lib.rs:18-29: include_bytes!(man.jpg) -> convert_image_to_mat -> FaceDetection::infer; same pin as the rendered bbox."""
+    image = mi.convert_image_to_mat(_bytes("man.jpg"))
+    faces = mi.FaceDetection(mi.FaceDetectionModel.BackCamera).infer(image, None)
+    assert len(faces) == 1
+    xmin, ymin, xmax, ymax = faces[0].bbox()
+    H, W = image.shape[:2]
+    assert int(xmin * W) == 195 and int(ymin * H) == 74 and int((xmax - xmin) * W) == 139 and int((ymax - ymin) * H) == 139
