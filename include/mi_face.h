@@ -210,6 +210,8 @@ typedef struct mi_pipeline mi_pipeline;
  * (NULL = "./models") — the three handles of the README.md:27-46 / lib.rs:18-40 flow. */
 int mi_pipeline_create(int fd_kind, const char *model_dir, int device, mi_pipeline **out);
 void mi_pipeline_free(mi_pipeline *p);
+/* mi_model_set_option on the three networks of the pipeline (e.g. "lanes": frame ranges on concurrent streams). */
+int mi_pipeline_set_option(mi_pipeline *p, const char *key, int value);
 /* For each of `batch` equally sized RGB frames (8UC3, rows of `stride` bytes, frames `stride*height` bytes apart):
  *   FaceDetection::infer(frame, None) -> faces[0] -> face_detection_to_roi -> FaceLandmark::infer(frame, roi)
  *   -> iris_roi_from_face_landmarks -> IrisLandmark::infer(frame, left, false) and (frame, right, true)

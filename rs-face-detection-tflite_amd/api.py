@@ -36,7 +36,7 @@ EXPORTS = [
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
-    "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_run",
+    "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_set_option", "mi_pipeline_run",
     "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor", "mi_jpeg_info", "mi_jpeg_decode_rgb",
 ]
 
@@ -178,6 +178,7 @@ def lib():
     L.mi_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
     L.mi_pipeline_free.argtypes = [vp]
     L.mi_pipeline_free.restype = None
+    L.mi_pipeline_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.mi_pipeline_run.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
     L.mi_face_detection_to_roi.argtypes = [C.POINTER(CDetection), C.c_int, C.c_int, C.POINTER(Rect)]
     L.mi_iris_roi_from_face_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(Rect)]
@@ -534,6 +535,9 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, key, value):
+        _check(self.L.mi_pipeline_set_option(self.h, key.encode(), int(value)))
 
     def run(self, frames, stream=None):
         """frames: uint8 [B,H,W,3] RGB (numpy, or a torch CUDA tensor).

@@ -717,6 +717,15 @@ int mi_pipeline_create(int fd_kind, const char* model_dir, int device, mi_pipeli
 
 void mi_pipeline_free(mi_pipeline* p) { delete p; }
 
+int mi_pipeline_set_option(mi_pipeline* p, const char* key, int value) {
+    return guarded([&] {
+        require(p && key, "null argument");
+        p->fd->model.m->set_option(key, value);
+        p->fl->model.m->set_option(key, value);
+        p->iris->model.m->set_option(key, value);
+    });
+}
+
 int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width, int height, int stride, mi_detection* faces,
                     int* face_counts, float* landmarks, int* present, float* eyes, int mem, void* stream) {
     return guarded([&] {

@@ -457,7 +457,9 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
     };
     mark();
     // heads beside the trunk (not while profiling: the per-launch events there assume one stream)
-    const bool fork = fork_ && !marks;
+    // (with several lanes the chunks already overlap; the head streams and node events are one set per model, and sharing
+    // them between concurrently captured lanes crashes hipGraph capture)
+    const bool fork = fork_ && !marks && lanes_ == 1;
     hipStream_t const trunk = s;
     unsigned used_heads = 0;
     auto node_event = [&](size_t k) {

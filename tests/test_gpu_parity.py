@@ -143,6 +143,15 @@ def test_chunking_graph_and_batch_invariance(gpu):
     # frame 7 alone == frame 7 inside the batch
     for a, b in zip(m.run(x[7:8]), base):
         np.testing.assert_array_equal(a[0], b[7])
+    # frame ranges on concurrent streams ("lanes"), captured into one hipGraph and eager (regression: sharing the output-head
+    # side streams between concurrently captured lanes crashed graph capture)
+    m.set_option("chunk", 0)
+    for lanes, graph in ((2, 1), (3, 1), (2, 0)):
+        m.set_option("lanes", lanes)
+        m.set_option("graph", graph)
+        for rep in range(2):
+            for a, b in zip(m.run(x), base):
+                np.testing.assert_array_equal(a, b)
     m.close()
 
 
