@@ -11,6 +11,7 @@ python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -1 "$OUT/bench.json" | cut -c1-200
 python3 tools/bench_configs.py > "$OUT/configs.log" 2>&1
 grep config "$OUT/configs.log"
+for m in "back 256" "front 256" "full 128" "landmark 512" "iris 1024"; do set -- $m; python3 tools/profile_model.py $1 $2 2>/dev/null | grep -v amdgpu > "$OUT/launches_$1.txt"; done
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 30 --no-cpu-baseline > "$OUT/trace.log" 2>&1
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/fetch.log" 2>&1

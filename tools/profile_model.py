@@ -1,4 +1,4 @@
-"""Per-launch event times of one model's plan (mi_model_profile): python tools/profile_model.py iris 1024 [fuse_level]"""
+"""Per-launch event times of one model's plan (mi_model_profile): python tools/profile_model.py iris 1024 [option=value ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,8 +9,9 @@ FILES = {"back": "face_detection_back.tflite", "front": "face_detection_front.tf
          "sparse": "face_detection_full_range_sparse.tflite", "landmark": "face_landmark.tflite", "iris": "iris_landmark.tflite"}
 name, B = sys.argv[1], int(sys.argv[2])
 m = mi.Model(os.path.join(ROOT, "models", FILES[name]))
-if len(sys.argv) > 3:
-    m.set_option("fuse_level", int(sys.argv[3]))
+for kv in sys.argv[3:]:  # engine options, e.g. fuse=4 reuse=0
+    k, v = kv.split("=")
+    m.set_option(k, int(v))
 h, w = m.input_dims[1], m.input_dims[2]
 x = torch.rand((B, h, w, 3), device="cuda")
 recs = m.profile(x, reps=5)

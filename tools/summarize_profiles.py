@@ -48,3 +48,13 @@ json.dump({"round": tag, "workload": "back256_b256", "kernel": label, "rocprof_n
            "note": "reads = 2 x FETCH_SIZE (gfx950 16B/lane stream correction) + WRITE_SIZE, KiB -> bytes"},
           open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(open(os.path.join(out, "pmc_summary.json")).read())
+# per-launch event profiles of every model (tools/profile_model.py) and the secondary configs, when collect_profiles.sh produced them
+base = os.path.dirname(os.path.normpath(trace))
+for fpath in glob.glob(os.path.join(base, "launches_*.txt")):
+    shutil.copy(fpath, os.path.join(out, "%s_%s" % (tag, os.path.basename(fpath))))
+if os.path.exists(os.path.join(base, "configs.log")):
+    with open(os.path.join(out, "configs_%s.jsonl" % tag), "w") as fh:
+        fh.writelines(l for l in open(os.path.join(base, "configs.log")) if l.startswith("{"))
+if os.path.exists(os.path.join(base, "bench.json")):
+    with open(os.path.join(out, "bench_%s_n1.json" % tag), "w") as fh:
+        fh.write(open(os.path.join(base, "bench.json")).read().strip().splitlines()[-1] + "\n")
