@@ -535,6 +535,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.prog = d_programs_ + node_prog_[i];
                 a.nstages = static_cast<int>(n.stages.size());
                 a.B = F;
+                a.bands = n.res_bands;
                 a.const_off = n.res_const_off;
                 a.const_floats = n.res_const_floats;
                 a.lds_bytes = n.res_lds_bytes;

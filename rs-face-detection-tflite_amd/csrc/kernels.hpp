@@ -156,6 +156,11 @@ struct ResStage {
     ResRef res_g;
     int act = ACT_NONE;
     int dw_off = -1;                   // DW: LDS floats, scratch [dw_pg*32][roundup8(C) + 4]
+    // Row bands (ResLaunch::bands > 1): a workgroup owns output rows [r0, r0 + band_rows) of an image of band_H rows.
+    //   role 1 (pointwise GATHER from global): produces rows [r0 - 1, r1 + 1) clipped to the image into a bordered LDS tensor
+    //           of band_rows interior rows (the halo rows of interior bands are recomputed, rows outside the image stay zero)
+    //   role 2 (DW from that tensor): produces rows [r0, r1) into global memory (skip read from global memory)
+    int band_role = 0, band_rows = 0, band_H = 0, pad2_ = 0;
     // float offsets into the weights blob: pointwise / k x k weights in A-fragment order; the stage's small constants, padded and
     // ready to be copied to LDS: [9][Cp] depthwise taps + [Cp] depthwise bias (DW only), [Cop] bias, [Cop] negative-side slopes
     long w_pw = -1, cblob = -1;
@@ -169,7 +174,8 @@ struct ResBases {
 };
 struct ResLaunch {
     const ResStage* prog = nullptr;  // device memory
-    int nstages = 0, B = 0;
+    int nstages = 0, B = 0;          // B = frames
+    int bands = 1;                   // workgroups per frame (row bands)
     int const_off = 0;               // LDS floats: start of the per-stage constants area (two halves of const_floats each)
     int const_floats = 0;
     int lds_bytes = 0;

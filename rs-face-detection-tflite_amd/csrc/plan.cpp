@@ -452,6 +452,77 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
     return true;
 }
 
+
+// Level 5, large frames: the bottleneck pair  r = act(PW(x));  y = act(PW(DW3x3(r)) + b + x')  (iris 32x32: 64 -> 32 -> 64
+// channels) whose frame does not fit in LDS runs as ONE launch cut into row bands: a workgroup recomputes the one-row halo of
+// r for its band, keeps r in LDS and reads x / x' and writes y in global memory — r never reaches HBM.
+bool build_banded_bottleneck(const Graph& g, const std::vector<Node>& ns, size_t i, Node* out) {
+    if (i + 1 >= ns.size()) return false;
+    const Node &a = ns[i], &b = ns[i + 1];
+    if (a.kind != Node::Block || a.w >= 0 || a.res >= 0 || a.in.size() != 1) return false;
+    if (b.kind != Node::Block || b.w < 0 || b.in.size() != 1 || b.in[0] != a.out) return false;
+    if (b.KH != 3 || b.KW != 3 || b.sh != 1 || b.sw != 1 || b.padding != Padding::Same) return false;
+    if (b.res < 0 || b.res_mode != RES_DIRECT || b.res == b.in[0]) return false;
+    if (std::find(g.outputs.begin(), g.outputs.end(), a.out) != g.outputs.end()) return false;
+    for (size_t k = 0; k < ns.size(); k++) {
+        if (k == i + 1) continue;
+        if (std::find(ns[k].in.begin(), ns[k].in.end(), a.out) != ns[k].in.end() || ns[k].res == a.out) return false;  // r has one reader
+    }
+    const auto &sx = g.tensors[a.in[0]].shape, &sr = g.tensors[a.out].shape, &sy = g.tensors[b.out].shape, &ss = g.tensors[b.res].shape;
+    if (sx.size() != 4 || sr.size() != 4 || sy.size() != 4 || ss.size() != 4) return false;
+    const int H = sx[1], W = sx[2], Cx = sx[3], Cr = sr[3], Cy = sy[3];
+    if (sr[1] != H || sr[2] != W || sy[1] != H || sy[2] != W || ss[1] != H || ss[2] != W) return false;
+    if (Cx % 4 || Cr % 4 || Cy % 4 || ss[3] % 4 || ss[3] > Cy || H * W <= 256 || W > 64) return false;
+    Node::Stage p, c;
+    ResStage& ps = p.st;
+    ps.kind = RES_STAGE_GATHER; ps.src_H = H; ps.src_W = W; ps.src_C = Cx; ps.KH = ps.KW = 1; ps.S = 1; ps.Kv = Cx;
+    ps.Wo = W; ps.Co = Cr; ps.act = a.act; ps.band_role = 1; ps.band_H = H;
+    p.member = 0; p.src_t = a.in[0];
+    ResStage& cs = c.st;
+    cs.kind = RES_STAGE_DW; cs.src_W = W; cs.src_C = Cr; cs.src_PS = Cr + 4; cs.src_b = 1; cs.src_off = 0;
+    cs.KH = cs.KW = 3; cs.S = 1; cs.pt = cs.pl = 1; cs.Kv = Cr; cs.Wo = W; cs.Co = Cy; cs.act = b.act;
+    cs.res_mode = RES_DIRECT; cs.res_C = ss[3]; cs.res_H = H; cs.res_W = W; cs.band_role = 2; cs.band_H = H;
+    c.member = 1; c.dst_t = b.out; c.res_t = b.res;
+    const int MT = (Cy + 31) / 32, Cp = (Cr + 7) & ~7;
+    const int const_max = std::max(resident_const_floats(ps), resident_const_floats(cs));
+    if (const_max > kResConstMax) return false;
+    // rows per band: as many as keep two workgroups on a CU (half of the 160 KB each)
+    int R = 0, total = 0, dw_pg = 1;
+    for (int r = std::min(H, 32); r >= 2; r--) {
+        const int buf = (r + 2) * (W + 2) * (Cr + 4);
+        const int PGn = (r * W + 31) / 32;
+        const int pg = std::max(1, std::min(PGn, (8 + MT - 1) / MT));
+        const int t = ((buf + 3) & ~3) + 2 * const_max + pg * 32 * (Cp + 4);
+        if (t * 4 <= 80 * 1024 - 512) { R = r; total = t; dw_pg = pg; break; }
+    }
+    if (R < 2) return false;
+    R = (H + ((H + R - 1) / R) - 1) / ((H + R - 1) / R);  // same band count, even bands
+    const int buf = (R + 2) * (W + 2) * (Cr + 4);
+    {
+        const int PGn = (R * W + 31) / 32;
+        dw_pg = std::max(1, std::min(PGn, (8 + MT - 1) / MT));
+        total = ((buf + 3) & ~3) + 2 * const_max + dw_pg * 32 * (Cp + 4);
+    }
+    ps.Ho = R + 2; ps.band_rows = R; ps.dst_off = 0; ps.dst_PS = Cr + 4; ps.dst_b = 1; ps.zero_dst = buf;
+    cs.src_H = R; cs.Ho = R; cs.band_rows = R; cs.dw_pg = dw_pg;
+    Node r;
+    r.kind = Node::Resident;
+    r.res_const_off = (buf + 3) & ~3;
+    r.res_const_floats = const_max;
+    cs.dw_off = r.res_const_off + 2 * const_max;
+    r.res_lds_bytes = total * 4;
+    r.res_bands = (H + R - 1) / R;
+    r.members = {a, b};
+    r.stages = {p, c};
+    r.in = {a.in[0]};
+    if (b.res != a.in[0]) r.in.push_back(b.res);
+    r.out = b.out;
+    r.src_ops = a.src_ops;
+    r.src_ops.insert(r.src_ops.end(), b.src_ops.begin(), b.src_ops.end());
+    *out = std::move(r);
+    return true;
+}
+
 std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget) {
     std::vector<Node> outv;
     for (size_t i = 0; i < ns.size();) {
@@ -467,9 +538,13 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
         }
         // worth a launch of its own: at least two fused nodes, or a k x k convolution (otherwise the generic direct conv)
         bool take = have && (best.members.size() >= 2 || (best.members[0].kind == Node::Conv && best.members[0].KH > 1));
+        Node banded;
         if (take) {
             outv.push_back(std::move(best));
             i = best_j + 1;
+        } else if (build_banded_bottleneck(g, ns, i, &banded)) {
+            outv.push_back(std::move(banded));
+            i += 2;
         } else {
             outv.push_back(ns[i]);
             i++;
@@ -798,7 +873,8 @@ std::string Plan::describe() const {
             os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
                << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
         if (n.kind == Node::Resident) {
-            os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, frame resident, " << n.res_lds_bytes << " B LDS";
+            os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, " << (n.res_bands > 1 ? "row-band resident" : "frame resident") << ", " << n.res_lds_bytes << " B LDS";
+            if (n.res_bands > 1) os << ", " << n.res_bands << " bands of " << n.stages[0].st.band_rows << " rows";
             for (int t : n.extra_out) os << " +t" << t;
         }
         os << " ops{";

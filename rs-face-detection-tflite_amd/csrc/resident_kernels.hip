@@ -75,6 +75,7 @@ struct SrcView {
 struct EpiView {
     int Ho, Wo, Co, MT;
     int dst_off, dst_row, dst_PS, dst_b;
+    bool dst_lds;   // the output goes to LDS (dst_off itself may be shifted below zero by a row band's halo row)
     float* dstg;
     int res_mode, res_C, res_off, res_row, res_PS, res_b, res_W;
     const float* resg;
@@ -84,7 +85,7 @@ struct EpiView {
 __device__ __forceinline__ EpiView make_epi(const ResStage& st, const ResBases& bs, int frame) {
     EpiView e;
     e.Ho = st.Ho; e.Wo = st.Wo; e.Co = st.Co; e.MT = (st.Co + 31) >> 5;
-    e.dst_off = st.dst_off; e.dst_b = st.dst_b; e.dst_row = st.Wo + 2 * st.dst_b; e.dst_PS = st.dst_PS;
+    e.dst_lds = st.dst_off >= 0; e.dst_off = st.dst_off; e.dst_b = st.dst_b; e.dst_row = st.Wo + 2 * st.dst_b; e.dst_PS = st.dst_PS;
     e.dstg = st.dst_g.base >= 0 ? resolve(bs, st.dst_g, frame) : nullptr;
     e.res_mode = st.res_mode; e.res_C = st.res_C; e.res_off = st.res_off; e.res_b = st.res_b; e.res_W = st.res_W;
     e.res_row = st.res_W + 2 * st.res_b; e.res_PS = st.res_PS;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, 
         MI_RES_USTAMP(6)
         // ---- epilogue: lane holds pixel q, output channels mt*32 + 8*gq + 4*h .. +3 in D[4*gq .. 4*gq+3]
         if (valid) {
-            float* dl = ep.dst_off >= 0 ? lds + ep.dst_off + ((oy + ep.dst_b) * ep.dst_row + ox + ep.dst_b) * ep.dst_PS : nullptr;
+            float* dl = ep.dst_lds ? lds + ep.dst_off + ((oy + ep.dst_b) * ep.dst_row + ox + ep.dst_b) * ep.dst_PS : nullptr;
             float* dg = ep.dstg ? ep.dstg + ((long)oy * ep.Wo + ox) * ep.Co : nullptr;
             const float* rl = lds + ep.res_off + (ep.res_mode == RES_DIRECT ? ((oy + ep.res_b) * ep.res_row + ox + ep.res_b) * ep.res_PS
                                                                             : ((2 * oy + ep.res_b) * ep.res_row + 2 * ox + ep.res_b) * ep.res_PS);
@@ -263,11 +264,11 @@ __device__ __forceinline__ int const_count(const ResStage& st) {  // floats, a m
     return (st.kind == RES_STAGE_DW ? 10 * Cp : 0) + 2 * Cop;
 }
 
-__global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __restrict__ prog, int nstages, int const_off, int const_floats, ResBases bs,
+__global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __restrict__ prog, int nstages, int const_off, int const_floats, int bands, ResBases bs,
                                                           unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x;
-    const int frame = blockIdx.x;
+    const int frame = blockIdx.x / bands, band = blockIdx.x - frame * bands;
     auto zero_dst = [&](const ResStage& st) {
         const int n4 = st.zero_dst >> 2, off = st.dst_off;
         for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(lds + off)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -309,9 +310,15 @@ __global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __rest
                 *reinterpret_cast<float4*>(lds + doff + ((y + db) * drow + x + db) * dPS + 4 * c4) = rld4(src + 4 * (long)i);
             }
         } else if (st.kind == RES_STAGE_DW) {
-            const EpiView ep = make_epi(st, bs, frame);
+            EpiView ep = make_epi(st, bs, frame);
+            if (st.band_role == 2) {  // this band's rows [r0, r1) of the image
+                const int r0 = band * st.band_rows, r1 = min(st.band_H, r0 + st.band_rows);
+                ep.Ho = r1 - r0;
+                if (ep.dstg) ep.dstg += (long)r0 * st.Wo * st.Co;
+                if (ep.resg) ep.resg += (long)r0 * st.Wo * st.res_C;
+            }
             const int Kv = st.Kv, Cp = (Kv + 7) & ~7, C4p = Cp >> 2, PSs = Cp + 4;
-            const int Wo = st.Wo, npix = st.Ho * Wo, PGn = (npix + 31) >> 5, dw_pg = st.dw_pg, dw_off = st.dw_off;
+            const int Wo = st.Wo, npix = ep.Ho * Wo, PGn = (npix + 31) >> 5, dw_pg = st.dw_pg, dw_off = st.dw_off;
             const int srow = st.src_W + 2 * st.src_b, sPS = st.src_PS, S = st.S;
             const int src0 = st.src_off + ((st.src_b - st.pt) * srow + st.src_b - st.pl) * sPS;  // tap (0,0) of output pixel (0,0)
             SrcView sv;
@@ -344,16 +351,24 @@ __global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __rest
                 if (pg1 < PGn) __syncthreads();  // the scratch is rewritten by the next batch
             }
         } else {
-            const EpiView ep = make_epi(st, bs, frame);
+            EpiView ep = make_epi(st, bs, frame);
             SrcView sv;
             sv.linear = false; sv.px_base = 0; sv.C = st.src_C; sv.KW = st.KW; sv.S = st.S; sv.Kv = st.Kv;
-            const int PGn = (st.Ho * st.Wo + 31) >> 5;
+            long src_rows = 0;
+            if (st.band_role == 1) {  // rows [r0 - 1, r1 + 1) of the image, clipped: local row 0 = image row lo
+                const int r0 = band * st.band_rows, r1 = min(st.band_H, r0 + st.band_rows);
+                const int lo = max(0, r0 - 1), hi = min(st.band_H, r1 + 1);
+                ep.Ho = hi - lo;
+                ep.dst_off += (lo - r0) * ep.dst_row * ep.dst_PS;  // LDS row of image row y is y - r0 + border
+                src_rows = lo;
+            }
+            const int PGn = (ep.Ho * st.Wo + 31) >> 5;
             if (st.src_off >= 0) {
                 sv.g = nullptr; sv.off = st.src_off; sv.row = st.src_W + 2 * st.src_b; sv.PS = st.src_PS; sv.b = st.src_b;
                 if (sv.KW == 1) run_units<2>(ep, sv, lds, cst, 0, PGn, ust);
                 else run_units<0>(ep, sv, lds, cst, 0, PGn, ust);
             } else {
-                sv.g = resolve(bs, st.src_g, frame); sv.off = 0; sv.row = st.src_W; sv.PS = st.src_C; sv.b = 0;
+                sv.g = resolve(bs, st.src_g, frame) + src_rows * st.src_W * st.src_C; sv.off = 0; sv.row = st.src_W; sv.PS = st.src_C; sv.b = 0;
                 run_units<1>(ep, sv, lds, cst, 0, PGn, ust);
             }
         }
@@ -384,15 +399,15 @@ int resident_const_floats(const ResStage& st) {
 }
 
 int launch_resident(const ResLaunch& a, void* stream) {
-    if (!a.prog || a.nstages < 1 || a.B < 1 || a.lds_bytes > 160 * 1024 || a.const_floats > kResConstMax) return (int)hipErrorInvalidValue;
+    if (!a.prog || a.nstages < 1 || a.B < 1 || a.bands < 1 || a.lds_bytes > 160 * 1024 || a.const_floats > kResConstMax) return (int)hipErrorInvalidValue;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(resident_kernel, dim3((unsigned)a.B), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages, a.const_off, a.const_floats,
-                       a.bases,
+    hipLaunchKernelGGL(resident_kernel, dim3((unsigned)(a.B * a.bands)), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages, a.const_off, a.const_floats,
+                       a.bands, a.bases,
 #ifdef MI_RES_STAMPS
                        g_res_stamps
 #else
