@@ -381,6 +381,58 @@ def test_batch256_properties(gpu, gold):
     fd.close()
 
 
+def test_config3_landmark_batch512_properties(gpu, oracle, gold):
+    """BASELINE config 3 at full size (512 ROIs 192x192 through the face-mesh net + projection + face flag): the batch is 8
+    distinct ROIs repeated 64 times in a shuffled order, so every copy must reproduce its original bit for bit (frames are
+    independent whatever workgroup, band or stage program they land in), and the 8 originals are checked against the oracle."""
+    torch = pytest.importorskip("torch")
+    fl = gpu.FaceLandmark()
+    rs = np.random.RandomState(5)
+    face = gold["man_face_u8"].astype(np.float32) / 255.0
+    base = np.stack([face, face[:, ::-1].copy(), np.roll(face, (9, -14), axis=(0, 1)), face * 0.7] + [rs.uniform(0, 1, face.shape).astype(np.float32) for _ in range(4)])
+    order = rs.permutation(512) % 8
+    xd = torch.from_numpy(base[order]).cuda()
+    lm, present, _flags = fl.infer_tensor(xd)
+    torch.cuda.synchronize()
+    lm, present = lm.cpu().numpy(), present.cpu().numpy()
+    first = {int(k): int(np.where(order == k)[0][0]) for k in range(8)}
+    for i in range(512):
+        np.testing.assert_array_equal(lm[i], lm[first[int(order[i])]])
+        assert present[i] == present[first[int(order[i])]]
+    assert present[first[0]] == 1 and present[first[2]] == 1          # the face crops carry a face
+    om = oracle.Model(model_path("landmark"))
+    raw, flag = om.run(base, nthreads=8)
+    for k in range(8):
+        want = raw[k].reshape(468, 3) / np.array([192.0, 192.0, 192.0])  # project_landmarks without ROI: x/w, y/h, z/w (transform.rs:351-372)
+        if present[first[k]]:
+            np.testing.assert_allclose(lm[first[k]], want, atol=2e-5)
+    fl.close()
+
+
+def test_config5_pipeline_128_frames_properties(gpu, man_image):
+    """BASELINE config 5 at its per-GPU size (128 frames 192x192, full-range detector -> mesh -> 2 x iris on the device): periodic
+    input, so results must be periodic bit for bit; noise frames give no face and zeroed downstream records."""
+    torch = pytest.importorskip("torch")
+    from PIL import Image
+    img = np.asarray(Image.fromarray(man_image).resize((192, 192)))
+    rs = np.random.RandomState(11)
+    period = [img, rs.randint(0, 256, img.shape).astype(np.uint8), np.roll(img, (7, -5), axis=(0, 1)), np.zeros_like(img)]
+    frames = torch.from_numpy(np.stack([period[b % 4] for b in range(128)])).cuda()
+    pipe = gpu.Pipeline(gpu.FaceDetectionModel.Full)
+    out = {k: v.cpu().numpy() for k, v in pipe.run(frames).items()}
+    for k, v in out.items():
+        for b in range(4, 128):
+            np.testing.assert_array_equal(v[b], v[b % 4], err_msg="%s frame %d" % (k, b))
+    assert out["face_counts"][0] >= 1 and out["face_counts"][2] >= 1 and out["face_counts"][3] == 0
+    assert out["present"][0] == 1 and out["present"][3] == 0
+    assert not out["landmarks"][3].any() and not out["eyes"][3].any()
+    # the shifted frame moves the face box by about the shift (5 px left, 7 px down at 192 px; anchors sit every 4 px)
+    c0 = (out["faces"][0][:2] + out["faces"][0][2:4]) / 2 * 192
+    c2 = (out["faces"][2][:2] + out["faces"][2][2:4]) / 2 * 192
+    assert abs((c2[0] - c0[0]) + 5) < 4 and abs((c2[1] - c0[1]) - 7) < 4
+    pipe.close()
+
+
 def _oracle_pipeline(oracle, models, img):
     """lib.rs:18-40 through the oracle, one frame."""
     fd, fl, ir = models
