@@ -52,3 +52,12 @@ torch.cuda.synchronize()
 dt = timeit(lambda: pipe.run(fd_))
 print(json.dumps({"config": "full_range 192x192 -> face_landmark -> 2x iris, 128 frames/GPU, all on device", "ms_per_batch": round(dt * 1e3, 3),
                   "frames_per_s": round(B / dt), "faces_found": int((out["face_counts"] > 0).sum().item()), "meshes": int(out["present"].sum().item())}))
+
+# convert_image_to_mat (utils.rs:8-21): JPEG bytes -> RGB, host entropy decoding + device sample arithmetic
+jpg = open(os.path.join(ROOT, "tests", "golden", "man.jpg"), "rb").read()
+for to_dev in (False, True):
+    for _ in range(3): mi.convert_image_to_mat(jpg, to_device=to_dev)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(50): mi.convert_image_to_mat(jpg, to_device=to_dev)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 50
+    print(json.dumps({"config": "convert_image_to_mat man.jpg 540x360 4:2:0 (%s)" % ("RGB left in HBM" if to_dev else "RGB copied to host"), "ms_per_image": round(dt * 1e3, 3), "images_per_s": round(1 / dt)}))
