@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 using namespace mi;
 
@@ -14,6 +15,8 @@ using namespace mi;
 int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 1024, H = argc > 2 ? atoi(argv[2]) : 8, C = argc > 3 ? atoi(argv[3]) : 128, NB = argc > 4 ? atoi(argv[4]) : 6;
     if (NB < 1 || H < 1 || C % 8 || B < 1) { printf("bad arguments\n"); return 1; }
+    const int NB_arg = NB; (void)NB_arg;
+    const bool banded = argc > 5 && std::string(argv[5]) == "band";   // row-band bottleneck (iris 32x32x64): one pointwise + one depthwise stage
     const int R = C / 2;
     size_t fs = (size_t)H * H * C;
     float *din, *dout, *dw;
@@ -28,6 +31,27 @@ int main(int argc, char** argv) {
     const int PSX = C + 4, PSR = R + 4;
     const int offX = 0, offR = H * H * PSX;                 // X unbordered, R bordered
     const int sizeR = (H + 2) * (H + 2) * PSR;
+    int bands = 1;
+    if (banded) {
+        const int BR = 8;
+        bands = (H + BR - 1) / BR;
+        ResStage a;
+        a.kind = RES_STAGE_GATHER; a.src_H = H; a.src_W = H; a.src_C = C; a.KH = a.KW = 1; a.S = 1; a.Kv = C;
+        a.Ho = BR + 2; a.Wo = H; a.Co = R; a.act = ACT_PRELU; a.band_role = 1; a.band_rows = BR; a.band_H = H;
+        a.src_g.base = 1; a.src_g.fs = (long)fs;
+        a.dst_off = 0; a.dst_PS = R + 4; a.dst_b = 1; a.zero_dst = (BR + 2) * (H + 2) * (R + 4);
+        a.w_pw = put((size_t)((R + 31) / 32 * 32) * C, 0.01f); a.cblob = put(resident_const_floats(a), 0.01f);
+        prog.push_back(a);
+        ResStage b;
+        b.kind = RES_STAGE_DW; b.src_off = 0; b.src_H = BR; b.src_W = H; b.src_C = R; b.src_PS = R + 4; b.src_b = 1;
+        b.KH = b.KW = 3; b.S = 1; b.pt = b.pl = 1; b.Kv = R; b.Ho = BR; b.Wo = H; b.Co = C; b.act = ACT_PRELU;
+        b.res_mode = RES_DIRECT; b.res_C = C; b.res_H = H; b.res_W = H; b.band_role = 2; b.band_rows = BR; b.band_H = H;
+        b.res_g.base = 1; b.res_g.fs = (long)fs; b.dst_g.base = 2; b.dst_g.fs = (long)fs;
+        b.w_pw = put((size_t)((C + 31) / 32 * 32) * R, 0.01f); b.cblob = put(resident_const_floats(b), 0.01f);
+        b.dw_pg = std::max(1, std::min((BR * H + 31) / 32, (8 + (C + 31) / 32 - 1) / ((C + 31) / 32)));
+        prog.push_back(b);
+        NB = 0;
+    } else
     {   // X <- input (pointwise identity would need weights; use a LOAD with border 0)
         ResStage st; st.kind = RES_STAGE_LOAD; st.src_H = H; st.src_W = H; st.src_C = C;
         st.src_g.base = 1; st.src_g.fs = (long)fs;
@@ -55,7 +79,8 @@ int main(int argc, char** argv) {
     int cmax = 0;
     for (auto& st : prog) cmax = std::max(cmax, resident_const_floats(st));
     ResLaunch L;
-    L.const_off = (offR + sizeR + 3) & ~3;
+    L.bands = bands;
+    L.const_off = banded ? ((prog[0].zero_dst + 3) & ~3) : (offR + sizeR + 3) & ~3;
     L.const_floats = cmax;
     int scratch = 0;
     for (auto& st : prog)
@@ -81,7 +106,8 @@ int main(int argc, char** argv) {
     printf("%.3f ms per launch = %.2f us per stage per round-of-512  %.2f TFLOP/s\n", ms, ms * 1e3 / L.nstages / std::max(1.0, B / 512.0), 2 * macs / ms / 1e9);
 #ifdef MI_RES_STAMPS
     {
-        size_t n8 = (size_t)B * L.nstages * 8;
+        const int WG = B * L.bands;
+        size_t n8 = (size_t)WG * L.nstages * 8;
         unsigned long long* dst; CK(hipMalloc(&dst, n8 * 8)); CK(hipMemset(dst, 0, n8 * 8));
         g_res_stamps = dst;
         hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
@@ -92,31 +118,31 @@ int main(int argc, char** argv) {
         std::vector<unsigned long long> h(n8);
         CK(hipMemcpy(h.data(), dst, n8 * 8, hipMemcpyDeviceToHost));
         unsigned long long tmin = ~0ull, tmax = 0;
-        for (int b = 0; b < B; b++) { tmin = std::min(tmin, h[(size_t)b * L.nstages * 8]); tmax = std::max(tmax, h[((size_t)b * L.nstages + L.nstages - 1) * 8 + 3]); }
+        for (int b = 0; b < WG; b++) { tmin = std::min(tmin, h[(size_t)b * L.nstages * 8]); tmax = std::max(tmax, h[((size_t)b * L.nstages + L.nstages - 1) * 8 + 3]); }
         size_t zeros[8] = {0};
         for (size_t i = 0; i < n8; i++) zeros[i & 7] += h[i] == 0;
         printf("zero stamps per slot: %zu %zu %zu %zu %zu %zu %zu %zu of %zu\n", zeros[0], zeros[1], zeros[2], zeros[3], zeros[4], zeros[5], zeros[6], zeros[7], n8 / 8);
         // the counters of different XCDs are not aligned: calibrate on the mean workgroup lifetime, which equals the launch's
         // event time when every workgroup is resident at once (B <= 256)
         double life = 0;
-        for (int b = 0; b < B; b++) life += h[((size_t)b * L.nstages + L.nstages - 1) * 8 + 3] - h[(size_t)b * L.nstages * 8];
-        const double tick_us = B <= 256 ? kms * 1e3 / (life / B) : 0.01;
+        for (int b = 0; b < WG; b++) life += h[((size_t)b * L.nstages + L.nstages - 1) * 8 + 3] - h[(size_t)b * L.nstages * 8];
+        const double tick_us = WG <= 256 ? kms * 1e3 / (life / WG) : (argc > 6 ? atof(argv[6]) : 0.00059);
         (void)tmin; (void)tmax;
-        printf("stamped launch %.3f ms, mean workgroup lifetime %.0f ticks -> %.5f us per tick\n", kms, life / B, tick_us);
+        printf("stamped launch %.3f ms, mean workgroup lifetime %.0f ticks -> %.5f us per tick\n", kms, life / WG, tick_us);
         printf("stage kind: prefetch-issue | work | closing barrier || first unit of wave 0: ring issue | mfma loop | epilogue   [us]\n");
         for (int st = 0; st < L.nstages; st++) {
             double a[6] = {0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < B; b++) {
+            for (int b = 0; b < WG; b++) {
                 const unsigned long long* q = &h[((size_t)b * L.nstages + st) * 8];
                 a[0] += q[1] - q[0]; a[1] += q[2] - q[1]; a[2] += q[3] - q[2];
                 if (q[7] > q[4]) { a[3] += q[5] - q[4]; a[4] += q[6] - q[5]; a[5] += q[7] - q[6]; }
             }
-            printf("  %2d: %d   %6.2f  %6.2f  %6.2f  ||  %6.2f  %6.2f  %6.2f\n", st, prog[st].kind, a[0] / B * tick_us, a[1] / B * tick_us, a[2] / B * tick_us,
-                   a[3] / B * tick_us, a[4] / B * tick_us, a[5] / B * tick_us);
+            printf("  %2d: %d   %6.2f  %6.2f  %6.2f  ||  %6.2f  %6.2f  %6.2f\n", st, prog[st].kind, a[0] / WG * tick_us, a[1] / WG * tick_us, a[2] / WG * tick_us,
+                   a[3] / WG * tick_us, a[4] / WG * tick_us, a[5] / WG * tick_us);
         }
         double tot = 0;
-        for (int b = 0; b < B; b++) tot += h[((size_t)b * L.nstages + L.nstages - 1) * 8 + 3] - h[(size_t)b * L.nstages * 8];
-        printf("  workgroup lifetime %.1f us\n", tot / B * tick_us);
+        for (int b = 0; b < WG; b++) tot += h[((size_t)b * L.nstages + L.nstages - 1) * 8 + 3] - h[(size_t)b * L.nstages * 8];
+        printf("  workgroup lifetime %.1f us\n", tot / WG * tick_us);
     }
 #endif
     return 0;
