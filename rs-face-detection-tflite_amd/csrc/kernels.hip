@@ -107,7 +107,7 @@ template <int K, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     // PP output pixels per thread (rows ly and ly + 8): every scalar-loaded weight pair then feeds PP packed FMAs, which
     // halves the scalar-cache round trips per FMA (they, not the VALU, set the pace at one pixel per thread)
-    constexpr int PP = CO <= 32 ? 2 : 1;
+    constexpr int PP = 2;
     constexpr int TW = 32, TH = 8 * PP;                  // output tile
     constexpr int IW = 2 * TW + K - 2, IH = 2 * TH + K - 2;  // input tile (stride 2)
     constexpr int RS = (IW * 3 + 1) & ~1;                // row stride in floats (even: 8-byte aligned float2 reads)
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
 
 template <int K, int CO>
 static int launch_stem(const ConvArgs& a, hipStream_t s) {
-    constexpr int TH = CO <= 32 ? 16 : 8;  // rows of a tile (two output pixels per thread up to 32 channels)
+    constexpr int TH = 16;  // rows of a tile (two output pixels per thread)
     unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + TH - 1) / TH));
     hipLaunchKernelGGL((stem_conv_kernel<K, CO>), dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
     return (int)hipGetLastError();
