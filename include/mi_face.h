@@ -226,6 +226,13 @@ int mi_pipeline_run(mi_pipeline *p, const uint8_t *frames, int batch, int width,
 /* ------------------------------------------------------------------------------------------------------------------
  * Host-side helpers the reference exports next to the three structs
  * ---------------------------------------------------------------------------------------------------------------- */
+/* transform::bbox_to_roi(bbox, image_size, rotation_keypoints, scale, mode) — transform.rs:44-109.  bbox = {xmin, ymin, xmax,
+ * ymax} normalised; rotation_keypoints = {x0, y0, x1, y1} in absolute pixels or NULL; size_mode 0 Default, 1 SquareLong,
+ * 2 SquareShort (transform.rs:24-34).  MI_EINVAL when the box is not normalised (the reference's Err). */
+int mi_bbox_to_roi(const double bbox[4], int image_w, int image_h, const double *rotation_keypoints, double scale_x,
+                   double scale_y, int size_mode, mi_rect *out);
+/* transform::bbox_from_landmarks(landmarks) — transform.rs:146-165: {xmin, ymin, xmax, ymax}; MI_EINVAL below 2 landmarks. */
+int mi_bbox_from_landmarks(const mi_landmark *landmarks, int count, double bbox_out[4]);
 /* face_detection_to_roi(face_detection, image_size, None) — face_landmark.rs:180-198 (SquareLong, scale 1.5). */
 int mi_face_detection_to_roi(const mi_detection *det, int image_w, int image_h, mi_rect *out);
 /* iris_roi_from_face_landmarks(face_landmarks, image_size) — iris_landmark.rs:268-292 (scale 2.3). */

@@ -186,6 +186,25 @@ inline std::pair<Rect, Rect> iris_roi_from_face_landmarks(const std::vector<Land
     return {Rect::from(l), Rect::from(r)};
 }
 
+// bbox_to_roi(bbox, image_size, rotation_keypoints, scale, mode) (transform.rs:44-109); SizeMode as in transform.rs:24-34
+enum class SizeMode { Default = 0, SquareLong = 1, SquareShort = 2 };
+inline Rect bbox_to_roi(const std::array<double, 4>& bbox, std::pair<int, int> image_size,
+                        std::optional<std::array<double, 4>> rotation_keypoints = std::nullopt, std::pair<double, double> scale = {1.0, 1.0},
+                        SizeMode mode = SizeMode::Default) {
+    mi_rect r{};
+    detail::check(mi_bbox_to_roi(bbox.data(), image_size.first, image_size.second, rotation_keypoints ? rotation_keypoints->data() : nullptr,
+                                 scale.first, scale.second, static_cast<int>(mode), &r));
+    return Rect::from(r);
+}
+// bbox_from_landmarks(landmarks) (transform.rs:146-165) -> {xmin, ymin, xmax, ymax}
+inline std::array<double, 4> bbox_from_landmarks(const std::vector<Landmark>& lm) {
+    std::vector<mi_landmark> c(lm.size());
+    for (size_t i = 0; i < lm.size(); i++) c[i] = mi_landmark{lm[i].x, lm[i].y, lm[i].z};
+    std::array<double, 4> out{};
+    detail::check(mi_bbox_from_landmarks(c.data(), static_cast<int>(c.size()), out.data()));
+    return out;
+}
+
 // convert_image_to_mat(im_bytes) (utils.rs:8-21): an owning RGB picture; `.image()` is the borrowed view the infer() calls take
 struct OwnedImage {
     std::vector<std::uint8_t> rgb;

@@ -37,7 +37,7 @@ EXPORTS = [
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
     "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_set_option", "mi_pipeline_run",
-    "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor", "mi_jpeg_info", "mi_jpeg_decode_rgb",
+    "mi_bbox_to_roi", "mi_bbox_from_landmarks", "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor", "mi_jpeg_info", "mi_jpeg_decode_rgb",
 ]
 
 
@@ -183,6 +183,8 @@ def lib():
     L.mi_face_detection_to_roi.argtypes = [C.POINTER(CDetection), C.c_int, C.c_int, C.POINTER(Rect)]
     L.mi_iris_roi_from_face_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(Rect)]
     L.mi_update_face_landmarks_with_iris_results.argtypes = [C.POINTER(CLandmark)] * 4
+    L.mi_bbox_to_roi.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_int, C.POINTER(Rect)]
+    L.mi_bbox_from_landmarks.argtypes = [C.POINTER(CLandmark), C.c_int, C.POINTER(C.c_double)]
     L.mi_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mi_jpeg_decode_rgb.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p]
     L.mi_image_to_tensor.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.c_int, C.c_int,
@@ -583,6 +585,26 @@ def iris_roi_from_face_landmarks(face_landmarks, image_size):
     a, b = Rect(), Rect()
     _check(lib().mi_iris_roi_from_face_landmarks(arr, int(image_size[0]), int(image_size[1]), C.byref(a), C.byref(b)))
     return a, b
+
+
+def bbox_to_roi(bbox, image_size, rotation_keypoints=None, scale=(1.0, 1.0), size_mode=0) -> Rect:
+    """transform.rs:44-109.  bbox (xmin, ymin, xmax, ymax) normalised; rotation_keypoints [(x0, y0), (x1, y1)] in pixels;
+    size_mode 0 Default, 1 SquareLong, 2 SquareShort."""
+    b = (C.c_double * 4)(*[float(v) for v in bbox])
+    kp = None
+    if rotation_keypoints is not None and len(rotation_keypoints) >= 2:   # fewer than two keypoints: rotation 0 (transform.rs:64-66)
+        kp = (C.c_double * 4)(*[float(v) for p in rotation_keypoints[:2] for v in p])
+    r = Rect()
+    _check(lib().mi_bbox_to_roi(b, int(image_size[0]), int(image_size[1]), kp, float(scale[0]), float(scale[1]), int(size_mode), C.byref(r)))
+    return r
+
+
+def bbox_from_landmarks(landmarks):
+    """transform.rs:146-165 -> (xmin, ymin, xmax, ymax)."""
+    arr = (CLandmark * max(len(landmarks), 1))(*[CLandmark(l.x, l.y, l.z) for l in landmarks])
+    out = (C.c_double * 4)()
+    _check(lib().mi_bbox_from_landmarks(arr, len(landmarks), out))
+    return tuple(out)
 
 
 def jpeg_info(im_bytes: bytes):

@@ -835,6 +835,28 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
 }
 
 // ------------------------------------------------------------------------------------------------ host helpers
+int mi_bbox_to_roi(const double bbox[4], int image_w, int image_h, const double* rotation_keypoints, double scale_x, double scale_y, int size_mode,
+                   mi_rect* out) {
+    return guarded([&] {
+        require(bbox && out, "null argument");
+        require(size_mode >= 0 && size_mode <= 2, "size_mode must be 0 (Default), 1 (SquareLong) or 2 (SquareShort)");
+        if (!mi::bbox_to_roi(bbox, image_w, image_h, rotation_keypoints, scale_x, scale_y, size_mode, out)) throw ApiError(MI_EINVAL, "bbox must be normalized");
+    });
+}
+
+int mi_bbox_from_landmarks(const mi_landmark* lm, int count, double bbox_out[4]) {
+    return guarded([&] {
+        require(lm && bbox_out, "null argument");
+        if (count < 2) throw ApiError(MI_EINVAL, "landmarks must contain at least 2 items");  // transform.rs:147-149
+        double xmin = INFINITY, ymin = INFINITY, xmax = -INFINITY, ymax = -INFINITY;
+        for (int i = 0; i < count; i++) {  // f64::min / max: a NaN operand is ignored, like fmin / fmax
+            xmin = std::fmin(xmin, lm[i].x); ymin = std::fmin(ymin, lm[i].y);
+            xmax = std::fmax(xmax, lm[i].x); ymax = std::fmax(ymax, lm[i].y);
+        }
+        bbox_out[0] = xmin; bbox_out[1] = ymin; bbox_out[2] = xmax; bbox_out[3] = ymax;
+    });
+}
+
 int mi_face_detection_to_roi(const mi_detection* det, int image_w, int image_h, mi_rect* out) {
     return guarded([&] {
         require(det && out, "null argument");

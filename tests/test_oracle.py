@@ -135,3 +135,33 @@ def test_update_face_landmarks_with_iris_results(mi, oracle):
     assert (got[33] == left[0]).all() and (got[263] == right[0]).all()   # eye corners: first entries of the maps
     with pytest.raises(mi.MiError):                              # the reference returns Err for a wrong landmark count
         mi.update_face_landmarks_with_iris_results(lm(face[:100]), mi.IrisResults(lm(left), []), mi.IrisResults(lm(right), []))
+
+
+def test_bbox_helpers_through_the_c_abi(mi, oracle):
+    """transform.rs:44-109 (bbox_to_roi / select_roi_size, all three SizeModes, rotation wrap) and 146-165 (bbox_from_landmarks)
+    through the C ABI (host-only: runs without a GPU) against the oracle's restatement, dtype for dtype (f64): bit-exact."""
+    import ctypes as C
+    rs = np.random.RandomState(7)
+    L = oracle.lib()
+    for _ in range(200):
+        x0, y0 = rs.rand(2) * 0.6
+        bbox = (x0, y0, x0 + 0.05 + rs.rand() * 0.3, y0 + 0.05 + rs.rand() * 0.3)
+        size = (int(rs.randint(64, 2000)), int(rs.randint(64, 2000)))
+        kp = [(rs.rand() * size[0], rs.rand() * size[1]), (rs.rand() * size[0], rs.rand() * size[1])] if rs.rand() < 0.8 else None
+        scale = (1.0 + rs.rand() * 2, 1.0 + rs.rand() * 2)
+        mode = int(rs.randint(0, 3))
+        got = mi.bbox_to_roi(bbox, size, kp, scale, mode)
+        want = oracle.Rect()
+        b = (C.c_double * 4)(*bbox)
+        k = (C.c_double * 4)(*[v for p in kp for v in p]) if kp else None
+        assert L.orc_bbox_to_roi(b, size[0], size[1], k, scale[0], scale[1], mode, C.byref(want)) == 0
+        for f in ("x_center", "y_center", "width", "height", "rotation"):
+            assert getattr(got, f) == getattr(want, f), f
+        assert -np.pi <= got.rotation < np.pi and got.normalized
+    with pytest.raises(mi.MiError):
+XX
+    pts = rs.rand(50, 3)
+    box = mi.bbox_from_landmarks([mi.Landmark(*map(float, p)) for p in pts])
+    assert box == (pts[:, 0].min(), pts[:, 1].min(), pts[:, 0].max(), pts[:, 1].max())
+    with pytest.raises(mi.MiError):
+        mi.bbox_from_landmarks([mi.Landmark(0.1, 0.2, 0.0)])
