@@ -159,7 +159,8 @@ def test_bbox_helpers_through_the_c_abi(mi, oracle):
             assert getattr(got, f) == getattr(want, f), f
         assert -np.pi <= got.rotation < np.pi and got.normalized
     with pytest.raises(mi.MiError):
-XX
+        mi.bbox_to_roi((0.1, 0.1, 2.5, 0.5), (100, 100))        # BBox::normalized is xmin >= -1 && xmax < 2 && ymin >= -1 (types.rs:133-135)
+    assert mi.bbox_to_roi((0.1, 0.1, 1.5, 0.5), (100, 100)).normalized   # ... so this box passes, as in the reference
     pts = rs.rand(50, 3)
     box = mi.bbox_from_landmarks([mi.Landmark(*map(float, p)) for p in pts])
     assert box == (pts[:, 0].min(), pts[:, 1].min(), pts[:, 0].max(), pts[:, 1].max())
