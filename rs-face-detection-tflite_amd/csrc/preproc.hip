@@ -25,9 +25,12 @@ namespace mi {
 namespace {
 
 // ---------------------------------------------------------------------------------------------- geometry (host + device)
-__host__ __device__ inline bool solve_homography(const float src[4][2], const float dst[4][2], double M[9]) {
+// `ws`: the 8x9 system.  The row swaps index it dynamically, so a local array lives in scratch memory on the device (a
+// dependent HBM round trip per access: 83 us per launch for one lane's elimination); the batched kernel passes LDS instead.
+__host__ __device__ inline bool solve_homography(const float src[4][2], const float dst[4][2], double M[9], double (*ws)[9] = nullptr) {
     // 8x8 system of cv::getPerspectiveTransform, Gauss-Jordan with partial pivoting in f64
-    double a[8][9];
+    double local[8][9];
+    double (*a)[9] = ws ? ws : local;
     for (int i = 0; i < 8; i++)
         for (int j = 0; j < 9; j++) a[i][j] = 0.0;
     for (int i = 0; i < 4; i++) {
@@ -66,7 +69,7 @@ __host__ __device__ inline bool inverse3(const double m[9], double o[9]) {
 }
 
 // transform.rs:190-257 — everything that depends only on (image size, ROI, output size, keep_aspect_ratio)
-__host__ __device__ inline PreGeom compute_geom(int width, int height, const RectD* roi_in, int out_w, int out_h, bool keep_aspect) {
+__host__ __device__ inline PreGeom compute_geom(int width, int height, const RectD* roi_in, int out_w, int out_h, bool keep_aspect, double (*ws)[9] = nullptr) {
     PreGeom g;
     for (int i = 0; i < 9; i++) g.Minv[i] = 0.0;
     g.pad_x = g.pad_y = 0.0;
@@ -94,7 +97,7 @@ __host__ __device__ inline PreGeom compute_geom(int width, int height, const Rec
     float src[4][2], dst[4][2] = {{0.f, 0.f}, {(float)g.warp_w, 0.f}, {(float)g.warp_w, (float)g.warp_h}, {0.f, (float)g.warp_h}};
     for (int i = 0; i < 4; i++) { src[i][0] = (float)p[i][0]; src[i][1] = (float)p[i][1]; }
     double M[9];
-    if (!solve_homography(src, dst, M) || !inverse3(M, g.Minv)) return g;
+    if (!solve_homography(src, dst, M, ws) || !inverse3(M, g.Minv)) return g;
     // OpenCV tile geometry of warpPerspective (BLOCK_SZ = 32): bh0 = min(16, h); bw0 = min(1024 / bh0, w)
     const int bh0 = g.warp_h < 16 ? g.warp_h : 16;
     g.bw0 = (1024 / bh0) < g.warp_w ? (1024 / bh0) : g.warp_w;
@@ -190,16 +193,18 @@ __device__ __forceinline__ Px resize_px(int pw, int ph, int dw, int dh, int dy, 
     return o;
 }
 
-__global__ void pre_geom_kernel(PreItems it, PreGeom* geom, double* padding) {
+__global__ __launch_bounds__(64) void pre_geom_kernel(PreItems it, PreGeom* geom, double* padding) {
+    __shared__ double sys[64][8][9];  // one 8x9 system per lane
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= it.N) return;
+    double (*ws)[9] = sys[threadIdx.x];
     PreGeom g;
     if (it.roi_valid && !it.roi_valid[i]) {
-        g = compute_geom(it.width, it.height, nullptr, it.out_w, it.out_h, it.keep_aspect != 0);
+        g = compute_geom(it.width, it.height, nullptr, it.out_w, it.out_h, it.keep_aspect != 0, ws);
         g.valid = 0;
         g.pad_x = g.pad_y = 0.0;
     } else {
-        g = compute_geom(it.width, it.height, it.rois ? &it.rois[i] : nullptr, it.out_w, it.out_h, it.keep_aspect != 0);
+        g = compute_geom(it.width, it.height, it.rois ? &it.rois[i] : nullptr, it.out_w, it.out_h, it.keep_aspect != 0, ws);
     }
     geom[i] = g;
     if (padding) { padding[4 * i] = g.pad_x; padding[4 * i + 1] = g.pad_y; padding[4 * i + 2] = g.pad_x; padding[4 * i + 3] = g.pad_y; }
