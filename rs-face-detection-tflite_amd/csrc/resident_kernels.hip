@@ -57,6 +57,14 @@ unsigned long long* g_res_stamps = nullptr;  // [workgroup][stage][8]: stage sta
 #define MI_RES_USTAMP(k)
 #endif
 
+// q / d for a wave-uniform divisor: the layer widths and channel-quad counts here are mostly powers of two (a shift instead
+// of the ~40-instruction software division; the stage programs are VALU-issue-bound, every instruction counts)
+struct Div {
+    int d, sh;  // sh >= 0: d == 1 << sh
+    __device__ __forceinline__ explicit Div(int dd) : d(dd), sh((dd & (dd - 1)) == 0 ? __builtin_ctz(dd) : -1) {}
+    __device__ __forceinline__ int div(int q) const { return sh >= 0 ? q >> sh : q / d; }
+};
+
 constexpr int kPF = 8;       // k-chunks of A fragments in flight per lane (LDS sources)
 constexpr int kPFG = 4;      // ... when the B fragments come from global memory too (they ride the same ring)
 constexpr int kNPre = (kResConstMax / 4 + 511) / 512;  // float4s per thread
@@ -114,6 +122,7 @@ __device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, 
     const int ngroups = nch / PF, rem = nch - ngroups * PF;
     // this lane's first (virtual) channel: tap and channel within the tap (the only divisions, once per stage)
     const int v_first = h * Ch;
+    const Div dWo(ep.Wo);
     const int tap0 = v_first / sv.C, c_first = v_first - tap0 * sv.C;
     const int ky0 = tap0 / sv.KW, kx0 = tap0 - ky0 * sv.KW;
 
@@ -122,7 +131,7 @@ __device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, 
         const int q = pg * 32 + pl;
         const bool valid = q < npix;
         const int qq = valid ? q : 0;
-        const int oy = qq / ep.Wo, ox = qq - oy * ep.Wo;
+        const int oy = dWo.div(qq), ox = qq - oy * ep.Wo;
         MI_RES_USTAMP(4)
         rf32x16 D;
 #pragma unroll
@@ -304,9 +313,10 @@ __global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __rest
             const float* src = resolve(bs, st.src_g, frame);
             const int sW = st.src_W, C4 = st.src_C >> 2, n = st.src_H * sW * C4;
             const int db = st.dst_b, drow = sW + 2 * db, dPS = st.dst_PS, doff = st.dst_off;
+            const Div dC4(C4), dW(sW);
             for (int i = tid; i < n; i += 512) {
-                const int px = i / C4, c4 = i - px * C4;
-                const int y = px / sW, x = px - y * sW;
+                const int px = dC4.div(i), c4 = i - px * C4;
+                const int y = dW.div(px), x = px - y * sW;
                 *reinterpret_cast<float4*>(lds + doff + ((y + db) * drow + x + db) * dPS + 4 * c4) = rld4(src + 4 * (long)i);
             }
         } else if (st.kind == RES_STAGE_DW) {
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __rest
             const int Wo = st.Wo, npix = ep.Ho * Wo, PGn = (npix + 31) >> 5, dw_pg = st.dw_pg, dw_off = st.dw_off;
             const int srow = st.src_W + 2 * st.src_b, sPS = st.src_PS, S = st.S;
             const int src0 = st.src_off + ((st.src_b - st.pt) * srow + st.src_b - st.pl) * sPS;  // tap (0,0) of output pixel (0,0)
+            const Div dC4p(C4p), dWo(Wo);
             SrcView sv;
             sv.g = nullptr; sv.off = dw_off; sv.row = 0; sv.PS = PSs; sv.b = 0; sv.C = Cp; sv.KW = 1; sv.S = 1; sv.Kv = Kv; sv.linear = true;
             for (int pg0 = 0; pg0 < PGn; pg0 += dw_pg) {
@@ -328,8 +339,8 @@ __global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __rest
                 const int px0 = pg0 * 32, px1 = min(npix, pg1 * 32);
                 // depthwise 3x3 (+ bias) of pixels [px0, px1), every channel quad once: (pixel, quad) items over all threads
                 for (int it = tid; it < (px1 - px0) * C4p; it += 512) {
-                    const int pxl = it / C4p, c0 = 4 * (it - pxl * C4p);
-                    const int q = px0 + pxl, oy = q / Wo, ox = q - oy * Wo;
+                    const int pxl = dC4p.div(it), c0 = 4 * (it - pxl * C4p);
+                    const int q = px0 + pxl, oy = dWo.div(q), ox = q - oy * Wo;
                     const float* p = lds + src0 + (oy * S * srow + ox * S) * sPS + c0;
                     float4 acc = rld4(cst + 9 * Cp + c0);  // weights and the LDS pad lanes are zero above the real channel count
 #pragma unroll
