@@ -426,7 +426,9 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
     const size_t nl = stats.size();
     const int nchunks = (batch + chunk_cap_ - 1) / chunk_cap_;
     std::vector<hipEvent_t> marks;
-    for (int r = 0; r < reps; r++) {
+    // one untimed pass first: the first launch of a kernel symbol in a process loads its code object (about a millisecond,
+    // which averaged over a few reps made the first layer of every kernel type look 3x slower than its twins)
+    for (int r = -1; r < reps; r++) {
         marks.clear();
         std::vector<std::string> labels;
         for (int start = 0; start < batch; start += chunk_cap_) enqueue_chunk(in, start, std::min(chunk_cap_, batch - start), s, &marks, &labels);
@@ -437,7 +439,7 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
             for (size_t i = 0; i < nl; i++) {
                 float ms = 0;
                 hip_check(hipEventElapsedTime(&ms, marks[c * (nl + 1) + i], marks[c * (nl + 1) + i + 1]), "hipEventElapsedTime");
-                stats[i].ms += ms / reps;
+                if (r >= 0) stats[i].ms += ms / reps;
             }
         for (hipEvent_t ev : marks) hipEventDestroy(ev);
     }
