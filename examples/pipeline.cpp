@@ -1,6 +1,8 @@
 // C++ counterpart of the reference's end-to-end test (/root/reference/src/lib.rs:18-40, README.md:27-46):
 //   detector -> faces[0] -> face_detection_to_roi -> FaceLandmark -> iris_roi_from_face_landmarks -> IrisLandmark x2.
 // usage: pipeline <raw-rgb-file> <width> <height> [model_dir]       (raw file = height*width*3 bytes, RGB)
+//        pipeline <picture.jpg> 0 0 [model_dir]                     (encoded bytes -> convert_image_to_mat, utils.rs:8-21, as the
+//                                                                    reference's test does with include_bytes!(man.jpg))
 // Prints one line per result so that tests can parse it.
 #include <cstdio>
 #include <fstream>
@@ -14,17 +16,24 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "usage: %s <raw-rgb> <width> <height> [model_dir]\n", argv[0]);
         return 2;
     }
-    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+    int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
     const std::string dir = argc > 4 ? argv[4] : "./models";
     std::ifstream f(argv[1], std::ios::binary);
     std::vector<std::uint8_t> px((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    if (px.size() != static_cast<std::size_t>(w) * h * 3) {
+    const bool encoded = w == 0 && h == 0;
+    if (!encoded && px.size() != static_cast<std::size_t>(w) * h * 3) {
         std::fprintf(stderr, "raw image has %zu bytes, expected %d\n", px.size(), w * h * 3);
         return 2;
     }
     try {
         using namespace mi_face;
-        const Image image{px.data(), w, h, 3 * w};
+        OwnedImage decoded;
+        if (encoded) {
+            decoded = convert_image_to_mat(px.data(), px.size());
+            w = decoded.width; h = decoded.height;
+            std::printf("decoded %d %d\n", w, h);
+        }
+        const Image image = encoded ? decoded.image() : Image{px.data(), w, h, 3 * w};
         FaceDetection face_detection(FaceDetectionModel::BackCamera, dir);
         const auto faces = face_detection.infer(image, std::nullopt);
         std::printf("faces %zu\n", faces.size());
@@ -44,6 +53,12 @@ int main(int argc, char** argv) {
         const IrisResults left = iris_landmark.infer(image, left_eye_roi, false);
         std::printf("right_iris_center %.9g %.9g left_iris_center %.9g %.9g contour %zu iris %zu\n", right.iris[0].x, right.iris[0].y,
                     left.iris[0].x, left.iris[0].y, left.eyeball_contour().size(), left.iris.size());
+        // iris_landmark.rs:380-398: mesh point 33 (left eye corner) becomes the first left contour landmark, 263 the right one
+        const auto refined = update_face_landmarks_with_iris_results(lmks, left, right);
+        std::printf("refined %zu lm33 %.9g %.9g lm263 %.9g %.9g contour0 %.9g %.9g %.9g %.9g\n", refined.size(), refined[33].x, refined[33].y,
+                    refined[263].x, refined[263].y, left.contour[0].x, left.contour[0].y, right.contour[0].x, right.contour[0].y);
+        const auto eye_box = bbox_from_landmarks(left.contour);
+        std::printf("left_eye_box %.9g %.9g %.9g %.9g\n", eye_box[0], eye_box[1], eye_box[2], eye_box[3]);
     } catch (const mi_face::Error& e) {
         std::fprintf(stderr, "mi_face error %d: %s\n", e.code(), e.what());
         return 1;

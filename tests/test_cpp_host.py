@@ -46,3 +46,13 @@ def test_cpp_pipeline_on_man_jpg(tmp_path, man_image):
     np.testing.assert_allclose([float(v) for v in out["lm0"][:3]], gold["man_face_landmarks"][0], atol=3e-3)
     assert out["right_iris_center"][-4:] == ["contour", "15", "iris", "5"]
     np.testing.assert_allclose([float(out["right_iris_center"][0]), float(out["right_iris_center"][1])], gold["man_eye_right_iris"][0, :2], atol=5e-3)
+    # update_face_landmarks_with_iris_results: mesh points 33 / 263 are replaced by the first contour landmark of each eye
+    r = out["refined"]
+    assert r[0] == "468" and r[2:4] == r[8:10] and r[5:7] == r[10:12]
+    # the same flow from the encoded bytes (convert_image_to_mat on the GPU path), like the reference's test (lib.rs:23-24)
+    r2 = subprocess.run([exe, os.path.join(GOLDEN, "man.jpg"), "0", "0", MODELS], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    out2 = {l.split()[0]: l.split()[1:] for l in r2.stdout.strip().splitlines()}
+    assert out2["decoded"] == ["540", "360"]
+    for key in ("faces", "bbox", "face_roi", "landmarks", "lm0", "refined"):
+        assert out2[key] == out[key], key      # the raw file was written from the same decode: identical pixels, identical results
