@@ -94,9 +94,10 @@ void Model::rebuild() {
     chain_off_.assign(NN, {});
     node_strip_.assign(NN, -1);
     res_cblob_.assign(NN, {});
+    res_wblk_.assign(NN, {});
     // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
     // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
-    auto pack_pw = [&](int wt) {
+    auto pack_pw = [&](int wt, int kblk = 0) {
         const auto& ws = g.tensors[wt].shape;
         const auto& src = g.tensors[wt].f32;
         // [O][KH][KW][I] read as [O][KH*KW*I]: the k x k stride-k convolutions of the stage programs contract over the
@@ -110,6 +111,7 @@ void Model::rebuild() {
                 for (int l = 0; l < 64; l++)
                     for (int e2 = 0; e2 < 4; e2++) {
                         int o = mt * 32 + (l & 31), c = (l >> 5) * Ch + 4 * j + e2;
+                        if (kblk == 16) c = 16 * (j / 2) + 8 * (l >> 5) + 4 * (j % 2) + e2;  // K-blocked order of the LDS-staged pointwise stages
                         if (o < O && c < I) r[((static_cast<size_t>(mt) * (Ch / 4) + j) * 64 + l) * 4 + e2] = src[static_cast<size_t>(o) * I + c];
                     }
         return put(r);
@@ -148,6 +150,12 @@ void Model::rebuild() {
                 chain_off_[i].push_back(mo);
             }
             // per stage: the small constants, padded the way the kernel copies them to LDS
+            res_wblk_[i].assign(n.stages.size(), -1);
+            for (size_t k = 0; k < n.stages.size(); k++)
+                if (n.stages[k].st.kblk) {
+                    const Node& m = n.members[static_cast<size_t>(n.stages[k].member)];
+                    res_wblk_[i][k] = pack_pw(m.kind == Node::Conv ? m.w : m.w2, n.stages[k].st.kblk);
+                }
             res_cblob_[i].assign(n.stages.size(), -1);
             for (size_t k = 0; k < n.stages.size(); k++) {
                 const Node::Stage& sg = n.stages[k];
@@ -238,8 +246,9 @@ void Model::rebuild() {
                 if (st.kind != RES_STAGE_LOAD) {
                     if (sg.dst_t >= 0) st.dst_g = ref(sg.dst_t);
                     if (sg.res_t >= 0) st.res_g = ref(sg.res_t);
-                    st.w_pw = chain_off_[i][static_cast<size_t>(sg.member)].w2;
-                    st.cblob = res_cblob_[i][static_cast<size_t>(&sg - n.stages.data())];
+                    const size_t k = static_cast<size_t>(&sg - n.stages.data());
+                    st.w_pw = st.kblk ? res_wblk_[i][k] : chain_off_[i][static_cast<size_t>(sg.member)].w2;
+                    st.cblob = res_cblob_[i][k];
                 }
                 progs.push_back(st);
             }

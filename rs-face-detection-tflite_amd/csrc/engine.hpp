@@ -87,6 +87,7 @@ class Model {
     std::vector<std::vector<MemberOff>> chain_off_;  // per node: offsets of each chain member's constants
 
     ResStage* d_programs_ = nullptr;        // stage programs of the Resident nodes (device memory)
+    std::vector<std::vector<long>> res_wblk_;   // per Resident node, per stage: K-blocked weight packing (-1: classic order)
     std::vector<std::vector<long>> res_cblob_;  // per Resident node, per stage: offset of its packed constants (-1: LOAD)
     std::vector<long> node_prog_;           // per node: first stage in d_programs_ (-1 none)
     float* d_arena_ = nullptr;

@@ -160,7 +160,11 @@ struct ResStage {
     //   role 1 (pointwise GATHER from global): produces rows [r0 - 1, r1 + 1) clipped to the image into a bordered LDS tensor
     //           of band_rows interior rows (the halo rows of interior bands are recomputed, rows outside the image stay zero)
     //   role 2 (DW from that tensor): produces rows [r0, r1) into global memory (skip read from global memory)
-    int band_role = 0, band_rows = 0, band_H = 0, pad2_ = 0;
+    int band_role = 0, band_rows = 0, band_H = 0;
+    // Pointwise GATHER from global memory with Kv % 16 == 0: the contraction runs in blocks of kblk = 16 channels that each wave
+    // stages through a private LDS slab at dw_off (coalesced 64 B per pixel instead of 16 B pieces 128 B apart); the weights are
+    // packed for that order (channel of (k-half h, chunk j, e) = 16*(j/2) + 8h + 4*(j%2) + e).  0 = classic order.
+    int kblk = 0;
     // float offsets into the weights blob: pointwise / k x k weights in A-fragment order; the stage's small constants, padded and
     // ready to be copied to LDS: [9][Cp] depthwise taps + [Cp] depthwise bias (DW only), [Cop] bias, [Cop] negative-side slopes
     long w_pw = -1, cblob = -1;
@@ -183,6 +187,7 @@ struct ResLaunch {
 };
 int launch_resident(const ResLaunch& a, void* stream);
 int resident_const_floats(const ResStage& st);  // LDS floats the stage's constants need
+constexpr int kResSlabFloats = 8 * 32 * 20;        // LDS floats of the 8 waves' staging slabs (kblk stages)
 constexpr int kResConstMax = 5120;               // most constants a stage may have (10 per thread, prefetched in registers)
 
 // ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).

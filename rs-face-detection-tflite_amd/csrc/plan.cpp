@@ -428,17 +428,28 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
         }
         return mx;
     };
+    // pointwise stages that read global memory stage their source through per-wave LDS slabs (K-blocked contraction order)
+    bool slabs = false;
+    for (Node::Stage& sg : S) {
+        ResStage& st = sg.st;
+        if (st.kind == RES_STAGE_GATHER && st.src_off < 0 && st.KH == 1 && st.Kv % 16 == 0) { st.kblk = 16; slabs = true; }
+    }
     const int half_cu = 80 * 1024 / 4;
     int scratch_max = scratch_for(8);
     for (int cap = 4; cap >= 1 && base_floats + scratch_max > half_cu && base_floats + scratch_for(1) <= half_cu; cap /= 2) scratch_max = scratch_for(cap);
     if (base_floats + scratch_max > half_cu) scratch_max = scratch_for(8);
+    if (slabs && base_floats + std::max(scratch_max, kResSlabFloats) > half_cu && base_floats + scratch_max <= half_cu) {
+        slabs = false;  // the slabs would cost the second workgroup per CU: keep the direct gather here
+        for (Node::Stage& sg : S) sg.st.kblk = 0;
+    }
+    if (slabs) scratch_max = std::max(scratch_max, kResSlabFloats);
     Node r;
     r.kind = Node::Resident;
     r.res_const_off = (high + 3) & ~3;
     r.res_const_floats = const_max;
     const int dw_off = r.res_const_off + 2 * const_max;
     for (Node::Stage& sg : S)
-        if (sg.st.kind == RES_STAGE_DW) sg.st.dw_off = dw_off;
+        if (sg.st.kind == RES_STAGE_DW || sg.st.kblk) sg.st.dw_off = dw_off;
     r.res_lds_bytes = (dw_off + scratch_max) * 4;
     if (r.res_lds_bytes > budget) return false;
     r.members = std::move(M);
@@ -487,12 +498,13 @@ bool build_banded_bottleneck(const Graph& g, const std::vector<Node>& ns, size_t
     const int const_max = std::max(resident_const_floats(ps), resident_const_floats(cs));
     if (const_max > kResConstMax) return false;
     // rows per band: as many as keep two workgroups on a CU (half of the 160 KB each)
+    const int slab = Cx % 16 == 0 ? kResSlabFloats : 0;  // the pointwise stage stages x through per-wave LDS slabs
     int R = 0, total = 0, dw_pg = 1;
     for (int r = std::min(H, 32); r >= 2; r--) {
         const int buf = (r + 2) * (W + 2) * (Cr + 4);
         const int PGn = (r * W + 31) / 32;
         const int pg = std::max(1, std::min(PGn, (8 + MT - 1) / MT));
-        const int t = ((buf + 3) & ~3) + 2 * const_max + pg * 32 * (Cp + 4);
+        const int t = ((buf + 3) & ~3) + 2 * const_max + std::max(pg * 32 * (Cp + 4), slab);
         if (t * 4 <= 80 * 1024 - 512) { R = r; total = t; dw_pg = pg; break; }
     }
     if (R < 2) return false;
@@ -501,8 +513,9 @@ bool build_banded_bottleneck(const Graph& g, const std::vector<Node>& ns, size_t
     {
         const int PGn = (R * W + 31) / 32;
         dw_pg = std::max(1, std::min(PGn, (8 + MT - 1) / MT));
-        total = ((buf + 3) & ~3) + 2 * const_max + dw_pg * 32 * (Cp + 4);
+        total = ((buf + 3) & ~3) + 2 * const_max + std::max(dw_pg * 32 * (Cp + 4), slab);
     }
+    if (slab) { ps.kblk = 16; }
     ps.Ho = R + 2; ps.band_rows = R; ps.dst_off = 0; ps.dst_PS = Cr + 4; ps.dst_b = 1; ps.zero_dst = buf;
     cs.src_H = R; cs.Ho = R; cs.band_rows = R; cs.dw_pg = dw_pg;
     Node r;
@@ -510,6 +523,7 @@ bool build_banded_bottleneck(const Graph& g, const std::vector<Node>& ns, size_t
     r.res_const_off = (buf + 3) & ~3;
     r.res_const_floats = const_max;
     cs.dw_off = r.res_const_off + 2 * const_max;
+    ps.dw_off = cs.dw_off;
     r.res_lds_bytes = total * 4;
     r.res_bands = (H + R - 1) / R;
     r.members = {a, b};

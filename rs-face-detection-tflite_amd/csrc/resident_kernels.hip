@@ -44,6 +44,13 @@ __device__ __forceinline__ float4 rmax4(float4 a, float4 b, float4 c, float4 d) 
     return make_float4(fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x)), fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y)),
                        fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z)), fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w)));
 }
+// LDS traffic between the lanes of ONE wave: the hardware executes a wave's LDS instructions in order; this only stops the
+// compiler from moving accesses across the hand-over.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ float* resolve(const ResBases& bs, const ResRef& r, int frame) {
     return bs.p[r.base] + r.root_off * bs.scale[r.base] + r.inner + (long)(frame + bs.frame0[r.base]) * r.fs;
 }
@@ -74,6 +81,7 @@ constexpr int kNPre = (kResConstMax / 4 + 511) / 512;  // float4s per thread
 struct SrcView {
     const float* g;   // global base (MODE 1)
     int off, row, PS, b, C, KW, S, Kv, px_base;
+    int slab;   // MODE 3: LDS floats of the 8 waves' staging slabs
     bool linear;
 };
 
@@ -105,12 +113,14 @@ __device__ __forceinline__ EpiView make_epi(const ResStage& st, const ResBases& 
 
 // MODE 0: B from LDS, 1: B from global memory, 2: B from LDS with the lane's virtual channels contiguous (pointwise sources
 // and the depthwise scratch: a plain pointer walk, no tap bookkeeping — VALU work does not overlap a wave's own dependent
-// MFMAs on this part, so every VALU op in the k-loop is paid in full).  Units: pixel groups [pg0, pg1) x all channel tiles.
+// MFMAs on this part, so every VALU op in the k-loop is paid in full), 3: pointwise from global memory in blocks of 16
+// channels staged through a wave-private LDS slab (the direct gather of mode 1 reads 16 B pieces 128 B apart: with 8 waves
+// the touched lines overflow the L1 and every line is fetched from L2 eight times).  Units: pixel groups [pg0, pg1) x all channel tiles.
 template <int MODE>
 __device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, float* lds, const float* cst_ep, int pg0, int pg1,
                                           unsigned long long* ustamps = nullptr) {
     constexpr int PF = MODE == 1 ? kPFG : kPF;
-    constexpr bool CONTIG = MODE == 2;
+    constexpr bool CONTIG = MODE == 2 || MODE == 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
     const int npix = ep.Ho * ep.Wo, PGn = pg1 - pg0;
@@ -176,6 +186,43 @@ __device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, 
             D = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf.w, D, 0, 0, 0);
         };
 
+        if constexpr (MODE == 3) {
+            // ---- K-blocked, LDS-staged: block b = channels [16b, 16b+16): lane loads 16 B of pixel (lane>>2) + 16i (a contiguous
+            // 64 B per pixel, 1 KiB per instruction), the slab row is [pixel][16 + 4 pad]; chunk 2b + jj reads slab[pl][8h + 4jj].
+            constexpr int SP = 20;
+            float* slab = lds + sv.slab + wave * (32 * SP);
+            const int nblk = sv.Kv >> 4;
+            const int lp = lane >> 2, piece = lane & 3;
+            const int q0 = min(pg * 32 + lp, npix - 1), q1 = min(pg * 32 + lp + 16, npix - 1);  // clamped: rows past the end are never stored
+            const float* g0 = sv.g + (long)q0 * sv.C + 4 * piece;
+            const float* g1 = sv.g + (long)q1 * sv.C + 4 * piece;
+            float* w0 = slab + lp * SP + 4 * piece;
+            const float* rd = slab + pl * SP + 8 * h;
+            float4 ringA3[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) ringA3[r] = a_next();
+            float4 x0 = rld4(g0), x1 = rld4(g1);
+            auto do_block = [&](float4& A0, float4& A1, int b) {  // A0 / A1: the ring slots of chunks 2b and 2b + 1 (static registers)
+                *reinterpret_cast<float4*>(w0) = x0;
+                *reinterpret_cast<float4*>(w0 + 16 * SP) = x1;
+                const int bn = min(b + 1, nblk - 1);  // the next block's pixels are on their way while this one is contracted
+                x0 = rld4(g0 + 16 * bn);
+                x1 = rld4(g1 + 16 * bn);
+                wave_sync();
+                const float4 b0 = rld4(rd), b1 = rld4(rd + 4);
+                wave_sync();  // the slab may be rewritten once every lane has read it (LDS executes a wave's accesses in order)
+                mfma4(A0, b0);
+                A0 = a_next();
+                mfma4(A1, b1);
+                A1 = a_next();
+            };
+            int b = 0;
+            for (; b + 1 < nblk; b += 2) {
+                do_block(ringA3[0], ringA3[1], b);
+                do_block(ringA3[2], ringA3[3], b + 1);
+            }
+            if (b < nblk) do_block(ringA3[0], ringA3[1], b);
+        } else {
         float4 ringA[PF], ringB[MODE == 1 ? PF : 1];
 #pragma unroll
         for (int r = 0; r < PF; r++) {
@@ -211,6 +258,7 @@ __device__ __forceinline__ void run_units(const EpiView& ep, const SrcView& sv, 
                     bcur = bn;
                 }
             }
+        }
         MI_RES_USTAMP(6)
         // ---- epilogue: lane holds pixel q, output channels mt*32 + 8*gq + 4*h .. +3 in D[4*gq .. 4*gq+3]
         if (valid) {
@@ -380,7 +428,9 @@ __global__ __launch_bounds__(512, 4) void resident_kernel(const ResStage* __rest
                 else run_units<0>(ep, sv, lds, cst, 0, PGn, ust);
             } else {
                 sv.g = resolve(bs, st.src_g, frame) + src_rows * st.src_W * st.src_C; sv.off = 0; sv.row = st.src_W; sv.PS = st.src_C; sv.b = 0;
-                run_units<1>(ep, sv, lds, cst, 0, PGn, ust);
+                sv.slab = st.dw_off;
+                if (st.kblk == 16) run_units<3>(ep, sv, lds, cst, 0, PGn, ust);
+                else run_units<1>(ep, sv, lds, cst, 0, PGn, ust);
             }
         }
         MI_RES_STAMP(2)
