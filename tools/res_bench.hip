@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
         a.kind = RES_STAGE_GATHER; a.src_H = H; a.src_W = H; a.src_C = C; a.KH = a.KW = 1; a.S = 1; a.Kv = C;
         a.Ho = BR + 2; a.Wo = H; a.Co = R; a.act = ACT_PRELU; a.band_role = 1; a.band_rows = BR; a.band_H = H;
         a.src_g.base = 1; a.src_g.fs = (long)fs;
+        a.kblk = (argc > 7 && atoi(argv[7]) == 0) ? 0 : 16;   // argv[7] = 0: direct gather (mode 1) instead of the LDS-staged K blocks
         a.dst_off = 0; a.dst_PS = R + 4; a.dst_b = 1; a.zero_dst = (BR + 2) * (H + 2) * (R + 4);
         a.w_pw = put((size_t)((R + 31) / 32 * 32) * C, 0.01f); a.cblob = put(resident_const_floats(a), 0.01f);
         prog.push_back(a);
@@ -85,6 +86,7 @@ int main(int argc, char** argv) {
     int scratch = 0;
     for (auto& st : prog)
         if (st.kind == RES_STAGE_DW) { st.dw_off = L.const_off + 2 * cmax; scratch = std::max(scratch, st.dw_pg * 32 * (((st.Kv + 7) & ~7) + 4)); }
+        else if (st.kblk) { st.dw_off = L.const_off + 2 * cmax; scratch = std::max(scratch, kResSlabFloats); }
     L.lds_bytes = (L.const_off + 2 * cmax + scratch) * 4;
     wb.resize(wb.size() + 4096, 0.f);  // slack for the A-fragment prefetch
     CK(hipMalloc(&dw, wb.size() * 4)); CK(hipMemcpy(dw, wb.data(), wb.size() * 4, hipMemcpyHostToDevice));
