@@ -98,9 +98,13 @@ class FaceDetection {
         int n = 0;
         mi_rect r{};
         if (roi) r = roi->c();
-        detail::check(mi_fd_infer_image(h_, image.rgb, image.width, image.height, image.stride, roi ? &r : nullptr, out.data(),
-                                        static_cast<int>(out.size()), &n));
-        std::vector<Detection> dets(static_cast<std::size_t>(n < 256 ? n : 256));
+        for (;;) {  // the reference returns every detection: when more were found than fit, ask again with that capacity
+            detail::check(mi_fd_infer_image(h_, image.rgb, image.width, image.height, image.stride, roi ? &r : nullptr, out.data(),
+                                            static_cast<int>(out.size()), &n));
+            if (n <= static_cast<int>(out.size())) break;
+            out.resize(static_cast<std::size_t>(n));
+        }
+        std::vector<Detection> dets(static_cast<std::size_t>(n));
         for (std::size_t i = 0; i < dets.size(); i++) {
             for (int k = 0; k < 16; k++) dets[i].data[k] = out[i].data[k];
             dets[i].score = out[i].score;

@@ -200,7 +200,7 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
                 hufftab *h = tc ? &ac[th] : &dc[th];
                 int total = 0;
                 for (int l = 1; l <= 16; l++) { h->counts[l] = seg[k + l]; total += seg[k + l]; }
-                if (total > 256) goto done;
+                if (total > 256 || k + 17 + (size_t)total > len - 2) goto done;
                 memcpy(h->symbols, seg + k + 17, (size_t)total);
                 h->present = 1;
                 build_huff(h);

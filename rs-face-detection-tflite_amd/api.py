@@ -217,6 +217,22 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _device_ready(x, device, dims=None, dtype="float32"):
+    """Checks made before a torch CUDA tensor's raw pointer is handed to the kernels: dtype, device ordinal and trailing
+    shape.  Then orders the call after the work already queued by torch: the library launches on the handle's own
+    (non-blocking) stream unless the caller passes one, and that stream has no ordering against torch's current stream, so
+    everything torch queued so far (the producer of `x`, the zero fills of the outputs allocated next to it) is waited
+    for here.  Callers that pass their own `stream` and pre-allocated outputs skip nothing by this: it is one host sync."""
+    import torch
+    if str(x.dtype) != "torch." + dtype:
+        raise ValueError("expected a %s tensor, got %s" % (dtype, x.dtype))
+    if not x.is_cuda or (x.device.index or 0) != device:
+        raise ValueError("tensor lives on %s but the handle is bound to cuda:%d" % (x.device, device))
+    if dims is not None and list(x.shape[1:]) != list(dims):
+        raise ValueError("expected frames of shape %s, got %s" % (list(dims), list(x.shape[1:])))
+    torch.cuda.current_stream(x.device).synchronize()
+
+
 def _ptr(x):
     """(pointer, mem) of a numpy array (host) or torch CUDA tensor (device)."""
     if _is_torch(x):
@@ -232,6 +248,7 @@ class Model:
     def __init__(self, path=None, device=0, handle=None, owner=None):
         self.L = lib()
         self._owner = owner
+        self.device = device
         if handle is not None:
             self.h = C.c_void_p(handle)
         else:
@@ -279,6 +296,7 @@ class Model:
         p, mem = _ptr(x_device)
         if mem != MI_MEM_DEVICE:
             raise ValueError("profile() needs a device tensor")
+        _device_ready(x_device, self.device, self.input_dims[1:])
         B = int(x_device.shape[0])
         cap = 1 << 20
         buf = C.create_string_buffer(cap)
@@ -298,6 +316,8 @@ class Model:
                 x = np.ascontiguousarray(x, np.float32)
                 p = C.c_void_p(x.ctypes.data)
                 outs = [np.empty([B] + d[1:], np.float32) for d in self.output_dims]
+        if mem == MI_MEM_DEVICE:
+            _device_ready(x, self.device, self.input_dims[1:])
         ptrs = (C.c_void_p * self.num_outputs)(*[_ptr(o)[0] for o in outs])
         _check(self.L.mi_model_run(self.h, p, B, ptrs, mem, C.c_void_p(stream or 0)))
         return outs
@@ -330,7 +350,8 @@ class FaceDetection:
         self.L.mi_fd_input_size(self.h, C.byref(w), C.byref(h))
         self.input_size = (w.value, h.value)
         self.num_anchors = self.L.mi_fd_num_anchors(self.h)
-        self.model = Model(handle=self.L.mi_fd_model(self.h), owner=self)
+        self.device = device
+        self.model = Model(handle=self.L.mi_fd_model(self.h), owner=self, device=device)
 
     def close(self):
         if getattr(self, "h", None):
@@ -351,10 +372,14 @@ class FaceDetection:
     def infer(self, image, roi=None, cap=256):
         """FaceDetection::infer(&Mat, Option<Rect>) -> Vec<Detection> (face_detection.rs:205-267)."""
         image, w, h, stride = _image_args(image)
-        out = (CDetection * cap)()
-        n = C.c_int()
-        _check(self.L.mi_fd_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
-                                        C.byref(roi) if roi is not None else None, out, cap, C.byref(n)))
+        while True:
+            out = (CDetection * cap)()
+            n = C.c_int()
+            _check(self.L.mi_fd_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
+                                            C.byref(roi) if roi is not None else None, out, cap, C.byref(n)))
+            if n.value <= cap:      # the reference returns every detection: never truncate silently
+                break
+            cap = n.value
         return [Detection(np.frombuffer(out[i].data, np.float32, 16).reshape(8, 2).copy(), float(out[i].score))
                 for i in range(min(n.value, cap))]
 
@@ -370,6 +395,7 @@ class FaceDetection:
             if counts is None:
                 counts = torch.zeros((B,), dtype=torch.int32, device=x.device)
             pp = C.c_void_p(padding.data_ptr()) if padding is not None else None
+            _device_ready(x, self.device, self.model.input_dims[1:])
         else:
             x = np.ascontiguousarray(x, np.float32)
             p = C.c_void_p(x.ctypes.data)
@@ -405,7 +431,8 @@ class FaceLandmark:
         self.h = C.c_void_p()
         p = model_path if model_path is not None else os.path.join(DEFAULT_MODEL_DIR, "face_landmark.tflite")
         _check(self.L.mi_fl_create(os.fsencode(p), device, C.byref(self.h)))
-        self.model = Model(handle=self.L.mi_fl_model(self.h), owner=self)
+        self.device = device
+        self.model = Model(handle=self.L.mi_fl_model(self.h), owner=self, device=device)
 
     def close(self):
         if getattr(self, "h", None):
@@ -438,6 +465,7 @@ class FaceLandmark:
             flags = torch.zeros((B,), dtype=torch.float32, device=x.device)
             rp = C.c_void_p(rois.data_ptr()) if rois is not None else None
             sp = C.c_void_p(image_sizes.data_ptr()) if image_sizes is not None else None
+            _device_ready(x, self.device, self.model.input_dims[1:])
         else:
             x = np.ascontiguousarray(x, np.float32)
             p = C.c_void_p(x.ctypes.data)
@@ -463,7 +491,8 @@ class IrisLandmark:
         self.h = C.c_void_p()
         p = model_path if model_path is not None else os.path.join(DEFAULT_MODEL_DIR, "iris_landmark.tflite")
         _check(self.L.mi_iris_create(os.fsencode(p), device, C.byref(self.h)))
-        self.model = Model(handle=self.L.mi_iris_model(self.h), owner=self)
+        self.device = device
+        self.model = Model(handle=self.L.mi_iris_model(self.h), owner=self, device=device)
 
     def close(self):
         if getattr(self, "h", None):
@@ -494,6 +523,7 @@ class IrisLandmark:
             iris = torch.zeros((B, NUM_IRIS_LANDMARKS, 3), dtype=torch.float32, device=x.device)
             g = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
             rp, sp, pp, fp_ = g(rois), g(image_sizes), g(padding), g(is_right_eye)
+            _device_ready(x, self.device, self.model.input_dims[1:])
         else:
             x = np.ascontiguousarray(x, np.float32)
             p = C.c_void_p(x.ctypes.data)
@@ -525,6 +555,7 @@ class Pipeline:
         self.L = lib()
         self.h = C.c_void_p()
         d = model_dir if model_dir is not None else DEFAULT_MODEL_DIR
+        self.device = device
         _check(self.L.mi_pipeline_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
 
     def close(self):
@@ -553,6 +584,9 @@ class Pipeline:
                        present=z((B,), torch.int32), eyes=z((B, 2, 76, 3), torch.float32))
             p = C.c_void_p(frames.data_ptr())
             stride = int(frames.stride(1))
+            if frames.dim() != 4 or frames.shape[3] != 3 or frames.stride(2) != 3 or frames.stride(3) != 1 or frames.stride(0) != stride * H:
+                raise ValueError("frames must be [B,H,W,3] with dense pixels and frames stride*H bytes apart")
+            _device_ready(frames, self.device, None, "uint8")
         else:
             frames = np.ascontiguousarray(frames, np.uint8)
             mem = MI_MEM_HOST

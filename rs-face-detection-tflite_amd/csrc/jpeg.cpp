@@ -13,6 +13,7 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
+constexpr int64_t kMaxPixels = int64_t(1) << 27;  // bounds the coefficient buffer (2 B x 3 planes per pixel) before it is allocated
 constexpr int kLook = 9;  // codes up to 9 bits resolve with one table read
 
 struct Huff {
@@ -20,10 +21,14 @@ struct Huff {
     uint8_t symbols[256] = {};
     uint16_t look[1 << kLook] = {};  // (length << 8) | symbol, 0 = longer code
     int maxcode[18] = {}, valoff[17] = {};
-    void build(const uint8_t counts[17]) {
+    // false = the length counts over-subscribe the code space (a code of length l would not fit in l bits): libjpeg's
+    // jdhuff.c rejects such a DHT ("bad Huffman table"); accepting it would index look[] / symbols[] out of range.
+    bool build(const uint8_t counts[17]) {
         int code = 0, k = 0;
+        present = false;
         std::memset(look, 0, sizeof look);
         for (int l = 1; l <= 16; l++) {
+            if (code + counts[l] > (1 << l)) return false;
             valoff[l] = k - code;
             for (int i = 0; i < counts[l]; i++, code++, k++)
                 if (l <= kLook)
@@ -33,6 +38,7 @@ struct Huff {
         }
         maxcode[17] = 0x7fffffff;
         present = true;
+        return true;
     }
 };
 
@@ -72,7 +78,11 @@ struct Bits {
         int code = static_cast<int>(peek(kLook));
         for (int l = kLook + 1; l <= 16; l++) {
             code = static_cast<int>(peek(l));
-            if (h.maxcode[l] >= 0 && code <= h.maxcode[l]) { skip(l); return h.symbols[code + h.valoff[l]]; }
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l]) {
+                skip(l);
+                const int at = code + h.valoff[l];
+                return at >= 0 && at < 256 ? h.symbols[at] : 0;
+            }
         }
         skip(16);
         return 0;  // corrupt stream: libjpeg warns and substitutes 0
@@ -128,8 +138,9 @@ struct Parser {
                     for (int l = 1; l <= 16; l++) { counts[l] = seg[k + l]; total += counts[l]; }
                     if (total > 256 || k + 17 + static_cast<size_t>(total) > body) bad("bad Huffman table");
                     Huff& h = tc ? ac[th] : dc[th];
+                    std::memset(h.symbols, 0, sizeof h.symbols);
                     std::memcpy(h.symbols, seg + k + 17, static_cast<size_t>(total));
-                    h.build(counts);
+                    if (!h.build(counts)) bad("bad Huffman table");
                     k += 17 + static_cast<size_t>(total);
                 }
             } else if (m == 0xC0 || m == 0xC1) {
@@ -138,6 +149,7 @@ struct Parser {
                 f->width = (seg[3] << 8) | seg[4];
                 f->ncomp = seg[5];
                 if (f->width <= 0 || f->height <= 0) bad("empty frame");
+                if (static_cast<int64_t>(f->width) * f->height > kMaxPixels) bad("picture too large (more than 2^27 pixels)");
                 if ((f->ncomp != 1 && f->ncomp != 3) || body < 6 + 3 * static_cast<size_t>(f->ncomp)) bad("unsupported component count (1 or 3)");
                 f->hmax = f->vmax = 1;
                 for (int c = 0; c < f->ncomp; c++) {
@@ -204,6 +216,9 @@ void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
         cp.coef_off = total;
         total += static_cast<size_t>(cp.bw) * cp.bh * 64;
     }
+    // every block costs at least two bits of entropy-coded data (one DC and one AC symbol): a header that promises more
+    // blocks than the remaining bytes can hold is refused before its coefficient buffer is allocated
+    if (total / 64 > 4 * (n - ecs) + 64) bad("truncated stream (fewer entropy-coded bytes than the frame header needs)");
     f.coef.assign(total, 0);
     Bits br{data + ecs, data + n};
     int pred[3] = {0, 0, 0};

@@ -15,13 +15,13 @@ class View {
     View(const uint8_t* p, size_t n) : p_(p), n_(n) {}
     template <typename T>
     T at(size_t off) const {
-        if (off + sizeof(T) > n_) throw std::runtime_error("tflite: read past end of buffer");
+        if (off > n_ || n_ - off < sizeof(T)) throw std::runtime_error("tflite: read past end of buffer");  // no off + size: it may wrap
         T v;
         std::memcpy(&v, p_ + off, sizeof(T));
         return v;
     }
     const uint8_t* ptr(size_t off, size_t len) const {
-        if (off + len > n_) throw std::runtime_error("tflite: span past end of buffer");
+        if (off > n_ || n_ - off < len) throw std::runtime_error("tflite: span past end of buffer");
         return p_ + off;
     }
     size_t size() const { return n_; }
@@ -58,7 +58,9 @@ class Table {
         size_t f = field(k);
         if (!f) return {};
         size_t v = f + v_->at<uint32_t>(f);
-        return {v + 4, v_->at<uint32_t>(v)};
+        const uint32_t len = v_->at<uint32_t>(v);
+        if (len > v_->size()) throw std::runtime_error("tflite: vector longer than the file");  // bounds every allocation sized by it
+        return {v + 4, len};
     }
     Table table_at(const Vec& vv, uint32_t i) const {
         size_t e = vv.start + 4 * static_cast<size_t>(i);
@@ -72,6 +74,7 @@ class Table {
     bool has(int k) const { return field(k) != 0; }
     std::vector<int> ints(int k) const {
         Vec vv = vec(k);
+        v_->ptr(vv.start, 4 * static_cast<size_t>(vv.len));  // the whole vector lies inside the file
         std::vector<int> out(vv.len);
         for (uint32_t i = 0; i < vv.len; i++) out[i] = v_->at<int32_t>(vv.start + 4 * static_cast<size_t>(i));
         return out;
@@ -128,6 +131,7 @@ std::vector<int64_t> read_index_vector(const Table& dm, int type_field, int valu
     Table t = dm.sub(value_field);
     Vec vv = t.vec(0);
     const View* v = t.view();
+    v->ptr(vv.start, static_cast<size_t>(vv.len) * (type == 1 ? 4 : type == 2 ? 2 : 1));
     out.resize(vv.len);
     for (uint32_t i = 0; i < vv.len; i++) {
         switch (type) {
@@ -154,9 +158,32 @@ void densify(const Table& sp, const std::vector<int>& shape, Fetch fetch, std::v
     }
     const int nd = static_cast<int>(shape.size());
     const int nl = static_cast<int>(order.size());
-    if (static_cast<int>(levels.size()) != nl) throw std::runtime_error("tflite: sparse metadata mismatch");
+    // Everything below indexes with file contents: validate them first (a malformed blob must end in MI_EMODEL, not in an
+    // out-of-bounds access). traversal_order is a permutation of [0, nl); nl = nd + number of block dimensions; every block
+    // dimension maps to a real dimension; dense sizes are positive; CSR levels carry both of their vectors.
+    const int nb = static_cast<int>(block_map.size());
+    if (nd < 1 || static_cast<int>(levels.size()) != nl || nl != nd + nb) throw std::runtime_error("tflite: sparse metadata mismatch");
+    {
+        std::vector<char> seen(nl, 0);
+        for (int v : order) {
+            if (v < 0 || v >= nl || seen[v]) throw std::runtime_error("tflite: sparse traversal order is not a permutation");
+            seen[v] = 1;
+        }
+        for (int v : block_map)
+            if (v < 0 || v >= nd) throw std::runtime_error("tflite: sparse block map out of range");
+        for (const Level& L : levels) {
+            if (L.format == 0 && L.dense_size <= 0) throw std::runtime_error("tflite: sparse dense level without a size");
+            if (L.format != 0 && L.format != 1) throw std::runtime_error("tflite: unknown sparse dimension format");
+            if (L.format == 1 && L.segments.empty()) throw std::runtime_error("tflite: sparse CSR level without segments");
+        }
+        for (int d : shape)
+            if (d <= 0) throw std::runtime_error("tflite: sparse tensor with an empty shape");
+    }
     std::vector<int> block_size;
-    for (int b = 0; b < static_cast<int>(block_map.size()); b++) block_size.push_back(levels[nd + b].dense_size);
+    for (int b = 0; b < nb; b++) {
+        if (levels[nd + b].dense_size <= 0) throw std::runtime_error("tflite: sparse block without a size");
+        block_size.push_back(levels[nd + b].dense_size);
+    }
     std::vector<int> idx(nl, 0);
     // iterative DFS over the levels
     struct Frame {
@@ -167,7 +194,12 @@ void densify(const Table& sp, const std::vector<int>& shape, Fetch fetch, std::v
     auto open_level = [&](int level, int64_t prev) {
         const Level& L = levels[level];
         if (L.format == 0) stack.push_back({level, prev, 0, L.dense_size});
-        else stack.push_back({level, prev, L.segments.at(prev), L.segments.at(prev + 1)});
+        else {
+            if (prev < 0 || static_cast<size_t>(prev) + 1 >= L.segments.size()) throw std::runtime_error("tflite: sparse segment index out of range");
+            const int64_t lo = L.segments[prev], hi = L.segments[prev + 1];
+            if (lo < 0 || hi < lo || static_cast<size_t>(hi) > L.indices.size()) throw std::runtime_error("tflite: sparse segment out of range");
+            stack.push_back({level, prev, lo, hi});
+        }
     };
     open_level(0, 0);
     while (!stack.empty()) {
@@ -182,7 +214,9 @@ void densify(const Table& sp, const std::vector<int>& shape, Fetch fetch, std::v
             idx[f.level] = static_cast<int>(f.cur);
             child = f.prev * L.dense_size + f.cur;
         } else {
-            idx[f.level] = static_cast<int>(L.indices.at(f.cur));
+            const int64_t at = L.indices.at(f.cur);
+            if (at < 0 || at > 0x3fffffff) throw std::runtime_error("tflite: sparse index out of range");
+            idx[f.level] = static_cast<int>(at);
             child = f.cur;
         }
         int level = f.level;
@@ -190,11 +224,14 @@ void densify(const Table& sp, const std::vector<int>& shape, Fetch fetch, std::v
         if (level + 1 == nl) {
             std::vector<int> coord(nl);
             for (int lv = 0; lv < nl; lv++) coord[order[lv]] = idx[lv];
-            std::vector<int> orig(coord.begin(), coord.begin() + nd);
+            std::vector<int64_t> orig(coord.begin(), coord.begin() + nd);
             for (size_t b = 0; b < block_map.size(); b++)
                 orig[block_map[b]] = orig[block_map[b]] * block_size[b] + coord[nd + static_cast<int>(b)];
             size_t lin = 0;
-            for (int d = 0; d < nd; d++) lin = lin * static_cast<size_t>(shape[d]) + static_cast<size_t>(orig[d]);
+            for (int d = 0; d < nd; d++) {
+                if (orig[d] < 0 || orig[d] >= shape[d]) throw std::runtime_error("tflite: sparse index out of range");
+                lin = lin * static_cast<size_t>(shape[d]) + static_cast<size_t>(orig[d]);
+            }
             if (lin >= dense.size()) throw std::runtime_error("tflite: sparse index out of range");
             dense[lin] = fetch(static_cast<size_t>(child));
         } else {
@@ -242,7 +279,13 @@ Graph parse_tflite(const uint8_t* data, size_t size) {
         Vec payload = model.table_at(buffers, bidx).vec(0);
         if (!payload.len) continue;
         const uint8_t* raw = view.ptr(payload.start, payload.len);
-        const size_t n = ti.elems();
+        // element count of a constant: non-negative dimensions, no overflow, and a size a real model can have (the largest
+        // constant in the seven shipped graphs has 0.6 M elements) — a mutated shape must not drive a multi-GB allocation
+        size_t n = 1;
+        for (int d : ti.shape) {
+            if (d < 0 || (d > 0 && n > (size_t(1) << 24) / static_cast<size_t>(d))) throw std::runtime_error("tflite: constant tensor shape out of range");
+            n *= static_cast<size_t>(d);
+        }
         ti.is_const = true;
         auto f32_at = [&](size_t k) {
             float f;
@@ -263,14 +306,16 @@ Graph parse_tflite(const uint8_t* data, size_t size) {
             else if (ti.dtype == 1) densify(sp, ti.shape, f16_at, ti.f32);
             else throw std::runtime_error("tflite: unsupported sparse tensor type");
         } else if (ti.dtype == 0) {
+            if (n * 4 > payload.len) throw std::runtime_error("tflite: constant shorter than its shape");
             ti.f32.resize(n);
             for (size_t k = 0; k < n; k++) ti.f32[k] = f32_at(k);
         } else if (ti.dtype == 1) {
+            if (n * 2 > payload.len) throw std::runtime_error("tflite: constant shorter than its shape");
             ti.f32.resize(n);
             for (size_t k = 0; k < n; k++) ti.f32[k] = f16_at(k);
         } else if (ti.dtype == 2) {
-            ti.i32.resize(n);
             if (n * 4 > payload.len) throw std::runtime_error("tflite: constant shorter than its shape");
+            ti.i32.resize(n);
             std::memcpy(ti.i32.data(), raw, n * 4);
         } else {
             ti.is_const = false;  // unsupported constant type: only an error if an op actually needs it
@@ -287,8 +332,8 @@ Graph parse_tflite(const uint8_t* data, size_t size) {
         op.op = static_cast<BuiltinOp>(op.raw_code);
         op.inputs = o.ints(1);
         op.outputs = o.ints(2);
-        for (int t : op.inputs)
-            if (t >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tflite: tensor index out of range");
+        for (int t : op.inputs)  // -1 = optional input absent; anything below is malformed
+            if (t < -1 || t >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tflite: tensor index out of range");
         for (int t : op.outputs)
             if (t < 0 || t >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tflite: tensor index out of range");
         if (op.outputs.empty()) throw std::runtime_error("tflite: operator without outputs");

@@ -1,0 +1,61 @@
+"""Host code that parses untrusted bytes (JPEG Huffman tables, sparse .tflite metadata), under sanitizers and
+under mutation.  CPU only — GPU AddressSanitizer is not available on the pool, so the device code is not covered here."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MODELS, ROOT
+
+CSRC = os.path.join(ROOT, "rs-face-detection-tflite_amd", "csrc")
+
+
+def test_parsers_under_asan_ubsan(tmp_path):
+    """tests/fuzz_host.cpp: the JPEG marker/Huffman decoder and the TFL3 reader (with the DENSIFY walk), compiled with
+    g++ -fsanitize=address,undefined, fed the shipped files and ~6000 byte-mutated copies.  Any out-of-bounds access aborts."""
+    exe = str(tmp_path / "fuzz_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fuzz_host.cpp"),
+                           os.path.join(CSRC, "jpeg.cpp"), os.path.join(CSRC, "tflite_graph.cpp"), "-o", exe])
+    files = [os.path.join(GOLDEN, "man.jpg"), os.path.join(GOLDEN, "jpeg", "c420_rst3.jpg"), os.path.join(GOLDEN, "jpeg", "grey.jpg"),
+             os.path.join(GOLDEN, "jpeg", "c444_rstrow.jpg"), os.path.join(MODELS, "face_detection_full_range_sparse.tflite"),
+             os.path.join(MODELS, "face_detection_front.tflite"), os.path.join(MODELS, "iris_landmark.tflite")]
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ok, refused = (int(v) for v in r.stdout.split()[1::2])
+    assert ok > 1000 and refused > 500      # both outcomes are exercised
+
+
+_MUTATE = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import rs_face_detection_tflite_amd as mi
+rs = np.random.RandomState(int(sys.argv[2]))
+orig = np.frombuffer(open(sys.argv[1], "rb").read(), np.uint8)
+ok = bad = 0
+for r in range(int(sys.argv[3])):
+    b = orig.copy()
+    # flatbuffer structure (vtables, offsets, shapes, options, sparsity metadata) sits at the END of these files, weights first
+    lo = int(len(b) * 0.0) if r %% 3 == 0 else max(0, len(b) - 60000)
+    for _ in range(rs.randint(1, 6)):
+        b[rs.randint(lo, len(b))] = rs.randint(0, 256)
+    try:
+        mi.plan_describe(b.tobytes(), 5)
+        ok += 1
+    except mi.MiError:
+        bad += 1
+print("ok", ok, "refused", bad)
+"""
+
+
+@pytest.mark.parametrize("name", ["face_detection_full_range_sparse.tflite", "face_detection_back.tflite", "face_landmark.tflite"])
+def test_mutated_models_never_crash_the_lowering(name):
+    """mi_plan_describe (parse + DENSIFY + lowering to launches, host only) on mutated blobs, in a child process so that a crash
+    is a test failure instead of the end of the test run: every blob gives a plan or MI_EMODEL."""
+    r = subprocess.run([sys.executable, "-c", _MUTATE % ROOT, os.path.join(MODELS, name), "7", "150"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    ok, refused = (int(v) for v in r.stdout.split()[1::2])
+    assert ok + refused == 150 and refused > 0

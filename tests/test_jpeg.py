@@ -49,6 +49,42 @@ def test_headers_and_refusals_without_gpu(mi, oracle):
         assert e.value.code == -4
 
 
+def _segment(marker, body):
+    return bytes([0xFF, marker]) + (len(body) + 2).to_bytes(2, "big") + body
+
+
+def test_malformed_huffman_tables_and_sizes_are_refused(mi, oracle):
+    """Untrusted bytes: a DHT whose length counts over-subscribe the code space (libjpeg: "bad Huffman table") used to index
+    the 512-entry look-up table far out of range; pictures larger than 2^27 pixels are refused before anything is allocated."""
+    sof = _segment(0xC0, bytes([8, 0, 16, 0, 16, 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1]))
+
+    def dht(counts):
+        total = sum(counts)
+        return _segment(0xC4, bytes([0x00]) + bytes(counts) + bytes(i % 251 for i in range(total)))
+
+    bad = ([200] + [0] * 15,            # 200 codes of length 1
+           [0, 5] + [0] * 14,           # 5 codes of length 2
+           [2, 1] + [0] * 14,           # both 1-bit codes used, then one more
+           [1] * 15 + [250])            # the last length overflows 16 bits
+    good = ([0] * 8 + [255] + [0] * 7,  # 255 codes of length 9 fit
+            [1] * 16)
+    for counts in bad:
+        with pytest.raises(mi.MiError) as e:
+            mi.jpeg_info(b"\xff\xd8" + dht(counts) + sof + b"\xff\xd9")      # headers only: walks the DHT before the frame header
+        assert "Huffman" in str(e.value)
+        with pytest.raises(mi.MiError) as e:
+            mi.convert_image_to_mat(b"\xff\xd8" + sof + dht(counts) + b"\xff\xd9")
+        assert "Huffman" in str(e.value)
+        with pytest.raises(ValueError):
+            oracle.jpeg_decode_rgb(b"\xff\xd8" + sof + dht(counts) + b"\xff\xd9")   # (no scan) the checker does not crash either
+    for counts in good:
+        assert mi.jpeg_info(b"\xff\xd8" + dht(counts) + sof + b"\xff\xd9") == (16, 16)
+    huge = b"\xff\xd8" + _segment(0xC0, bytes([8, 0xFF, 0xFF, 0xFF, 0xFF, 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])) + b"\xff\xd9"
+    with pytest.raises(mi.MiError) as e:
+        mi.jpeg_info(huge)
+    assert "too large" in str(e.value)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rel", FILES)
 def test_gpu_decode_is_bit_exact(mi, oracle, rel):
