@@ -13,9 +13,12 @@
  *     stages through its own device buffers) or MI_MEM_DEVICE (HIP device pointers on the handle's GPU).
  *   - `stream` is a hipStream_t passed as void* (NULL = the handle's own stream).  With MI_MEM_DEVICE and a caller
  *     stream the call is asynchronous with respect to the host; with MI_MEM_HOST it returns after results landed.
- *   - handles are bound to one GPU (`device` = HIP ordinal).  One handle may be used from one thread at a time
- *     (the reference's `infer(&self)` rebuilds an interpreter per call; here the interpreter state — activation
- *     arena, captured hipGraphs — lives in the handle). Use one handle per worker thread/stream.
+ *   - handles are bound to one GPU (`device` = HIP ordinal).  Like the reference's `infer(&self)` (face_detection.rs:205),
+ *     every entry point may be called on one handle from several threads at once: the interpreter state the reference
+ *     rebuilds per call (here: activation arena, captured hipGraphs, staging buffers) lives in the handle, so calls on one
+ *     handle are serialised by an internal mutex, and a call on a different caller stream than the previous one first waits
+ *     on the device for that previous call's work.  Results equal the single-caller ones; for calls that actually overlap
+ *     on the GPU use one handle per worker thread / stream.  mi_last_error() is thread-local.
  *   - all outputs are caller-allocated with explicit capacities.
  */
 #ifndef MI_FACE_H_
@@ -141,7 +144,8 @@ int mi_fd_anchors(const mi_fd *h, float *out_xy, int cap); /* ssd_generate_ancho
  *   in       f32 [batch,H,W,3] in [-1,1] (what image_to_tensor produced)
  *   padding  NULL (no letterbox) or f64 [batch][4] = (left, top, right, bottom) per frame (ImageTensor.padding)
  *   out      [batch][cap_per_frame] detections, descending head-score order; counts[b] = number found in frame b
- *            (may exceed cap_per_frame: only the first cap_per_frame are stored).  out/counts follow `mem`. */
+ *            (may exceed cap_per_frame: only the first cap_per_frame are stored; with MI_MEM_HOST the unused slots are
+ *            zeroed, with MI_MEM_DEVICE they are left untouched).  out/counts follow `mem`. */
 int mi_fd_infer_tensor(mi_fd *h, const float *in, int batch, const double *padding, mi_detection *out,
                        int cap_per_frame, int *counts, int mem, void *stream);
 /* Post-network stage only, on raw outputs (regressors [batch,N,16], classificators [batch,N]). */

@@ -34,6 +34,7 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace mi {
 
@@ -534,8 +535,7 @@ int launch_inst3(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * g.bands)), dim3(256), (size_t)g.lds_bytes, s, a, g);
-    return (int)hipGetLastError();
+    return (int)launch_kernel(kern, dim3((unsigned)(a.B * g.bands)), dim3(256), (size_t)g.lds_bytes, s, a, g);
 }
 
 template <int MTG, int S, int KS, int PG, bool SLOW>

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -83,9 +84,41 @@ void require(bool ok, const char* msg) {
 
 }  // namespace
 
+// Concurrency (face_detection.rs:205: `infer(&self)` may be called from several threads): a handle's interpreter state —
+// activation arena, captured hipGraphs, staging buffers — is shared by its callers, so calls on one handle are SERIALISED
+// by `mu`, and because a call on a caller-supplied stream returns before its kernels finish, the next call on a
+// DIFFERENT stream first waits (on the device, hipStreamWaitEvent) for the event the previous call recorded.  Results
+// are therefore the same as with one caller; for parallel execution use one handle per worker thread / stream.
 struct mi_model {
     std::unique_ptr<mi::Model> m;
+    std::mutex mu;
+    hipEvent_t done = nullptr;     // recorded after the last enqueued call
+    hipStream_t last = nullptr;    // stream of that call
+    bool busy = false;
+    ~mi_model() {
+        if (done) hipEventDestroy(done);
+    }
 };
+
+namespace {
+// One call's claim on a handle: holds the mutex, orders this call's stream after the previous call's work.
+// Construct after hipSetDevice; the destructor (also on the error paths) records the new tail of the handle's work.
+struct Use {
+    mi_model& h;
+    hipStream_t s;
+    std::unique_lock<std::mutex> lock;
+    Use(mi_model& handle, hipStream_t stream) : h(handle), s(stream), lock(handle.mu) {
+        if (h.busy && h.last != s) mi::hip_check(hipStreamWaitEvent(s, h.done, 0), "hipStreamWaitEvent");
+    }
+    ~Use() {
+        if (!h.done && hipEventCreateWithFlags(&h.done, hipEventDisableTiming) != hipSuccess) h.done = nullptr;
+        if (h.done && hipEventRecord(h.done, s) == hipSuccess) {
+            h.last = s;
+            h.busy = true;
+        }
+    }
+};
+}  // namespace
 
 struct mi_fd {
     mi_model model;
@@ -181,6 +214,8 @@ int mi_model_run(mi_model* m, const float* in, int batch, float* const* outs, in
         require(m && in && outs, "null argument");
         require(batch > 0, "batch must be positive");
         require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        mi::hip_check(hipSetDevice(m->m->device()), "hipSetDevice");
+        Use use(*m, stream ? static_cast<hipStream_t>(stream) : m->m->stream());
         m->m->run(in, batch, outs, mem, static_cast<hipStream_t>(stream));
     });
 }
@@ -188,6 +223,7 @@ int mi_model_run(mi_model* m, const float* in, int batch, float* const* outs, in
 int mi_model_debug_tensor(mi_model* m, int tensor_index, int frame, float* dst, size_t cap, size_t* n) {
     return guarded([&] {
         require(m && dst, "null argument");
+        std::lock_guard<std::mutex> lock(m->mu);
         size_t got = m->m->debug_tensor(tensor_index, frame, dst, cap);
         if (n) *n = got;
     });
@@ -222,6 +258,7 @@ size_t mi_plan_describe(const uint8_t* tflite, size_t nbytes, int fuse_level, ch
 int mi_model_set_option(mi_model* m, const char* key, int value) {
     return guarded([&] {
         require(m && key, "null argument");
+        std::lock_guard<std::mutex> lock(m->mu);
         m->m->set_option(key, value);
     });
 }
@@ -231,6 +268,7 @@ size_t mi_model_profile(mi_model* m, const float* in_device, int batch, int reps
     int rc = guarded([&] {
         require(m && in_device, "null argument");
         require(batch > 0 && reps > 0, "batch and reps must be positive");
+        std::lock_guard<std::mutex> lock(m->mu);
         auto stats = m->m->profile(in_device, batch, reps, nullptr);
         std::string s = "[";
         char line[512];
@@ -351,6 +389,9 @@ static void fd_post(mi_fd* h, const float* d_boxes, const float* d_scores, int b
     a.padding = d_pad;
     a.out = static_cast<float*>(h->d_out.get(sizeof(mi_detection) * static_cast<size_t>(cap) * batch));
     a.counts = static_cast<int*>(h->d_counts.get(sizeof(int) * batch));
+    // the kernel stores min(count, cap) detections per frame: the rest of the caller's host buffer reads as zeros, not as
+    // whatever the staging buffer held before
+    mi::hip_check(hipMemsetAsync(a.out, 0, sizeof(mi_detection) * static_cast<size_t>(cap) * batch, s), "hipMemsetAsync");
     int rc = mi::launch_postprocess(a, s);
     if (rc) throw std::runtime_error(std::string("postprocess kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
     mi::hip_check(hipMemcpyAsync(out, a.out, sizeof(mi_detection) * static_cast<size_t>(cap) * batch, hipMemcpyDeviceToHost, s), "D2H detections");
@@ -369,6 +410,7 @@ int mi_fd_infer_tensor(mi_fd* h, const float* in, int batch, const double* paddi
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
         const float* din = in;
         if (mem == MI_MEM_HOST) {
             size_t bytes = m.input_elems() * sizeof(float) * batch;
@@ -390,6 +432,7 @@ int mi_fd_postprocess(mi_fd* h, const float* raw_boxes, const float* raw_scores,
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
         const float *db = raw_boxes, *ds = raw_scores;
         if (mem == MI_MEM_HOST) {
             size_t nb = sizeof(float) * 16 * h->n_anchors * batch, ns = sizeof(float) * h->n_anchors * batch;
@@ -412,6 +455,7 @@ int mi_fd_infer_image(mi_fd* h, const uint8_t* rgb, int width, int height, int s
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = m.stream();
+        Use use(h->model, s);
         float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
         double pad[4];
         // image_to_tensor(image, roi, (w,h), keep_aspect_ratio = true, (-1,1), flip = false) — face_detection.rs:219
@@ -466,6 +510,7 @@ int mi_fl_infer_tensor(mi_fl* h, const float* in, int batch, const mi_rect* rois
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
         const size_t lm_bytes = sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * batch;
         mi::ProjArgs a;
         a.B = batch;
@@ -520,6 +565,7 @@ int mi_fl_infer_image(mi_fl* h, const uint8_t* rgb, int width, int height, int s
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = m.stream();
+        Use use(h->model, s);
         float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
         double pad[4];
         // image_to_tensor(image, roi, (192,192), keep_aspect_ratio = false, (0,1), false) — face_landmark.rs:250
@@ -621,6 +667,7 @@ int mi_iris_infer_tensor(mi_iris* h, const float* in, int batch, const mi_rect* 
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
         const size_t cb = sizeof(float) * 3 * MI_NUM_EYE_LANDMARKS * batch, ib = sizeof(float) * 3 * MI_NUM_IRIS_LANDMARKS * batch;
         if (mem == MI_MEM_DEVICE) {
             m.run_device(in, batch, s);
@@ -666,6 +713,7 @@ int mi_iris_infer_image(mi_iris* h, const uint8_t* rgb, int width, int height, i
         mi::Model& m = *h->model.m;
         mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
         hipStream_t s = m.stream();
+        Use use(h->model, s);
         float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
         double pad[4];
         // image_to_tensor(image, roi, (64,64), keep_aspect_ratio = true, (0,1), is_right_eye) — iris_landmark.rs:188-189
@@ -720,6 +768,7 @@ void mi_pipeline_free(mi_pipeline* p) { delete p; }
 int mi_pipeline_set_option(mi_pipeline* p, const char* key, int value) {
     return guarded([&] {
         require(p && key, "null argument");
+        std::lock_guard<std::mutex> l0(p->fd->model.mu), l1(p->fl->model.mu), l2(p->iris->model.mu);
         p->fd->model.m->set_option(key, value);
         p->fl->model.m->set_option(key, value);
         p->iris->model.m->set_option(key, value);
@@ -737,12 +786,15 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         mi::Model& irm = *p->iris->model.m;
         mi::hip_check(hipSetDevice(fdm.device()), "hipSetDevice");
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fdm.stream();
+        Use use_fd(p->fd->model, s), use_fl(p->fl->model, s), use_ir(p->iris->model, s);  // the pipeline's own three handles, fixed order
         const int B = batch, cap = 4;
         const size_t frame_bytes = static_cast<size_t>(stride) * height;
         const uint8_t* d_frames = frames;
         if (mem == MI_MEM_HOST) {
             d_frames = static_cast<const uint8_t*>(p->frames.get(frame_bytes * B));
-            mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, frame_bytes * B, hipMemcpyHostToDevice, s), "H2D frames");
+            // the last frame's last row owns 3 * width bytes, not a whole stride
+            const size_t host_bytes = frame_bytes * (B - 1) + static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width;
+            mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, host_bytes, hipMemcpyHostToDevice, s), "H2D frames");
         }
         auto* d_geom = static_cast<mi::PreGeom*>(p->geom.get(sizeof(mi::PreGeom) * 2 * B));
         // (w, h) of the source image of every ROI, for Rect::scaled in project_landmarks

@@ -19,6 +19,7 @@
 #include <cstdint>
 
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace mi {
 
@@ -204,8 +205,7 @@ int launch_chain_inst(const ChainArgs& a, const ChainGeom& g, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(512), (size_t)g.lds_bytes, s, a, g);
-    return (int)hipGetLastError();
+    return (int)launch_kernel(kern, dim3((unsigned)a.B), dim3(512), (size_t)g.lds_bytes, s, a, g);
 }
 
 }  // namespace

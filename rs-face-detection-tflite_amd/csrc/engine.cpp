@@ -1,5 +1,8 @@
 // engine.cpp — see engine.hpp.
 #include "engine.hpp"
+#include "launch.hpp"
+
+#include <mutex>
 
 #include <algorithm>
 #include <cstring>
@@ -50,6 +53,8 @@ Model::~Model() {
 }
 
 void Model::invalidate_graphs() {
+    // a replay may still be running on a caller's stream (asynchronous entry points): let the device drain first
+    if (!graphs_.empty()) (void)hipDeviceSynchronize();
     for (auto& kv : graphs_) hipGraphExecDestroy(kv.second);
     graphs_.clear();
 }
@@ -463,7 +468,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         if (!marks) return;
         hipEvent_t ev;
         hip_check(hipEventCreate(&ev), "hipEventCreate");
-        hip_check(hipEventRecord(ev, s), "hipEventRecord");
+        hip_check(hipEventRecord(ev, s), "hipEventRecord");  // profiling marks: eager launches only
         marks->push_back(ev);
     };
     mark();
@@ -490,10 +495,10 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             }
             s = head_streams_[head_slot_[i]];
             if (head_wait_[i] >= 0) {
-                hip_check(hipStreamWaitEvent(s, node_event(static_cast<size_t>(head_wait_[i])), 0), "hipStreamWaitEvent");
+                hip_check(wait_event(s, node_event(static_cast<size_t>(head_wait_[i]))), "hipStreamWaitEvent");
             } else {  // reads the graph input: order it behind whatever the trunk stream was doing before this plan
-                hip_check(hipEventRecord(node_event(plan_.nodes.size()), trunk), "hipEventRecord");
-                hip_check(hipStreamWaitEvent(s, node_event(plan_.nodes.size()), 0), "hipStreamWaitEvent");
+                hip_check(record_event(node_event(plan_.nodes.size()), trunk), "hipEventRecord");
+                hip_check(wait_event(s, node_event(plan_.nodes.size())), "hipStreamWaitEvent");
             }
             used_heads |= 1u << head_slot_[i];
         }
@@ -657,14 +662,14 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             }
         }
         if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-        if (fork && event_after_[i]) hip_check(hipEventRecord(node_event(i), s), "hipEventRecord");
+        if (fork && event_after_[i]) hip_check(record_event(node_event(i), s), "hipEventRecord");
         mark();
     }
     s = trunk;
     for (int k = 0; k < 3; k++)  // join: the trunk stream continues (post-processing, the next chunk) after every head
         if (used_heads & (1u << k)) {
-            hip_check(hipEventRecord(node_event(plan_.nodes.size() + 1 + k), head_streams_[static_cast<size_t>(k)]), "hipEventRecord");
-            hip_check(hipStreamWaitEvent(trunk, node_event(plan_.nodes.size() + 1 + k), 0), "hipStreamWaitEvent");
+            hip_check(record_event(node_event(plan_.nodes.size() + 1 + k), head_streams_[static_cast<size_t>(k)]), "hipEventRecord");
+            hip_check(wait_event(trunk, node_event(plan_.nodes.size() + 1 + k)), "hipStreamWaitEvent");
         }
     last_chunk_frames_ = F;
 }
@@ -683,18 +688,18 @@ void Model::enqueue_all(const float* in, int batch, hipStream_t s) {
             hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
             lane_events_.push_back(ev);
         }
-        hip_check(hipEventRecord(lane_events_[0], s), "hipEventRecord");
+        hip_check(record_event(lane_events_[0], s), "hipEventRecord");
         int lane = 0;
         for (int start = 0; start < batch; start += chunk_cap_, lane = (lane + 1) % lanes_) {
             hipStream_t ls = lane == 0 ? s : side_streams_[lane - 1];
-            if (lane > 0 && start < chunk_cap_ * lanes_) hip_check(hipStreamWaitEvent(ls, lane_events_[0], 0), "hipStreamWaitEvent");
+            if (lane > 0 && start < chunk_cap_ * lanes_) hip_check(wait_event(ls, lane_events_[0]), "hipStreamWaitEvent");
             arena_lane_ = lane;
             enqueue_chunk(in, start, std::min(chunk_cap_, batch - start), ls);
         }
         arena_lane_ = 0;
         for (int l = 1; l < lanes_; l++) {
-            hip_check(hipEventRecord(lane_events_[l], side_streams_[l - 1]), "hipEventRecord");
-            hip_check(hipStreamWaitEvent(s, lane_events_[l], 0), "hipStreamWaitEvent");
+            hip_check(record_event(lane_events_[l], side_streams_[l - 1]), "hipEventRecord");
+            hip_check(wait_event(s, lane_events_[l]), "hipStreamWaitEvent");
         }
         return;
     }
@@ -716,19 +721,22 @@ void Model::run_device(const float* in, int batch, hipStream_t stream) {
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
         if (graphs_.size() > 16) invalidate_graphs();
-        hipGraph_t graph = nullptr;
-        hip_check(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        // The plan becomes a hipGraph built node by node (launch.hpp) — no stream capture, which is process-wide runtime
+        // state that other host threads break (and are broken by).
+        GraphRecorder rec;
+        hip_check(hipGraphCreate(&rec.graph, 0), "hipGraphCreate");
+        current_recorder() = &rec;
         try {
             enqueue_all(in, batch, s);
         } catch (...) {
-            hipStreamEndCapture(s, &graph);
-            if (graph) hipGraphDestroy(graph);
+            current_recorder() = nullptr;
+            hipGraphDestroy(rec.graph);
             throw;
         }
-        hip_check(hipStreamEndCapture(s, &graph), "hipStreamEndCapture");
+        current_recorder() = nullptr;
         hipGraphExec_t exec = nullptr;
-        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
+        hipError_t e = hipGraphInstantiate(&exec, rec.graph, nullptr, nullptr, 0);
+        hipGraphDestroy(rec.graph);
         hip_check(e, "hipGraphInstantiate");
         it = graphs_.emplace(key, exec).first;
     }

@@ -14,6 +14,7 @@
 #include <cstdint>
 
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace mi {
 
@@ -210,8 +211,7 @@ template <int K, int CO>
 static int launch_stem(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 16;  // rows of a tile (two output pixels per thread)
     unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + TH - 1) / TH));
-    hipLaunchKernelGGL((stem_conv_kernel<K, CO>), dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    return (int)launch_kernel(stem_conv_kernel<K, CO>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
 }
 
 // true when (and how) the specialised stem kernel takes this convolution
@@ -234,8 +234,7 @@ int launch_conv(const ConvArgs& a, void* stream) {
     long total = (long)a.B * a.Ho * a.Wo * (a.Cop >> 2);
     if (total <= 0) return 0;
     unsigned blocks = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(conv_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return (int)hipGetLastError();
+    return (int)launch_kernel(conv_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise 3x3
@@ -284,10 +283,9 @@ int launch_dw(const DwArgs& a, void* stream) {
     if (total <= 0) return 0;
     unsigned blocks = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
-    if (V == 4) hipLaunchKernelGGL(dw_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
-    else if (V == 2) hipLaunchKernelGGL(dw_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(dw_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    if (V == 4) return (int)launch_kernel(dw_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+    if (V == 2) return (int)launch_kernel(dw_kernel<2>, dim3(blocks), dim3(256), 0, s, a);
+    return (int)launch_kernel(dw_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise fallbacks
@@ -389,41 +387,34 @@ __global__ void copy_kernel(EltArgs a) {
 static inline unsigned nblocks(long n) { return (unsigned)((n + 255) / 256); }
 int launch_add(const EltArgs& a, void* s) {
     long n = (long)a.B * a.H * a.W * a.C;
-    if (n > 0) hipLaunchKernelGGL(add_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(add_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a) : 0;
 }
 int launch_act(const EltArgs& a, void* s) {
     long n = (long)a.B * a.H * a.W * a.C;
-    if (n > 0) hipLaunchKernelGGL(act_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(act_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a) : 0;
 }
 int launch_maxpool(const EltArgs& a, void* s) {
     long n = (long)a.B * a.Ho * a.Wo * a.C;
     // TF SAME pads (only non-zero for odd inputs): total = max(0,(out-1)*stride + filter - in), before = total/2
     int tph = (a.Ho - 1) * a.p2 + a.p0 - a.H, tpw = (a.Wo - 1) * a.p3 + a.p1 - a.W;
     int pt = tph > 0 ? tph / 2 : 0, pl = tpw > 0 ? tpw / 2 : 0;
-    if (n > 0) hipLaunchKernelGGL(maxpool_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a, pt, pl);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(maxpool_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a, pt, pl) : 0;
 }
 int launch_padc(const EltArgs& a, void* s) {
     long n = (long)a.B * a.Ho * a.Wo * a.Co;
-    if (n > 0) hipLaunchKernelGGL(pad_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(pad_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a) : 0;
 }
 int launch_resize2x(const EltArgs& a, void* s) {
     long n = (long)a.B * a.Ho * a.Wo * a.C;
-    if (n > 0) hipLaunchKernelGGL(resize_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(resize_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a) : 0;
 }
 int launch_depth_to_space(const EltArgs& a, void* s) {
     long n = (long)a.B * a.Ho * a.Wo * a.Co;
-    if (n > 0) hipLaunchKernelGGL(d2s_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(d2s_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a) : 0;
 }
 int launch_copy_strided(const EltArgs& a, void* s) {
     long n = (long)a.B * a.C;
-    if (n > 0) hipLaunchKernelGGL(copy_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a);
-    return (int)hipGetLastError();
+    return n > 0 ? (int)launch_kernel(copy_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)s, a) : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ SSD post-processing

@@ -346,7 +346,8 @@ void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int 
     if (!g.valid) throw std::runtime_error("ROI is empty or degenerate (singular perspective transform)");
     uint8_t* d_img = static_cast<uint8_t*>(d_scratch);
     PreGeom* d_geom = reinterpret_cast<PreGeom*>(d_img + align256(static_cast<size_t>(stride) * height));
-    hip_check(hipMemcpyAsync(d_img, rgb_host, static_cast<size_t>(stride) * height, hipMemcpyHostToDevice, s), "H2D image");
+    // the caller's last row owns 3 * width bytes, not a whole stride (a cv::Mat ROI view ends there)
+    hip_check(hipMemcpyAsync(d_img, rgb_host, static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width, hipMemcpyHostToDevice, s), "H2D image");
     hip_check(hipMemcpyAsync(d_geom, &g, sizeof g, hipMemcpyHostToDevice, s), "H2D geometry");
     PreItems it{};
     it.frames = d_img; it.frame_bytes = 0; it.width = width; it.height = height; it.stride = stride;

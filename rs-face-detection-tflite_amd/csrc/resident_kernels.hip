@@ -32,6 +32,7 @@
 #include <cstdint>
 
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace mi {
 
@@ -467,15 +468,14 @@ int launch_resident(const ResLaunch& a, void* stream) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(resident_kernel, dim3((unsigned)(a.B * a.bands)), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages, a.const_off, a.const_floats,
-                       a.bands, a.bases,
+    return (int)launch_kernel(resident_kernel, dim3((unsigned)(a.B * a.bands)), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages,
+                              a.const_off, a.const_floats, a.bands, a.bases,
 #ifdef MI_RES_STAMPS
-                       g_res_stamps
+                              g_res_stamps
 #else
-                       nullptr
+                              nullptr
 #endif
     );
-    return (int)hipGetLastError();
 }
 
 }  // namespace mi

@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "launch.hpp"
 
 namespace mi {
 
@@ -1073,8 +1074,7 @@ int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
         configured[two] = true;
     }
     const int wgs = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds_bytes, s, pa);
-    return (int)hipGetLastError();
+    return (int)launch_kernel(kern, dim3((unsigned)wgs), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds_bytes, s, pa);
 }
 
 unsigned long long* g_strip_stamps = nullptr;  // set by the development harness (MI_STRIP_STAMPS builds)
@@ -1111,8 +1111,7 @@ int launch_strip_inst(const BlockArgs& a, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_bytes, s, sa);
-    return (int)hipGetLastError();
+    return (int)launch_kernel(kern, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_bytes, s, sa);
 }
 
 }  // namespace

@@ -77,3 +77,30 @@ def test_no_cpu_fallback(mi):
     with pytest.raises(mi.MiError) as e:
         mi.FaceDetection(mi.FaceDetectionModel.BackCamera)
     assert e.value.code == -4
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/mi_face.h must compile as C99 (no C++-isms), alone and from a C translation unit
+    that takes the address of every declared function with its declared type."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "mi_face.h")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    src = tmp_path / "use.c"
+    names = _declared_functions()
+    src.write_text('#include "mi_face.h"\n#include <stdio.h>\nint main(void) {\n  const void *f[] = {%s};\n'
+                   '  mi_detection d; mi_rect r; mi_landmark l;\n'
+                   '  printf("%%d %%d %%d %%d\\n", (int)(sizeof f / sizeof f[0]), (int)sizeof d, (int)sizeof r, (int)sizeof l);\n  return 0;\n}\n'
+                   % ", ".join("(const void *)%s" % n for n in names))
+    exe = str(tmp_path / "use")
+    lib = os.path.dirname(mi_lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe, "-L", lib,
+                           "-lmiface", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    n, sd, sr, sl = (int(v) for v in out.stdout.split())
+    assert n == len(names) and (sd, sr, sl) == (68, 48, 24)      # types.rs layouts: 17 f32; 5 f64 + flag (padded); 3 f64
+
+
+def mi_lib_path():
+    import rs_face_detection_tflite_amd as m
+    return m.LIB_PATH
