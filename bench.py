@@ -1,35 +1,96 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json metric: faces/sec at batch=256 (256x256 BackCamera) per GPU, 1/2/4/8-GPU weak scaling.
 
-One "step" = one pass of the hot path over one batch per GPU: BackCamera BlazeFace network + SSD decode + sigmoid +
-weighted NMS + letterbox removal on 256 synthetic 256x256 frames (configs[1] of BASELINE.json),
-inputs already resident in HBM.  One process per GPU; with N > 1 the frozen .tflite is broadcast from rank 0 over
-RCCL (torch.distributed "nccl"), frames are sharded 256/GPU, and no data-path collective exists (frames are independent).
+    python bench.py                      # N = 1, configs[1] of BASELINE.json (the headline)
+    python bench.py --gpus 8             # starts 8 ranks itself (one process per GPU, RCCL) and prints rank 0's line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8
+    python bench.py --config 3           # FaceLandmark 192x192, 512 ROIs/GPU           (configs[2])
+    python bench.py --config 5 --gpus 8  # full_range -> mesh -> 2 x iris, 128 frames/GPU (configs[4])
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event timed) and
-`cpu_baseline` (the C oracle on the host cores — a *port*: the reference's TFLite path cannot be built here).
+One "step" = one pass of the hot path over one batch per GPU, inputs already resident in HBM:
+  config 2 (default; with --gpus N it is configs[3]): BackCamera network + SSD decode + sigmoid + weighted NMS + letterbox
+           removal on 256 synthetic 256x256 frames per GPU;
+  config 3: face-mesh network + face flag + landmark projection on 512 ROIs per GPU;
+  config 5: mi_pipeline_run on 128 RGB frames of 192x192 per GPU (device pre-processing, three networks, ROI maths).
+One process per GPU.  With N > 1 the frozen .tflite bytes are broadcast from rank 0 over RCCL (torch.distributed "nccl"),
+frames are sharded per GPU and no data-path collective exists (frames are independent): "scaling": "weak".
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, timed live with HIP events on the launch stream) and, at
+N = 1, `cpu_baseline` (the C oracle on the host cores — a *port*: the reference's TFLite path cannot be built here).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 F32_PEAK_TFLOPS = 157.3  # dense f32 (MFMA = packed VALU FMA), /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+# ------------------------------------------------------------------------------------------------- launcher (N > 1, no torchrun)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without an external launcher: this process makes NO GPU call (torch.cuda.device_count()
+    only counts), starts N fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, lets rank 0 print the
+    JSON line on the inherited stdout and exits with the first non-zero child status."""
+    n = args.gpus
+    if not args.rehearse:
+        import torch
+        visible = torch.cuda.device_count()
+        if visible < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run a smaller job under that label\n" % (n, visible))
+            return 2
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    rc = 0
+    deadline = time.time() + 3600
+    alive = list(procs)
+    while alive and time.time() < deadline:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:        # a rank died: the others would wait at the next barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    for p in alive:
+        p.kill()
+        rc = rc or 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------- synthetic inputs
+def _gold():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
 
 
 def make_frames(batch, seed, size=256):
     """SURVEY.md §8d config 2 frame mix: 50% U(-1,1) noise, 50% face-bearing (committed man-face tensor with a seeded
     +-32 px roll and 0.8-1.2 gain) so that NMS sees real candidates."""
-    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
-    face = (gold["man_back_u8"].astype(np.float64) * 2.0 / 255.0 - 1.0).astype(np.float32)
+    import numpy as np
+    face = (_gold()["man_back_u8"].astype(np.float64) * 2.0 / 255.0 - 1.0).astype(np.float32)
     rs = np.random.RandomState(seed)
     x = np.empty((batch, size, size, 3), np.float32)
     for b in range(batch):
@@ -41,8 +102,33 @@ def make_frames(batch, seed, size=256):
     return x
 
 
+def make_rois(batch, seed):
+    """Config 3: 50% the committed 192x192 face crop with a seeded jitter, 50% U(0,1)."""
+    import numpy as np
+    face = _gold()["man_face_u8"].astype(np.float32) / np.float32(255.0)
+    rs = np.random.RandomState(seed)
+    x = np.empty((batch, 192, 192, 3), np.float32)
+    for b in range(batch):
+        if b % 2 == 0:
+            x[b] = rs.uniform(0, 1, (192, 192, 3)).astype(np.float32)
+        else:
+            x[b] = np.roll(face, (int(rs.randint(-8, 9)), int(rs.randint(-8, 9))), axis=(0, 1))
+    return x
+
+
+def make_rgb_frames(batch, seed, size=192):
+    """Config 5: 192x192 RGB frames, 50% the man picture (resized, seeded shift), 50% noise."""
+    import numpy as np
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "man.jpg")).convert("RGB").resize((size, size)))
+    rs = np.random.RandomState(seed)
+    return np.stack([np.roll(img, (int(rs.randint(-10, 11)), int(rs.randint(-10, 11))), axis=(0, 1)) if b % 2
+                     else rs.randint(0, 256, img.shape).astype(np.uint8) for b in range(batch)])
+
+
+# ------------------------------------------------------------------------------------------------- CPU baseline (oracle = port)
 def cpu_baseline(x_host, threads):
-    """The oracle (CPU port of the same graph + glue) on the GPU box's host cores, bounded sample."""
+    """The oracle (CPU port of the same graph + glue) on the GPU box's host cores, bounded sample: all cores over frames."""
     from oracle import pyoracle as po
     om = po.Model(os.path.join(ROOT, "models", "face_detection_back.tflite"))
     anchors = po.ssd_anchors(po.FD_BACK)
@@ -56,27 +142,134 @@ def cpu_baseline(x_host, threads):
             po.fd_postprocess(rb[f], rs[f], anchors, 256.0)
         frames += n
     dt = time.time() - t0
-    return {"value": round(frames / dt, 1), "unit": "faces/s", "cores": threads, "kind": "port",
+    return {"value": round(frames / dt, 1), "unit": "faces/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": "%d frames of the same batch (net + decode + NMS), C oracle, OpenMP over frames, %.1f s" % (frames, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse", type=int, default=None)
-    ap.add_argument("--chunk", type=int, default=None)
-    ap.add_argument("--lanes", type=int, default=None)
-    args = ap.parse_args()
+def cpu_baseline_1thread(x_host):
+    """The reference's own operating point (face_detection.rs:207-210: one image per call, one thread, the interpreter
+    rebuilt inside every call): model parse + run + post-processing per frame, one thread."""
+    from oracle import pyoracle as po
+    path = os.path.join(ROOT, "models", "face_detection_back.tflite")
+    anchors = po.ssd_anchors(po.FD_BACK)
+    t0 = time.time()
+    frames = 0
+    while time.time() - t0 < 8.0:
+        om = po.Model(path)                                    # InterpreterBuilder::build + allocate_tensors, per call
+        rb, rs = om.run(x_host[frames % len(x_host)][None], nthreads=1)
+        po.fd_postprocess(rb[0], rs[0], anchors, 256.0)
+        frames += 1
+    dt = time.time() - t0
+    return {"value": round(frames / dt, 2), "unit": "faces/s", "cores": 1, "kind": "port",
+            "sample": "%d single-frame calls (model parse + net + decode + NMS each), C oracle, 1 thread, %.1f s" % (frames, dt)}
 
+
+# ------------------------------------------------------------------------------------------------- roofline helpers
+def kernel_source_hash():
+    """Hash of the kernel + planner sources: stamps profiles/pmc_summary.json so a stale PMC figure is never reported."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rs-face-detection-tflite_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def is_valu_kernel(label):
+    """The strip / stem kernels do their contractions with packed VALU FMAs (v_pk_fma_f32), the others on MFMA; both have the
+    same dense f32 peak on gfx950."""
+    return label.startswith(("strip_", "stem_conv"))
+
+
+def roofline_of(records, workload_tag):
+    """records: list of per-launch dicts {"kernel","ms","bytes","macs"} (HIP-event timed, grouped by kernel symbol as rocprofv3 --stats does)."""
+    by = {}
+    for r in records:
+        k = by.setdefault(r["kernel"], {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "calls": 0})
+        k["ms"] += r["ms"]; k["bytes"] += r["bytes"]; k["macs"] += r["macs"]; k["calls"] += 1
+    dom = max(by, key=lambda k: by[k]["ms"])
+    d = by[dom]
+    gbps = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    tflops = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
+    hbm_frac, flop_frac = gbps / HBM_PEAK_GBS, tflops / F32_PEAK_TFLOPS
+    traffic, note = None, "no PMC summary for this workload"
+    tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(tpath):
+        try:
+            for pm in json.load(open(tpath)).get("entries", []):
+                if pm.get("workload") == workload_tag and pm.get("kernel") == dom:
+                    if pm.get("source_hash") == kernel_source_hash():
+                        traffic, note = pm.get("hbm_bytes_per_launch"), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/pmc_summary.json, same kernel sources"
+                    else:
+                        note = "profiles/pmc_summary.json was measured on other kernel sources: not reported"
+        except Exception:  # noqa: BLE001
+            pass
+    common = {"kernel": dom, "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 5),
+              "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]), "algorithmic_flops_per_launch": round(2 * d["macs"] / d["calls"]),
+              "hbm_GBps": round(gbps, 1), "hbm_frac": round(hbm_frac, 4), "f32_TFLOPs": round(tflops, 2), "f32_frac": round(flop_frac, 4),
+              "traffic_note": note}
+    if hbm_frac >= flop_frac:
+        roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic}
+    else:   # FLOP-bound launch: the dense f32 rate; "pipe" says whether the kernel reaches it on MFMA or with packed VALU FMAs
+        roof = {"bound": "f32", "pipe": "valu v_pk_fma_f32" if is_valu_kernel(dom) else "mfma f32", "achieved": round(tflops, 2),
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic}
+    roof.update(common)
+    roof["net_event_ms"] = round(sum(r["ms"] for r in records), 4)
+    roof["kernels"] = {k: {"ms": round(v["ms"], 4), "calls": v["calls"], "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                           "TFLOPs": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in by.items()}
+    return roof
+
+
+# ------------------------------------------------------------------------------------------------- one rank
+MODEL_FILES = {2: ["face_detection_back.tflite"], 3: ["face_landmark.tflite"],
+               5: ["face_detection_full_range.tflite", "face_landmark.tflite", "iris_landmark.tflite"]}
+DEFAULT_BATCH = {2: 256, 3: 512, 5: 128}
+
+
+def rehearse(args, rank, world):
+    """CPU rehearsal of the N > 1 plumbing (gloo): rendezvous, model broadcast, host-side lowering of the received bytes,
+    sharding, barrier + max-over-ranks timing, one JSON line from rank 0 — no kernels, `value` null."""
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    import rs_face_detection_tflite_amd as mi
+    mdist = import_module("rs_face_detection_tflite_amd.dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    plans = []
+    for f in MODEL_FILES[args.config]:
+        blob = mdist.broadcast_model_bytes(os.path.join(ROOT, "models", f) if rank == 0 else "/nonexistent", dist, dev)
+        plans.append(hashlib.md5(mi.plan_describe(blob, 5).encode()).hexdigest())
+    B = args.batch or DEFAULT_BATCH[args.config]
+    lo, hi = mdist.shard_range(world * B, world, rank)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    dist.barrier()
+    elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    shards = [None] * world
+    dist.all_gather_object(shards, (lo, hi, plans))
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal (gloo, CPU, no kernels)", "value": None, "unit": "faces/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "rehearsal": True, "config": {"workload": "config %d" % args.config, "global_batch": world * B,
+                                                        "shards": [s[:2] for s in shards], "plans_identical": all(s[2] == plans for s in shards)}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_rank(args):
+    import numpy as np
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.rehearse:
+        return rehearse(args, rank, world)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -86,44 +279,73 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    import rs_face_detection_tflite_amd as mi
     import ctypes as C
-
-    # ---- weights: rank 0 reads the frozen .tflite, every other rank receives it over RCCL/xGMI (one-time, timed apart)
     from importlib import import_module
+    import rs_face_detection_tflite_amd as mi
     mdist = import_module("rs_face_detection_tflite_amd.dist")
-    path = os.path.join(ROOT, "models", "face_detection_back.tflite") if rank == 0 else "/nonexistent"
+
+    # ---- weights: rank 0 reads the frozen .tflite files, every other rank receives them over RCCL/xGMI (one-time, timed apart)
     torch.cuda.synchronize()
     t0 = time.time()
-    model_bytes = mdist.broadcast_model_bytes(path, dist, device)
+    blobs = [mdist.broadcast_model_bytes(os.path.join(ROOT, "models", f) if rank == 0 else "/nonexistent", dist, device) for f in MODEL_FILES[args.config]]
     torch.cuda.synchronize()
     bcast_ms = (time.time() - t0) * 1e3 if world > 1 else 0.0
-    L = mi.lib()
-    h = C.c_void_p()
-    rc = L.mi_fd_create_from_bytes(int(mi.FaceDetectionModel.BackCamera), model_bytes, len(model_bytes), local_rank, C.byref(h))
-    if rc != 0:
-        raise SystemExit("mi_fd_create_from_bytes failed: %s" % L.mi_last_error().decode())
-    model = mi.Model(handle=L.mi_fd_model(h), owner=True)
-    if args.fuse is not None:
-        model.set_option("fuse", args.fuse)
-    if args.chunk is not None:
-        model.set_option("chunk", args.chunk)
-    if args.lanes is not None:
-        model.set_option("lanes", args.lanes)
 
-    B, cap = args.batch, 16
-    x_host = make_frames(B, seed=rank)
-    x = torch.from_numpy(x_host).to(device)
-    out = torch.zeros((B, cap, 17), dtype=torch.float32, device=device)
-    counts = torch.zeros((B,), dtype=torch.int32, device=device)
+    B = args.batch or DEFAULT_BATCH[args.config]
     stream = torch.cuda.Stream(device=device)
-    sp = C.c_void_p(stream.cuda_stream)
+    sp = stream.cuda_stream
+    x_host = None
+    if args.config == 2:
+        fd = mi.FaceDetection(mi.FaceDetectionModel.BackCamera, device=local_rank, model_bytes=blobs[0])
+        models, tag = [(fd.model, None)], "back256_b%d" % B
+        for key in ("fuse", "chunk", "lanes"):
+            if getattr(args, key) is not None:
+                fd.model.set_option(key, getattr(args, key))
+        cap = 16
+        x_host = make_frames(B, seed=rank)
+        x = torch.from_numpy(x_host).to(device)
+        out = torch.zeros((B, cap, 17), dtype=torch.float32, device=device)
+        counts = torch.zeros((B,), dtype=torch.int32, device=device)
+        L, h = mi.lib(), fd.h
+        xp, op, cp, spp = C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(counts.data_ptr()), C.c_void_p(sp)
 
-    def step():
-        rc = L.mi_fd_infer_tensor(h, C.c_void_p(x.data_ptr()), B, None, C.c_void_p(out.data_ptr()), cap,
-                                  C.c_void_p(counts.data_ptr()), mi.MI_MEM_DEVICE, sp)
-        if rc != 0:
-            raise RuntimeError(L.mi_last_error().decode())
+        def step():  # straight through the C ABI, asynchronous on `stream`
+            if L.mi_fd_infer_tensor(h, xp, B, None, op, cap, cp, mi.MI_MEM_DEVICE, spp) != 0:
+                raise RuntimeError(L.mi_last_error().decode())
+        found = lambda: int((counts > 0).sum().item())
+        metric, unit = "faces/sec at batch=256 (256x256 back-camera) per GPU", "faces/s"
+        workload = ("BackCamera BlazeFace 256x256, batch=%d frames/GPU, net + SSD decode + sigmoid + weighted NMS (configs[1]%s); "
+                    "50%% noise / 50%% face-bearing frames, inputs resident in HBM" % (B, ", sharded as configs[3]" if world > 1 else ""))
+        models[0] = (fd.model, x)
+        keep = fd
+    elif args.config == 3:
+        fl = mi.FaceLandmark(device=local_rank, model_bytes=blobs[0])
+        tag = "landmark192_b%d" % B
+        x = torch.from_numpy(make_rois(B, seed=rank)).to(device)
+        res = {}
+        def step():
+            res["lm"], res["present"], _ = fl.infer_tensor(x, stream=sp)
+        found = lambda: int(res["present"].sum().item())
+        metric, unit = "ROIs/sec, FaceLandmark 192x192 at batch=512 per GPU (configs[2])", "ROIs/s"
+        workload = "FaceLandmark 192x192, batch=%d ROIs/GPU, net + face flag + landmark projection (configs[2]); 50%% noise / 50%% face crops, inputs resident in HBM" % B
+        models = [(fl.model, x)]
+        keep = fl
+    else:
+        pipe = mi.Pipeline(mi.FaceDetectionModel.Full, device=local_rank, model_bytes=blobs)
+        tag = "pipeline192_b%d" % B
+        frames = torch.from_numpy(make_rgb_frames(B, seed=rank)).to(device)
+        res = {}
+        def step():
+            res.update(pipe.run(frames, stream=sp))
+        found = lambda: int(res["present"].sum().item())
+        metric, unit = "frames/sec, full_range detection -> face_landmark -> 2 x iris_landmark at 128 frames per GPU (configs[4])", "frames/s"
+        workload = ("full_range 192x192 -> faces[0] ROI -> face_landmark 192x192 -> eye ROIs -> 2 x iris_landmark 64x64, batch=%d RGB frames/GPU, "
+                    "every stage on the device (configs[4]); 50%% noise / 50%% face-bearing frames, frames resident in HBM" % B)
+        g = torch.Generator(device="cpu").manual_seed(rank)
+        models = [(pipe.models[0], torch.rand((B, 192, 192, 3), generator=g).mul(2).sub(1).to(device)),
+                  (pipe.models[1], torch.rand((B, 192, 192, 3), generator=g).to(device)),
+                  (pipe.models[2], torch.rand((2 * B, 64, 64, 3), generator=g).to(device))]
+        keep = pipe
 
     torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -141,65 +363,55 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, dist, device)
-    n_faces = int((counts > 0).sum().item())
+    n_found = found()
 
-    result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: HIP events between launches on the launch stream (eager replays of the
-        # same plan on the same resident inputs), grouped by kernel symbol like rocprofv3 --stats does.
-        recs = model.profile(x, reps=5)
-        by = {}
-        for r in recs:
-            k = by.setdefault(r["kernel"], {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "calls": 0})
-            k["ms"] += r["ms"]; k["bytes"] += r["bytes"]; k["macs"] += r["macs"]; k["calls"] += 1
-        dom = max(by, key=lambda k: by[k]["ms"])
-        d = by[dom]
-        achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(tpath):
-            try:
-                pm = json.load(open(tpath))
-                if pm.get("workload") == "back256_b%d" % B and pm.get("kernel") == dom:
-                    traffic = pm.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # Which roof binds the dominant kernel: its algorithmic bytes against HBM, or its algorithmic FLOPs against the dense
-        # f32 rate (157.3 TFLOP/s: v_mfma_f32_* and v_pk_fma_f32 have the same peak on gfx950; the row-pipelined chain
-        # kernels keep the intermediate rows of up to 4 layers in LDS, so their launches are FLOP-bound, not HBM-bound).
-        tflops = 2 * d["macs"] / (d["ms"] * 1e-3) / 1e12
-        hbm_frac, flop_frac = achieved / HBM_PEAK_GBS, tflops / F32_PEAK_TFLOPS
-        common = {"kernel": dom, "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 5),
-                  "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]), "algorithmic_flops_per_launch": round(2 * d["macs"] / d["calls"]),
-                  "hbm_GBps": round(achieved, 1), "hbm_frac": round(hbm_frac, 4), "f32_TFLOPs": round(tflops, 2), "f32_frac": round(flop_frac, 4)}
-        if hbm_frac >= flop_frac:
-            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic}
-        else:
-            roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic}
-        roofline.update(common)
-        roofline["net_event_ms"] = round(sum(r["ms"] for r in recs), 4)
-        roofline["kernels"] = {k: {"ms": round(v["ms"], 4), "calls": v["calls"], "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                                   "TFLOPs": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in by.items()}
+        # ---- roofline of the dominant kernel: HIP events between launches on the launch stream (eager replays of the same plans on
+        # resident inputs of the same shapes), grouped by kernel symbol like rocprofv3 --stats does.
+        recs = []
+        for m, xin in models:
+            recs += m.profile(xin, reps=5)
         value = world * B * args.steps / elapsed
         result = {
-            "metric": "faces/sec at batch=256 (256x256 back-camera) per GPU", "value": round(value, 1), "unit": "faces/s",
+            "metric": metric, "value": round(value, 1), "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BackCamera BlazeFace 256x256, batch=256 frames/GPU, net + SSD decode + sigmoid + weighted NMS "
-                                   "(configs[1]); 50% noise / 50% face-bearing frames, inputs resident in HBM",
-                       "global_batch": world * B, "frames_with_faces": n_faces, "parallelism": "frames sharded %d/GPU, no data-path collective" % B,
-                       "weight_broadcast_ms": round(bcast_ms, 3), "plan": model.describe().splitlines()[0]},
-            "roofline": roofline,
+            "config": {"workload": workload, "global_batch": world * B, "frames_with_faces": n_found,
+                       "parallelism": "frames sharded %d/GPU, one process per GPU, no data-path collective" % B,
+                       "weight_broadcast_ms": round(bcast_ms, 3), "weight_broadcast_bytes": sum(len(b) for b in blobs),
+                       "plan": " | ".join(m.describe().splitlines()[0] for m, _ in models)},
+            "roofline": roofline_of(recs, tag),
         }
-        if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N = 1 only
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:  # CPU baseline: rank 0 at N = 1 only
             threads = min(os.cpu_count() or 1, 64)
             result["cpu_baseline"] = cpu_baseline(x_host, threads)
-    L.mi_fd_free(h)
+            result["cpu_baseline_1thread"] = cpu_baseline_1thread(x_host)
+    keep.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE config: 2 = headline (4 with --gpus N), 3 = face mesh, 5 = pipeline")
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU (default 256 / 512 / 128 for config 2 / 3 / 5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing over gloo (no kernels)")
+    ap.add_argument("--fuse", type=int, default=None)
+    ap.add_argument("--chunk", type=int, default=None)
+    ap.add_argument("--lanes", type=int, default=None)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.rehearse):
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

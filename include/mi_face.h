@@ -213,7 +213,13 @@ typedef struct mi_pipeline mi_pipeline;
 /* Loads the detector selected by `fd_kind` plus face_landmark.tflite and iris_landmark.tflite from `model_dir`
  * (NULL = "./models") — the three handles of the README.md:27-46 / lib.rs:18-40 flow. */
 int mi_pipeline_create(int fd_kind, const char *model_dir, int device, mi_pipeline **out);
+/* Same, from bytes already in memory (each rank of a multi-GPU job receives the three frozen graphs by RCCL broadcast). */
+int mi_pipeline_create_from_bytes(int fd_kind, const uint8_t *fd_tflite, size_t fd_nbytes, const uint8_t *fl_tflite,
+                                  size_t fl_nbytes, const uint8_t *iris_tflite, size_t iris_nbytes, int device,
+                                  mi_pipeline **out);
 void mi_pipeline_free(mi_pipeline *p);
+/* The pipeline's three engine handles (borrowed): which = 0 detector, 1 face mesh, 2 iris; NULL otherwise. */
+mi_model *mi_pipeline_model(mi_pipeline *p, int which);
 /* mi_model_set_option on the three networks of the pipeline (e.g. "lanes": frame ranges on concurrent streams). */
 int mi_pipeline_set_option(mi_pipeline *p, const char *key, int value);
 /* For each of `batch` equally sized RGB frames (8UC3, rows of `stride` bytes, frames `stride*height` bytes apart):

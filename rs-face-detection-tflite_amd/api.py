@@ -36,7 +36,7 @@ EXPORTS = [
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
-    "mi_pipeline_create", "mi_pipeline_free", "mi_pipeline_set_option", "mi_pipeline_run",
+    "mi_pipeline_create", "mi_pipeline_create_from_bytes", "mi_pipeline_model", "mi_pipeline_free", "mi_pipeline_set_option", "mi_pipeline_run",
     "mi_bbox_to_roi", "mi_bbox_from_landmarks", "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor", "mi_jpeg_info", "mi_jpeg_decode_rgb",
 ]
 
@@ -176,6 +176,9 @@ def lib():
     L.mi_iris_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.POINTER(CLandmark),
                                       C.POINTER(CLandmark)]
     L.mi_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
+    L.mi_pipeline_create_from_bytes.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.mi_pipeline_model.argtypes = [vp, C.c_int]
+    L.mi_pipeline_model.restype = vp
     L.mi_pipeline_free.argtypes = [vp]
     L.mi_pipeline_free.restype = None
     L.mi_pipeline_set_option.argtypes = [vp, C.c_char_p, C.c_int]
@@ -340,12 +343,15 @@ def _image_args(image):
 class FaceDetection:
     """BlazeFace detector — mirrors face_detection.rs:146-267."""
 
-    def __init__(self, model_type=FaceDetectionModel.FrontCamera, model_path=None, device=0):
+    def __init__(self, model_type=FaceDetectionModel.FrontCamera, model_path=None, device=0, model_bytes=None):
         self.L = lib()
         self.h = C.c_void_p()
         # model_path is a DIRECTORY (face_detection.rs:157-161); default "./models" resolved against the repo here
         d = model_path if model_path is not None else DEFAULT_MODEL_DIR
-        _check(self.L.mi_fd_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
+        if model_bytes is not None:      # the frozen .tflite already in memory (e.g. after an RCCL broadcast)
+            _check(self.L.mi_fd_create_from_bytes(int(model_type), model_bytes, len(model_bytes), device, C.byref(self.h)))
+        else:
+            _check(self.L.mi_fd_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
         w, h = C.c_int(), C.c_int()
         self.L.mi_fd_input_size(self.h, C.byref(w), C.byref(h))
         self.input_size = (w.value, h.value)
@@ -426,11 +432,14 @@ class FaceDetection:
 class FaceLandmark:
     """468-point face mesh — mirrors face_landmark.rs:200-306."""
 
-    def __init__(self, model_path=None, device=0):
+    def __init__(self, model_path=None, device=0, model_bytes=None):
         self.L = lib()
         self.h = C.c_void_p()
         p = model_path if model_path is not None else os.path.join(DEFAULT_MODEL_DIR, "face_landmark.tflite")
-        _check(self.L.mi_fl_create(os.fsencode(p), device, C.byref(self.h)))
+        if model_bytes is not None:
+            _check(self.L.mi_fl_create_from_bytes(model_bytes, len(model_bytes), device, C.byref(self.h)))
+        else:
+            _check(self.L.mi_fl_create(os.fsencode(p), device, C.byref(self.h)))
         self.device = device
         self.model = Model(handle=self.L.mi_fl_model(self.h), owner=self, device=device)
 
@@ -486,11 +495,14 @@ class FaceLandmark:
 class IrisLandmark:
     """Iris / eye-contour model — mirrors iris_landmark.rs:130-248."""
 
-    def __init__(self, model_path=None, device=0):
+    def __init__(self, model_path=None, device=0, model_bytes=None):
         self.L = lib()
         self.h = C.c_void_p()
         p = model_path if model_path is not None else os.path.join(DEFAULT_MODEL_DIR, "iris_landmark.tflite")
-        _check(self.L.mi_iris_create(os.fsencode(p), device, C.byref(self.h)))
+        if model_bytes is not None:
+            _check(self.L.mi_iris_create_from_bytes(model_bytes, len(model_bytes), device, C.byref(self.h)))
+        else:
+            _check(self.L.mi_iris_create(os.fsencode(p), device, C.byref(self.h)))
         self.device = device
         self.model = Model(handle=self.L.mi_iris_model(self.h), owner=self, device=device)
 
@@ -551,12 +563,17 @@ class IrisLandmark:
 class Pipeline:
     """Batched detector -> mesh -> iris flow of lib.rs:18-40 / README.md:27-46, every stage on the GPU."""
 
-    def __init__(self, model_type=FaceDetectionModel.BackCamera, model_dir=None, device=0):
+    def __init__(self, model_type=FaceDetectionModel.BackCamera, model_dir=None, device=0, model_bytes=None):
         self.L = lib()
         self.h = C.c_void_p()
         d = model_dir if model_dir is not None else DEFAULT_MODEL_DIR
         self.device = device
-        _check(self.L.mi_pipeline_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
+        if model_bytes is not None:   # (detector, face_landmark, iris_landmark) .tflite blobs, e.g. received by RCCL broadcast
+            fd_b, fl_b, ir_b = model_bytes
+            _check(self.L.mi_pipeline_create_from_bytes(int(model_type), fd_b, len(fd_b), fl_b, len(fl_b), ir_b, len(ir_b), device, C.byref(self.h)))
+        else:
+            _check(self.L.mi_pipeline_create(int(model_type), os.fsencode(d), device, C.byref(self.h)))
+        self.models = [Model(handle=self.L.mi_pipeline_model(self.h, k), owner=self, device=device) for k in range(3)]
 
     def close(self):
         if getattr(self, "h", None):

@@ -763,7 +763,29 @@ int mi_pipeline_create(int fd_kind, const char* model_dir, int device, mi_pipeli
     });
 }
 
+int mi_pipeline_create_from_bytes(int fd_kind, const uint8_t* fd_tflite, size_t fd_nbytes, const uint8_t* fl_tflite, size_t fl_nbytes,
+                                  const uint8_t* iris_tflite, size_t iris_nbytes, int device, mi_pipeline** out) {
+    return guarded([&] {
+        require(out && fd_tflite && fl_tflite && iris_tflite && fd_nbytes && fl_nbytes && iris_nbytes, "null argument");
+        auto p = std::make_unique<mi_pipeline>();
+        mi_fd* fd = nullptr;
+        mi_fl* fl = nullptr;
+        mi_iris* ir = nullptr;
+        if (int rc = mi_fd_create_from_bytes(fd_kind, fd_tflite, fd_nbytes, device, &fd)) throw ApiError(rc, g_error);
+        p->fd.reset(fd);
+        if (int rc = mi_fl_create_from_bytes(fl_tflite, fl_nbytes, device, &fl)) throw ApiError(rc, g_error);
+        p->fl.reset(fl);
+        if (int rc = mi_iris_create_from_bytes(iris_tflite, iris_nbytes, device, &ir)) throw ApiError(rc, g_error);
+        p->iris.reset(ir);
+        *out = p.release();
+    });
+}
+
 void mi_pipeline_free(mi_pipeline* p) { delete p; }
+mi_model* mi_pipeline_model(mi_pipeline* p, int which) {
+    if (!p) return nullptr;
+    return which == 0 ? &p->fd->model : which == 1 ? &p->fl->model : which == 2 ? &p->iris->model : nullptr;
+}
 
 int mi_pipeline_set_option(mi_pipeline* p, const char* key, int value) {
     return guarded([&] {

@@ -76,3 +76,33 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no external launcher starts two rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rendezvous on 127.0.0.1) and rank 0 prints the one JSON line with n_gpus = 2.  Here as a CPU rehearsal
+    (--rehearse: gloo, the weight broadcast + host-side lowering + sharding + max-over-ranks timing, no kernels)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    for cfg, nfiles in ((2, 1), (5, 3)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "3", "--config", str(cfg)],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1                                     # exactly one JSON line, from rank 0
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["rehearsal"] is True and out["value"] is None and out["scaling"] == "weak"
+        B = {2: 256, 5: 128}[cfg]
+        assert out["config"]["shards"] == [[0, B], [B, 2 * B]] and out["config"]["plans_identical"] is True
+        assert out["ms_per_step"] >= 2.0                           # max over ranks: rank 1 sleeps 2 ms per step
+    # fewer GPUs visible than asked for (none here): refuse instead of running a smaller job under the label
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and "visible" in r.stderr
+    # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
