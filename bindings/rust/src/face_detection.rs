@@ -1,0 +1,88 @@
+//! face_detection.rs:117-267 of the reference.
+use crate::types::{Detection, Image, Rect};
+use crate::{check, ffi, roi_ptr};
+use anyhow::Error;
+use std::ffi::CString;
+
+/// face_detection.rs:117-123 (discriminants = `MI_FD_*` of mi_face.h)
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+#[repr(i32)]
+pub enum FaceDetectionModel {
+    FrontCamera = 0,
+    BackCamera = 1,
+    Short = 2,
+    Full = 3,
+    FullSparse = 4,
+}
+
+pub struct FaceDetection {
+    handle: *mut ffi::mi_fd,
+}
+
+// libmiface serialises calls on one handle (mi_face.h, conventions)
+unsafe impl Send for FaceDetection {}
+unsafe impl Sync for FaceDetection {}
+
+impl FaceDetection {
+    /// `FaceDetection::new(model_type, model_path)` — face_detection.rs:153-195.  `model_path` is the model DIRECTORY
+    /// (default "./models"); the file name follows from `model_type` (125-129, 163-185).
+    pub fn new(model_type: FaceDetectionModel, model_path: Option<String>) -> Result<FaceDetection, Error> {
+        Self::new_on_device(model_type, model_path, 0)
+    }
+
+    /// Same, bound to the HIP device `device` (one process per GPU in the sharded configurations).
+    pub fn new_on_device(model_type: FaceDetectionModel, model_path: Option<String>, device: i32) -> Result<FaceDetection, Error> {
+        let dir = CString::new(model_path.unwrap_or_else(|| String::from("./models")))?;
+        let mut handle: *mut ffi::mi_fd = std::ptr::null_mut();
+        check(unsafe { ffi::mi_fd_create(model_type as i32, dir.as_ptr(), device, &mut handle) })?;
+        Ok(FaceDetection { handle })
+    }
+
+    /// `infer(&self, image, roi) -> Result<Vec<Detection>>` — face_detection.rs:205-267: image_to_tensor (letterbox to the
+    /// model size, [-1, 1]) -> network -> decode_boxes -> sigmoid -> threshold -> weighted NMS -> letterbox removal, all on
+    /// the GPU.  Detections come back in descending head-score order, normalised to the picture.
+    pub fn infer(&self, image: &Image, roi: Option<Rect>) -> Result<Vec<Detection>, Error> {
+        let c_roi = roi.map(|r| r.to_mi());
+        let mut cap = 64usize;
+        loop {
+            let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; cap];
+            let mut n: i32 = 0;
+            check(unsafe {
+                ffi::mi_fd_infer_image(self.handle, image.data.as_ptr(), image.width, image.height, image.stride, roi_ptr(&c_roi),
+                                       out.as_mut_ptr(), cap as i32, &mut n)
+            })?; // MI_ERANGE = the letterbox assert! of transform.rs:121-122
+            let n = n.max(0) as usize;
+            if n <= cap {
+                return Ok(out[..n].iter().map(Detection::from_mi).collect());
+            }
+            cap = n; // the reference returns every detection: ask again with room for all of them
+        }
+    }
+
+    /// Batched form for tensors already at the model's resolution (BASELINE configs 2 and 4): `input` is f32 NHWC
+    /// `[batch, H, W, 3]` in [-1, 1] in HOST memory; `padding` = one `(left, top, right, bottom)` per frame or empty.
+    pub fn infer_tensor(&self, input: &[f32], batch: usize, padding: &[[f64; 4]], cap_per_frame: usize) -> Result<Vec<Vec<Detection>>, Error> {
+        if !padding.is_empty() && padding.len() != batch {
+            return Err(Error::msg("padding must be empty or hold one entry per frame"));
+        }
+        let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; batch * cap_per_frame];
+        let mut counts = vec![0i32; batch];
+        let pad_ptr = if padding.is_empty() { std::ptr::null() } else { padding.as_ptr() as *const f64 };
+        check(unsafe {
+            ffi::mi_fd_infer_tensor(self.handle, input.as_ptr(), batch as i32, pad_ptr, out.as_mut_ptr(), cap_per_frame as i32,
+                                    counts.as_mut_ptr(), ffi::MI_MEM_HOST, std::ptr::null_mut())
+        })?;
+        Ok((0..batch)
+            .map(|b| {
+                let n = (counts[b].max(0) as usize).min(cap_per_frame);
+                out[b * cap_per_frame..b * cap_per_frame + n].iter().map(Detection::from_mi).collect()
+            })
+            .collect())
+    }
+}
+
+impl Drop for FaceDetection {
+    fn drop(&mut self) {
+        unsafe { ffi::mi_fd_free(self.handle) }
+    }
+}

@@ -203,6 +203,21 @@ __device__ __forceinline__ void strip_row2(const float* me0, const float* me1, c
     constexpr int C = K::C;
     float wd[18], wp0[C], wp1[C];
     float4 xbuf[2][2][3];
+#ifdef MI_ABL_NOSMEM  // timing ablation (development harness only): weights come from one scalar register, no scalar loads
+    float abl_w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aA[0][0].x)));
+    auto load_first = [&](int st) {
+        asm volatile("" : "+s"(abl_w));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[i] = abl_w;
+#pragma unroll
+        for (int i = 0; i < C; i++) wp0[i] = abl_w;
+    };
+    auto load_second = [&](int st) {
+        asm volatile("" : "+s"(abl_w));
+#pragma unroll
+        for (int i = 0; i < C; i++) wp1[i] = abl_w;
+    };
+#else
     auto load_first = [&](int st) {
         const cfloat* p = cst;
         asm volatile("" : "+s"(p));
@@ -217,12 +232,22 @@ __device__ __forceinline__ void strip_row2(const float* me0, const float* me1, c
 #pragma unroll
         for (int i = 0; i < C; i++) wp1[i] = p[K::OFF_DW + st * K::ST_F + 32 + C + i];
     };
+#endif
     auto load_x = [&](int q, float4 (&x)[2][3]) {
+#ifdef MI_ABL_NOLDSX  // timing ablation: pixels from registers instead of LDS
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            x[0][kx] = xres0[(q + kx) % CQ];
+            x[1][kx] = xres0[(q + kx + 1) % CQ];
+            asm volatile("" : "+v"(x[0][kx].x), "+v"(x[0][kx].y), "+v"(x[0][kx].z), "+v"(x[0][kx].w), "+v"(x[1][kx].x), "+v"(x[1][kx].y), "+v"(x[1][kx].z), "+v"(x[1][kx].w));
+        }
+#else
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
             x[0][kx] = sld4(me0 + kx * C + 4 * q);
             x[1][kx] = sld4(me1 + kx * C + 4 * q);
         }
+#endif
     };
     {   // both rows start from skip + bias, in that order (the same arithmetic as strip_row whichever row of a pair a row is)
         const cfloat* bp = cst + K::OFF_BIAS;
@@ -256,7 +281,9 @@ __device__ __forceinline__ void strip_row2(const float* me0, const float* me1, c
 #pragma unroll
     for (int st = 0; st < 2 * CQ; st++) {
         const int q = st >> 1, h = st & 1;
+#ifndef MI_ABL_NOWAIT
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#endif
         load_second(st);
         __builtin_amdgcn_sched_barrier(0);
         const float4 (&x)[2][3] = xbuf[q & 1];
@@ -291,7 +318,9 @@ __device__ __forceinline__ void strip_row2(const float* me0, const float* me1, c
         }
         asm volatile("" : "+v"(p0), "+v"(p1));
         __builtin_amdgcn_sched_barrier(0);
+#ifndef MI_ABL_NOWAIT
         __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
         if (st + 1 < 2 * CQ) {
             load_first(st + 1);
             if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
@@ -929,7 +958,9 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         // raw s_barrier with an LDS-only wait, so that the stores of the last block and the DMA of block 0 stay in flight across it
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
+#ifndef MI_ABL_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
     };
     auto store_row = [&](int e, const float4 (&o)[CQ]) {  // transposed through LDS: 1 KiB of consecutive bytes per store instruction

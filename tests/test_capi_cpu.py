@@ -104,3 +104,47 @@ def test_header_is_plain_c99(tmp_path):
 def mi_lib_path():
     import rs_face_detection_tflite_amd as m
     return m.LIB_PATH
+
+
+def _c_prototypes():
+    """name -> number of parameters, from include/mi_face.h"""
+    src = open(os.path.join(ROOT, "include", "mi_face.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(mi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return protos
+
+
+def test_rust_shim_declarations_match_the_header():
+    """bindings/rust is source only (no rustc in the image).  What can be checked without a compiler: every `extern "C"` item
+    of src/ffi.rs names a function the header declares, with the same number of parameters, and the #[repr(C)] structs list
+    the header's fields in the header's order."""
+    protos = _c_prototypes()
+    ffi = open(os.path.join(ROOT, "bindings", "rust", "src", "ffi.rs")).read()
+    block = ffi[ffi.index('extern "C" {'):]
+    decls = re.findall(r"pub fn (mi_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", block, flags=re.S)
+    assert len(decls) >= 24
+    for name, args in decls:
+        assert name in protos, "ffi.rs declares %s, which mi_face.h does not" % name
+        n = len([a for a in args.split(",") if ":" in a])
+        assert n == protos[name], "%s: %d parameters in ffi.rs, %d in mi_face.h" % (name, n, protos[name])
+    for needed in ("mi_fd_create", "mi_fd_infer_image", "mi_fl_create", "mi_fl_infer_image", "mi_iris_create", "mi_iris_infer_image",
+                   "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_last_error"):
+        assert needed in dict(decls)
+    fields = lambda body: re.findall(r"pub (\w+):", body)
+    struct = lambda name: ffi[ffi.index("pub struct %s {" % name):].split("}")[0]
+    assert fields(struct("mi_detection")) == ["data", "score"]
+    assert fields(struct("mi_rect")) == ["x_center", "y_center", "width", "height", "rotation", "normalized"]
+    assert fields(struct("mi_landmark")) == ["x", "y", "z"]
+    # every module lib.rs names exists, and braces / parentheses balance in every source file
+    src_dir = os.path.join(ROOT, "bindings", "rust", "src")
+    lib_rs = open(os.path.join(src_dir, "lib.rs")).read()
+    for mod in re.findall(r"pub mod (\w+);", lib_rs):
+        assert os.path.exists(os.path.join(src_dir, mod + ".rs")), mod
+    for f in os.listdir(src_dir):
+        text = re.sub(r"//.*", "", open(os.path.join(src_dir, f)).read())
+        text = re.sub(r'"(?:[^"\\]|\\.)*"', '""', text)
+        for a, b in ("{}", "()", "[]"):
+            assert text.count(a) == text.count(b), (f, a)
