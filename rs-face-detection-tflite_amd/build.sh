@@ -3,13 +3,16 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 SRC="$HERE/csrc"
-OUT="$HERE/libmiface.so"
+# Development variants (in-kernel stamps ...): MI_VARIANT=name MI_EXTRA_FLAGS="-D..." -> build-name/, libmiface-name.so
+VARIANT="${MI_VARIANT:-}"
+OUT="$HERE/libmiface${VARIANT:+-$VARIANT}.so"
+BUILD="$HERE/build${VARIANT:+-$VARIANT}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result -I"$HERE/../include")
+FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result -I"$HERE/../include" ${MI_EXTRA_FLAGS:-})
 OBJ=()
-mkdir -p "$HERE/build"
+mkdir -p "$BUILD"
 for f in tflite_graph.cpp plan.cpp host_glue.cpp jpeg.cpp engine.cpp capi.cpp jpeg_kernels.hip kernels.hip block_kernels.hip strip_kernels.hip chain_kernels.hip resident_kernels.hip preproc.hip; do
-  o="$HERE/build/${f%.*}.o"
+  o="$BUILD/${f%.*}.o"
   if [[ ! -f "$o" || "$SRC/$f" -nt "$o" || -n "$(find "$SRC" -name '*.hpp' -newer "$o" -print -quit)" || "$HERE/../include/mi_face.h" -nt "$o" ]]; then
     echo "  hipcc $f"
     case "$f" in

@@ -190,7 +190,9 @@ void Model::rebuild() {
         if (n.b >= 0) node_b_[i] = put(g.tensors[n.b].f32);
         if (n.b2 >= 0) node_b2_[i] = put(g.tensors[n.b2].f32);
         if (n.alpha >= 0) node_alpha_[i] = put(g.tensors[n.alpha].f32);
-        if (n.kind == Node::Conv) {
+        if (n.kind == Node::Conv && n.gemm_head) {
+            node_w_[i] = put(g.tensors[n.w].f32);  // [O][KH*KW*I] as stored: the GEMM's W[N][K]
+        } else if (n.kind == Node::Conv) {
             const auto& ws = g.tensors[n.w].shape;  // [O][KH][KW][I]
             const auto& src = g.tensors[n.w].f32;
             int O = ws[0], KH = ws[1], KW = ws[2], I = ws[3], Cop = (O + 3) & ~3;
@@ -361,7 +363,7 @@ float* Model::tensor_ptr_mut(int t, int chunk_start, long* fs) const {
 std::string Model::node_label(const Node& n) const {
     const Graph& g = plan_.graph;
     switch (n.kind) {
-        case Node::Conv: return "conv_generic_kernel";
+        case Node::Conv: return n.gemm_head ? "head_gemm_kernel" : "conv_generic_kernel";
         case Node::Dw: return "dw_kernel";
         case Node::Block: {
             const int Co = g.tensors[n.out].shape.back();
@@ -524,6 +526,16 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         float* op = tensor_ptr_mut(n.out, chunk_start, &out_fs);
         switch (n.kind) {
             case Node::Conv: {
+                if (n.gemm_head) {
+                    HeadGemmArgs h;
+                    h.in = ip; h.out = op; h.in_fs = in_fs; h.out_fs = out_fs;
+                    h.w = d_weights_ + node_w_[i];
+                    h.bias = ep.bias; h.alpha = ep.alpha; h.act = ep.act;
+                    h.B = F; h.K = si[1] * si[2] * si[3]; h.N = so[3];
+                    rc = launch_head_gemm(h, s);
+                    if (labels) labels->back() = "head_gemm_kernel";
+                    break;
+                }
                 ConvArgs a;
                 a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
                 a.w = d_weights_ + node_w_[i];

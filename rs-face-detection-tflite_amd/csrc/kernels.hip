@@ -288,6 +288,57 @@ int launch_dw(const DwArgs& a, void* stream) {
     return (int)launch_kernel(dw_kernel<1>, dim3(blocks), dim3(256), 0, s, a);
 }
 
+// ------------------------------------------------------------------------------------------------ frame-batched head GEMM
+// out[b][n] = act(bias[n] + sum_k x[b][k] * W[n][k]) on v_mfma_f32_32x32x2_f32: one wave per 32 frames x 32 outputs.  The
+// contraction index is split in two halves (lanes 0-31 take k in [0, K/2), lanes 32-63 take [K/2, K)), so every lane reads
+// its operands as float4 of four consecutive k: four MFMAs per pair of 16-byte loads, both operands straight from L2.
+typedef float hg_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__global__ __launch_bounds__(256) void head_gemm_kernel(HeadGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * 32, b0 = blockIdx.y * 32;
+    if (n0 >= a.N) return;  // whole wave
+    const int r = lane & 31, h = lane >> 5, K2 = a.K >> 1;
+    const float* xp = a.in + (long)min(b0 + r, a.B - 1) * a.in_fs + h * K2;   // rows past the batch / the outputs re-read the
+    const float* wp = a.w + (long)min(n0 + r, a.N - 1) * a.K + h * K2;        // last valid one; their results are not stored
+    hg_f32x16 D;
+#pragma unroll
+    for (int e = 0; e < 16; e++) D[e] = 0.f;
+    float4 xa = ld4(xp), wa = ld4(wp);
+    for (int j = 0; j < K2; j += 4) {
+        const int jn = min(j + 4, K2 - 4);
+        const float4 xn = ld4(xp + jn), wn = ld4(wp + jn);  // next chunk in flight under this chunk's MFMAs
+        D = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.x, wa.x, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.y, wa.y, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.z, wa.z, D, 0, 0, 0);
+        D = __builtin_amdgcn_mfma_f32_32x32x2f32(xa.w, wa.w, D, 0, 0, 0);
+        xa = xn; wa = wn;
+    }
+    // D[v]: frame b0 + 4 * h + 8 * (v / 4) + v % 4, output n0 + r
+    const int n = n0 + r;
+    if (n >= a.N) return;
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    const float slope = a.act == ACT_PRELU ? a.alpha[n] : (a.act == ACT_NONE ? 1.f : 0.f);
+    const float hi = a.act == ACT_RELU6 ? 6.f : INFINITY;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+        const int b = b0 + 4 * h + 8 * (v >> 2) + (v & 3);
+        if (b >= a.B) continue;
+        const float t = D[v] + bias;
+        a.out[(long)b * a.out_fs + n] = fminf(fmaxf(t, 0.f) + slope * fminf(t, 0.f), hi);
+    }
+}
+
+bool head_gemm_supports(int K, int N) { return K >= 16 && (K % 8) == 0 && N >= 1; }
+
+int launch_head_gemm(const HeadGemmArgs& a, void* stream) {
+    if (!head_gemm_supports(a.K, a.N) || a.B < 1 || (a.in_fs & 3) || (reinterpret_cast<uintptr_t>(a.in) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15))
+        return (int)hipErrorInvalidValue;
+    const unsigned tiles_n = (unsigned)((a.N + 31) / 32);
+    return (int)launch_kernel(head_gemm_kernel, dim3((tiles_n + 3) / 4, (unsigned)((a.B + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
+}
+
 // ------------------------------------------------------------------------------------------------ element-wise fallbacks
 __global__ void add_kernel(EltArgs a) {  // out = act(a + b), same shape
     long per = (long)a.H * a.W * a.C;

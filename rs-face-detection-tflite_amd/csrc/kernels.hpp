@@ -36,6 +36,20 @@ struct ConvArgs {
     Epilogue ep;
 };
 
+// Convolution whose window is the whole frame (VALID, H == KH, W == KW: the 3x3-stride-3 mesh head 32 -> 1404, the 2x2 iris
+// heads 128 -> 213 / 15): per frame a matrix-vector product over K = KH*KW*C contiguous floats, so over a batch a plain
+// GEMM  out[B][N] = x[B][K] * W[N][K]^T + bias  whose weights are read once per 32 frames instead of once per frame.
+struct HeadGemmArgs {
+    const float* in = nullptr;   // frame b: K contiguous floats at in + b * in_fs
+    const float* w = nullptr;    // [N][K] (TFLite OHWI as stored)
+    const float* bias = nullptr; // [N] or null
+    const float* alpha = nullptr;
+    float* out = nullptr;        // frame b: N floats at out + b * out_fs
+    long in_fs = 0, out_fs = 0;
+    int B = 0, K = 0, N = 0;
+    int act = ACT_NONE;
+};
+
 struct DwArgs {
     const float* in = nullptr;
     const float* w = nullptr;   // [3][3][C]
@@ -214,6 +228,8 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream);
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
 int strip_pipe_rows_per_step(int H, int hint = 0);
 int launch_chain(const ChainArgs& a, void* stream);
+int launch_head_gemm(const HeadGemmArgs& a, void* stream);
+bool head_gemm_supports(int K, int N);
 bool chain_kernel_supports(const ChainArgs& a);
 int launch_add(const EltArgs& a, void* stream);
 int launch_act(const EltArgs& a, void* stream);

@@ -234,6 +234,8 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
             const auto& si = g.tensors[n.in[0]].shape;
             if (si[1] * si[2] > 256) return false;  // row-pipelined chains stay what they are
             for (const Node& m : n.members) M.push_back(m);
+        } else if (n.kind == Node::Conv && n.gemm_head) {
+            return false;  // a whole-frame convolution is a GEMM over the batch: its weights are read once per 32 frames there, once per frame here
         } else if (n.kind == Node::Block || n.kind == Node::Conv) {
             M.push_back(n);
         } else {
@@ -745,6 +747,19 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
         plan.nodes = std::move(fusedv);
     }
 
+    // ---- whole-frame convolutions (VALID, window = frame, one output pixel: the mesh and iris output heads) as batch GEMMs
+    if (fuse_level >= 2) {
+        for (Node& n : plan.nodes) {
+            if (n.kind != Node::Conv || n.res >= 0 || n.in.size() != 1) continue;
+            const auto& si = g.tensors[n.in[0]].shape;
+            const auto& so = g.tensors[n.out].shape;
+            if (si.size() != 4 || so.size() != 4 || si[1] != n.KH || si[2] != n.KW || so[1] != 1 || so[2] != 1) continue;
+            if (n.padding != Padding::Valid && !(n.KH == 1 && n.KW == 1)) continue;
+            if (si[1] * si[2] < 2) continue;  // 1x1 frames: pointwise, the stage programs / block kernels have them
+            n.gemm_head = head_gemm_supports(n.KH * n.KW * si[3], so[3]);
+        }
+    }
+
     // ---- level 5: frame-resident stage programs
     if (fuse_level >= 5) {
         reorder_branches(plan.nodes);
@@ -882,6 +897,7 @@ std::string Plan::describe() const {
         for (size_t d = 1; d < so.size(); d++) os << (d > 1 ? "x" : "") << so[d];
         os << "]";
         if (n.kind == Node::Conv || n.kind == Node::Dw || (n.kind == Node::Block && n.w >= 0)) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
+        if (n.kind == Node::Conv && n.gemm_head) os << " whole-frame window: GEMM over the batch";
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
         if (n.kind == Node::Chain)
             os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")

@@ -479,3 +479,8 @@ int launch_resident(const ResLaunch& a, void* stream) {
 }
 
 }  // namespace mi
+
+#ifdef MI_RES_STAMPS
+// stamps build only (tools/res_stamps.py): where the per-stage s_memtime stamps of the next launches go
+extern "C" void mi_debug_set_res_stamps(unsigned long long* p) { mi::g_res_stamps = p; }
+#endif

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     auto step = [&](int t, const float4 (&xin)[CQ], float4 (&xout)[CQ], v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
         const int m = t - 2 * role;  // pair index of this block in this step
         const int c0 = lo_j - 1 + 2 * m;
-        bool hand_over = false;
+        bool hand_over = false, store_out = false;
         float4 o0[CQ], o1[CQ];
         if (!tail && active && m >= 0 && m < P) {
             const float *me0, *me1;
@@ -1061,12 +1061,12 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
             if (m >= 1) {  // rows c0 - 1 and c0 are finished
                 strip_act<CQ, RELU>(oacc0, cst + K::OFF_SLOPE, hi, o0);
                 strip_act<CQ, RELU>(oacc1, cst + K::OFF_SLOPE, hi, o1);
-                if (NH2 || role < S - 1) {
-                    hand_over = true;
-                } else {
-                    store_row(c0 - 1, o0);
-                    store_row(c0, o1);
-                }
+                if (NH2 || role < S - 1) hand_over = true;
+#ifdef MI_ABL_STORE_EARLY
+                else { store_row(c0 - 1, o0); store_row(c0, o1); }
+#else
+                else store_out = true;  // the last block's rows go to memory in the hand-over phase, while the others write their rings
+#endif
             }
             if (role == 0 && m + 2 < P) {
                 wave_sync();
@@ -1081,6 +1081,9 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         if (hand_over) {
             hand_row(c0 - 1, 0, o0);
             hand_row(c0, 1, o1);
+        } else if (store_out) {
+            store_row(c0 - 1, o0);
+            store_row(c0, o1);
         }
         wg_barrier();
     };
