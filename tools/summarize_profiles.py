@@ -1,60 +1,108 @@
-"""Turns raw rocprofv3 output under gpurun_out/ into the small, committed summaries under profiles/.
-usage: python tools/summarize_profiles.py <round-tag> <trace-dir> <fetch-dir> <write-dir>
-PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate
-passes, are reported in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide (16 B/lane) coalesced read stream,
-so reads = 2 x FETCH_SIZE for the block / strip / chain kernels (their loads are 16 B/lane, plain or LDS-DMA); other kernels are
-listed uncorrected."""
-import collections, csv, glob, json, os, shutil, statistics, sys
+"""Turns the raw rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into the small, committed summaries under
+profiles/.   usage: python tools/summarize_profiles.py r02
+PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate passes, are
+reported in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide (16 B/lane) coalesced read stream, so reads = 2 x FETCH_SIZE
+for the block / strip / chain kernels (their loads are 16 B/lane, plain or LDS-DMA); other kernels are listed uncorrected.
+pmc_summary.json is stamped with a hash of the kernel sources: bench.py reports `traffic` only while that hash still matches."""
+import collections, csv, glob, json, os, re, shutil, statistics, sys
 
-tag, trace, fetch, write = sys.argv[1:5]
+tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+base = os.path.join(root, "gpurun_out", "prof_" + tag)
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
-ks = glob.glob(os.path.join(trace, "*", "*_kernel_stats.csv"))[0]
-shutil.copy(ks, os.path.join(out, "%s_kernel_stats.csv" % tag))
 
-def load(d):
-    by = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0])):
-        by[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    return by
-f, w = load(fetch), load(write)
-rows = []
-for k in sorted(f, key=lambda k: -sum(f[k])):
-    if not k.startswith("void mi::") and not k.startswith("mi::"):
-        continue
-    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel"))
-    fk, wk = statistics.mean(f[k]), statistics.mean(w.get(k, [0]))
-    rows.append({"kernel": k, "dispatches": len(f[k]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
-                 "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
-with open(os.path.join(out, "%s_pmc_by_kernel.csv" % tag), "w", newline="") as fh:
-    wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
-    wr.writeheader()
-    wr.writerows(rows)
-dom = max(csv.DictReader(open(ks)), key=lambda r: float(r["TotalDurationNs"]))
-name = dom["Name"]
-pm = next(r for r in rows if r["kernel"] == name)
-import re
+
+def one(pattern):
+    hits = glob.glob(os.path.join(base, pattern), recursive=True)
+    return hits[0] if hits else None
+
+
 def label(name):
     # rocprofv3 symbol -> the label mi_model_profile / bench.py use: template arguments as integers, SLOW / CPT dropped for block kernels
     m = re.search(r"(\w+)<([^>]*)>", name.replace("(anonymous namespace)::", ""))
-    if not m: return name
+    if not m:
+        m2 = re.search(r"(\w+)\(", name.replace("(anonymous namespace)::", ""))
+        return m2.group(1) if m2 else name
     args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2).split(",")]
-    if m.group(1) == "block_kernel": args = args[:5]
+    if m.group(1) == "block_kernel":
+        args = args[:5]
+    if m.group(1) == "stem_conv_kernel":
+        return "stem_conv_kernel"
     return "%s<%s>" % (m.group(1), ",".join(args))
-label = label(name)
-json.dump({"round": tag, "workload": "back256_b256", "kernel": label, "rocprof_name": name, "calls": int(dom["Calls"]),
-           "avg_ns": float(dom["AverageNs"]), "hbm_bytes_per_launch": pm["hbm_bytes_per_launch"],
-           "note": "reads = 2 x FETCH_SIZE (gfx950 16B/lane stream correction) + WRITE_SIZE, KiB -> bytes"},
-          open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
-print(open(os.path.join(out, "pmc_summary.json")).read())
-# per-launch event profiles of every model (tools/profile_model.py) and the secondary configs, when collect_profiles.sh produced them
-base = os.path.dirname(os.path.normpath(trace))
+
+
+# ---- kernel stats per config
+for c in (2, 3, 5):
+    ks = one("trace_c%d/**/*_kernel_stats.csv" % c)
+    if ks:
+        shutil.copy(ks, os.path.join(out, "%s_kernel_stats_config%d.csv" % (tag, c)))
+
+
+def load(d):
+    by = collections.defaultdict(list)
+    f = one(d + "/**/*_counter_collection.csv")
+    if not f:
+        return by
+    for r in csv.DictReader(open(f)):
+        by[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return by
+
+
+# ---- HBM traffic of config 2's kernels
+f, w = load("fetch"), load("write")
+rows = []
+for (k, _c) in sorted(f, key=lambda kc: -sum(f[kc])):
+    if "mi::" not in k:
+        continue
+    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel"))
+    fk, wk = statistics.mean(f[(k, "FETCH_SIZE")]), statistics.mean(w.get((k, "WRITE_SIZE"), [0]))
+    rows.append({"kernel": k, "label": label(k), "dispatches": len(f[(k, "FETCH_SIZE")]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
+                 "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
+if rows:
+    with open(os.path.join(out, "%s_pmc_by_kernel.csv" % tag), "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        wr.writerows(rows)
+    import bench
+    ks2 = os.path.join(out, "%s_kernel_stats_config2.csv" % tag)
+    avg = {label(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(ks2))} if os.path.exists(ks2) else {}
+    by_label = collections.defaultdict(list)
+    for r in rows:
+        by_label[r["label"]].append(r)
+    entries = [{"round": tag, "workload": "back256_b256", "kernel": lab, "source_hash": bench.kernel_source_hash(), "rocprof_avg_ns": avg.get(lab),
+                "hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / sum(r["dispatches"] for r in rs)),
+                "note": "reads = 2 x FETCH_SIZE (gfx950 16 B/lane stream correction) + WRITE_SIZE, KiB -> bytes; separate --pmc passes"}
+               for lab, rs in by_label.items()]
+    json.dump({"entries": entries}, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+
+# ---- SQ counters of config 2 (where a wave's cycles go)
+sq = {}
+for i in range(1, 5):
+    for (k, c), v in load("sq%d" % i).items():
+        sq.setdefault(k, {})[c] = statistics.mean(v)
+with open(os.path.join(out, "%s_sq_counters_bench.txt" % tag), "w") as fh:
+    fh.write("# rocprofv3 --pmc passes of tools/collect_profiles.sh on bench.py (BackCamera 256 frames): per kernel, averages per dispatch;\n"
+             "# cyc/wave = 4 x SQ_WAVE_CYCLES / SQ_WAVES; wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu / salu = SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES; instruction counts per wave\n")
+    for k, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+        if "mi::" not in k or not c.get("SQ_WAVES"):
+            continue
+        wv, wc = c["SQ_WAVES"], max(c.get("SQ_WAVE_CYCLES", 0), 1)
+        g = lambda n: c.get(n, 0)
+        fh.write("%-34s waves %6d cyc/wave %8.0f wait %.2f (lds %.2f) valu %.2f salu %.2f | VALU %.0f SALU %.0f LDS %.0f SMEM %.0f VMEM %.0f\n" % (
+            label(k), wv, 4 * wc / wv, g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_LDS") / wc, g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_SCA") / wc,
+            g("SQ_INSTS_VALU") / wv, g("SQ_INSTS_SALU") / wv, g("SQ_INSTS_LDS") / wv, g("SQ_INSTS_SMEM") / wv, (g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")) / wv))
+
+# ---- bench lines, per-launch event lists, secondary configs
+for c in (2, 3, 5):
+    p = os.path.join(base, "bench_c%d.json" % c)
+    if os.path.exists(p) and open(p).read().strip():
+        with open(os.path.join(out, "bench_%s_config%d_n1.json" % (tag, c)), "w") as fh:
+            fh.write(open(p).read().strip().splitlines()[-1] + "\n")
 for fpath in glob.glob(os.path.join(base, "launches_*.txt")):
     shutil.copy(fpath, os.path.join(out, "%s_%s" % (tag, os.path.basename(fpath))))
 if os.path.exists(os.path.join(base, "configs.log")):
     with open(os.path.join(out, "configs_%s.jsonl" % tag), "w") as fh:
         fh.writelines(l for l in open(os.path.join(base, "configs.log")) if l.startswith("{"))
-if os.path.exists(os.path.join(base, "bench.json")):
-    with open(os.path.join(out, "bench_%s_n1.json" % tag), "w") as fh:
-        fh.write(open(os.path.join(base, "bench.json")).read().strip().splitlines()[-1] + "\n")
+print("wrote", sorted(f for f in os.listdir(out) if tag in f or f == "pmc_summary.json"))
