@@ -46,14 +46,71 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g)
     const int rowf4 = a.W * g.C4;
     const int nch = g.Ch >> 2;
 
-    // ---- load the frame (coalesced), zero border / pad channels
-    for (int i = tid; i < ((a.H + 2) * g.RS) >> 2; i += 512) reinterpret_cast<float4*>(tile)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    for (int i = tid; i < a.H * rowf4; i += 512) {
-        int r = i / rowf4, e = i - r * rowf4;
-        int px = e / g.C4, c4 = e - px * g.C4;
-        *reinterpret_cast<float4*>(tile + (r + 1) * g.RS + (px + 1) * g.PS + 4 * c4) = cld4(in + 4 * (long)i);
-    }
+    // small per-block constants -> LDS (depthwise taps [9][Cs] zero-padded to Cp, depthwise bias, pointwise bias, negative slopes)
+    auto stage_consts = [&](const ChainBlock& cb, int Cs, int Cos) {
+        for (int i = tid; i < 9 * g.Cp; i += 512) {
+            int c = i % g.Cp;
+            lds[g.off_wdw + i] = c < Cs ? cb.w_dw[(i / g.Cp) * Cs + c] : 0.f;
+        }
+        for (int i = tid; i < g.Cp; i += 512) lds[g.off_bdw + i] = (i < Cs && cb.b_dw) ? cb.b_dw[i] : 0.f;
+        for (int i = tid; i < MT * 32; i += 512) {
+            lds[g.off_bias + i] = (i < Cos && cb.bias) ? cb.bias[i] : 0.f;
+            lds[g.off_alpha + i] = (i < Cos && cb.act == ACT_PRELU) ? cb.alpha[i] : (cb.act == ACT_NONE ? 1.f : 0.f);
+        }
+    };
+    // One 32-pixel group on this wave: depthwise chunk j (4 channels of this lane's k-half) by `dw`, the MFMAs of chunk j
+    // interleaved with the depthwise math of chunk j + 1, pointwise weights streamed from L2 one chunk ahead.
+    auto contract = [&](const ChainBlock& cb, int nchk, auto&& dw, f32x16c (&D)[MT]) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) D[m][e] = 0.f;
+        auto a_frag = [&](int j, float4 (&av)[MT]) {  // packed [tile][chunk][lane][4] in global/L2
+#pragma unroll
+            for (int m = 0; m < MT; m++) av[m] = cld4(cb.w_pw + (((long)m * nchk + j) * 64 + lane) * 4);
+        };
+        auto mfma_chunk = [&](const float4 (&av)[MT], const float4& bf) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bf.x, D[m], 0, 0, 0);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bf.y, D[m], 0, 0, 0);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bf.z, D[m], 0, 0, 0);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf.w, D[m], 0, 0, 0);
+            }
+        };
+        float4 bf, av[MT];
+        dw(0, bf);
+        a_frag(0, av);
+        for (int j = 0; j + 1 < nchk; j++) {
+            float4 bn, an[MT];
+            mfma_chunk(av, bf);
+            a_frag(j + 1, an);
+            dw(j + 1, bn);
+            bf = bn;
+#pragma unroll
+            for (int m = 0; m < MT; m++) av[m] = an[m];
+            constexpr int NM = 4 * MT;
+#pragma unroll
+            for (int k = 0; k < NM; k++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, (19 + NM - 1) / NM, 0);  // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, (20 + NM - 1) / NM, 0);  // VALU
+            }
+        }
+        mfma_chunk(av, bf);
+    };
+    // bias (+ skip) + activation of the 4 channels (m, gq) of this lane, in place in D
+    auto finish = [&](f32x16c (&D)[MT], int m, int gq, const float4& skip, float hi) {
+        const int ch = m * 32 + 8 * gq + 4 * h;
+        const float4 bb = cld4(lds + g.off_bias + ch), al = cld4(lds + g.off_alpha + ch);
+        const float4 v = make_float4(D[m][4 * gq] + bb.x + skip.x, D[m][4 * gq + 1] + bb.y + skip.y, D[m][4 * gq + 2] + bb.z + skip.z, D[m][4 * gq + 3] + bb.w + skip.w);
+        D[m][4 * gq] = fminf(fmaxf(v.x, 0.f) + al.x * fminf(v.x, 0.f), hi);
+        D[m][4 * gq + 1] = fminf(fmaxf(v.y, 0.f) + al.y * fminf(v.y, 0.f), hi);
+        D[m][4 * gq + 2] = fminf(fmaxf(v.z, 0.f) + al.z * fminf(v.z, 0.f), hi);
+        D[m][4 * gq + 3] = fminf(fmaxf(v.w, 0.f) + al.w * fminf(v.w, 0.f), hi);
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
     // this wave's pixel group
     const int q = wave * 32 + pl;
     const bool valid = q < a.H * a.W;
@@ -62,31 +119,83 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g)
     const int base0 = oy * g.RS + ox * g.PS + h * g.Ch;  // tap (ky, kx) = base0 + ky*RS + kx*PS (input row oy-1+ky at slot oy+ky)
     float* centre = tile + (oy + 1) * g.RS + (ox + 1) * g.PS;
 
+    for (int i = tid; i < ((a.H + 2) * g.RS) >> 2; i += 512) reinterpret_cast<float4*>(tile)[i] = zero4;
+    if (a.pre.on) {
+        // ---- the stride-2 block in front of the chain: its (2H x 2W x Cin) input comes straight from global memory (L2 / MALL),
+        // its output becomes the resident frame
+        const ChainBlock& cb = a.pre.blk;
+        const int Cin = a.pre.Cin, Chp = Cin >> 1, Hi = 2 * a.H, Wi = 2 * a.W;
+        stage_consts(cb, Cin, a.C);
+        __syncthreads();
+        if (wave_active) {
+            const float* src = a.pre.in + (long)b * a.pre.in_fs;
+            const float* wdw = lds + g.off_wdw;
+            const float* bdw = lds + g.off_bdw;
+            f32x16c D[MT];
+            auto dw = [&](int j, float4& bf) {
+                const int c0 = h * Chp + 4 * j;
+                bf = cld4(bdw + c0);
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        // SAME on an even size: no pad before, one zero row / column after.  The load is unconditional (clamped
+                        // address) and the tap weight is zeroed instead: a predicated load would put a branch and a full
+                        // memory round trip around every one of the nine taps
+                        const int iy = 2 * oy + ky, ix = 2 * ox + kx;
+                        const bool inside = iy < Hi && ix < Wi;
+                        float4 w = cld4(wdw + (ky * 3 + kx) * g.Cp + c0);
+                        if (!inside) w = zero4;
+                        const float4 d = cld4(src + ((long)min(iy, Hi - 1) * Wi + min(ix, Wi - 1)) * Cin + c0);
+                        bf.x = fmaf(d.x, w.x, bf.x);
+                        bf.y = fmaf(d.y, w.y, bf.y);
+                        bf.z = fmaf(d.z, w.z, bf.z);
+                        bf.w = fmaf(d.w, w.w, bf.w);
+                    }
+            };
+            contract(cb, Chp >> 2, dw, D);
+            const float hi = cb.act == ACT_RELU6 ? 6.f : INFINITY;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = m * 32 + 8 * gq + 4 * h;
+                    if (ch >= a.C) continue;
+                    float4 sk = zero4;
+                    if (cb.has_res && ch < Cin) {  // 2x2 max-pool of the input, channels above Cin are the zero pad
+                        const float* p0 = src + ((long)(2 * oy) * Wi + 2 * ox) * Cin + ch;
+                        const float4 s0 = cld4(p0), s1 = cld4(p0 + Cin), s2 = cld4(p0 + (long)Wi * Cin), s3 = cld4(p0 + (long)Wi * Cin + Cin);
+                        sk = make_float4(fmaxf(fmaxf(s0.x, s1.x), fmaxf(s2.x, s3.x)), fmaxf(fmaxf(s0.y, s1.y), fmaxf(s2.y, s3.y)),
+                                         fmaxf(fmaxf(s0.z, s1.z), fmaxf(s2.z, s3.z)), fmaxf(fmaxf(s0.w, s1.w), fmaxf(s2.w, s3.w)));
+                    }
+                    finish(D, m, gq, sk, hi);
+                    if (valid) *reinterpret_cast<float4*>(centre + ch) = make_float4(D[m][4 * gq], D[m][4 * gq + 1], D[m][4 * gq + 2], D[m][4 * gq + 3]);
+                }
+        }
+        __syncthreads();
+    } else {
+        // ---- load the frame (coalesced)
+        __syncthreads();
+        for (int i = tid; i < a.H * rowf4; i += 512) {
+            int r = i / rowf4, e = i - r * rowf4;
+            int px = e / g.C4, c4 = e - px * g.C4;
+            *reinterpret_cast<float4*>(tile + (r + 1) * g.RS + (px + 1) * g.PS + 4 * c4) = cld4(in + 4 * (long)i);
+        }
+    }
+
     for (int blk = 0; blk < a.nblocks; blk++) {
         const ChainBlock& cb = a.blocks[blk];
         // ---- stage this block's small constants (previous block's readers are past the barrier below)
-        for (int i = tid; i < 9 * g.Cp; i += 512) {
-            int c = i % g.Cp;
-            lds[g.off_wdw + i] = c < a.C ? cb.w_dw[(i / g.Cp) * a.C + c] : 0.f;
-        }
-        for (int i = tid; i < g.Cp; i += 512) lds[g.off_bdw + i] = (i < a.C && cb.b_dw) ? cb.b_dw[i] : 0.f;
-        for (int i = tid; i < MT * 32; i += 512) {
-            lds[g.off_bias + i] = (i < a.C && cb.bias) ? cb.bias[i] : 0.f;
-            lds[g.off_alpha + i] = (i < a.C && cb.act == ACT_PRELU) ? cb.alpha[i] : (cb.act == ACT_NONE ? 1.f : 0.f);
-        }
+        stage_consts(cb, a.C, a.C);
         __syncthreads();
         const float* wdw = lds + g.off_wdw;
         const float* bdw = lds + g.off_bdw;
 
         f32x16c D[MT];
         if (wave_active) {
-#pragma unroll
-            for (int m = 0; m < MT; m++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) D[m][e] = 0.f;
-            auto dw_chunk = [&](int j, float4& bf) {
+            auto dw = [&](int j, float4& bf) {
                 const float* wj = wdw + h * g.Ch + 4 * j;
-                bf = make_float4(0.f, 0.f, 0.f, 0.f);
+                bf = zero4;
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -101,39 +210,7 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g)
                 const float4 bb = cld4(bdw + h * g.Ch + 4 * j);
                 bf.x += bb.x; bf.y += bb.y; bf.z += bb.z; bf.w += bb.w;
             };
-            auto a_frag = [&](int j, float4 (&av)[MT]) {  // packed [tile][chunk][lane][4] in global/L2
-#pragma unroll
-                for (int m = 0; m < MT; m++) av[m] = cld4(cb.w_pw + (((long)m * nch + j) * 64 + lane) * 4);
-            };
-            auto mfma_chunk = [&](const float4 (&av)[MT], const float4& bf) {
-#pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bf.x, D[m], 0, 0, 0);
-                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bf.y, D[m], 0, 0, 0);
-                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bf.z, D[m], 0, 0, 0);
-                    D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bf.w, D[m], 0, 0, 0);
-                }
-            };
-            float4 bf, av[MT];
-            dw_chunk(0, bf);
-            a_frag(0, av);
-            for (int j = 0; j + 1 < nch; j++) {
-                float4 bn, an[MT];
-                mfma_chunk(av, bf);
-                a_frag(j + 1, an);
-                dw_chunk(j + 1, bn);
-                bf = bn;
-#pragma unroll
-                for (int m = 0; m < MT; m++) av[m] = an[m];
-                constexpr int NM = 4 * MT;
-#pragma unroll
-                for (int k = 0; k < NM; k++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, (19 + NM - 1) / NM, 0);  // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, (20 + NM - 1) / NM, 0);  // VALU
-                }
-            }
-            mfma_chunk(av, bf);
+            contract(cb, nch, dw, D);
             // ---- epilogue into registers (reads x at the centre pixel), written back after the barrier
             const float hi = cb.act == ACT_RELU6 ? 6.f : INFINITY;
 #pragma unroll
@@ -142,16 +219,7 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g)
                 for (int gq = 0; gq < 4; gq++) {
                     const int ch = m * 32 + 8 * gq + 4 * h;
                     if (ch >= a.C) continue;
-                    const float4 bb = cld4(lds + g.off_bias + ch), al = cld4(lds + g.off_alpha + ch);
-                    float4 v = make_float4(D[m][4 * gq] + bb.x, D[m][4 * gq + 1] + bb.y, D[m][4 * gq + 2] + bb.z, D[m][4 * gq + 3] + bb.w);
-                    if (cb.has_res) {
-                        const float4 rv = cld4(centre + ch);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-                    }
-                    D[m][4 * gq] = fminf(fmaxf(v.x, 0.f) + al.x * fminf(v.x, 0.f), hi);
-                    D[m][4 * gq + 1] = fminf(fmaxf(v.y, 0.f) + al.y * fminf(v.y, 0.f), hi);
-                    D[m][4 * gq + 2] = fminf(fmaxf(v.z, 0.f) + al.z * fminf(v.z, 0.f), hi);
-                    D[m][4 * gq + 3] = fminf(fmaxf(v.w, 0.f) + al.w * fminf(v.w, 0.f), hi);
+                    finish(D, m, gq, cb.has_res ? cld4(centre + ch) : zero4, hi);
                 }
         }
         __syncthreads();  // every wave has read x for this block
@@ -168,11 +236,63 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g)
         __syncthreads();
     }
     // ---- write the frame back (coalesced 16 B per lane, consecutive addresses)
-    float* out = a.out + (long)b * a.out_fs;
-    for (int i = tid; i < a.H * rowf4; i += 512) {
-        int r = i / rowf4, e = i - r * rowf4;
-        int px = e / g.C4, c4 = e - px * g.C4;
-        *reinterpret_cast<float4*>(out + 4 * (long)i) = cld4(tile + (r + 1) * g.RS + (px + 1) * g.PS + 4 * c4);
+    if (a.write_out) {
+        float* out = a.out + (long)b * a.out_fs;
+        for (int i = tid; i < a.H * rowf4; i += 512) {
+            int r = i / rowf4, e = i - r * rowf4;
+            int px = e / g.C4, c4 = e - px * g.C4;
+            *reinterpret_cast<float4*>(out + 4 * (long)i) = cld4(tile + (r + 1) * g.RS + (px + 1) * g.PS + 4 * c4);
+        }
+    }
+    if (a.post.on) {
+        // ---- the stride-2 block behind the chain: taps from the resident frame, output straight to global memory
+        const ChainBlock& cb = a.post.blk;
+        const int Ho = a.H >> 1, Wo = a.W >> 1, Co = a.post.Co, npo = Ho * Wo;
+        stage_consts(cb, a.C, Co);
+        __syncthreads();
+        const float* wdw = lds + g.off_wdw;
+        const float* bdw = lds + g.off_bdw;
+        for (int grp = wave; grp * 32 < npo; grp += 8) {  // wave-uniform
+            const int qo = grp * 32 + pl;
+            const bool vo = qo < npo;
+            const int py = vo ? qo / Wo : 0, px = vo ? qo - (qo / Wo) * Wo : 0;
+            // SAME on an even size: taps at image rows 2py .. 2py+2 = tile slots 2py+1 .. 2py+3 (slot H+1 is the zero border)
+            const float* t0 = tile + (2 * py + 1) * g.RS + (2 * px + 1) * g.PS;
+            f32x16c D[MT];
+            auto dw = [&](int j, float4& bf) {
+                const int c0 = h * g.Ch + 4 * j;
+                bf = cld4(bdw + c0);
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float4 w = cld4(wdw + (ky * 3 + kx) * g.Cp + c0);
+                        const float4 d = cld4(t0 + ky * g.RS + kx * g.PS + c0);
+                        bf.x = fmaf(d.x, w.x, bf.x);
+                        bf.y = fmaf(d.y, w.y, bf.y);
+                        bf.z = fmaf(d.z, w.z, bf.z);
+                        bf.w = fmaf(d.w, w.w, bf.w);
+                    }
+            };
+            contract(cb, nch, dw, D);
+            const float hi = cb.act == ACT_RELU6 ? 6.f : INFINITY;
+            float* dst = a.post.out + (long)b * a.post.out_fs + (long)qo * Co;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = m * 32 + 8 * gq + 4 * h;
+                    if (ch >= Co) continue;
+                    float4 sk = zero4;
+                    if (cb.has_res && ch < a.C) {  // 2x2 max-pool of the resident frame, zero channel pad above C
+                        const float4 s0 = cld4(t0 + ch), s1 = cld4(t0 + g.PS + ch), s2 = cld4(t0 + g.RS + ch), s3 = cld4(t0 + g.RS + g.PS + ch);
+                        sk = make_float4(fmaxf(fmaxf(s0.x, s1.x), fmaxf(s2.x, s3.x)), fmaxf(fmaxf(s0.y, s1.y), fmaxf(s2.y, s3.y)),
+                                         fmaxf(fmaxf(s0.z, s1.z), fmaxf(s2.z, s3.z)), fmaxf(fmaxf(s0.w, s1.w), fmaxf(s2.w, s3.w)));
+                    }
+                    finish(D, m, gq, sk, hi);
+                    if (vo) *reinterpret_cast<float4*>(dst + ch) = make_float4(D[m][4 * gq], D[m][4 * gq + 1], D[m][4 * gq + 2], D[m][4 * gq + 3]);
+                }
+        }
     }
 }
 
@@ -192,6 +312,8 @@ bool make_chain_geom(const ChainArgs& a, ChainGeom* out) {
     if (g.lds_bytes > 158 * 1024) return false;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!aligned16(a.in) || !aligned16(a.out) || (a.in_fs & 3) || (a.out_fs & 3)) return false;
+    if (a.pre.on && (a.pre.Cin % 8 || a.pre.Cin < 8 || a.pre.Cin > a.C || !aligned16(a.pre.in) || (a.pre.in_fs & 3))) return false;
+    if (a.post.on && ((a.H & 1) || (a.W & 1) || a.post.Co % 4 || a.post.Co < a.C || a.post.Co > g.MT * 32 || !aligned16(a.post.out) || (a.post.out_fs & 3))) return false;
     *out = g;
     return true;
 }

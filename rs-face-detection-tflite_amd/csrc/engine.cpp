@@ -132,7 +132,9 @@ void Model::rebuild() {
                 if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
                 if (m.alpha >= 0) mo.alpha = put(g.tensors[m.alpha].f32);
                 const auto& ws = g.tensors[m.w2].shape;  // [O][1][1][I]
-                if (m.sh == 2) {  // stride-2 tail of a row pipeline
+                if (n.chain_pre || n.chain_post) {
+                    // frame-resident chain with stride-2 edge stages: block-kernel packing only
+                } else if (m.sh == 2) {  // stride-2 tail of a row pipeline
                     std::vector<float> sc(static_cast<size_t>(strip_consts_s2_floats(ws[3], ws[0])));
                     strip_pack_consts_s2(ws[3], ws[0], g.tensors[m.w].f32.data(), m.b >= 0 ? g.tensors[m.b].f32.data() : nullptr, g.tensors[m.w2].f32.data(),
                                          m.b2 >= 0 ? g.tensors[m.b2].f32.data() : nullptr, m.alpha >= 0 ? g.tensors[m.alpha].f32.data() : nullptr, m.act, sc.data());
@@ -372,6 +374,10 @@ std::string Model::node_label(const Node& n) const {
         }
         case Node::Chain: {
             const auto& so = g.tensors[n.out].shape;
+            if (n.chain_pre || n.chain_post) {
+                const auto& sm = g.tensors[n.members[n.chain_pre ? 1 : 0].in[0]].shape;
+                return "chain_kernel<" + std::to_string((sm.back() + 31) / 32) + ">";
+            }
             if (g.tensors[n.in[0]].shape[1] * g.tensors[n.in[0]].shape[2] <= 256) return "chain_kernel<" + std::to_string((so.back() + 31) / 32) + ">";
             const auto& sin = g.tensors[n.in[0]].shape;
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
@@ -579,20 +585,45 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             }
             case Node::Chain: {
                 ChainArgs a;
+                auto fill = [&](ChainBlock& cb, size_t k) {
+                    const MemberOff& mo = chain_off_[i][k];
+                    cb.w_dw = d_weights_ + mo.w;
+                    cb.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
+                    cb.w_pw = d_weights_ + mo.w2;
+                    cb.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
+                    cb.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
+                    cb.act = n.members[k].act;
+                    cb.has_res = n.members[k].res >= 0;
+                };
+                if (n.chain_pre || n.chain_post) {  // frame-resident chain with the stride-2 blocks around it in the same launch
+                    const size_t k0 = n.chain_pre ? 1 : 0, k1 = n.members.size() - (n.chain_post ? 1 : 0);
+                    const auto& sm = g.tensors[n.members[k0].in[0]].shape;  // the resident frame
+                    a.B = F; a.H = sm[1]; a.W = sm[2]; a.C = sm[3]; a.nblocks = static_cast<int>(k1 - k0);
+                    for (size_t k = k0; k < k1; k++) fill(a.blocks[k - k0], k);
+                    const int t_main = n.members[k1 - 1].out;   // the chain's own output tensor
+                    a.write_out = !n.chain_post || !n.extra_out.empty();
+                    if (a.write_out) { a.out = tensor_ptr_mut(t_main, chunk_start, &a.out_fs); } else { a.out = op; a.out_fs = out_fs; }
+                    if (n.chain_pre) {
+                        a.pre.on = 1; fill(a.pre.blk, 0);
+                        a.pre.in = ip; a.pre.in_fs = in_fs; a.pre.Cin = si[3];
+                        a.in = ip; a.in_fs = in_fs;
+                    } else {
+                        a.in = ip; a.in_fs = in_fs;
+                    }
+                    if (n.chain_post) {
+                        const int t_post = n.members.back().out;
+                        a.post.on = 1; fill(a.post.blk, n.members.size() - 1);
+                        a.post.out = tensor_ptr_mut(t_post, chunk_start, &a.post.out_fs);
+                        a.post.Co = g.tensors[t_post].shape[3];
+                    }
+                    if (!chain_kernel_supports(a)) throw std::runtime_error("chain node with edge stages without a kernel");
+                    rc = launch_chain(a, s);
+                    break;
+                }
                 a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
                 a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.nblocks = static_cast<int>(n.members.size());
                 if (a.nblocks <= kMaxChain && a.H * a.W <= 256 && chain_kernel_supports(a)) {  // frame-resident in LDS
-                    for (size_t k = 0; k < n.members.size(); k++) {
-                        const MemberOff& mo = chain_off_[i][k];
-                        ChainBlock& cb = a.blocks[k];
-                        cb.w_dw = d_weights_ + mo.w;
-                        cb.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
-                        cb.w_pw = d_weights_ + mo.w2;
-                        cb.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
-                        cb.alpha = mo.alpha >= 0 ? d_weights_ + mo.alpha : nullptr;
-                        cb.act = n.members[k].act;
-                        cb.has_res = n.members[k].res >= 0;
-                    }
+                    for (size_t k = 0; k < n.members.size(); k++) fill(a.blocks[k], k);
                     rc = launch_chain(a, s);
                     break;
                 }

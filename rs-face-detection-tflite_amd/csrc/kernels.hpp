@@ -88,12 +88,28 @@ struct ChainBlock {
     int act = ACT_NONE;
     int has_res = 0;               // skip connection = the block's own input
 };
+// Optional stride-2 BlazeBlock run by the chain's launch in front of (`pre`) or behind (`post`) the resident blocks:
+// DW3x3 s2 (TF SAME on an even size: taps at rows 2oy..2oy+2) -> PW -> [+ 2x2 max-pool of its input, zero channel-padded] -> act.
+//   pre : reads its (2H x 2W x Cin) input from global memory, leaves its H x W x C output in the LDS tile instead of HBM
+//   post: reads the chain's final H x W x C frame from the tile, writes its (H/2 x W/2 x Co) output to global memory
+struct ChainEdge {
+    int on = 0;
+    ChainBlock blk;                // weights in the block kernel's packing; blk.has_res = max-pool skip
+    const float* in = nullptr;     // pre: input tensor
+    long in_fs = 0;
+    int Cin = 0;                   // pre: input channels (the input is 2H x 2W x Cin)
+    float* out = nullptr;          // post: output tensor
+    long out_fs = 0;
+    int Co = 0;                    // post: output channels (<= 32 * ceil(C / 32))
+};
 struct ChainArgs {
     const float* in = nullptr;
     float* out = nullptr;
     long in_fs = 0, out_fs = 0;
     int B = 0, H = 0, W = 0, C = 0, nblocks = 0;
     ChainBlock blocks[kMaxChain];
+    ChainEdge pre, post;
+    int write_out = 1;             // 0: nobody but `post` reads the chain's own output: it is not written
 };
 
 struct EltArgs {  // ADD / activation / MAX_POOL / channel PAD / RESIZE / DEPTH_TO_SPACE fallbacks (un-fused graphs)

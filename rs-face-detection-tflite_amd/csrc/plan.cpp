@@ -232,7 +232,7 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
         const Node& n = ns[k];
         if (n.kind == Node::Chain) {
             const auto& si = g.tensors[n.in[0]].shape;
-            if (si[1] * si[2] > 256) return false;  // row-pipelined chains stay what they are
+            if (si[1] * si[2] > 256 || n.chain_pre || n.chain_post) return false;  // row-pipelined chains and chains with stride-2 edge stages stay what they are
             for (const Node& m : n.members) M.push_back(m);
         } else if (n.kind == Node::Conv && n.gemm_head) {
             return false;  // a whole-frame convolution is a GEMM over the batch: its weights are read once per 32 frames there, once per frame here
@@ -696,6 +696,53 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
             }
             return c;
         };
+        // The stride-2 BlazeBlocks on either side of a frame-resident chain join its launch (chain_kernels.hip, ChainEdge): the
+        // one in front (DW3x3 s2 -> PW -> + 2x2 max-pool skip -> act; the producer of the chain's input, read by nobody else) gathers
+        // its taps from global memory and leaves its output in the LDS tile; the one behind reads the tile and writes global memory.
+        // `next` = index in plan.nodes of the node after the chain (advanced past an absorbed block).
+        auto edge_block = [&](const Node& e) {
+            return e.kind == Node::Block && e.w >= 0 && e.KH == 3 && e.KW == 3 && e.sh == 2 && e.sw == 2 && e.padding == Padding::Same &&
+                   (e.res < 0 || (e.res == e.in[0] && e.res_mode == RES_MAXPOOL));
+        };
+        auto is_output = [&](int t) { return std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end(); };
+        auto attach_edges = [&](Node& c, std::vector<Node>& done, size_t& next, ChainArgs ca) {
+            const auto& sc = g.tensors[c.in[0]].shape;  // H x W x C of the resident frame
+            const int tin = c.in[0], tout = c.out;
+            if (!done.empty() && (sc[1] % 1) == 0) {
+                const Node& e = done.back();
+                const auto& se = g.tensors[e.in.empty() ? tin : e.in[0]].shape;
+                const int users = c.members.front().res == tin ? 2 : 1;
+                if (edge_block(e) && e.out == tin && uses(tin) == users && !is_output(tin) && se.size() == 4 && se[1] == 2 * sc[1] && se[2] == 2 * sc[2] &&
+                    se[3] % 8 == 0 && se[3] <= sc[3]) {
+                    ca.pre.on = 1; ca.pre.Cin = se[3]; ca.pre.in = reinterpret_cast<const float*>(0x3000); ca.pre.in_fs = static_cast<long>(g.tensors[e.in[0]].elems());
+                    if (chain_kernel_supports(ca)) {
+                        c.members.insert(c.members.begin(), e);
+                        c.src_ops.insert(c.src_ops.begin(), e.src_ops.begin(), e.src_ops.end());
+                        c.in = {e.in[0]};
+                        c.chain_pre = true;
+                        done.pop_back();
+                    } else {
+                        ca.pre.on = 0;
+                    }
+                }
+            }
+            if (next < plan.nodes.size()) {
+                const Node& e = plan.nodes[next];
+                const auto& so = g.tensors[e.out].shape;
+                if (edge_block(e) && e.in[0] == tout && so.size() == 4 && sc[1] % 2 == 0 && sc[2] % 2 == 0 && so[1] * 2 == sc[1] && so[2] * 2 == sc[2]) {
+                    ca.post.on = 1; ca.post.Co = so[3]; ca.post.out = reinterpret_cast<float*>(0x4000); ca.post.out_fs = static_cast<long>(g.tensors[e.out].elems());
+                    if (chain_kernel_supports(ca)) {
+                        const bool others = uses(tout) > (e.res == tout ? 2 : 1) || is_output(tout);
+                        c.members.push_back(e);
+                        c.src_ops.insert(c.src_ops.end(), e.src_ops.begin(), e.src_ops.end());
+                        c.chain_post = true;
+                        if (others) c.extra_out = {e.out};   // the chain's own output is still read (output heads): both are written
+                        else c.out = e.out;
+                        next++;
+                    }
+                }
+            }
+        };
         const int pipe_max = fuse_level >= 4 ? pipe_max_opt : 0;
         std::vector<Node> fusedv;
         for (size_t i = 0; i < plan.nodes.size();) {
@@ -712,8 +759,10 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
                     ca.B = 1; ca.H = si[1]; ca.W = si[2]; ca.C = si[3];
                     ca.nblocks = std::min(run, kMaxChain);
                     if (si[1] * si[2] <= 256 && si[3] % 8 == 0 && chain_kernel_supports(ca)) {
-                        fusedv.push_back(make_chain(i, i + ca.nblocks - 1));
+                        Node c = make_chain(i, i + ca.nblocks - 1);
                         i += ca.nblocks;
+                        if (fuse_level >= 5) attach_edges(c, fusedv, i, ca);
+                        fusedv.push_back(std::move(c));
                         continue;
                     }
                 }
@@ -900,13 +949,18 @@ std::string Plan::describe() const {
         if (n.kind == Node::Conv && n.gemm_head) os << " whole-frame window: GEMM over the batch";
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
         if (n.kind == Node::Chain)
-            os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
-               << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
+            if (n.chain_pre || n.chain_post)
+                os << " x" << n.members.size() << " blocks, frame resident in LDS" << (n.chain_pre ? ", stride-2 block in front" : "") << (n.chain_post ? ", stride-2 block behind" : "");
+            else
+                os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
+                   << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
         if (n.kind == Node::Resident) {
             os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, " << (n.res_bands > 1 ? "row-band resident" : "frame resident") << ", " << n.res_lds_bytes << " B LDS";
             if (n.res_bands > 1) os << ", " << n.res_bands << " bands of " << n.stages[0].st.band_rows << " rows";
             for (int t : n.extra_out) os << " +t" << t;
         }
+        if (n.kind == Node::Chain)
+            for (int t : n.extra_out) os << " +t" << t;
         os << " ops{";
         for (size_t k = 0; k < n.src_ops.size(); k++) os << (k ? "," : "") << n.src_ops[k];
         os << "}\n";

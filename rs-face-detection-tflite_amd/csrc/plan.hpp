@@ -35,6 +35,7 @@ struct Node {
     std::vector<Stage> stages;
     int res_const_off = 0, res_const_floats = 0, res_lds_bytes = 0;
     int res_bands = 1;           // Resident: workgroups per frame (row bands; 1 = the whole frame is resident)
+    bool chain_pre = false, chain_post = false;  // frame-resident Chain: members.front() / members.back() is the stride-2 block before / after the resident blocks
     bool gemm_head = false;      // Conv whose window is the whole frame: runs as a GEMM over the batch (head_gemm_kernel)
     std::vector<int> extra_out;  // Resident: further tensors the launch writes to global memory (besides `out`)
     std::vector<int> in;   // activation inputs (tensor ids)
