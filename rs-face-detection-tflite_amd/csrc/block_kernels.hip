@@ -44,7 +44,15 @@ namespace {
 
 constexpr int kPrefetch = 8;          // float4 registers per thread for the next step's rows
 constexpr int kALdsMax = 40 * 1024;   // pointwise weights are staged in LDS when they fit in this many bytes
-constexpr int kCUs = 256;
+// compute units of the current device (MI355X: 256); asked once, 256 when no device answers (host-only planning)
+static int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
 
 int lds_budget() {
     static const int v = getenv("MI_BLOCK_LDS") ? atoi(getenv("MI_BLOCK_LDS")) : 80 * 1024;  // tuning aid
@@ -497,7 +505,7 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     static const int max_per_cu = getenv("MI_BLOCK_PERCU") ? atoi(getenv("MI_BLOCK_PERCU")) : 2;  // tuning aid
     const int per_cu = std::max(1, std::min(max_per_cu, (160 * 1024) / g.lds_bytes));
     const int max_bands = (a.Ho + R - 1) / R;
-    int bands = std::min(max_bands, std::max(1, (kCUs * per_cu + a.B / 2) / std::max(1, a.B)));
+    int bands = std::min(max_bands, std::max(1, (cu_count() * per_cu + a.B / 2) / std::max(1, a.B)));
     g.band = single_step ? R : ((a.Ho + bands - 1) / bands + R - 1) / R * R;
     g.bands = (a.Ho + g.band - 1) / g.band;
     // skip connection straight from the ring when it is the block's own input tensor

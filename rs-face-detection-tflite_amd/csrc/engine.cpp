@@ -548,6 +548,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2]; a.Co = so[3]; a.Cop = (a.Co + 3) & ~3;
                 a.KH = n.KH; a.KW = n.KW; a.sh = n.sh; a.sw = n.sw;
                 if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
+                if (n.ept >= 0) { a.pt = n.ept; a.pl = n.epl; }
                 a.ep = ep;
                 if (labels) labels->back() = conv_kernel_label(a);
                 rc = launch_conv(a, s);
@@ -560,6 +561,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2];
                 a.KH = n.KH; a.KW = n.KW; a.sh = n.sh; a.sw = n.sw;
                 if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
+                if (n.ept >= 0) { a.pt = n.ept; a.pl = n.epl; }
                 a.ep = ep;
                 rc = launch_dw(a, s);
                 break;
@@ -667,6 +669,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Ho = so[1]; a.Wo = so[2]; a.Co = so[3];
                 a.sh = n.sh; a.sw = n.sw;
                 if (a.has_dw && n.padding == Padding::Same) { same_pad(a.H, 3, a.sh, a.Ho, &a.pt); same_pad(a.W, 3, a.sw, a.Wo, &a.pl); }
+                if (a.has_dw && n.ept >= 0) { a.pt = n.ept; a.pl = n.epl; }
                 a.ep = ep;
                 a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
                 const bool strip = strip_ && strip_kernel_supports(a);

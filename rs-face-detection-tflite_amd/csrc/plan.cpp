@@ -114,6 +114,55 @@ struct Rewriter {
         }
     }
 
+    // Spatial PAD (zeros) in front of VALID convolutions — how the MLIR-converted full_range_sparse graph writes every
+    // convolution — folds into its consumers: as SAME when the amounts are TF's SAME amounts for that consumer (3x3 stride 1 with
+    // 1/1/1/1), as explicit pads before the first row / column otherwise (the kernels bound-check the far side).
+    void fold_spatial_pads() {
+        for (size_t i = 0; i < nodes.size(); i++) {
+            Node& pd = nodes[i];
+            if (pd.dead || pd.kind != Node::Pad || is_graph_output(pd.out)) continue;
+            const auto& pv = g.tensors[pd.pads].i32;
+            const auto& si = shape(pd.in[0]);
+            if (pv.size() != 8 || si.size() != 4 || pv[0] || pv[1] || pv[6] || pv[7]) continue;   // batch / channel pads: not this rule
+            const int pt = pv[2], pb = pv[3], pl = pv[4], pr = pv[5];
+            if (pt < 0 || pb < 0 || pl < 0 || pr < 0 || pt > 1 || pl > 1) continue;             // the kernels keep a one-pixel border
+            std::vector<int> cons = consumers(pd.out);
+            if (cons.empty()) continue;
+            bool ok = true;
+            for (int ci : cons) {
+                const Node& c = nodes[ci];
+                ok &= (c.kind == Node::Conv || c.kind == Node::Dw) && c.padding == Padding::Valid && c.in.size() == 1 && c.in[0] == pd.out && c.res != pd.out && c.ept < 0;
+            }
+            if (!ok) continue;
+            for (int ci : cons) {
+                Node& c = nodes[ci];
+                const auto& so = shape(c.out);
+                int bt, bl, oh, ow;
+                same_pad_of(si[1], c.KH, c.sh, bt, oh);
+                same_pad_of(si[2], c.KW, c.sw, bl, ow);
+                const int tot_h = std::max(0, (oh - 1) * c.sh + c.KH - si[1]), tot_w = std::max(0, (ow - 1) * c.sw + c.KW - si[2]);
+                c.in[0] = pd.in[0];
+                if (oh == so[1] && ow == so[2] && bt == pt && bl == pl && tot_h - bt == pb && tot_w - bl == pr) {
+                    c.padding = Padding::Same;
+                } else {
+                    c.ept = pt; c.epl = pl;
+                }
+                c.src_ops.insert(c.src_ops.begin(), pd.src_ops.begin(), pd.src_ops.end());
+            }
+            // the PAD op is executed by its consumers; with several consumers the op index is listed once (the first)
+            for (size_t k = 1; k < cons.size(); k++) {
+                Node& c = nodes[cons[k]];
+                c.src_ops.erase(c.src_ops.begin(), c.src_ops.begin() + static_cast<long>(pd.src_ops.size()));
+            }
+            pd.dead = true;
+        }
+    }
+    static void same_pad_of(int in, int k, int stride, int& before, int& out) {
+        out = (in + stride - 1) / stride;
+        const int total = std::max(0, (out - 1) * stride + k - in);
+        before = total / 2;
+    }
+
     // Would the fused MFMA kernel take this node? (shape-level check with placeholder, 16-byte aligned pointers)
     bool block_supported(const Node& f) const {
         const auto& si = shape(f.in[0]);
@@ -131,6 +180,7 @@ struct Rewriter {
             a.pt = std::max(0, (a.Ho - 1) * a.sh + 3 - a.H) / 2;
             a.pl = std::max(0, (a.Wo - 1) * a.sw + 3 - a.W) / 2;
         }
+        if (a.has_dw && f.ept >= 0) { a.pt = f.ept; a.pl = f.epl; }
         if (f.res >= 0) {
             a.ep.res = f.res == f.in[0] ? a.in : reinterpret_cast<const float*>(0x3000);
             a.ep.res_fs = static_cast<long>(g.tensors[f.res].elems());
@@ -156,7 +206,7 @@ struct Rewriter {
             f.in = d.in;
             f.w2 = c.w; f.b2 = c.b;
             f.w = d.w; f.b = d.b;
-            f.KH = d.KH; f.KW = d.KW; f.sh = d.sh; f.sw = d.sw; f.padding = d.padding;
+            f.KH = d.KH; f.KW = d.KW; f.sh = d.sh; f.sw = d.sw; f.padding = d.padding; f.ept = d.ept; f.epl = d.epl;
             f.src_ops = d.src_ops;
             f.src_ops.insert(f.src_ops.end(), c.src_ops.begin(), c.src_ops.end());
             if (!block_supported(f)) continue;
@@ -654,6 +704,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
     }
 
     Rewriter rw{g, nodes};
+    if (fuse_level >= 1) rw.fold_spatial_pads();
     if (fuse_level >= 1) rw.fuse_epilogues();
     if (fuse_level >= 2) rw.fuse_blocks();
     for (auto& n : nodes)
@@ -947,6 +998,7 @@ std::string Plan::describe() const {
         os << "]";
         if (n.kind == Node::Conv || n.kind == Node::Dw || (n.kind == Node::Block && n.w >= 0)) os << " k" << n.KH << "x" << n.KW << " s" << n.sh;
         if (n.kind == Node::Conv && n.gemm_head) os << " whole-frame window: GEMM over the batch";
+        if (n.ept >= 0) os << " pad" << n.ept << "/" << n.epl;
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
         if (n.kind == Node::Chain)
             if (n.chain_pre || n.chain_post)

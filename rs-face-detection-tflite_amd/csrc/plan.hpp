@@ -45,6 +45,8 @@ struct Node {
     int w = -1, b = -1;
     int KH = 1, KW = 1, sh = 1, sw = 1;
     Padding padding = Padding::Same;
+    int ept = -1, epl = -1;        // explicit zero pad before the first row / column (a spatial PAD op folded into this node;
+                                   // padding == Valid then means "valid on the padded input"); -1: none
     // Block: pointwise stage
     int w2 = -1, b2 = -1;
     // fused epilogue
