@@ -875,6 +875,11 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     const bool tail = NH2 && w >= 2 * S;
     const int p = tail ? 0 : (w & 1), role = tail ? S : (w >> 1);
     const int hf = tail ? w - 2 * S : 0;
+    // Static issue priority for the two ends of the pipeline: block 0's waves (they also wait for and issue the DMA) and the
+    // waves of the last stage (the last block stores to memory; a stride-2 tail wave serves both strips alone).  A step ends
+    // when its slowest wave reaches the barrier, and these are the slowest: measured on the harness (tools/strip_bench.hip)
+    // -1.5 % (4 blocks at 128^2), -3 % (64^2), -6 % / -7 % (with a stride-2 tail); any other choice of waves is neutral or slower.
+    if (role == 0 || tail || (NH2 == 0 && role == S - 1)) __builtin_amdgcn_s_setprio(1);
     // wave-private scratch: block 0 waves own two pairs of DMA row buffers each, the waves that store one transposition buffer
     float* scratch = lds + RING_F + (role == 0 ? p * 4 * BUF_F : 8 * BUF_F + (tail ? hf : p) * BUF_F);
     const int unit = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + p;
