@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiface.so")
+LIB_PATH = os.environ.get("MIFACE_LIB") or os.path.join(_HERE, "libmiface.so")   # MIFACE_LIB: a development variant built by build.sh (MI_VARIANT)
 REPO_ROOT = os.path.dirname(_HERE)
 DEFAULT_MODEL_DIR = os.path.join(REPO_ROOT, "models")
 

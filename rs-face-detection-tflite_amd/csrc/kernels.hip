@@ -122,23 +122,26 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     const int b = t / tiles_y;
     const float* in = a.in + (long)b * a.in_fs;
     const int ix0 = tx0 * 2 - a.pl, iy0 = ty0 * 2 - a.pt;
-    // all loads of the tile are issued before the first LDS write (a load -> wait -> write loop pays one HBM round trip per
-    // iteration: 15 of them in a row made this kernel latency-bound at 2.1 TB/s)
-    constexpr int NLD = (IH * IW * 3 + 255) / 256;
-    float stage[NLD];
+    // All loads of the tile are issued before the first LDS write (a load -> wait -> write loop pays one HBM round trip per
+    // iteration).  Thread e owns float e of every tile row (a row is IW * 3 <= 201 consecutive floats of the image): the column
+    // arithmetic is done once per thread, a row costs an add and a select — the flat (index -> row, column) mapping this
+    // replaces spent a third of the kernel's VALU instructions on divisions and bounds tests.  Loads are unconditional
+    // (clamped address, value zeroed afterwards): a predicated load would put a branch around each of them.
+    constexpr int ROWF = IW * 3;
+    static_assert(ROWF <= 256, "one thread per float of a tile row");
+    const int e_col = min(tid, ROWF - 1);
+    const int ix = ix0 + e_col / 3;
+    const bool x_ok = tid < ROWF && ix >= 0 && ix < a.W;
+    const float* colp = in + (long)min(max(ix, 0), a.W - 1) * 3 + (e_col - (e_col / 3) * 3);
+    float stage[IH];
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int i = tid + 256 * k;
-        const int r = i / (IW * 3), e = i - r * (IW * 3);
-        const int iy = iy0 + r, ix = ix0 + e / 3;
-        stage[k] = 0.f;
-        if (i < IH * IW * 3 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) stage[k] = in[((long)iy * a.W) * 3 + (long)ix0 * 3 + e];
-    }
+    for (int r = 0; r < IH; r++) stage[r] = colp[(long)min(max(iy0 + r, 0), a.H - 1) * a.W * 3];   // iy0 + r is wave-uniform
+    if (tid < ROWF) {
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int i = tid + 256 * k;
-        const int r = i / (IW * 3), e = i - r * (IW * 3);
-        if (i < IH * IW * 3) tile[r * RS + e] = stage[k];
+        for (int r = 0; r < IH; r++) {
+            const int iy = iy0 + r;
+            tile[r * RS + tid] = (x_ok && iy >= 0 && iy < a.H) ? stage[r] : 0.f;
+        }
     }
     __syncthreads();
     const int lx = tid & (TW - 1), ly = tid / TW;
@@ -181,20 +184,30 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     const float* __restrict__ bias = a.ep.bias;
     const float* __restrict__ al = prelu ? a.ep.alpha : a.ep.bias;  // always a readable array: no branch around the loads
     constexpr int C4 = CO / 4;
+    const bool relu = a.ep.act == ACT_RELU;  // wave-uniform: the three detector stems; one packed add + one packed max per channel pair
 #pragma unroll
     for (int p = 0; p < PP; p++) {
         __syncthreads();  // all reads of the input tile (p = 0) / of the previous half's output image are done; reuse the LDS
+        if (relu) {
 #pragma unroll
-        for (int o = 0; o < CO; o += 4) {
-            float r[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const float acc = (e & 1) ? acc2[p][(o + e) >> 1].y : acc2[p][(o + e) >> 1].x;
-                const float v = acc + bias[o + e];
-                const float sl = prelu ? al[o + e] : base_slope;
-                r[e] = fminf(fmaxf(v, 0.f) + sl * fminf(v, 0.f), hi);
+            for (int o = 0; o < CO; o += 4) {
+                const v2f r0 = __builtin_elementwise_max(acc2[p][o >> 1] + v2f{bias[o], bias[o + 1]}, v2f{0.f, 0.f});
+                const v2f r1 = __builtin_elementwise_max(acc2[p][(o >> 1) + 1] + v2f{bias[o + 2], bias[o + 3]}, v2f{0.f, 0.f});
+                *reinterpret_cast<float4*>(otile + tid * OS + o) = make_float4(r0.x, r0.y, r1.x, r1.y);
             }
-            *reinterpret_cast<float4*>(otile + tid * OS + o) = make_float4(r[0], r[1], r[2], r[3]);
+        } else {
+#pragma unroll
+            for (int o = 0; o < CO; o += 4) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float acc = (e & 1) ? acc2[p][(o + e) >> 1].y : acc2[p][(o + e) >> 1].x;
+                    const float v = acc + bias[o + e];
+                    const float sl = prelu ? al[o + e] : base_slope;
+                    r[e] = fminf(fmaxf(v, 0.f) + sl * fminf(v, 0.f), hi);
+                }
+                *reinterpret_cast<float4*>(otile + tid * OS + o) = make_float4(r[0], r[1], r[2], r[3]);
+            }
         }
         __syncthreads();
         for (int i = tid; i < 8 * TW * C4; i += 256) {
