@@ -298,9 +298,12 @@ def run_rank(args):
     if args.config == 2:
         fd = mi.FaceDetection(mi.FaceDetectionModel.BackCamera, device=local_rank, model_bytes=blobs[0])
         models, tag = [(fd.model, None)], "back256_b%d" % B
-        for key in ("fuse", "chunk", "lanes"):
+        for key in ("fuse", "chunk", "lanes", "heads"):
             if getattr(args, key) is not None:
                 fd.model.set_option(key, getattr(args, key))
+        for kv in args.opt:
+            k, v = kv.split("=")
+            fd.model.set_option(k, int(v))
         cap = 16
         x_host = make_frames(B, seed=rank)
         x = torch.from_numpy(x_host).to(device)
@@ -406,6 +409,8 @@ def main():
     ap.add_argument("--fuse", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--lanes", type=int, default=None)
+    ap.add_argument("--heads", type=int, default=None)
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development), config 2 only")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

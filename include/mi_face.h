@@ -109,7 +109,8 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * "fuse" (0 = op-by-op kernels, 1 = epilogue fusion, 2 = BlazeBlock fusion, 3 = + frame-resident chains of small-spatial
  * blocks, 4 = + row-pipelined chains of narrow blocks; default 4), "pipe" (blocks per row-pipelined chain, 2..4, 0 = none),
  * "pipe_rows" (1 = one row per pipeline step instead of two), "strip" (0 = LDS-ring block kernel for every block),
- * "fork" (0 = output heads run on the trunk's stream instead of beside it), "reuse", "lanes". Takes effect on the next run. */
+ * "fork" (0 = output heads run on the trunk's stream instead of beside it), "heads" (side streams the output heads are spread
+ * over, 1..4), "reuse", "lanes". Takes effect on the next run. */
 int mi_model_set_option(mi_model *m, const char *key, int value);
 /* Host-only: parse + lower a .tflite blob WITHOUT touching a GPU and write the launch plan text (same format as
  * mi_model_describe). Returns bytes needed (incl. NUL), 0 on error (see mi_last_error). Used by CPU-side tests. */

@@ -15,6 +15,8 @@ void hip_check(hipError_t e, const char* what) {
 }
 
 namespace {
+constexpr int kHeadStreams = 4;  // most side streams for output heads that run beside the trunk (option "heads")
+
 void same_pad(int in, int k, int stride, int out, int* before) {
     int total = std::max(0, (out - 1) * stride + k - in);
     *before = total / 2;
@@ -67,7 +69,8 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
     else if (key == "pipe_rows") { pipe_rows_ = value == 1 ? 1 : 0; }                         // 1: one row per pipeline step (strip_pipe_kernel)
     else if (key == "strip") { strip_ = value != 0; }
-    else if (key == "fork") { fork_ = value != 0; }                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
+    else if (key == "fork") { fork_ = value != 0; }
+    else if (key == "heads") { head_streams_opt_ = std::min(kHeadStreams, std::max(1, value)); dirty_ = true; }  // side streams the output heads are spread over                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
     else if (key == "lanes") lanes_ = std::min(4, std::max(1, value));
     else throw std::runtime_error("unknown option '" + key + "'");
@@ -308,9 +311,11 @@ void Model::rebuild() {
                 if (makes) prod = static_cast<int>(j);
             }
             if (n.res >= 0 && n.res != n.in[0]) continue;  // two producers: keep it on the trunk
-            int& sl = slot_of_producer[prod + 1];
-            if (sl < 0) sl = slots++ % 3;
-            head_slot_[i] = sl;
+            // heads are spread round robin over `heads` side streams (option, default 1).  They are independent of each other, but
+            // on BackCamera (four small heads behind the last trunk launch) every extra parallel branch of the replay graph cost
+            // more than it hid: 1.675 ms per step with 1 stream, 1.69 / 1.68 / 1.72 with 2 / 3 / 4
+            (void)slot_of_producer;
+            head_slot_[i] = slots++ % std::max(1, std::min(head_streams_opt_, kHeadStreams));
             head_wait_[i] = prod;
             if (prod >= 0) event_after_[prod] = 1;
         }
@@ -487,7 +492,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
     hipStream_t const trunk = s;
     unsigned used_heads = 0;
     auto node_event = [&](size_t k) {
-        if (head_events_.size() < plan_.nodes.size() + 4) head_events_.resize(plan_.nodes.size() + 4, nullptr);
+        if (head_events_.size() < plan_.nodes.size() + 2 + kHeadStreams) head_events_.resize(plan_.nodes.size() + 2 + kHeadStreams, nullptr);
         if (!head_events_[k]) hip_check(hipEventCreateWithFlags(&head_events_[k], hipEventDisableTiming), "hipEventCreate");
         return head_events_[k];
     };
@@ -712,7 +717,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         mark();
     }
     s = trunk;
-    for (int k = 0; k < 3; k++)  // join: the trunk stream continues (post-processing, the next chunk) after every head
+    for (int k = 0; k < kHeadStreams; k++)  // join: the trunk stream continues (post-processing, the next chunk) after every head
         if (used_heads & (1u << k)) {
             hip_check(record_event(node_event(plan_.nodes.size() + 1 + k), head_streams_[static_cast<size_t>(k)]), "hipEventRecord");
             hip_check(wait_event(trunk, node_event(plan_.nodes.size() + 1 + k)), "hipStreamWaitEvent");
