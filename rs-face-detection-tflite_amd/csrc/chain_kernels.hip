@@ -32,6 +32,7 @@ __device__ __forceinline__ float4 cld4(const float* p) { return *reinterpret_cas
 struct ChainGeom {
     int Cp, Ch, C4, PS, RS, MT;
     int off_wdw, off_bdw, off_bias, off_alpha;  // LDS offsets (floats)
+    int off_t8;    // where `post`'s output is kept for the heads that read it ([pixels][post.Co + 4]); -1: not kept
     int lds_bytes;
 };
 
@@ -290,8 +291,62 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(ChainArgs a, ChainGeom g)
                                          fmaxf(fmaxf(s0.z, s1.z), fmaxf(s2.z, s3.z)), fmaxf(fmaxf(s0.w, s1.w), fmaxf(s2.w, s3.w)));
                     }
                     finish(D, m, gq, sk, hi);
-                    if (vo) *reinterpret_cast<float4*>(dst + ch) = make_float4(D[m][4 * gq], D[m][4 * gq + 1], D[m][4 * gq + 2], D[m][4 * gq + 3]);
+                    if (vo) {
+                        const float4 v = make_float4(D[m][4 * gq], D[m][4 * gq + 1], D[m][4 * gq + 2], D[m][4 * gq + 3]);
+                        *reinterpret_cast<float4*>(dst + ch) = v;
+                        if (g.off_t8 >= 0) *reinterpret_cast<float4*>(lds + g.off_t8 + qo * (Co + 4) + ch) = v;
+                    }
                 }
+        }
+    }
+    // ---- output heads: stacked 1x1 convolutions on the resident frame / on `post`'s output; unit = (32 pixels, 32 stacked rows)
+    for (int hd = 0; hd < kChainHeads; hd++) {
+        const ChainHead& H = a.heads[hd];
+        if (!H.on) continue;
+        __syncthreads();  // `post`'s LDS copy is complete (and every earlier stage is done with the constants)
+        const bool from_post = H.src == 1;
+        const int Wh = from_post ? a.W >> 1 : a.W, np = from_post ? (a.H >> 1) * (a.W >> 1) : a.H * a.W;
+        const int Cs = from_post ? a.post.Co : a.C, Chs = Cs >> 1, nchs = Chs >> 2;
+        const int Cot = H.Co_a + H.Co_b, MTh = (Cot + 31) >> 5, ng = (np + 31) >> 5;
+        for (int u = wave; u < ng * MTh; u += 8) {  // wave-uniform
+            const int grp = u % ng, mt = u / ng;
+            const int qh = grp * 32 + pl;
+            const bool vh = qh < np;
+            const int qc = vh ? qh : 0;
+            const float* px = from_post ? lds + g.off_t8 + qc * (Cs + 4) : tile + (qc / Wh + 1) * g.RS + (qc % Wh + 1) * g.PS;
+            f32x16c D1;
+#pragma unroll
+            for (int e = 0; e < 16; e++) D1[e] = 0.f;
+            const float* wa = H.w_pw + ((long)mt * nchs * 64 + lane) * 4;
+            float4 av = cld4(wa);
+            for (int j = 0; j < nchs; j++) {
+                const float4 an = cld4(wa + 256 * min(j + 1, nchs - 1));  // next chunk's weights under this chunk's MFMAs
+                const float4 bf = cld4(px + h * Chs + 4 * j);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf.x, D1, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf.y, D1, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf.z, D1, 0, 0, 0);
+                D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf.w, D1, 0, 0, 0);
+                av = an;
+            }
+            if (!vh) continue;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int ch = mt * 32 + 8 * gq + 4 * h;   // stacked row
+                if (ch >= Cot) continue;
+                float v[4] = {D1[4 * gq], D1[4 * gq + 1], D1[4 * gq + 2], D1[4 * gq + 3]};
+                if (H.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += ch + e < Cot ? H.bias[ch + e] : 0.f;
+                }
+                if (ch < H.Co_a) {  // Co_a % 4 == 0: the quad lies in one head
+                    *reinterpret_cast<float4*>(H.out_a + (long)b * H.out_a_fs + (long)qh * H.Co_a + ch) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    float* ob = H.out_b + (long)b * H.out_b_fs + (long)qh * H.Co_b + (ch - H.Co_a);
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        if (ch + e < Cot) ob[e] = v[e];
+                }
+            }
         }
     }
 }
@@ -308,8 +363,19 @@ bool make_chain_geom(const ChainArgs& a, ChainGeom* out) {
     off = (off + 3) & ~3;
     g.off_bias = off; off += g.MT * 32;
     g.off_alpha = off; off += g.MT * 32;
+    g.off_t8 = -1;
+    for (int hd = 0; hd < kChainHeads; hd++) {
+        const ChainHead& H = a.heads[hd];
+        if (!H.on) continue;
+        if (H.Co_a < 4 || H.Co_a % 4 || H.Co_b < 0 || H.Co_a + H.Co_b > 128 || !H.out_a || (H.Co_b && !H.out_b) || !H.w_pw) return false;
+        if ((reinterpret_cast<uintptr_t>(H.out_a) & 15) || (H.out_a_fs & 3) || (reinterpret_cast<uintptr_t>(H.w_pw) & 15)) return false;
+        if (H.src == 1) {
+            if (!a.post.on) return false;
+            if (g.off_t8 < 0) { g.off_t8 = off; off += (a.H >> 1) * (a.W >> 1) * (a.post.Co + 4); }
+        }
+    }
     g.lds_bytes = off * 4;
-    if (g.lds_bytes > 158 * 1024) return false;
+    if (g.lds_bytes > 160 * 1024 - 256) return false;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (!aligned16(a.in) || !aligned16(a.out) || (a.in_fs & 3) || (a.out_fs & 3)) return false;
     if (a.pre.on && (a.pre.Cin % 8 || a.pre.Cin < 8 || a.pre.Cin > a.C || !aligned16(a.pre.in) || (a.pre.in_fs & 3))) return false;

@@ -100,6 +100,7 @@ void Model::rebuild() {
     const size_t NN = plan_.nodes.size();
     node_w_.assign(NN, -1); node_b_.assign(NN, -1); node_w2_.assign(NN, -1); node_b2_.assign(NN, -1); node_alpha_.assign(NN, -1);
     chain_off_.assign(NN, {});
+    chain_head_off_.assign(NN, {});
     node_strip_.assign(NN, -1);
     res_cblob_.assign(NN, {});
     res_wblk_.assign(NN, {});
@@ -149,6 +150,36 @@ void Model::rebuild() {
                     mo.strip = put(sc);
                 }
                 chain_off_[i].push_back(mo);
+            }
+            // output heads of the launch: the weights of a pair stacked [Co_a + Co_b][C] in A-fragment order, the biases stacked
+            for (const Node::HeadPair& hp : n.head_pairs) {
+                const Node* hn[2] = {&n.head_nodes[static_cast<size_t>(hp.a)], hp.b >= 0 ? &n.head_nodes[static_cast<size_t>(hp.b)] : nullptr};
+                auto wt = [&](const Node& m) { return m.kind == Node::Conv ? m.w : m.w2; };
+                auto bt = [&](const Node& m) { return m.kind == Node::Conv ? m.b : m.b2; };
+                const int I = g.tensors[wt(*hn[0])].shape[3];
+                std::vector<float> rows, bias;
+                for (const Node* m : hn) {
+                    if (!m) continue;
+                    const auto& w = g.tensors[wt(*m)];
+                    if (w.shape[3] != I || w.shape[1] != 1 || w.shape[2] != 1) throw std::runtime_error("engine: output heads of a pair differ in their input width");
+                    rows.insert(rows.end(), w.f32.begin(), w.f32.end());
+                    if (bt(*m) >= 0) bias.insert(bias.end(), g.tensors[bt(*m)].f32.begin(), g.tensors[bt(*m)].f32.end());
+                    else bias.insert(bias.end(), static_cast<size_t>(w.shape[0]), 0.f);
+                }
+                const int O = static_cast<int>(rows.size()) / I, MT = (O + 31) / 32, Ch = I / 2;
+                std::vector<float> r(static_cast<size_t>(MT) * 32 * I, 0.f);
+                for (int mt = 0; mt < MT; mt++)
+                    for (int j = 0; j < Ch / 4; j++)
+                        for (int l = 0; l < 64; l++)
+                            for (int e2 = 0; e2 < 4; e2++) {
+                                const int o = mt * 32 + (l & 31), c = (l >> 5) * Ch + 4 * j + e2;
+                                if (o < O) r[((static_cast<size_t>(mt) * (Ch / 4) + j) * 64 + l) * 4 + e2] = rows[static_cast<size_t>(o) * I + c];
+                            }
+                bias.resize(static_cast<size_t>(MT) * 32, 0.f);
+                MemberOff mo;
+                mo.w2 = put(r);
+                mo.b2 = put(bias);
+                chain_head_off_[i].push_back(mo);
             }
             continue;
         }
@@ -436,12 +467,17 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
         }
         if (n.kind == Node::Chain) {
             st.macs = 0;
+            for (int t : n.extra_out) st.bytes += 4 * elems(t) * batch;
             for (const Node& m : n.members) {
                 const auto& mo = g.tensors[m.out].shape;
                 st.macs += static_cast<double>(mo[1]) * mo[2] * g.tensors[m.in[0]].shape[3] * (9 + mo[3]) * batch;
             }
             for (const Node& m : n.members)
                 for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) st.bytes += 4 * elems(c);
+            for (const Node& m : n.head_nodes) {
+                st.macs += elems(m.out) * g.tensors[m.in[0]].shape[3] * batch;
+                for (int c : {m.w, m.b, m.w2, m.b2}) st.bytes += 4 * elems(c);
+            }
         }
         std::string d;
         for (size_t k = 1; k < si.size(); k++) d += (k > 1 ? "x" : "") + std::to_string(si[k]);
@@ -608,7 +644,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     a.B = F; a.H = sm[1]; a.W = sm[2]; a.C = sm[3]; a.nblocks = static_cast<int>(k1 - k0);
                     for (size_t k = k0; k < k1; k++) fill(a.blocks[k - k0], k);
                     const int t_main = n.members[k1 - 1].out;   // the chain's own output tensor
-                    a.write_out = !n.chain_post || !n.extra_out.empty();
+                    a.write_out = n.out == t_main || std::find(n.extra_out.begin(), n.extra_out.end(), t_main) != n.extra_out.end();
                     if (a.write_out) { a.out = tensor_ptr_mut(t_main, chunk_start, &a.out_fs); } else { a.out = op; a.out_fs = out_fs; }
                     if (n.chain_pre) {
                         a.pre.on = 1; fill(a.pre.blk, 0);
@@ -622,6 +658,21 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         a.post.on = 1; fill(a.post.blk, n.members.size() - 1);
                         a.post.out = tensor_ptr_mut(t_post, chunk_start, &a.post.out_fs);
                         a.post.Co = g.tensors[t_post].shape[3];
+                    }
+                    for (size_t k = 0; k < n.head_pairs.size(); k++) {
+                        const Node::HeadPair& hp = n.head_pairs[k];
+                        ChainHead& H = a.heads[hp.src];
+                        H.on = 1; H.src = hp.src;
+                        H.w_pw = d_weights_ + chain_head_off_[i][k].w2;
+                        H.bias = d_weights_ + chain_head_off_[i][k].b2;
+                        const int ta = n.head_nodes[static_cast<size_t>(hp.a)].out;
+                        H.Co_a = g.tensors[ta].shape.back();
+                        H.out_a = tensor_ptr_mut(ta, chunk_start, &H.out_a_fs);
+                        if (hp.b >= 0) {
+                            const int tb = n.head_nodes[static_cast<size_t>(hp.b)].out;
+                            H.Co_b = g.tensors[tb].shape.back();
+                            H.out_b = tensor_ptr_mut(tb, chunk_start, &H.out_b_fs);
+                        }
                     }
                     if (!chain_kernel_supports(a)) throw std::runtime_error("chain node with edge stages without a kernel");
                     rc = launch_chain(a, s);

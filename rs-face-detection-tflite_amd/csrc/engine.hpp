@@ -85,6 +85,7 @@ class Model {
     std::vector<long> node_strip_;  // strip-kernel constants of a Block node (strip_pack_consts), -1 when the shape does not qualify
     struct MemberOff { long w = -1, b = -1, w2 = -1, b2 = -1, alpha = -1, strip = -1; };
     std::vector<std::vector<MemberOff>> chain_off_;  // per node: offsets of each chain member's constants
+    std::vector<std::vector<MemberOff>> chain_head_off_;  // per node, per head pair: stacked weights (w2) and bias (b2)
 
     ResStage* d_programs_ = nullptr;        // stage programs of the Resident nodes (device memory)
     std::vector<std::vector<long>> res_wblk_;   // per Resident node, per stage: K-blocked weight packing (-1: classic order)

@@ -102,6 +102,20 @@ struct ChainEdge {
     long out_fs = 0;
     int Co = 0;                    // post: output channels (<= 32 * ceil(C / 32))
 };
+// Output heads run by the chain's launch: up to two 1x1 convolutions without activation on the same resident tensor (the SSD
+// regressor and classifier heads), contracted as ONE pointwise product with their rows stacked (A rows [0, Co_a) then [Co_a,
+// Co_a + Co_b)); each writes its own tensor.  src: 0 = the chain's final frame (H x W x C, the LDS tile), 1 = the output of
+// `post` (H/2 x W/2 x post.Co, kept in LDS for this purpose).
+struct ChainHead {
+    int on = 0, src = 0;
+    const float* w_pw = nullptr;   // stacked rows in A-fragment order (block_weight_dims(C_src, Co_a + Co_b))
+    const float* bias = nullptr;   // [Co_a + Co_b] stacked, or null
+    int Co_a = 0, Co_b = 0;        // Co_a % 4 == 0; Co_b may be ragged (2, 6 classifier channels), 0 = no second head
+    float* out_a = nullptr;
+    float* out_b = nullptr;
+    long out_a_fs = 0, out_b_fs = 0;
+};
+constexpr int kChainHeads = 2;
 struct ChainArgs {
     const float* in = nullptr;
     float* out = nullptr;
@@ -109,7 +123,8 @@ struct ChainArgs {
     int B = 0, H = 0, W = 0, C = 0, nblocks = 0;
     ChainBlock blocks[kMaxChain];
     ChainEdge pre, post;
-    int write_out = 1;             // 0: nobody but `post` reads the chain's own output: it is not written
+    ChainHead heads[kChainHeads];
+    int write_out = 1;             // 0: nobody but `post` / the heads reads the chain's own output: it is not written
 };
 
 struct EltArgs {  // ADD / activation / MAX_POOL / channel PAD / RESIZE / DEPTH_TO_SPACE fallbacks (un-fused graphs)

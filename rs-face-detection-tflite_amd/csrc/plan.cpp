@@ -756,6 +756,35 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
                    (e.res < 0 || (e.res == e.in[0] && e.res_mode == RES_MAXPOOL));
         };
         auto is_output = [&](int t) { return std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end(); };
+        std::vector<char> absorbed(plan.nodes.size(), 0);
+        // 1x1 convolutions without activation or skip whose result only reaches graph outputs through views (RESHAPE /
+        // CONCATENATION): the SSD heads.  Those that read tensor t, at plan positions >= from.
+        auto view_only = [&](int t) {
+            for (int depth = 0; depth < 4; depth++) {
+                if (is_output(t)) return true;
+                int next_t = -1, n_cons = 0;
+                for (const Node& m : plan.nodes) {
+                    const bool reads = std::find(m.in.begin(), m.in.end(), t) != m.in.end() || m.res == t;
+                    if (!reads) continue;
+                    n_cons++;
+                    if (m.kind != Node::Reshape && m.kind != Node::Concat) return false;
+                    next_t = m.out;
+                }
+                if (n_cons != 1) return false;
+                t = next_t;
+            }
+            return false;
+        };
+        auto heads_on = [&](int t, size_t from) {
+            std::vector<size_t> hs;
+            for (size_t k = from; k < plan.nodes.size(); k++) {
+                const Node& m = plan.nodes[k];
+                if (absorbed[k] || m.in.size() != 1 || m.in[0] != t || m.res >= 0 || m.act != ACT_NONE) continue;
+                const bool pw = (m.kind == Node::Conv && m.KH == 1 && m.KW == 1 && m.sh == 1 && m.sw == 1 && !m.gemm_head) || (m.kind == Node::Block && m.w < 0);
+                if (pw && view_only(m.out)) hs.push_back(k);
+            }
+            return hs;
+        };
         auto attach_edges = [&](Node& c, std::vector<Node>& done, size_t& next, ChainArgs ca) {
             const auto& sc = g.tensors[c.in[0]].shape;  // H x W x C of the resident frame
             const int tin = c.in[0], tout = c.out;
@@ -793,10 +822,55 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
                     }
                 }
             }
+            // output heads on the chain's final frame (src 0) and on the block behind it (src 1)
+            const int t_post = c.chain_post ? c.members.back().out : -1;
+            for (int src = 0; src < 2; src++) {
+                const int t = src == 0 ? tout : t_post;
+                if (t < 0) continue;
+                std::vector<size_t> hs = heads_on(t, next);
+                if (hs.empty() || hs.size() > 2) continue;
+                // a = the head whose channel count is a multiple of 4 (the regressors), b = the other one
+                auto co = [&](size_t k) { return g.tensors[plan.nodes[k].out].shape.back(); };
+                size_t ka = hs[0], kb = hs.size() > 1 ? hs[1] : static_cast<size_t>(-1);
+                if (hs.size() > 1 && (co(ka) % 4 != 0 || (co(kb) % 4 == 0 && co(kb) > co(ka)))) std::swap(ka, kb);
+                if (co(ka) % 4 != 0) continue;
+                ChainArgs cb = ca;
+                ChainHead& H = cb.heads[src];
+                H.on = 1; H.src = src; H.Co_a = co(ka); H.Co_b = kb != static_cast<size_t>(-1) ? co(kb) : 0;
+                H.w_pw = reinterpret_cast<const float*>(0x5000); H.out_a = reinterpret_cast<float*>(0x6000); H.out_b = H.Co_b ? reinterpret_cast<float*>(0x7000) : nullptr;
+                H.out_a_fs = H.out_b_fs = 64;
+                if (!chain_kernel_supports(cb)) continue;
+                ca = cb;
+                Node::HeadPair hp;
+                hp.src = src;
+                hp.a = static_cast<int>(c.head_nodes.size());
+                c.head_nodes.push_back(plan.nodes[ka]);
+                if (H.Co_b) { hp.b = static_cast<int>(c.head_nodes.size()); c.head_nodes.push_back(plan.nodes[kb]); }
+                c.head_pairs.push_back(hp);
+                for (size_t k : {ka, kb}) {
+                    if (k == static_cast<size_t>(-1)) continue;
+                    absorbed[k] = 1;
+                    c.extra_out.push_back(plan.nodes[k].out);
+                    c.src_ops.insert(c.src_ops.end(), plan.nodes[k].src_ops.begin(), plan.nodes[k].src_ops.end());
+                }
+            }
+            // the chain's final frame needs no memory when every reader runs inside this launch
+            if (c.chain_post && c.out == tout && !is_output(tout)) {
+                bool read = false;
+                for (size_t k = next; k < plan.nodes.size(); k++) {
+                    const Node& m = plan.nodes[k];
+                    read |= !absorbed[k] && (std::find(m.in.begin(), m.in.end(), tout) != m.in.end() || m.res == tout);
+                }
+                if (!read) {
+                    c.out = t_post;
+                    c.extra_out.erase(std::find(c.extra_out.begin(), c.extra_out.end(), t_post));
+                }
+            }
         };
         const int pipe_max = fuse_level >= 4 ? pipe_max_opt : 0;
         std::vector<Node> fusedv;
         for (size_t i = 0; i < plan.nodes.size();) {
+            if (absorbed[i]) { i++; continue; }  // an output head that runs inside an earlier chain's launch
             if (chainable(plan.nodes[i])) {
                 const auto& si = g.tensors[plan.nodes[i].in[0]].shape;
                 size_t j = i;
@@ -963,6 +1037,10 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
                 const auto& so2 = g.tensors[m.out].shape;
                 macs += static_cast<double>(so2[1]) * so2[2] * g.tensors[m.in[0]].shape[3] * (9 + so2[3]);
             }
+            for (const Node& m : n.head_nodes) {
+                for (int c : {m.w, m.b, m.w2, m.b2}) bytes += 4 * elems(c);
+                macs += elems(m.out) * g.tensors[m.in[0]].shape[3];
+            }
             continue;
         }
         if (n.res >= 0 && !(n.kind == Node::Block && n.res == n.in[0])) bytes += 4 * elems(n.res);
@@ -1002,7 +1080,8 @@ std::string Plan::describe() const {
         if (n.kind == Node::Block && n.w < 0) os << " pointwise";
         if (n.kind == Node::Chain)
             if (n.chain_pre || n.chain_post)
-                os << " x" << n.members.size() << " blocks, frame resident in LDS" << (n.chain_pre ? ", stride-2 block in front" : "") << (n.chain_post ? ", stride-2 block behind" : "");
+                os << " x" << n.members.size() << " blocks, frame resident in LDS" << (n.chain_pre ? ", stride-2 block in front" : "") << (n.chain_post ? ", stride-2 block behind" : "")
+                   << (n.head_nodes.empty() ? "" : ", " + std::to_string(n.head_nodes.size()) + " output heads");
             else
                 os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
                    << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");

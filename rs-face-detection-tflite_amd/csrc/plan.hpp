@@ -35,6 +35,11 @@ struct Node {
     std::vector<Stage> stages;
     int res_const_off = 0, res_const_floats = 0, res_lds_bytes = 0;
     int res_bands = 1;           // Resident: workgroups per frame (row bands; 1 = the whole frame is resident)
+    // frame-resident Chain: output heads run by its launch.  head_nodes = the absorbed 1x1 convolutions; a pair = up to two of them
+    // on the same tensor (src 0: the chain's final frame, 1: chain_post's output), contracted as one stacked product
+    struct HeadPair { int src = 0, a = -1, b = -1; };
+    std::vector<Node> head_nodes;
+    std::vector<HeadPair> head_pairs;
     bool chain_pre = false, chain_post = false;  // frame-resident Chain: members.front() / members.back() is the stride-2 block before / after the resident blocks
     bool gemm_head = false;      // Conv whose window is the whole frame: runs as a GEMM over the batch (head_gemm_kernel)
     std::vector<int> extra_out;  // Resident: further tensors the launch writes to global memory (besides `out`)
