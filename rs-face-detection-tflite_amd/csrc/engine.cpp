@@ -183,6 +183,44 @@ void Model::rebuild() {
             }
             continue;
         }
+        if (n.kind == Node::Resident && n.bneck) {
+            // bottleneck pairs (bneck_kernels.hip): per pair the first pointwise matrix with its contraction index in the MFMA result
+            // order, the second in the block kernel's order, and one blob of small constants
+            for (size_t k = 0; k + 1 < n.members.size(); k += 2) {
+                const Node &pa = n.members[k], &pb = n.members[k + 1];
+                const auto& w1s = g.tensors[pa.w2].shape;  // [Cm][1][1][C]
+                const int Cm = w1s[0], C = w1s[3];
+                const auto& w1 = g.tensors[pa.w2].f32;
+                std::vector<float> r(static_cast<size_t>(Cm) * C, 0.f);
+                const int NCH1 = C / 8;
+                for (int t = 0; t < Cm / 32; t++)
+                    for (int j = 0; j < NCH1; j++)
+                        for (int l = 0; l < 64; l++)
+                            for (int e = 0; e < 4; e++)
+                                r[((static_cast<size_t>(t) * NCH1 + j) * 64 + l) * 4 + e] = w1[static_cast<size_t>(32 * t + (l & 31)) * C + 32 * (j / 4) + 8 * (j % 4) + 4 * (l >> 5) + e];
+                MemberOff ma, mb;
+                ma.w2 = put(r);
+                mb.w2 = pack_pw(pb.w2);
+                std::vector<float> cb(static_cast<size_t>(bneck_const_floats(C, Cm)), 0.f);
+                auto slope = [&](const Node& m, int c) { return m.act == ACT_PRELU ? g.tensors[m.alpha].f32[static_cast<size_t>(c)] : (m.act == ACT_NONE ? 1.f : 0.f); };
+                for (int c = 0; c < Cm; c++) {
+                    cb[static_cast<size_t>(c)] = pa.b2 >= 0 ? g.tensors[pa.b2].f32[static_cast<size_t>(c)] : 0.f;
+                    cb[static_cast<size_t>(Cm + c)] = slope(pa, c);
+                    for (int tap = 0; tap < 9; tap++) cb[static_cast<size_t>(2 * Cm + tap * Cm + c)] = g.tensors[pb.w].f32[static_cast<size_t>(tap) * Cm + c];
+                    cb[static_cast<size_t>(11 * Cm + c)] = pb.b >= 0 ? g.tensors[pb.b].f32[static_cast<size_t>(c)] : 0.f;
+                }
+                for (int c = 0; c < C; c++) {
+                    cb[static_cast<size_t>(12 * Cm + c)] = pb.b2 >= 0 ? g.tensors[pb.b2].f32[static_cast<size_t>(c)] : 0.f;
+                    cb[static_cast<size_t>(12 * Cm + C + c)] = slope(pb, c);
+                }
+                ma.strip = put(cb);
+                chain_off_[i].push_back(ma);
+                chain_off_[i].push_back(mb);
+            }
+            res_wblk_[i].clear();
+            res_cblob_[i].clear();
+            continue;
+        }
         if (n.kind == Node::Resident) {
             for (const Node& m : n.members) {
                 MemberOff mo;
@@ -419,7 +457,7 @@ std::string Model::node_label(const Node& n) const {
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
             return std::string(strip_pipe_rows_per_step(sin[1], pipe_rows_) == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<") + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
-        case Node::Resident: return "resident_kernel";
+        case Node::Resident: return n.bneck ? "bneck_kernel" : "resident_kernel";
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -608,6 +646,23 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 break;
             }
             case Node::Resident: {
+                if (n.bneck) {
+                    BneckArgs a;
+                    a.in = ip; a.in_fs = in_fs; a.out = op; a.out_fs = out_fs;
+                    a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Cm = g.tensors[n.members[0].out].shape[3];
+                    a.nblocks = static_cast<int>(n.members.size() / 2);
+                    a.bands = n.res_bands;
+                    for (int k = 0; k < a.nblocks; k++) {
+                        const MemberOff &ma = chain_off_[i][static_cast<size_t>(2 * k)], &mb = chain_off_[i][static_cast<size_t>(2 * k + 1)];
+                        a.blocks[k].w1 = d_weights_ + ma.w2;
+                        a.blocks[k].w2 = d_weights_ + mb.w2;
+                        a.blocks[k].consts = d_weights_ + ma.strip;
+                        a.blocks[k].hi1 = n.members[static_cast<size_t>(2 * k)].act == ACT_RELU6 ? 6.f : INFINITY;
+                        a.blocks[k].hi2 = n.members[static_cast<size_t>(2 * k + 1)].act == ACT_RELU6 ? 6.f : INFINITY;
+                    }
+                    rc = launch_bneck(a, s);
+                    break;
+                }
                 ResLaunch a;
                 a.prog = d_programs_ + node_prog_[i];
                 a.nstages = static_cast<int>(n.stages.size());

@@ -259,6 +259,28 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream);
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
 int strip_pipe_rows_per_step(int H, int hint = 0);
 int launch_chain(const ChainArgs& a, void* stream);
+
+// ---- bottleneck blocks with the wide tensor in registers (bneck_kernels.hip):
+//   r = act1(W1 . x + b1) (C -> Cm);  y = act2(W2 . (DW3x3(r) + b_dw) + b2 + x) (Cm -> C)
+struct BneckBlock {
+    const float* w1 = nullptr;      // [Cm/32 tiles][C/8 chunks][64 lanes][4]: lane (row r, half h), e -> W1[32 t + r][32 (j/4) + 8 (j%4) + 4 h + e]
+    const float* w2 = nullptr;      // block kernel's A-fragment packing of W2 [C][Cm]
+    const float* consts = nullptr;  // bneck_const_floats(): [b1 Cm][slope1 Cm][dw taps 9 x Cm][b_dw Cm][b2 C][slope2 C] (slope: PReLU alpha, 0 = ReLU, 1 = none)
+    float hi1 = 0.f, hi2 = 0.f;     // upper clamps (6 for ReLU6, +inf otherwise)
+};
+constexpr int kMaxBneck = 6;
+struct BneckArgs {
+    const float* in = nullptr;
+    float* out = nullptr;
+    long in_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, C = 0, Cm = 0, nblocks = 0;
+    int bands = 1;                  // workgroups per frame: 1 = the frame (<= 256 pixels) is resident, a run of blocks per launch;
+                                    // > 1: row bands of ceil(H / bands) rows (<= 256 pixels each), one block per launch
+    BneckBlock blocks[kMaxBneck];
+};
+bool bneck_kernel_supports(const BneckArgs& a);
+int bneck_const_floats(int C, int Cm);
+int launch_bneck(const BneckArgs& a, void* stream);
 int launch_head_gemm(const HeadGemmArgs& a, void* stream);
 bool head_gemm_supports(int K, int N);
 bool chain_kernel_supports(const ChainArgs& a);

@@ -589,9 +589,86 @@ bool build_banded_bottleneck(const Graph& g, const std::vector<Node>& ns, size_t
     return true;
 }
 
+// Level 5: runs of bottleneck pairs  r = act(PW(x));  y = act(PW(DW3x3(r)) + b + x)  on 64 / 128 channels (the iris network) for the
+// register-resident kernel (bneck_kernels.hip): frames of <= 256 pixels take the whole run in one launch, larger frames one pair per
+// launch in row bands of 256 pixels.  Returns the number of plan nodes consumed (0: no match).
+size_t build_bneck(const Graph& g, const std::vector<Node>& ns, size_t i, Node* out) {
+    auto pair_at = [&](size_t k, int x_t) {
+        if (k + 1 >= ns.size()) return false;
+        const Node &a = ns[k], &b = ns[k + 1];
+        if (a.kind != Node::Block || a.w >= 0 || a.res >= 0 || a.in.size() != 1 || a.in[0] != x_t) return false;
+        if (b.kind != Node::Block || b.w < 0 || b.in.size() != 1 || b.in[0] != a.out) return false;
+        if (b.KH != 3 || b.KW != 3 || b.sh != 1 || b.sw != 1 || b.padding != Padding::Same || b.ept >= 0 || b.epl >= 0) return false;
+        if (b.res != x_t || b.res_mode != RES_DIRECT) return false;
+        if (std::find(g.outputs.begin(), g.outputs.end(), a.out) != g.outputs.end()) return false;
+        for (size_t q = 0; q < ns.size(); q++) {
+            if (q == k + 1) continue;
+            if (std::find(ns[q].in.begin(), ns[q].in.end(), a.out) != ns[q].in.end() || ns[q].res == a.out) return false;  // r has one reader
+        }
+        const auto &sx = g.tensors[x_t].shape, &sr = g.tensors[a.out].shape, &sy = g.tensors[b.out].shape;
+        if (sx.size() != 4 || sr.size() != 4 || sy.size() != 4 || sy != sx || sr[1] != sx[1] || sr[2] != sx[2]) return false;
+        return true;
+    };
+    if (i >= ns.size() || ns[i].in.size() != 1) return 0;
+    const int x0 = ns[i].in[0];
+    if (!pair_at(i, x0)) return 0;
+    const auto& sx = g.tensors[x0].shape;
+    const int H = sx[1], W = sx[2], C = sx[3], Cm = g.tensors[ns[i].out].shape[3];
+    BneckArgs ba;
+    ba.in = reinterpret_cast<const float*>(0x1000); ba.out = reinterpret_cast<float*>(0x2000);
+    ba.in_fs = ba.out_fs = static_cast<long>(g.tensors[x0].elems());
+    ba.B = 1; ba.H = H; ba.W = W; ba.C = C; ba.Cm = Cm;
+    for (BneckBlock& bk : ba.blocks) { bk.w1 = bk.w2 = bk.consts = reinterpret_cast<const float*>(0x3000); }
+    size_t npairs = 1;
+    if (H * W <= 256) {
+        if (H * W < 128) return 0;  // a quarter of the waves would have pixels: the stage programs do these
+        // the whole run: the next pair reads this pair's output, which nobody else may need before the run ends ... unless it is written
+        int x = ns[i + 1].out;
+        while (npairs < static_cast<size_t>(kMaxBneck) && pair_at(i + 2 * npairs, x)) {
+            bool other = std::find(g.outputs.begin(), g.outputs.end(), x) != g.outputs.end();
+            for (size_t q = 0; q < ns.size() && !other; q++) {
+                if (q == i + 2 * npairs || q == i + 2 * npairs + 1) continue;
+                other = std::find(ns[q].in.begin(), ns[q].in.end(), x) != ns[q].in.end() || ns[q].res == x;
+            }
+            if (other) break;  // an intermediate frame that somebody else reads ends the run
+            x = ns[i + 2 * npairs + 1].out;
+            npairs++;
+        }
+        ba.bands = 1;
+    } else {
+        if (W > 256 || 256 / W < 2) return 0;
+        const int R = 256 / W;
+        ba.bands = (H + R - 1) / R;
+    }
+    ba.nblocks = static_cast<int>(npairs);
+    if (!bneck_kernel_supports(ba)) return 0;
+    Node r;
+    r.kind = Node::Resident;
+    r.bneck = true;
+    r.res_bands = ba.bands;
+    r.in = {x0};
+    r.out = ns[i + 2 * npairs - 1].out;
+    for (size_t k = i; k < i + 2 * npairs; k++) {
+        r.members.push_back(ns[k]);
+        r.src_ops.insert(r.src_ops.end(), ns[k].src_ops.begin(), ns[k].src_ops.end());
+    }
+    *out = std::move(r);
+    return 2 * npairs;
+}
+
 std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget) {
     std::vector<Node> outv;
+    static const bool no_bneck = getenv("MI_NO_BNECK") != nullptr;  // development aid
     for (size_t i = 0; i < ns.size();) {
+        {
+            Node bn;
+            const size_t used = no_bneck ? 0 : build_bneck(g, ns, i, &bn);
+            if (used) {
+                outv.push_back(std::move(bn));
+                i += used;
+                continue;
+            }
+        }
         Node best;
         size_t best_j = 0;
         bool have = false;
@@ -1085,7 +1162,9 @@ std::string Plan::describe() const {
             else
                 os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
                    << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
-        if (n.kind == Node::Resident) {
+        if (n.kind == Node::Resident && n.bneck) {
+            os << " x" << n.members.size() / 2 << " bottleneck blocks, wide tensor in registers, " << (n.res_bands > 1 ? std::to_string(n.res_bands) + " row bands" : std::string("frame resident"));
+        } else if (n.kind == Node::Resident) {
             os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, " << (n.res_bands > 1 ? "row-band resident" : "frame resident") << ", " << n.res_lds_bytes << " B LDS";
             if (n.res_bands > 1) os << ", " << n.res_bands << " bands of " << n.stages[0].st.band_rows << " rows";
             for (int t : n.extra_out) os << " +t" << t;

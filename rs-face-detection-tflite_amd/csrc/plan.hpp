@@ -35,6 +35,8 @@ struct Node {
     std::vector<Stage> stages;
     int res_const_off = 0, res_const_floats = 0, res_lds_bytes = 0;
     int res_bands = 1;           // Resident: workgroups per frame (row bands; 1 = the whole frame is resident)
+    bool bneck = false;          // Resident without stages: members are (pointwise C -> Cm, depthwise block Cm -> C + skip) pairs run by
+                                 // bneck_kernels.hip with the C-channel tensor in registers
     // frame-resident Chain: output heads run by its launch.  head_nodes = the absorbed 1x1 convolutions; a pair = up to two of them
     // on the same tensor (src 0: the chain's final frame, 1: chain_post's output), contracted as one stacked product
     struct HeadPair { int src = 0, a = -1, b = -1; };
