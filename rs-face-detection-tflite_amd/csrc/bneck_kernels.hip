@@ -55,7 +55,9 @@ unsigned long long* g_bneck_stamps = nullptr;
 #define MI_BN_STAMP(k)
 #endif
 
-template <int MT, int MTA>
+// WL: the (single) block's pointwise matrices are staged in LDS (row bands).  A compile-time switch: a run-time choice between an LDS
+// and a global pointer makes the loads FLAT, and a flat load waits on vmcnt AND lgkmcnt — i.e. for the next item's x as well.
+template <int MT, int MTA, bool WL>
 __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g) {
     constexpr int C = 32 * MT, Cm = 32 * MTA, Chm = Cm / 2;
     constexpr int NCH1 = C / 8;   // chunks of the first contraction (4 channels of each half per chunk)
@@ -77,6 +79,14 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
     float* my_r = rt + (oy + 1) * g.RSa + (ox + 1) * PSa;
     const int total = a.B * a.bands;
 
+    // workgroup barrier that orders LDS traffic only (raw s_barrier behind lgkmcnt(0)): __syncthreads() also waits for every global
+    // load and store in flight — the next item's x, the previous item's stores — which is exactly what must stay in flight
+    auto wg_barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
     float cr[NCR];
     auto fetch_consts = [&](const BneckBlock& bk) {
 #pragma unroll
@@ -99,17 +109,14 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
     // The wave's 32 pixels are 32 C consecutive floats of the tensor: they travel lane-linear (1 KiB per instruction; in the MFMA
     // result layout every lane would ask for 16-byte pieces 4 C bytes apart, one cache-line lookup each: a third of a band's time)
     // and are turned through the slab.
-    constexpr bool PERSIST = MT <= 2;  // 64-channel kernels walk over several items with the next x in flight; with 128 channels there are no registers for that
+    constexpr bool PERSIST = WL;  // 64-channel kernels walk over several items with the next x in flight; with 128 channels there are no registers for that
     float4 xv[NLD];
     auto prefetch_x = [&](int it) {
         const int frame = it / a.bands, band = it - frame * a.bands, r0 = band * g.R, nv = nvalid_of(it);
         const float* xg = a.in + (long)frame * a.in_fs + ((long)r0 * W + wave * 32) * C;
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {  // unconditional loads at clamped addresses (a branch per load serialises them), zeroed afterwards
-            const int i = lane + 64 * k;
-            xv[k] = nld4(xg + 4 * min(i, max(nv * C4 - 1, 0)));
-            if (i >= nv * C4) xv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < NLD; k++)  // unconditional loads at clamped addresses; pieces past the valid pixels are zeroed where xv is consumed
+            xv[k] = nld4(xg + 4 * min(lane + 64 * k, max(nv * C4 - 1, 0)));  // (a select here would make the wave wait for the data at once)
     };
 
     // r = act1(W1 . x + b1) for one 32-pixel group whose x comes from `xb` (static register indices: the chunk loop is unrolled);
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
     auto pw1 = [&](const BneckBlock& bk, const float* cst, auto&& xb, float* dst, bool store, bool keep) {
         // weights: from LDS in the walking (row-band) kernels — a global load here would have to wait for the next item's x, which was
         // issued before it (vmcnt retires in order) — from L2 otherwise
-        const float* w1p = (PERSIST && g.off_w >= 0) ? lds + g.off_w : bk.w1;
+        const float* w1p = WL ? lds + g.off_w : bk.w1;
         nf32x16 Da[MTA];
 #pragma unroll
         for (int t = 0; t < MTA; t++)
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
         for (int i = tid; i < ((g.R + 2) * g.RSa) >> 2; i += 512) reinterpret_cast<float4*>(rt)[i] = zero4;
         commit_consts(0);
     }
-    if (PERSIST && g.off_w >= 0) {
+    if (WL) {
         for (int i = tid; i < (C * Cm) >> 2; i += 512) {
             reinterpret_cast<float4*>(lds + g.off_w)[i] = nld4(a.blocks[0].w1 + 4 * i);
             reinterpret_cast<float4*>(lds + g.off_w + C * Cm)[i] = nld4(a.blocks[0].w2 + 4 * i);
@@ -182,7 +189,11 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
         nf32x16 X[MT];
         if (PERSIST) {
 #pragma unroll
-            for (int k = 0; k < NLD; k++) *reinterpret_cast<float4*>(slab + sl_off(lane, k)) = xv[k];
+            for (int k = 0; k < NLD; k++) {
+                float4 t = xv[k];
+                if (lane + 64 * k >= nvalid * C4) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(slab + sl_off(lane, k)) = t;
+            }
         } else {  // 8 loads at a time: 16 in flight cost more registers than the kernel has to spare
             const float* xg = a.in + (long)frame * a.in_fs + ((long)r0 * W + wave * 32) * C;
 #pragma unroll
@@ -208,12 +219,28 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
                 const float4 t = nld4(slab + pl * PSx + 32 * m + 8 * gq + 4 * h);
                 X[m][4 * gq] = t.x; X[m][4 * gq + 1] = t.y; X[m][4 * gq + 2] = t.z; X[m][4 * gq + 3] = t.w;
             }
+        // ---- row bands: this wave's piece of the rows above / below the band (the last 2 ceil(W / 32) waves have one each); its x is
+        // asked for now ...
+        const int npieces = (W + 31) >> 5, hu = wave - (8 - 2 * npieces);
+        const bool has_halo = PERSIST && a.bands > 1 && hu >= 0;  // row bands exist for 64 channels only (make_bneck_geom)
+        const int hside = has_halo ? hu / npieces : 0, hx = (has_halo ? hu - hside * npieces : 0) * 32 + pl;
+        const int hiy = hside == 0 ? r0 - 1 : r0 + g.R;
+        const bool hrow = has_halo && hiy >= 0 && hiy < a.H, hv = hx < W;
+        float4 xq[PERSIST ? NCH1 : 1];
+        if (PERSIST && hrow) {  // wave-uniform
+            const float* xh = a.in + (long)frame * a.in_fs + ((long)hiy * W + (hv ? hx : 0)) * C + 4 * h;
+#pragma unroll
+            for (int j = 0; j < NCH1; j++) xq[PERSIST ? j : 0] = nld4(xh + 32 * (j >> 2) + 8 * (j & 3));
+        }
+        // ... and, behind it, the next item's x: it has this whole item to arrive.  (vmcnt retires in order: any global load issued
+        // after the prefetch would have to wait for it — which is why the walking kernels keep their weights in LDS.)
+        if (PERSIST && item + (int)gridDim.x < total) prefetch_x(item + gridDim.x);
         if (!g.slab_sep) {  // the slabs lie over r's region: every wave has its x before r is cleared
-            __syncthreads();
+            wg_barrier();
             for (int i = tid; i < ((g.R + 2) * g.RSa) >> 2; i += 512) reinterpret_cast<float4*>(rt)[i] = zero4;
             commit_consts(0);
         }
-        __syncthreads();
+        wg_barrier();
         MI_BN_STAMP(1)
 
         for (int blk = 0; blk < a.nblocks; blk++) {
@@ -225,37 +252,21 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
             pw1(bk, cst, [&](int j) { return make_float4(X[j >> 2][4 * (j & 3)], X[j >> 2][4 * (j & 3) + 1], X[j >> 2][4 * (j & 3) + 2], X[j >> 2][4 * (j & 3) + 3]); },
                 my_r, in_tile, valid);
             MI_BN_STAMP(2)
-            // ---- row bands: r of the rows above and below the band, from x in global memory (the last waves, 32-pixel pieces of those rows)
-            if (a.bands > 1) {
-                const int npieces = (W + 31) >> 5;  // per halo row
-                for (int u = wave - (8 - 2 * npieces); u >= 0 && u < 2 * npieces; u += 8) {  // wave-uniform
-                    const int side = u / npieces, piece = u - side * npieces;
-                    const int iy = side == 0 ? r0 - 1 : r0 + g.R;
-                    const int hx = piece * 32 + pl;
-                    const bool hv = hx < W;
-                    float* dst = rt + (side == 0 ? 0 : g.R + 1) * g.RSa + ((hv ? hx : 0) + 1) * PSa;
-                    if (iy < 0 || iy >= a.H) {  // outside the image: zero (an earlier band of this workgroup may have left a row here)
-                        if (hv) {
+            // ---- row bands: r of the rows above and below the band
+            if (PERSIST && has_halo && blk == 0) {  // wave-uniform
+                float* dst = rt + (hside == 0 ? 0 : g.R + 1) * g.RSa + ((hv ? hx : 0) + 1) * PSa;
+                if (hrow) {
+                    pw1(bk, cst, [&](int j) { return xq[PERSIST ? j : 0]; }, dst, hv, true);
+                } else if (hv) {  // outside the image: zero (an earlier band of this workgroup may have left a row here)
 #pragma unroll
-                            for (int t = 0; t < MTA; t++)
+                    for (int t = 0; t < MTA; t++)
 #pragma unroll
-                                for (int gq = 0; gq < 4; gq++) *reinterpret_cast<float4*>(dst + 32 * t + 8 * gq + 4 * h) = zero4;
-                        }
-                        continue;
-                    }
-                    const float* xh = a.in + (long)frame * a.in_fs + ((long)iy * W + (hv ? hx : 0)) * C + 4 * h;
-                    float4 xq[NCH1];
-#pragma unroll
-                    for (int j = 0; j < NCH1; j++) xq[j] = nld4(xh + 32 * (j >> 2) + 8 * (j & 3));
-                    pw1(bk, cst, [&](int j) { return xq[j]; }, dst, hv, true);
+                        for (int gq = 0; gq < 4; gq++) *reinterpret_cast<float4*>(dst + 32 * t + 8 * gq + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             MI_BN_STAMP(3)
-            // the next item's x starts its trip now — behind this item's last global loads (vmcnt retires in order: a load issued after
-            // it would have to wait for it) — and lands under the depthwise / second pointwise stage and the stores
-            if (PERSIST && blk == 0 && item + (int)gridDim.x < total) prefetch_x(item + gridDim.x);
             if (more) commit_consts((blk + 1) & 1);  // the other half: its last readers finished before the previous block's closing barrier
-            __syncthreads();
+            wg_barrier();
             MI_BN_STAMP(4)
             // ---- depthwise 3x3 on r (this lane: 4 channels of its half per chunk) -> second pointwise conv over all C output channels
             nf32x16 D[MT];
@@ -280,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
                             bf.w = fmaf(d.w, w.w, bf.w);
                         }
                 };
-                const float* w2p = (PERSIST && g.off_w >= 0) ? lds + g.off_w + C * Cm : bk.w2;
+                const float* w2p = WL ? lds + g.off_w + C * Cm : bk.w2;
                 auto a_frag = [&](int j, float4 (&av)[MT]) {
 #pragma unroll
                     for (int m = 0; m < MT; m++) av[m] = nld4(w2p + ((m * NCH2 + j) * 64 + lane) * 4);
@@ -323,11 +334,11 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
                     X[m][4 * gq + 2] = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), bk.hi2);
                     X[m][4 * gq + 3] = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), bk.hi2);
                 }
-            if (more) __syncthreads();  // every wave has read r: the next block may overwrite it
+            if (more) wg_barrier();  // every wave has read r: the next block may overwrite it
         }
         MI_BN_STAMP(6)
         // ---- the result leaves the registers the way x came in
-        if (!g.slab_sep) __syncthreads();  // every wave is done with r: the slabs may overwrite it
+        if (!g.slab_sep) wg_barrier();  // every wave is done with r: the slabs may overwrite it
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void bneck_kernel(BneckArgs a, BneckGeom g)
         if (!PERSIST) break;
         item += gridDim.x;
         if (item >= total) break;
-        __syncthreads();  // the next item overwrites r
+        wg_barrier();  // the next item overwrites r
     }
 }
 
@@ -357,7 +368,7 @@ bool make_bneck_geom(const BneckArgs& a, BneckGeom* out) {
     if (a.C % 32 || a.Cm % 32 || a.C < 64 || a.C > 128 || a.Cm < 32 || a.Cm > 64 || a.nblocks < 1 || a.nblocks > kMaxBneck) return false;
     if (a.H < 1 || a.W < 1 || a.W > 256 || a.bands < 1) return false;
     g.R = (a.H + a.bands - 1) / a.bands;
-    if (g.R * a.W > 256 || (a.bands > 1 && (a.nblocks != 1 || (g.R * a.W) % 32 || 2 * ((a.W + 31) / 32) > 8))) return false;
+    if (g.R * a.W > 256 || (a.bands > 1 && (a.nblocks != 1 || a.C > 64 || (g.R * a.W) % 32 || 2 * ((a.W + 31) / 32) > 8))) return false;
     g.PSa = a.Cm + 4;
     g.RSa = (a.W + 2) * g.PSa;
     g.PSx = a.C + 4;
@@ -370,7 +381,11 @@ bool make_bneck_geom(const BneckArgs& a, BneckGeom* out) {
     g.off_slab = g.slab_sep ? off : 0;
     if (g.slab_sep) off += sfl;
     g.off_w = -1;
-    if (a.bands > 1 && a.C <= 64 && g.slab_sep && (off + 2 * a.C * a.Cm) * 4 <= 160 * 1024 - 256) { g.off_w = off; off += 2 * a.C * a.Cm; }
+    if (a.bands > 1) {  // row bands: the walking kernel (weights in LDS, slabs beside r)
+        if (!g.slab_sep || (off + 2 * a.C * a.Cm) * 4 > 160 * 1024 - 256) return false;
+        g.off_w = off;
+        off += 2 * a.C * a.Cm;
+    }
     g.lds_bytes = off * 4;
     if (g.lds_bytes > 160 * 1024 - 256) return false;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -390,9 +405,9 @@ int bneck_cu_count() {
     return n;
 }
 
-template <int MT, int MTA>
+template <int MT, int MTA, bool WL>
 int launch_bneck_inst(const BneckArgs& a, const BneckGeom& g, hipStream_t s) {
-    auto kern = bneck_kernel<MT, MTA>;
+    auto kern = bneck_kernel<MT, MTA, WL>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -401,7 +416,7 @@ int launch_bneck_inst(const BneckArgs& a, const BneckGeom& g, hipStream_t s) {
     }
     // row bands: one workgroup per CU walks over its share of the bands (the next band's x in flight under the current band's MFMAs)
     unsigned grid = (unsigned)(a.B * a.bands);
-    if (MT <= 2 && g.slab_sep) grid = std::min(grid, (unsigned)bneck_cu_count());  // walking kernels: one workgroup per CU
+    if (WL) grid = std::min(grid, (unsigned)bneck_cu_count());  // walking kernels: one workgroup per CU
     return (int)launch_kernel(kern, dim3(grid), dim3(512), (size_t)g.lds_bytes, s, a, g);
 }
 
@@ -422,10 +437,12 @@ int launch_bneck(const BneckArgs& a, void* stream) {
 #endif
     hipStream_t s = (hipStream_t)stream;
     const int MT = a.C / 32, MTA = a.Cm / 32;
-    if (MT == 2 && MTA == 1) return launch_bneck_inst<2, 1>(a, g, s);
-    if (MT == 4 && MTA == 2) return launch_bneck_inst<4, 2>(a, g, s);
-    if (MT == 4 && MTA == 1) return launch_bneck_inst<4, 1>(a, g, s);
-    if (MT == 2 && MTA == 2) return launch_bneck_inst<2, 2>(a, g, s);
+    const bool wl = g.off_w >= 0;
+    if (MT == 2 && MTA == 1) return wl ? launch_bneck_inst<2, 1, true>(a, g, s) : launch_bneck_inst<2, 1, false>(a, g, s);
+    if (MT == 2 && MTA == 2) return wl ? launch_bneck_inst<2, 2, true>(a, g, s) : launch_bneck_inst<2, 2, false>(a, g, s);
+    if (wl) return (int)hipErrorInvalidValue;
+    if (MT == 4 && MTA == 2) return launch_bneck_inst<4, 2, false>(a, g, s);
+    if (MT == 4 && MTA == 1) return launch_bneck_inst<4, 1, false>(a, g, s);
     return (int)hipErrorInvalidValue;
 }
 
