@@ -102,7 +102,10 @@ __device__ __forceinline__ float4 res_from_global(const Epilogue& ep, int b, int
 // MTG: output-channel tiles kept in accumulators at once; S: stride; KS: 3 (depthwise stage) or 1 (pointwise only);
 // PG: 32-pixel groups per wave per step; CPT: compile-time padded channel count (0 = runtime); SLOW: variants that may stream the pointwise weights from global/L2 and read
 // the skip from global memory (large-channel / cross-tensor-skip layers; small, never on the hot path).
-template <int MTG, int S, int KS, int PG, bool SLOW, int CPT>
+// ALDS: the pointwise weights are staged in LDS (g.a_lds), else streamed from L2.  A template parameter, not a run-time choice:
+// selecting between an LDS and a global pointer at run time turns the load into a FLAT load, whose wait covers vmcnt and lgkmcnt —
+// every weight fragment then also waits for the next step's rows, which are meant to stay in flight across the compute phase.
+template <int MTG, int S, int KS, int PG, bool SLOW, int CPT, bool ALDS>
 __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) {
     // CPT > 0: padded channel count known at compile time (hot shapes) so that every tap / chunk offset of the LDS reads
     // folds into the ds_read immediate instead of costing a VALU add per load (49 of ~160 VALU ops per chunk at runtime Cp).
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
         // negative-side slope: PReLU alpha, 0 for ReLU/ReLU6, 1 for "no activation"
         lds[g.off_alpha + i] = (i < a.Co && a.ep.act == ACT_PRELU) ? a.ep.alpha[i] : (a.ep.act == ACT_NONE ? 1.f : 0.f);
     }
-    if (g.a_lds)
+    if (ALDS)
         for (int i = tid; i < (g.MT * 32 * g.Cp) >> 2; i += 256) reinterpret_cast<float4*>(lds + g.off_a)[i] = ld4(a.w_pw + 4 * (long)i);
 
     // prefetch geometry: float4 number (tid + 256k) of the contiguous block of new rows -> (row, LDS offset in its slot)
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
                 for (int m = 0; m < MTG; m++) {
                     int mt = min(mt0 + m, g.MT - 1);
                     long ao = (((long)mt * (g.Ch >> 2) + j) * 64 + lane) * 4;
-                    av[m] = (SLOW && !g.a_lds) ? ld4(a.w_pw + ao) : ld4(aL + ao);
+                    av[m] = ALDS ? ld4(aL + ao) : ld4(a.w_pw + ao);
                 }
                 float4 bf[PG];
                 if (KS == 3) {
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
                     for (int m = 0; m < MTG; m++) {
                         int mt = min(mt0 + m, g.MT - 1);
                         long ao = (((long)mt * nch + j) * 64 + lane) * 4;
-                        av[m] = (SLOW && !g.a_lds) ? ld4(a.w_pw + ao) : ld4(aL + ao);
+                        av[m] = ALDS ? ld4(aL + ao) : ld4(a.w_pw + ao);
                     }
                 };
                 auto mfma_chunk = [&](const float4 (&av)[MTG], const float4 (&bf)[PG]) {
@@ -534,9 +537,9 @@ bool make_geom(const BlockArgs& a, BlockGeom* out) {
     return make_geom_pg(a, 1, out);
 }
 
-template <int MTG, int S, int KS, int PG, bool SLOW, int CPT>
-int launch_inst3(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
-    auto kern = block_kernel<MTG, S, KS, PG, SLOW, CPT>;
+template <int MTG, int S, int KS, int PG, bool SLOW, int CPT, bool ALDS>
+int launch_inst4(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
+    auto kern = block_kernel<MTG, S, KS, PG, SLOW, CPT, ALDS>;
     static bool configured = false;  // one attribute call per instantiation (one GPU per process here)
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -544,6 +547,14 @@ int launch_inst3(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
         configured = true;
     }
     return (int)launch_kernel(kern, dim3((unsigned)(a.B * g.bands)), dim3(256), (size_t)g.lds_bytes, s, a, g);
+}
+
+template <int MTG, int S, int KS, int PG, bool SLOW, int CPT>
+int launch_inst3(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
+    if constexpr (SLOW) {
+        if (!g.a_lds) return launch_inst4<MTG, S, KS, PG, SLOW, CPT, false>(a, g, s);
+    }
+    return launch_inst4<MTG, S, KS, PG, SLOW, CPT, true>(a, g, s);
 }
 
 template <int MTG, int S, int KS, int PG, bool SLOW>
