@@ -228,6 +228,23 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
             for (int ky = 0; ky < KS; ky++) base[p][ky] = wrap(ring0 + rr * S + ky) * g.RS + (oxc * S - a.pl + 1) * g.PS + h * g.Ch;
         }
         for (int mt0 = 0; mt0 < g.MT; mt0 += MTG) {
+            // Skip connection from another tensor (SLOW variants): its 16-byte pieces are asked for BEFORE the contraction and land under
+            // the MFMAs; read in the epilogue, each of the MTG * 4 quads paid a full memory round trip after the last MFMA.
+            float4 rvq[SLOW ? PG : 1][SLOW ? MTG : 1][4];
+            if constexpr (SLOW) {
+                if (rk == 3) {
+#pragma unroll
+                    for (int p = 0; p < PG; p++)
+#pragma unroll
+                        for (int m = 0; m < MTG; m++)
+#pragma unroll
+                            for (int gq = 0; gq < 4; gq++) {
+                                const int ch = (mt0 + m) * 32 + 8 * gq + 4 * h;
+                                rvq[p][m][gq] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (valid[p] && mt0 + m < g.MT && ch < a.Co && ch < a.ep.res_C) rvq[p][m][gq] = res_from_global(a.ep, b, oys + rp[p], ox[p], a.Wo, ch);
+                            }
+                }
+            }
             f32x16 D[PG][MTG];
 #pragma unroll
             for (int p = 0; p < PG; p++)
@@ -411,7 +428,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
                             float4 rv;
                             if (rk == 1) rv = ld4(rd[p] + ch);
                             else if (rk == 2) rv = max4(ld4(r0[p] + ch), ld4(r0[p] + g.PS + ch), ld4(r1[p] + ch), ld4(r1[p] + g.PS + ch));
-                            else if (SLOW) rv = res_from_global(a.ep, b, oys + rp[p], ox[p], a.Wo, ch);
+                            else if (SLOW) rv = rvq[SLOW ? p : 0][SLOW ? m : 0][gq];
                             else rv = make_float4(0.f, 0.f, 0.f, 0.f);
                             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                         }
