@@ -70,6 +70,10 @@ struct BlockGeom {
     int res_lds;           // skip connection served from the LDS ring
     int lds_bytes;
     int PG;
+    // Small grids (few frames x few pixels, many output channels: the 12x12 / 6x6 layers of full_range at 128 frames): the output
+    // tiles of a band are spread over nsplit workgroups (the depthwise stage is recomputed per pass anyway) and, when a step has
+    // at most two 32-pixel groups, over the waves that would have no pixels (wmod groups; wave -> group wave % wmod, tile share wave / wmod)
+    int nsplit, wmod, mt_per;  // mt_per: tiles per (workgroup, tile share)
     unsigned long long* stamps;  // diagnostic builds only (MI_BLOCK_STAMPS): 8 accumulators per wave
 };
 
@@ -124,7 +128,10 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 31, h = lane >> 5;
-    const int b = blockIdx.x / g.bands, band = blockIdx.x % g.bands;
+    const int bsp = blockIdx.x / g.nsplit, sp = blockIdx.x - bsp * g.nsplit;
+    const int b = bsp / g.bands, band = bsp % g.bands;
+    const int wq = wave % g.wmod, wshare = wave / g.wmod;
+    const int mt_lo = min(g.MT, (sp * (4 / g.wmod) + wshare) * g.mt_per), mt_hi = min(g.MT, mt_lo + g.mt_per);
     const int oy0 = band * g.band, oy1 = min(oy0 + g.band, a.Ho);
     const int iy_base = oy0 * S - a.pt;  // input row held by ring slot 0 at band start
     const float* in = a.in + (long)b * a.in_fs;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
     int rp[PG], ox[PG];
 #pragma unroll
     for (int p = 0; p < PG; p++) {
-        int q = (wave * PG + p) * 32 + pl;
+        int q = (wq * PG + p) * 32 + pl;
         rp[p] = q / a.Wo;
         ox[p] = q - rp[p] * a.Wo;
     }
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
 #pragma unroll
             for (int ky = 0; ky < KS; ky++) base[p][ky] = wrap(ring0 + rr * S + ky) * g.RS + (oxc * S - a.pl + 1) * g.PS + h * g.Ch;
         }
-        for (int mt0 = 0; mt0 < g.MT; mt0 += MTG) {
+        for (int mt0 = mt_lo; mt0 < mt_hi; mt0 += MTG) {
             // Skip connection from another tensor (SLOW variants): its 16-byte pieces are asked for BEFORE the contraction and land under
             // the MFMAs; read in the epilogue, each of the MTG * 4 quads paid a full memory round trip after the last MFMA.
             float4 rvq[SLOW ? PG : 1][SLOW ? MTG : 1][4];
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
                             for (int gq = 0; gq < 4; gq++) {
                                 const int ch = (mt0 + m) * 32 + 8 * gq + 4 * h;
                                 rvq[p][m][gq] = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (valid[p] && mt0 + m < g.MT && ch < a.Co && ch < a.ep.res_C) rvq[p][m][gq] = res_from_global(a.ep, b, oys + rp[p], ox[p], a.Wo, ch);
+                                if (valid[p] && mt0 + m < mt_hi && ch < a.Co && ch < a.ep.res_C) rvq[p][m][gq] = res_from_global(a.ep, b, oys + rp[p], ox[p], a.Wo, ch);
                             }
                 }
             }
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) 
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
                     const int ch = (mt0 + m) * 32 + 8 * gq + 4 * h;
-                    if (mt0 + m >= g.MT || ch >= a.Co) continue;
+                    if (mt0 + m >= mt_hi || ch >= a.Co) continue;
                     const float4 bb = ld4(biasL + ch), al = ld4(alphaL + ch);
                     const bool has_res = rk != 0 && ch < a.ep.res_C;
 #pragma unroll
@@ -528,6 +535,20 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     int bands = std::min(max_bands, std::max(1, (cu_count() * per_cu + a.B / 2) / std::max(1, a.B)));
     g.band = single_step ? R : ((a.Ho + bands - 1) / bands + R - 1) / R * R;
     g.bands = (a.Ho + g.band - 1) / g.band;
+    g.nsplit = 1; g.wmod = 4; g.mt_per = g.MT;
+    {
+        static const int no_split = getenv("MI_BLOCK_NOSPLIT") ? atoi(getenv("MI_BLOCK_NOSPLIT")) : 0;  // tuning aid
+        const long wgs = (long)a.B * g.bands;
+        const int groups = (std::min(R, a.Ho) * a.Wo + 32 * PG - 1) / (32 * PG);  // waves of a step that have pixels
+        if (!no_split && g.MT >= 2 && wgs * 2 <= cu_count()) {
+            const int wmod = groups <= 1 ? 1 : (groups == 2 ? 2 : 4), wdiv = 4 / wmod;
+            int nsplit = (int)std::min<long>((2L * cu_count() + wgs - 1) / wgs, (g.MT + wdiv - 1) / wdiv);
+            nsplit = std::max(1, nsplit);
+            const int per = (g.MT + nsplit * wdiv - 1) / (nsplit * wdiv);
+            nsplit = (g.MT + per * wdiv - 1) / (per * wdiv);
+            g.nsplit = nsplit; g.wmod = wmod; g.mt_per = per;
+        }
+    }
     // skip connection straight from the ring when it is the block's own input tensor
     g.res_lds = 0;
     if (a.ep.res == a.in && a.ep.res_fs == a.in_fs && a.ep.res_C == a.C) {
@@ -563,7 +584,7 @@ int launch_inst4(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    return (int)launch_kernel(kern, dim3((unsigned)(a.B * g.bands)), dim3(256), (size_t)g.lds_bytes, s, a, g);
+    return (int)launch_kernel(kern, dim3((unsigned)(a.B * g.bands * g.nsplit)), dim3(256), (size_t)g.lds_bytes, s, a, g);
 }
 
 template <int MTG, int S, int KS, int PG, bool SLOW, int CPT>
@@ -606,7 +627,7 @@ const char* block_kernel_label(const BlockArgs& a, char* buf, size_t cap) {
     BlockGeom g;
     if (!make_geom(a, &g)) return "block_kernel<?>";
     const bool slow = !g.a_lds || (a.ep.res_mode != RES_NONE && !g.res_lds);
-    snprintf(buf, cap, "block_kernel<%d,%d,%d,%d,%d>", std::min(4, g.MT), a.has_dw ? a.sh : 1, a.has_dw ? 3 : 1, g.PG, slow ? 1 : 0);
+    snprintf(buf, cap, "block_kernel<%d,%d,%d,%d,%d>", std::min(4, g.mt_per), a.has_dw ? a.sh : 1, a.has_dw ? 3 : 1, g.PG, slow ? 1 : 0);
     return buf;
 }
 
@@ -621,7 +642,7 @@ int launch_block(const BlockArgs& a, void* stream) {
     g.stamps = g_stamp_ptr;
 #endif
     hipStream_t s = (hipStream_t)stream;
-    const int MTG = std::min(4, g.MT);
+    const int MTG = std::min(4, g.mt_per);
     const int S = a.sh, K = a.has_dw ? 3 : 1, PG = g.PG;
 #define MI_BLOCK_CASE(M, SS, KK, P) \
     if (MTG == M && S == SS && K == KK && PG == P) return launch_inst<M, SS, KK, P>(a, g, s);
