@@ -28,6 +28,10 @@ def label(name):
     args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2).split(",")]
     if m.group(1) == "block_kernel":
         args = args[:5]
+    if m.group(1) == "chain_kernel":
+        args = args[:1]   # the label carries the tile count only (not the unit-split flag)
+    if m.group(1) == "bneck_kernel":
+        return "bneck_kernel"
     if m.group(1) == "stem_conv_kernel":
         return "stem_conv_kernel"
     return "%s<%s>" % (m.group(1), ",".join(args))
@@ -56,7 +60,7 @@ rows = []
 for (k, _c) in sorted(f, key=lambda kc: -sum(f[kc])):
     if "mi::" not in k:
         continue
-    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel"))
+    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel"))
     fk, wk = statistics.mean(f[(k, "FETCH_SIZE")]), statistics.mean(w.get((k, "WRITE_SIZE"), [0]))
     rows.append({"kernel": k, "label": label(k), "dispatches": len(f[(k, "FETCH_SIZE")]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
                  "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
