@@ -698,7 +698,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     cb.act = n.members[k].act;
                     cb.has_res = n.members[k].res >= 0;
                 };
-                if (n.chain_pre || n.chain_post) {  // frame-resident chain with the stride-2 blocks around it in the same launch
+                if (n.chain_pre || n.chain_post || !n.head_pairs.empty()) {  // frame-resident chain with stride-2 blocks around it and / or output heads in the same launch
                     const size_t k0 = n.chain_pre ? 1 : 0, k1 = n.members.size() - (n.chain_post ? 1 : 0);
                     const auto& sm = g.tensors[n.members[k0].in[0]].shape;  // the resident frame
                     a.B = F; a.H = sm[1]; a.W = sm[2]; a.C = sm[3]; a.nblocks = static_cast<int>(k1 - k0);

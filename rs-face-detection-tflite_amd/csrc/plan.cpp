@@ -282,7 +282,7 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
         const Node& n = ns[k];
         if (n.kind == Node::Chain) {
             const auto& si = g.tensors[n.in[0]].shape;
-            if (si[1] * si[2] > 256 || n.chain_pre || n.chain_post) return false;  // row-pipelined chains and chains with stride-2 edge stages stay what they are
+            if (si[1] * si[2] > 256 || n.chain_pre || n.chain_post || !n.head_pairs.empty()) return false;  // row-pipelined chains and chains with stride-2 edge stages / output heads stay what they are
             for (const Node& m : n.members) M.push_back(m);
         } else if (n.kind == Node::Conv && n.gemm_head) {
             return false;  // a whole-frame convolution is a GEMM over the batch: its weights are read once per 32 frames there, once per frame here
@@ -1161,7 +1161,7 @@ std::string Plan::describe() const {
                    << (n.head_nodes.empty() ? "" : ", " + std::to_string(n.head_nodes.size()) + " output heads");
             else
                 os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
-                   << (n.members.back().sh == 2 ? " (stride-2 tail)" : "");
+                   << (n.members.back().sh == 2 ? " (stride-2 tail)" : "") << (n.head_nodes.empty() ? "" : ", " + std::to_string(n.head_nodes.size()) + " output heads");
         if (n.kind == Node::Resident && n.bneck) {
             os << " x" << n.members.size() / 2 << " bottleneck blocks, wide tensor in registers, " << (n.res_bands > 1 ? std::to_string(n.res_bands) + " row bands" : std::string("frame resident"));
         } else if (n.kind == Node::Resident) {

@@ -60,6 +60,43 @@ def test_network_raw_outputs_vs_oracle(gpu, oracle, name, fuse):
     m.close()
 
 
+@pytest.fixture(scope="module")
+def synth_models(tmp_path_factory):
+    """The synthetic graphs of tests/synth_tflite.py written out as .tflite files (oracle and product both read files)."""
+    import synth_tflite
+    d = tmp_path_factory.mktemp("synth")
+    out = {}
+    for name, (make, h, w) in synth_tflite.CASES.items():
+        p = d / (name + ".tflite")
+        p.write_bytes(make())
+        out[name] = (str(p), h, w)
+    return out
+
+
+@pytest.mark.parametrize("case", ["iris_32x20_ragged_bands", "iris_16x16_c64_run", "iris_12x20_c128", "iris_24x24_fallback", "back_96", "back_160_c16",
+                                  "full_64", "full_80_c48"])
+@pytest.mark.parametrize("fuse", [0, 2, 3, 4, 5])
+def test_synthetic_graphs_vs_oracle(gpu, oracle, synth_models, case, fuse):
+    """The reference graphs' operator chains on OTHER shapes (ragged row bands, partial pixel groups, odd channel counts, chains with
+    edge stages and heads at 12x12 / 6x6 / 20x20, double blocks): every lowering level against the oracle, odd batch, replayed graph."""
+    path, h, w = synth_models[case]
+    m = gpu.Model(path)
+    m.set_option("fuse", fuse)
+    om = oracle.Model(path)
+    rs = np.random.RandomState(100 + fuse)
+    x = rs.uniform(-1, 1, (5, h, w, 3)).astype(np.float32)
+    refs = om.run(x, nthreads=5)
+    outs = m.run(x)
+    for o, r in zip(outs, refs):
+        _raw_close(o, r)
+    xd = __import__("torch").from_numpy(x).cuda()
+    for _ in range(2):
+        outs_d = m.run(xd)
+    for o, r in zip(outs_d, refs):
+        _raw_close(o.cpu().numpy(), r)
+    m.close()
+
+
 @pytest.mark.parametrize("name", list(MODEL_FILES))
 @pytest.mark.parametrize("budget_kib", [40, 78, 156])
 def test_stage_programs_vs_oracle(gpu, oracle, name, budget_kib):

@@ -166,3 +166,24 @@ def test_bbox_helpers_through_the_c_abi(mi, oracle):
     assert box == (pts[:, 0].min(), pts[:, 1].min(), pts[:, 0].max(), pts[:, 1].max())
     with pytest.raises(mi.MiError):
         mi.bbox_from_landmarks([mi.Landmark(0.1, 0.2, 0.0)])
+
+
+def test_synthetic_graphs_oracles_agree_and_lower(tmp_path):
+    """tests/synth_tflite.py: the flatbuffers it writes are read alike by the C oracle, the numpy evaluation and the product's reader,
+    the two oracles agree on them bit for bit, and the planner lowers them at every level (host side, no GPU)."""
+    import rs_face_detection_tflite_amd as mi
+    import synth_tflite
+    from oracle import pyoracle
+    from oracle.np import evaluate, tfl3
+    for name, (make, h, w) in synth_tflite.CASES.items():
+        blob = make()
+        p = tmp_path / (name + ".tflite")
+        p.write_bytes(blob)
+        x = np.random.RandomState(3).uniform(-1, 1, (2, h, w, 3)).astype(np.float32)
+        refs = pyoracle.Model(str(p)).run(x, nthreads=2)
+        ref2 = evaluate.run(tfl3.load(str(p)), x)
+        assert len(refs) == len(ref2) >= 1
+        for a, b in zip(refs, ref2):
+            np.testing.assert_allclose(np.asarray(a).reshape(np.asarray(b).shape), np.asarray(b), rtol=0, atol=2e-5 * max(1.0, float(np.abs(b).max())))
+        sizes = [int(mi.plan_describe(blob, lvl).splitlines()[0].split()[2].split("=")[1]) for lvl in range(6)]
+        assert sizes == sorted(sizes, reverse=True) and sizes[5] < sizes[0], (name, sizes)
