@@ -299,6 +299,30 @@ def full_like(seed, size, c=32, cm=12):
     return g.finish()
 
 
+def mesh_like(seed, size, c0=16):
+    """face-mesh style: stem 3x3 s2 + PReLU -> 2 blocks(c0) -> s2 to 2c0 -> 2 blocks -> s2 to 4c0 -> 2 blocks -> s2 to 8c0 -> 3 blocks -> s2 -> 2 blocks;
+    two branches of small-spatial work ending in whole-frame convolutions (the GEMM heads)."""
+    g = GraphBuilder(seed, [1, size, size, 3])
+    x = g.prelu(g.conv(g.input, c0, 3, 2))
+    for mult, nb in ((1, 2), (2, 2), (4, 2), (8, 3)):
+        if mult > 1:
+            x = g.blaze_block(x, mult * c0, 2, act="prelu")
+        for _ in range(nb):
+            x = g.blaze_block(x, act="prelu")
+    x = g.blaze_block(x, 8 * c0, 2, act="prelu")
+    for _ in range(2):
+        x = g.blaze_block(x, act="prelu")
+    n, h, w, c = g.shape(x)
+    a = g.prelu(g.conv(x, 32))
+    a = g.blaze_block(a, act="prelu")
+    out_a = g.conv(a, 47, h, 1, VALID)          # window = frame: [1,1,1,47]
+    b = g.blaze_block(x, act="prelu")
+    b = g.prelu(g.conv(b, 32))
+    out_b = g.conv(b, 1, h, 1, VALID)
+    g.outputs = [out_a, out_b]
+    return g.finish()
+
+
 CASES = {
     # name: (builder, input H, input W): what it aims at
     "iris_32x20_ragged_bands": (lambda: iris_like(11, 40, 64, 64, 32, 2), 40, 64),        # 20 x 32 frame: bands of 8, 8, 4 rows
@@ -307,6 +331,9 @@ CASES = {
     "iris_24x24_fallback": (lambda: iris_like(14, 48, 48, 64, 32, 1), 48, 48),            # band rows do not tile 32-pixel groups: stage programs
     "back_96": (lambda: back_like(21, 96), 96, 96),                                        # chains at 12x12x96 / 6x6x96 with edges and heads
     "back_160_c16": (lambda: back_like(22, 160, 16, 2, 4), 160, 160),                      # 16-channel pipelines, 20x20 / 10x10 chains
+    "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads
+    "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
+    "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames
     "full_64": (lambda: full_like(31, 64), 64, 64),                                        # double blocks, odd middle widths
     "full_80_c48": (lambda: full_like(32, 80, 48, 20), 80, 80),
 }

@@ -74,7 +74,7 @@ def synth_models(tmp_path_factory):
 
 
 @pytest.mark.parametrize("case", ["iris_32x20_ragged_bands", "iris_16x16_c64_run", "iris_12x20_c128", "iris_24x24_fallback", "back_96", "back_160_c16",
-                                  "full_64", "full_80_c48"])
+                                  "back_128_c32", "mesh_160", "mesh_96_c24", "full_64", "full_80_c48"])
 @pytest.mark.parametrize("fuse", [0, 2, 3, 4, 5])
 def test_synthetic_graphs_vs_oracle(gpu, oracle, synth_models, case, fuse):
     """The reference graphs' operator chains on OTHER shapes (ragged row bands, partial pixel groups, odd channel counts, chains with
@@ -95,6 +95,22 @@ def test_synthetic_graphs_vs_oracle(gpu, oracle, synth_models, case, fuse):
     for o, r in zip(outs_d, refs):
         _raw_close(o.cpu().numpy(), r)
     m.close()
+
+
+@pytest.mark.parametrize("batch", [1, 97, 300])
+def test_walking_band_kernel_many_items(gpu, oracle, synth_models, batch):
+    """Row-band bottleneck launches put one workgroup on every CU and let it walk over its share of the bands with the next band's
+    input in flight: batches whose band count is below, around and well above the CU count (ragged last bands included), for the
+    synthetic 20 x 32 frame and for the real iris graph."""
+    for path, h, w, lo in ((synth_models["iris_32x20_ragged_bands"][0], 40, 64, -1.0), (model_path("iris"), 64, 64, 0.0)):
+        m = gpu.Model(path)
+        om = oracle.Model(path)
+        x = np.random.RandomState(7 + batch).uniform(lo, 1, (batch, h, w, 3)).astype(np.float32)
+        refs = om.run(x, nthreads=8)
+        outs = m.run(x)
+        for o, r in zip(outs, refs):
+            _raw_close(o, r)
+        m.close()
 
 
 @pytest.mark.parametrize("name", list(MODEL_FILES))
