@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
     int oy = (int)(q % a.Ho);
     int b = (int)(q / a.Ho);
     const float* in = a.in + (long)b * a.in_fs;
+    const bool vec4 = (a.C & 3) == 0 && (a.in_fs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;  // same accumulation order either way
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ky = 0; ky < a.KH; ky++) {
         int iy = oy * a.sh - a.pt + ky;
@@ -74,7 +75,18 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
             if (ix < 0 || ix >= a.W) continue;
             const float* ip = in + ((long)iy * a.W + ix) * a.C;
             const float4* wp = reinterpret_cast<const float4*>(a.w + ((long)(ky * a.KW + kx) * a.C) * a.Cop) + g;
-            for (int c = 0; c < a.C; c++) {
+            int c = 0;
+            if (vec4) {  // the pixel's channels as float4s (front / short: 36 -> 42 and 42 -> 48 channels, which no fused kernel takes)
+                for (; c + 4 <= a.C; c += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(ip + c);
+                    const float4 w0 = wp[(long)c * G], w1 = wp[(long)(c + 1) * G], w2 = wp[(long)(c + 2) * G], w3 = wp[(long)(c + 3) * G];
+                    acc.x = fmaf(x.x, w0.x, acc.x); acc.y = fmaf(x.x, w0.y, acc.y); acc.z = fmaf(x.x, w0.z, acc.z); acc.w = fmaf(x.x, w0.w, acc.w);
+                    acc.x = fmaf(x.y, w1.x, acc.x); acc.y = fmaf(x.y, w1.y, acc.y); acc.z = fmaf(x.y, w1.z, acc.z); acc.w = fmaf(x.y, w1.w, acc.w);
+                    acc.x = fmaf(x.z, w2.x, acc.x); acc.y = fmaf(x.z, w2.y, acc.y); acc.z = fmaf(x.z, w2.z, acc.z); acc.w = fmaf(x.z, w2.w, acc.w);
+                    acc.x = fmaf(x.w, w3.x, acc.x); acc.y = fmaf(x.w, w3.y, acc.y); acc.z = fmaf(x.w, w3.z, acc.z); acc.w = fmaf(x.w, w3.w, acc.w);
+                }
+            }
+            for (; c < a.C; c++) {
                 float x = ip[c];
                 float4 w = wp[(long)c * G];
                 acc.x = fmaf(x, w.x, acc.x);
@@ -97,6 +109,38 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
     }
 }
 
+
+// Pointwise convolution to at most 4 output channels (the classifier heads: 48 -> 1 at 48x48 in full_range, 88 -> 2 in front / short):
+// one thread = one pixel, its C input channels read as float4s, the [C][4] filter through the scalar cache.  (The generic kernel above
+// reads the pixel scalar by scalar: 48 four-byte loads 192 bytes apart per lane.)
+__global__ __launch_bounds__(256) void pw_few_kernel(ConvArgs a) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per_frame = (long)a.Ho * a.Wo;
+    if (p >= (long)a.B * per_frame) return;
+    const int b = (int)(p / per_frame);
+    const long q = p - (long)b * per_frame;
+    const int oy = (int)(q / a.Wo), ox = (int)(q - (long)oy * a.Wo);
+    const float* ip = a.in + (long)b * a.in_fs + q * a.C;
+    const float4* __restrict__ w = reinterpret_cast<const float4*>(a.w);  // [C][Cop = 4], uniform
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < a.C; j += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(ip + j);
+        const float4 w0 = w[j], w1 = w[j + 1], w2 = w[j + 2], w3 = w[j + 3];
+        acc.x = fmaf(x.x, w0.x, acc.x); acc.y = fmaf(x.x, w0.y, acc.y); acc.z = fmaf(x.x, w0.z, acc.z); acc.w = fmaf(x.x, w0.w, acc.w);
+        acc.x = fmaf(x.y, w1.x, acc.x); acc.y = fmaf(x.y, w1.y, acc.y); acc.z = fmaf(x.y, w1.z, acc.z); acc.w = fmaf(x.y, w1.w, acc.w);
+        acc.x = fmaf(x.z, w2.x, acc.x); acc.y = fmaf(x.z, w2.y, acc.y); acc.z = fmaf(x.z, w2.z, acc.z); acc.w = fmaf(x.z, w2.w, acc.w);
+        acc.x = fmaf(x.w, w3.x, acc.x); acc.y = fmaf(x.w, w3.y, acc.y); acc.z = fmaf(x.w, w3.z, acc.z); acc.w = fmaf(x.w, w3.w, acc.w);
+    }
+    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    float* op = a.out + (long)b * a.out_fs + q * a.Co;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (j < a.Co) {
+            float r = v[j] + (a.ep.bias ? a.ep.bias[j] : 0.f);
+            r += load_res(a.ep, b, oy, ox, a.Wo, j);
+            op[j] = apply_act(r, a.ep.act, a.ep.alpha, j);
+        }
+}
 
 // ------------------------------------------------------------------------------------------------ stem convolution
 // First layer of every graph: K x K, stride 2, 3 input channels (RGB) -> CO channels, + bias + ReLU/PReLU.
@@ -234,7 +278,11 @@ static bool stem_applicable(const ConvArgs& a) {
     return (a.KH == 5 && a.Co == 24) || (a.KH == 3 && (a.Co == 16 || a.Co == 32 || a.Co == 64));
 }
 
-const char* conv_kernel_label(const ConvArgs& a) { return stem_applicable(a) ? "stem_conv_kernel" : "conv_generic_kernel"; }
+static bool pw_few_applicable(const ConvArgs& a) {
+    return a.KH == 1 && a.KW == 1 && a.sh == 1 && a.sw == 1 && a.Cop == 4 && a.C % 4 == 0 && a.H == a.Ho && a.W == a.Wo && (a.in_fs & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+}
+const char* conv_kernel_label(const ConvArgs& a) { return stem_applicable(a) ? "stem_conv_kernel" : (pw_few_applicable(a) ? "pw_few_kernel" : "conv_generic_kernel"); }
 
 int launch_conv(const ConvArgs& a, void* stream) {
     if (stem_applicable(a)) {
@@ -247,6 +295,7 @@ int launch_conv(const ConvArgs& a, void* stream) {
     long total = (long)a.B * a.Ho * a.Wo * (a.Cop >> 2);
     if (total <= 0) return 0;
     unsigned blocks = (unsigned)((total + 255) / 256);
+    if (pw_few_applicable(a)) return (int)launch_kernel(pw_few_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)launch_kernel(conv_generic_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
 }
 
