@@ -602,6 +602,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             const auto& sr = g.tensors[n.res].shape;
             ep.res = tensor_ptr(n.res, in, chunk_start, &ep.res_fs);
             ep.res_mode = n.res_mode;
+            ep.res_after = n.res_after ? 1 : 0;
             ep.res_C = sr.back();
             ep.res_H = dim(sr, 1);
             ep.res_W = dim(sr, 2);

@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(ConvArgs a) {
         int c = 4 * g + j;
         if (c < a.Co) {
             float r = v[j] + (a.ep.bias ? a.ep.bias[c] : 0.f);
-            r += load_res(a.ep, b, oy, ox, a.Wo, c);
-            op[c] = apply_act(r, a.ep.act, a.ep.alpha, c);
+            const float sk = load_res(a.ep, b, oy, ox, a.Wo, c);
+            if (!a.ep.res_after) r += sk;
+            r = apply_act(r, a.ep.act, a.ep.alpha, c);
+            if (a.ep.res_after) r += sk;
+            op[c] = r;
         }
     }
 }
@@ -137,8 +140,11 @@ __global__ __launch_bounds__(256) void pw_few_kernel(ConvArgs a) {
     for (int j = 0; j < 4; j++)
         if (j < a.Co) {
             float r = v[j] + (a.ep.bias ? a.ep.bias[j] : 0.f);
-            r += load_res(a.ep, b, oy, ox, a.Wo, j);
-            op[j] = apply_act(r, a.ep.act, a.ep.alpha, j);
+            const float sk = load_res(a.ep, b, oy, ox, a.Wo, j);
+            if (!a.ep.res_after) r += sk;
+            r = apply_act(r, a.ep.act, a.ep.alpha, j);
+            if (a.ep.res_after) r += sk;
+            op[j] = r;
         }
 }
 

@@ -24,6 +24,8 @@ struct Epilogue {
     int res_C = 0;                 // channels present in res (pixel stride of res)
     int res_W = 0, res_H = 0;      // source spatial size (RES_MAXPOOL / RES_UP2X)
     int act = ACT_NONE;
+    int res_after = 0;             // 1: out = act(conv + bias) + skip (a convolution with a fused activation followed by ADD: the lateral
+                                   // connections of full_range's decoder), 0: out = act(conv + bias + skip)
 };
 
 struct ConvArgs {

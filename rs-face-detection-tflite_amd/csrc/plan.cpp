@@ -62,6 +62,14 @@ struct Rewriter {
                     fused.res = other;
                     fused.res_mode = RES_DIRECT;
                     fused.act = c.act;
+                } else if (c.kind == Node::Add && n.kind == Node::Conv && n.res < 0 && n.act != ACT_NONE && c.act == ACT_NONE && c.in.size() == 2) {
+                    // a convolution with a FUSED activation, then ADD: the skip joins behind the activation
+                    int other = c.in[0] == n.out ? c.in[1] : c.in[0];
+                    if (other == n.out || g.tensors[other].is_const) break;
+                    if (shape(other) != shape(n.out)) break;
+                    fused.res = other;
+                    fused.res_mode = RES_DIRECT;
+                    fused.res_after = true;
                 } else if (c.kind == Node::Act && n.act == ACT_NONE) {
                     fused.act = c.act;
                     fused.alpha = c.alpha;
@@ -73,6 +81,7 @@ struct Rewriter {
                 n.dead = true;
                 nodes[ci] = fused;
                 i = static_cast<size_t>(ci);  // continue folding from the new position
+                if (fused.res_after) break;   // nothing folds behind a post-activation skip
             }
         }
         // Skip-path simplification: res <- PAD(channels) <- MAX_POOL 2x2/2 | RESIZE x2, each with a single consumer.
@@ -320,7 +329,7 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
     auto add_ext_in = [&](int t) { if (std::find(ext_in.begin(), ext_in.end(), t) == ext_in.end()) ext_in.push_back(t); };
     for (size_t m = 0; m < M.size(); m++) {
         const Node& n = M[m];
-        if (n.in.size() != 1) return false;
+        if (n.in.size() != 1 || n.res_after) return false;
         const int src = n.in[0];
         if (shp(src).size() != 4 || shp(n.out).size() != 4) return false;
         const int H = shp(src)[1], W = shp(src)[2], C = shp(src)[3];
@@ -525,7 +534,7 @@ bool build_banded_bottleneck(const Graph& g, const std::vector<Node>& ns, size_t
     if (a.kind != Node::Block || a.w >= 0 || a.res >= 0 || a.in.size() != 1) return false;
     if (b.kind != Node::Block || b.w < 0 || b.in.size() != 1 || b.in[0] != a.out) return false;
     if (b.KH != 3 || b.KW != 3 || b.sh != 1 || b.sw != 1 || b.padding != Padding::Same) return false;
-    if (b.res < 0 || b.res_mode != RES_DIRECT || b.res == b.in[0]) return false;
+    if (b.res < 0 || b.res_mode != RES_DIRECT || b.res == b.in[0] || b.res_after) return false;
     if (std::find(g.outputs.begin(), g.outputs.end(), a.out) != g.outputs.end()) return false;
     for (size_t k = 0; k < ns.size(); k++) {
         if (k == i + 1) continue;
@@ -599,7 +608,7 @@ size_t build_bneck(const Graph& g, const std::vector<Node>& ns, size_t i, Node* 
         if (a.kind != Node::Block || a.w >= 0 || a.res >= 0 || a.in.size() != 1 || a.in[0] != x_t) return false;
         if (b.kind != Node::Block || b.w < 0 || b.in.size() != 1 || b.in[0] != a.out) return false;
         if (b.KH != 3 || b.KW != 3 || b.sh != 1 || b.sw != 1 || b.padding != Padding::Same || b.ept >= 0 || b.epl >= 0) return false;
-        if (b.res != x_t || b.res_mode != RES_DIRECT) return false;
+        if (b.res != x_t || b.res_mode != RES_DIRECT || b.res_after) return false;
         if (std::find(g.outputs.begin(), g.outputs.end(), a.out) != g.outputs.end()) return false;
         for (size_t q = 0; q < ns.size(); q++) {
             if (q == k + 1) continue;
@@ -803,7 +812,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
             const auto& si = g.tensors[n.in[0]].shape;
             const auto& so = g.tensors[n.out].shape;
             if (si.size() != 4 || si != so) return false;
-            if (n.res >= 0 && !(n.res == n.in[0] && n.res_mode == RES_DIRECT)) return false;
+            if (n.res >= 0 && !(n.res == n.in[0] && n.res_mode == RES_DIRECT && !n.res_after)) return false;
             return true;
         };
         auto links = [&](size_t j) {  // node j+1 continues the chain that node j is in
@@ -829,7 +838,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
         // its taps from global memory and leaves its output in the LDS tile; the one behind reads the tile and writes global memory.
         // `next` = index in plan.nodes of the node after the chain (advanced past an absorbed block).
         auto edge_block = [&](const Node& e) {
-            return e.kind == Node::Block && e.w >= 0 && e.KH == 3 && e.KW == 3 && e.sh == 2 && e.sw == 2 && e.padding == Padding::Same &&
+            return e.kind == Node::Block && !e.res_after && e.w >= 0 && e.KH == 3 && e.KW == 3 && e.sh == 2 && e.sw == 2 && e.padding == Padding::Same &&
                    (e.res < 0 || (e.res == e.in[0] && e.res_mode == RES_MAXPOOL));
         };
         auto is_output = [&](int t) { return std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end(); };

@@ -61,6 +61,7 @@ struct Node {
     int alpha = -1;
     int res = -1;
     int res_mode = RES_NONE;
+    bool res_after = false;        // the skip is added behind the activation (Epilogue::res_after): block / generic convolution kernels only
     // misc
     int pads = -1;                 // PAD: paddings tensor
     int axis = 0;                  // CONCAT

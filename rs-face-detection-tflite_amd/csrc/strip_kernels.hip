@@ -1162,6 +1162,7 @@ bool strip_kernel_supports(const BlockArgs& a) {
     if (off || !a.w_strip || !a.has_dw || a.sh != 1 || a.sw != 1 || a.pt != 1 || a.pl != 1) return false;
     if (a.C != a.Co || (a.C != 16 && a.C != 24 && a.C != 32) || a.H != a.Ho || a.W != a.Wo) return false;
     if (a.ep.res_mode != RES_NONE) {
+        if (a.ep.res_after) return false;  // skip behind the activation: block / generic kernels only
         if (a.ep.res_mode != RES_DIRECT || a.ep.res != a.in || a.ep.res_fs != a.in_fs || a.ep.res_C != a.C) return false;
     }
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
