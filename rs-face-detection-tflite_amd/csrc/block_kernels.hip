@@ -571,7 +571,10 @@ bool make_geom(const BlockArgs& a, BlockGeom* out) {
     static const int forced = getenv("MI_BLOCK_PG") ? atoi(getenv("MI_BLOCK_PG")) : 0;  // tuning aid
     const int MT = (a.Co + 31) / 32;
     BlockGeom g2;
-    if (forced != 1 && MT <= 2 && make_geom_pg(a, 2, &g2) && g2.R * a.Wo >= 192) {
+    // ... and not when the skip comes from another tensor: those variants carry the prefetched skip quads as well, two groups per wave
+    // push them past 256 registers (one workgroup per CU); measured on full_range's 96x96x8 -> 32 blocks: 0.130 -> 0.103 ms
+    const bool foreign_skip = a.ep.res_mode != RES_NONE && !(a.ep.res == a.in && a.ep.res_fs == a.in_fs && a.ep.res_C == a.C);
+    if (forced != 1 && (forced == 2 || !foreign_skip) && MT <= 2 && make_geom_pg(a, 2, &g2) && g2.R * a.Wo >= 192) {
         *out = g2;
         return true;
     }
