@@ -1126,7 +1126,9 @@ int strips_band_rows(const BlockArgs& a, int strips) {
     const long per_row_waves = (long)a.B * strips;
     long bands = std::max<long>(1, (3072 + per_row_waves / 2) / per_row_waves);
     int rows = (int)((a.H + bands - 1) / bands);
-    rows = std::max(rows, std::min(a.H, 12));
+    // ... as long as that leaves enough waves to fill the chip: small batches (the 64 ROIs of the device pipeline) take shorter bands
+    const int floor_rows = per_row_waves * ((a.H + 11) / 12) >= 2048 ? 12 : (per_row_waves * ((a.H + 7) / 8) >= 1024 ? 8 : 4);
+    rows = std::max(rows, std::min(a.H, floor_rows));
     return rows;
 }
 
