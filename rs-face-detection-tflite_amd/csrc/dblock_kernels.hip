@@ -1,0 +1,294 @@
+// dblock_kernels.hip — full_range's "double BlazeBlock" as ONE launch:
+//
+//   a = act1( W1 . (DW3x3(x) + b_dw1) + b1 )         depthwise, pointwise C -> Cm (Cm = C / 4 in the reference's graph)
+//   y = act2( W2 . (DW3x3(a) + b_dw2) + b2 + x )     depthwise, pointwise Cm -> C, skip around both
+//
+// (face_detection_full_range.tflite: 32 -> 8 -> 32 at 96x96, 48 -> 12 -> 48 / 64 -> 16 -> 64 at 48x48, 96 -> 24 -> 96 / 128 -> 32 -> 128 at
+// 24x24; DEPTHWISE_CONV_2D, CONV_2D + fused RELU, DEPTHWISE_CONV_2D, CONV_2D, ADD, RELU behind `interpreter.invoke()`,
+// /root/reference/src/face_detection_lite/face_detection.rs:235)  As two block-kernel launches the pair reads
+// x twice (input of the first, skip of the second — the latter in 16-byte pieces) and round-trips the narrow tensor a through HBM;
+// at 128 frames both launches are latency-bound (0.18 ms per pair at 96x96 for 0.3 GB of traffic).
+//
+// Here one 512-thread workgroup per CU WALKS over row bands: a band of RB output rows needs a on RB + 2 rows and x on RB + 4 rows.
+//   * the band's rows of x arrive lane-linear (one contiguous piece of the frame) in registers — asked for while the PREVIOUS band
+//     is being computed — and are laid out as a zero-bordered LDS tensor; a lives in a second LDS tensor and never leaves the CU;
+//   * both stages are the block kernel's inner loop: depthwise 3x3 on the VALU in the MFMA operand layout (lane = pixel x k-half),
+//     v_mfma_f32_32x32x2_f32 over the output tiles, pointwise weights in LDS (a global load inside the loop would have to wait for the
+//     next band's rows: vmcnt retires in order); stage 2 adds the skip from the centre pixel of x in LDS;
+//   * halo rows of a (one above, one below the band) are recomputed; rows outside the image are written as zeros (TF SAME padding).
+// Exact f32 (MFMA f32 = fmaf chain); matches two block-kernel launches to reassociation of nothing: same operations, same order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <type_traits>
+
+#include "kernels.hpp"
+#include "launch.hpp"
+
+namespace mi {
+
+typedef float df32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ float4 dld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+constexpr int kDbPrefetch = 12;  // float4 registers per thread for the next band's rows of x
+
+struct DblockGeom {
+    int RB, bands;            // output rows per band, bands per frame
+    int Cp, Cmp;              // channel counts padded to 8
+    int PSx, RSx, PSa, RSa;   // LDS pixel / row strides (floats)
+    int off_a, off_c, off_w1, off_w2;  // LDS offsets (floats): a tensor, constants, the two pointwise matrices
+    int cfl;                  // floats of the constants blob
+    int lds_bytes;
+};
+
+// constants blob (floats): [dw1 taps 9 x Cp][b_dw1 Cp][b1 32][slope1 32][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
+template <int MT>
+__global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xt = lds;               // x: [(RB + 4)][(W + 2)][PSx], row 0 = image row r0 - 2
+    float* at = lds + g.off_a;     // a: [(RB + 2)][(W + 2)][PSa], row 0 = image row r0 - 1
+    const float* cst = lds + g.off_c;
+    const float* w1L = lds + g.off_w1;
+    const float* w2L = lds + g.off_w2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pl = lane & 31, h = lane >> 5;
+    const int W = a.W, C4 = a.C >> 2;
+    const int Ch = g.Cp >> 1, Chm = g.Cmp >> 1, nch1 = Ch >> 2, nch2 = Chm >> 2;
+    const int o_bdw1 = 9 * g.Cp, o_b1 = 10 * g.Cp, o_sl1 = o_b1 + 32, o_wdw2 = o_sl1 + 32, o_bdw2 = o_wdw2 + 9 * g.Cmp, o_b2 = o_bdw2 + g.Cmp, o_sl2 = o_b2 + 32 * MT;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int total = a.B * g.bands;
+    // LDS-only workgroup barrier: __syncthreads() would also wait for the next band's rows and for this band's stores
+    auto wg_barrier = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // the rows of x a band needs: image rows [r0 - 2, r0 + RB + 2) clipped to the image = one contiguous piece of the frame
+    auto band_rows = [&](int it, int& frame, int& r0, int& lo, int& hi) {
+        frame = it / g.bands;
+        r0 = (it - frame * g.bands) * g.RB;
+        lo = max(0, r0 - 2);
+        hi = min(a.H, r0 + g.RB + 2);
+    };
+    float4 xv[kDbPrefetch];
+    auto prefetch = [&](int it) {
+        int frame, r0, lo, hi;
+        band_rows(it, frame, r0, lo, hi);
+        const int n4 = (hi - lo) * W * C4;
+        const float* src = a.in + (long)frame * a.in_fs + (long)lo * W * a.C;
+#pragma unroll
+        for (int k = 0; k < kDbPrefetch; k++) xv[k] = dld4(src + 4 * (long)min(tid + 512 * k, n4 - 1));  // clamped; pieces past the end are not used
+    };
+
+    // ---- once per workgroup: clear both tensors (their border columns stay zero), stage the constants and the weights
+    for (int i = tid; i < ((g.RB + 4) * g.RSx) >> 2; i += 512) reinterpret_cast<float4*>(xt)[i] = zero4;
+    for (int i = tid; i < ((g.RB + 2) * g.RSa) >> 2; i += 512) reinterpret_cast<float4*>(at)[i] = zero4;
+    for (int i = tid; i < g.cfl; i += 512) lds[g.off_c + i] = a.consts[i];
+    for (int i = tid; i < (32 * g.Cp) >> 2; i += 512) reinterpret_cast<float4*>(lds + g.off_w1)[i] = dld4(a.w1 + 4 * i);
+    for (int i = tid; i < (32 * MT * g.Cmp) >> 2; i += 512) reinterpret_cast<float4*>(lds + g.off_w2)[i] = dld4(a.w2 + 4 * i);
+    int item = blockIdx.x;
+    prefetch(item);
+
+    // depthwise 3x3 (+ bias) of 4 channels of this lane's k-half at tap origin `t0`, then MFMAs: one 32-pixel group, NT output tiles
+    auto contract = [&](const float* t0, int RS, int PS, int Cpad, int nchk, const float* wdw, const float* bdw, const float* wL, auto& D, auto NTc) {
+        constexpr int NT = decltype(NTc)::value;
+        const int Chh = Cpad >> 1;
+#pragma unroll
+        for (int m = 0; m < NT; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) D[m][e] = 0.f;
+        for (int j = 0; j < nchk; j++) {
+            const int c0 = h * Chh + 4 * j;
+            float4 bf = dld4(bdw + c0);
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const float4 w = dld4(wdw + (ky * 3 + kx) * Cpad + c0);
+                    const float4 d = dld4(t0 + ky * RS + kx * PS + c0);
+                    bf.x = fmaf(d.x, w.x, bf.x);
+                    bf.y = fmaf(d.y, w.y, bf.y);
+                    bf.z = fmaf(d.z, w.z, bf.z);
+                    bf.w = fmaf(d.w, w.w, bf.w);
+                }
+#pragma unroll
+            for (int m = 0; m < NT; m++) {
+                const float4 av = dld4(wL + ((m * nchk + j) * 64 + lane) * 4);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf.x, D[m], 0, 0, 0);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf.y, D[m], 0, 0, 0);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf.z, D[m], 0, 0, 0);
+                D[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf.w, D[m], 0, 0, 0);
+            }
+        }
+    };
+
+    for (;;) {
+        int frame, r0, lo, hi;
+        band_rows(item, frame, r0, lo, hi);
+        // ---- x: registers -> zero-bordered LDS tensor; row slots without an image row are cleared
+        {
+            const int rowf4 = W * C4, n4 = (hi - lo) * rowf4;
+#pragma unroll
+            for (int k = 0; k < kDbPrefetch; k++) {
+                const int i = tid + 512 * k;
+                if (i < n4) {
+                    const int rr = i / rowf4, e = i - rr * rowf4, px = e / C4, c4 = e - px * C4;
+                    *reinterpret_cast<float4*>(xt + (lo - (r0 - 2) + rr) * g.RSx + (px + 1) * g.PSx + 4 * c4) = xv[k];
+                }
+            }
+            for (int s = 0; s < g.RB + 4; s++) {  // uniform
+                const int iy = r0 - 2 + s;
+                if (iy >= lo && iy < hi) continue;
+                for (int e = tid; e < (W * g.PSx) >> 2; e += 512) *reinterpret_cast<float4*>(xt + s * g.RSx + g.PSx + 4 * e) = zero4;
+            }
+        }
+        if (item + (int)gridDim.x < total) prefetch(item + gridDim.x);  // the next band's rows travel under this band's work
+        wg_barrier();
+        // ---- stage 1: a on rows [r0 - 1, r0 + RB + 1): 32-pixel groups round-robin over the waves
+        {
+            const int npx = (g.RB + 2) * W, ngr = (npx + 31) >> 5;
+            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
+                const int q = grp * 32 + pl;
+                const bool valid = q < npx;
+                const int la = valid ? q / W : 0, ox = valid ? q - (q / W) * W : 0;
+                const int iy = r0 - 1 + la;
+                float* dst = at + la * g.RSa + (ox + 1) * g.PSa;
+                df32x16 D[1];
+                contract(xt + la * g.RSx + ox * g.PSx, g.RSx, g.PSx, g.Cp, nch1, cst, cst + o_bdw1, w1L, D, std::integral_constant<int, 1>{});
+                const bool inside = iy >= 0 && iy < a.H;
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = 8 * gq + 4 * h;
+                    if (ch >= g.Cmp || !valid) continue;
+                    const float4 bb = dld4(cst + o_b1 + ch), sl = dld4(cst + o_sl1 + ch);
+                    float4 v = make_float4(D[0][4 * gq] + bb.x, D[0][4 * gq + 1] + bb.y, D[0][4 * gq + 2] + bb.z, D[0][4 * gq + 3] + bb.w);
+                    v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi1);
+                    v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi1);
+                    v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi1);
+                    v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi1);
+                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the image are the second depthwise conv's zero padding
+                    *reinterpret_cast<float4*>(dst + ch) = v;
+                }
+            }
+        }
+        wg_barrier();
+        // ---- stage 2: y on rows [r0, r0 + RB) inside the image
+        {
+            const int rows = min(g.RB, a.H - r0), npx = rows * W, ngr = (npx + 31) >> 5;
+            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
+                const int q = grp * 32 + pl;
+                const bool valid = q < npx;
+                const int la = valid ? q / W : 0, ox = valid ? q - (q / W) * W : 0;
+                df32x16 D[MT];
+                contract(at + la * g.RSa + ox * g.PSa, g.RSa, g.PSa, g.Cmp, nch2, cst + o_wdw2, cst + o_bdw2, w2L, D, std::integral_constant<int, MT>{});
+                const float* xs = xt + (la + 2) * g.RSx + (ox + 1) * g.PSx;  // the skip: x at this pixel
+                float* yo = a.out + (long)frame * a.out_fs + ((long)(r0 + la) * W + ox) * a.C;
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int ch = 32 * m + 8 * gq + 4 * h;
+                        if (ch >= a.C || !valid) continue;
+                        const float4 bb = dld4(cst + o_b2 + ch), sl = dld4(cst + o_sl2 + ch), sk = dld4(xs + ch);
+                        float4 v = make_float4(D[m][4 * gq] + bb.x + sk.x, D[m][4 * gq + 1] + bb.y + sk.y, D[m][4 * gq + 2] + bb.z + sk.z, D[m][4 * gq + 3] + bb.w + sk.w);
+                        v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi2);
+                        v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi2);
+                        v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi2);
+                        v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi2);
+                        *reinterpret_cast<float4*>(yo + ch) = v;
+                    }
+            }
+        }
+        item += gridDim.x;
+        if (item >= total) break;
+        wg_barrier();  // the next band overwrites both tensors
+    }
+}
+
+bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
+    DblockGeom g{};
+    if (a.C % 8 || a.C < 8 || a.C > 128 || a.Cm % 4 || a.Cm < 4 || a.Cm > 32 || a.H < 1 || a.W < 2 || a.B < 1) return false;
+    g.Cp = a.C;
+    g.Cmp = (a.Cm + 7) & ~7;
+    g.PSx = g.Cp + 4; g.RSx = (a.W + 2) * g.PSx;
+    g.PSa = g.Cmp + 4; g.RSa = (a.W + 2) * g.PSa;
+    const int MT = (a.C + 31) / 32;
+    g.cfl = 10 * g.Cp + 64 + 10 * g.Cmp + 64 * MT;
+    const int wfl = 32 * g.Cp + 32 * MT * g.Cmp;
+    // rows per band: as many as LDS and the prefetch registers hold (fewer bands = less halo work)
+    int RB = 0;
+    for (int r = std::min(a.H, 32); r >= 1; r--) {
+        const long fl = (long)(r + 4) * g.RSx + (long)(r + 2) * g.RSa + g.cfl + wfl + 16;
+        const long n4 = (long)(r + 4) * a.W * (a.C / 4);
+        if (fl * 4 <= 160 * 1024 - 256 && n4 <= (long)kDbPrefetch * 512) { RB = r; break; }
+    }
+    if (RB < 2) return false;
+    g.bands = (a.H + RB - 1) / RB;
+    g.RB = (a.H + g.bands - 1) / g.bands;  // even bands
+    int off = (g.RB + 4) * g.RSx;
+    off = (off + 3) & ~3;
+    g.off_a = off; off += (g.RB + 2) * g.RSa; off = (off + 3) & ~3;
+    g.off_c = off; off += (g.cfl + 3) & ~3;
+    g.off_w1 = off; off += 32 * g.Cp;
+    g.off_w2 = off; off += 32 * MT * g.Cmp;
+    g.lds_bytes = off * 4;
+    if (g.lds_bytes > 160 * 1024 - 256) return false;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!aligned16(a.in) || !aligned16(a.out) || !aligned16(a.w1) || !aligned16(a.w2) || !a.consts || (a.in_fs & 3) || (a.out_fs & 3)) return false;
+    *out = g;
+    return true;
+}
+
+int dblock_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+template <int MT>
+int launch_dblock_inst(const DblockArgs& a, const DblockGeom& g, hipStream_t s) {
+    auto kern = dblock_kernel<MT>;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    const unsigned grid = (unsigned)std::min<long>((long)a.B * g.bands, dblock_cu_count());
+    return (int)launch_kernel(kern, dim3(grid), dim3(512), (size_t)g.lds_bytes, s, a, g);
+}
+
+}  // namespace
+
+bool dblock_kernel_supports(const DblockArgs& a) {
+    DblockGeom g;
+    return make_dblock_geom(a, &g);
+}
+
+int dblock_const_floats(int C, int Cm) {
+    const int Cmp = (Cm + 7) & ~7, MT = (C + 31) / 32;
+    return 10 * C + 64 + 10 * Cmp + 64 * MT;
+}
+
+int launch_dblock(const DblockArgs& a, void* stream) {
+    DblockGeom g;
+    if (!make_dblock_geom(a, &g)) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch ((a.C + 31) / 32) {
+        case 1: return launch_dblock_inst<1>(a, g, s);
+        case 2: return launch_dblock_inst<2>(a, g, s);
+        case 3: return launch_dblock_inst<3>(a, g, s);
+        case 4: return launch_dblock_inst<4>(a, g, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace mi

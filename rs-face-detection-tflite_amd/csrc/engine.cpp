@@ -183,6 +183,36 @@ void Model::rebuild() {
             }
             continue;
         }
+        if (n.kind == Node::Resident && n.dblock) {
+            // double block (dblock_kernels.hip): both pointwise matrices in the block kernel's packing, one blob of small constants
+            const Node &pa = n.members[0], &pb = n.members[1];
+            const int C = g.tensors[pa.in[0]].shape[3], Cm = g.tensors[pa.out].shape[3], Cmp = (Cm + 7) & ~7, MT = (C + 31) / 32;
+            MemberOff ma, mb;
+            ma.w2 = pack_pw(pa.w2);
+            mb.w2 = pack_pw(pb.w2);
+            std::vector<float> cb(static_cast<size_t>(dblock_const_floats(C, Cm)), 0.f);
+            auto slope = [&](const Node& m, int c) { return m.act == ACT_PRELU ? g.tensors[m.alpha].f32[static_cast<size_t>(c)] : (m.act == ACT_NONE ? 1.f : 0.f); };
+            size_t o = 0;
+            for (int tap = 0; tap < 9; tap++)
+                for (int c = 0; c < C; c++) cb[o + static_cast<size_t>(tap) * C + c] = g.tensors[pa.w].f32[static_cast<size_t>(tap) * C + c];
+            o += static_cast<size_t>(9) * C;
+            for (int c = 0; c < C; c++) cb[o + c] = pa.b >= 0 ? g.tensors[pa.b].f32[static_cast<size_t>(c)] : 0.f;
+            o += static_cast<size_t>(C);
+            for (int c = 0; c < Cm; c++) { cb[o + c] = pa.b2 >= 0 ? g.tensors[pa.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + 32 + c] = slope(pa, c); }
+            o += 64;
+            for (int tap = 0; tap < 9; tap++)
+                for (int c = 0; c < Cm; c++) cb[o + static_cast<size_t>(tap) * Cmp + c] = g.tensors[pb.w].f32[static_cast<size_t>(tap) * Cm + c];
+            o += static_cast<size_t>(9) * Cmp;
+            for (int c = 0; c < Cm; c++) cb[o + c] = pb.b >= 0 ? g.tensors[pb.b].f32[static_cast<size_t>(c)] : 0.f;
+            o += static_cast<size_t>(Cmp);
+            for (int c = 0; c < C; c++) { cb[o + c] = pb.b2 >= 0 ? g.tensors[pb.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + static_cast<size_t>(32) * MT + c] = slope(pb, c); }
+            ma.strip = put(cb);
+            chain_off_[i].push_back(ma);
+            chain_off_[i].push_back(mb);
+            res_wblk_[i].clear();
+            res_cblob_[i].clear();
+            continue;
+        }
         if (n.kind == Node::Resident && n.bneck) {
             // bottleneck pairs (bneck_kernels.hip): per pair the first pointwise matrix with its contraction index in the MFMA result
             // order, the second in the block kernel's order, and one blob of small constants
@@ -457,7 +487,7 @@ std::string Model::node_label(const Node& n) const {
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
             return std::string(strip_pipe_rows_per_step(sin[1], pipe_rows_) == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<") + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
-        case Node::Resident: return n.bneck ? "bneck_kernel" : "resident_kernel";
+        case Node::Resident: return n.dblock ? "dblock_kernel" : (n.bneck ? "bneck_kernel" : "resident_kernel");
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -652,6 +682,18 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 break;
             }
             case Node::Resident: {
+                if (n.dblock) {
+                    DblockArgs a;
+                    a.in = ip; a.in_fs = in_fs; a.out = op; a.out_fs = out_fs;
+                    a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Cm = g.tensors[n.members[0].out].shape[3];
+                    a.w1 = d_weights_ + chain_off_[i][0].w2;
+                    a.w2 = d_weights_ + chain_off_[i][1].w2;
+                    a.consts = d_weights_ + chain_off_[i][0].strip;
+                    a.hi1 = n.members[0].act == ACT_RELU6 ? 6.f : INFINITY;
+                    a.hi2 = n.members[1].act == ACT_RELU6 ? 6.f : INFINITY;
+                    rc = launch_dblock(a, s);
+                    break;
+                }
                 if (n.bneck) {
                     BneckArgs a;
                     a.in = ip; a.in_fs = in_fs; a.out = op; a.out_fs = out_fs;

@@ -665,10 +665,56 @@ size_t build_bneck(const Graph& g, const std::vector<Node>& ns, size_t i, Node* 
     return 2 * npairs;
 }
 
+// Level 5: full_range's double block  a = act(PW(DW3x3(x)));  y = act(PW(DW3x3(a)) + x)  (two stride-1 BlazeBlocks, the skip around
+// both) as one launch of dblock_kernels.hip.  Returns the number of plan nodes consumed (0: no match).
+size_t build_dblock(const Graph& g, const std::vector<Node>& ns, size_t i, Node* out) {
+    if (i + 1 >= ns.size()) return 0;
+    const Node &a = ns[i], &b = ns[i + 1];
+    auto dw_block = [](const Node& n) {
+        return n.kind == Node::Block && n.w >= 0 && n.KH == 3 && n.KW == 3 && n.sh == 1 && n.sw == 1 && n.padding == Padding::Same && n.ept < 0 && n.epl < 0 && n.in.size() == 1;
+    };
+    if (!dw_block(a) || !dw_block(b) || a.res >= 0 || b.in[0] != a.out) return 0;
+    if (b.res != a.in[0] || b.res_mode != RES_DIRECT || b.res_after) return 0;
+    if (std::find(g.outputs.begin(), g.outputs.end(), a.out) != g.outputs.end()) return 0;
+    for (size_t q = 0; q < ns.size(); q++) {
+        if (q == i + 1) continue;
+        if (std::find(ns[q].in.begin(), ns[q].in.end(), a.out) != ns[q].in.end() || ns[q].res == a.out) return 0;  // a has one reader
+    }
+    const auto &sx = g.tensors[a.in[0]].shape, &sa = g.tensors[a.out].shape, &sy = g.tensors[b.out].shape;
+    if (sx.size() != 4 || sa.size() != 4 || sy != sx || sa[1] != sx[1] || sa[2] != sx[2]) return 0;
+    if (sx[1] * sx[2] <= 256) return 0;  // small frames: the per-block launches with their tiles spread over the chip do better
+    DblockArgs da;
+    da.in = reinterpret_cast<const float*>(0x1000); da.out = reinterpret_cast<float*>(0x2000);
+    da.in_fs = da.out_fs = static_cast<long>(g.tensors[a.in[0]].elems());
+    da.B = 1; da.H = sx[1]; da.W = sx[2]; da.C = sx[3]; da.Cm = sa[3];
+    da.consts = da.w1 = da.w2 = reinterpret_cast<const float*>(0x3000);
+    if (!dblock_kernel_supports(da)) return 0;
+    Node r;
+    r.kind = Node::Resident;
+    r.dblock = true;
+    r.in = {a.in[0]};
+    r.out = b.out;
+    r.members = {a, b};
+    r.src_ops = a.src_ops;
+    r.src_ops.insert(r.src_ops.end(), b.src_ops.begin(), b.src_ops.end());
+    *out = std::move(r);
+    return 2;
+}
+
 std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget) {
     std::vector<Node> outv;
     static const bool no_bneck = getenv("MI_NO_BNECK") != nullptr;  // development aid
+    static const bool no_dblock = getenv("MI_NO_DBLOCK") != nullptr;  // development aid
     for (size_t i = 0; i < ns.size();) {
+        {
+            Node db;
+            const size_t used = no_dblock ? 0 : build_dblock(g, ns, i, &db);
+            if (used) {
+                outv.push_back(std::move(db));
+                i += used;
+                continue;
+            }
+        }
         {
             Node bn;
             const size_t used = no_bneck ? 0 : build_bneck(g, ns, i, &bn);
@@ -1171,7 +1217,10 @@ std::string Plan::describe() const {
             else
                 os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
                    << (n.members.back().sh == 2 ? " (stride-2 tail)" : "") << (n.head_nodes.empty() ? "" : ", " + std::to_string(n.head_nodes.size()) + " output heads");
-        if (n.kind == Node::Resident && n.bneck) {
+        if (n.kind == Node::Resident && n.dblock) {
+            os << " double block (" << graph.tensors[n.members[0].in[0]].shape[3] << " -> " << graph.tensors[n.members[0].out].shape[3] << " -> " << graph.tensors[n.members[1].out].shape[3]
+               << " channels), walking row bands, narrow tensor in LDS";
+        } else if (n.kind == Node::Resident && n.bneck) {
             os << " x" << n.members.size() / 2 << " bottleneck blocks, wide tensor in registers, " << (n.res_bands > 1 ? std::to_string(n.res_bands) + " row bands" : std::string("frame resident"));
         } else if (n.kind == Node::Resident) {
             os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, " << (n.res_bands > 1 ? "row-band resident" : "frame resident") << ", " << n.res_lds_bytes << " B LDS";
