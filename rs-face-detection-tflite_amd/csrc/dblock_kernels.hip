@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -43,7 +44,14 @@ struct DblockGeom {
     int off_a, off_c, off_w1, off_w2;  // LDS offsets (floats): a tensor, constants, the two pointwise matrices
     int cfl;                  // floats of the constants blob
     int lds_bytes;
+    unsigned long long* stamps;  // diagnostic builds only (MI_DBLOCK_STAMPS): 8 s_memtime stamps per wave, last band of the workgroup
 };
+#ifdef MI_DBLOCK_STAMPS
+unsigned long long* g_dblock_stamps = nullptr;
+#define MI_DB_STAMP(k) if (g.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); g.stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_DB_STAMP(k)
+#endif
 
 // constants blob (floats): [dw1 taps 9 x Cp][b_dw1 Cp][b1 32][slope1 32][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
 template <int MT>
@@ -127,19 +135,26 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
         }
     };
 
+    MI_DB_STAMP(0)
     for (;;) {
         int frame, r0, lo, hi;
         band_rows(item, frame, r0, lo, hi);
+        MI_DB_STAMP(1)
         // ---- x: registers -> zero-bordered LDS tensor; row slots without an image row are cleared
         {
             const int rowf4 = W * C4, n4 = (hi - lo) * rowf4;
+            // float4 number tid + 512 k -> (row, pixel, channel quad) without a division per element (two software divisions per
+            // element were a third of a band's time): the position advances by 512 float4s = dpx pixels + dc4 quads per step
+            int px = tid / C4, c4 = tid - px * C4;          // position within the band's rows, in pixels (all rows concatenated)
+            const int dpx = 512 / C4, dc4 = 512 - dpx * C4;
+            int rr = px / W;
+            px -= rr * W;
 #pragma unroll
             for (int k = 0; k < kDbPrefetch; k++) {
-                const int i = tid + 512 * k;
-                if (i < n4) {
-                    const int rr = i / rowf4, e = i - rr * rowf4, px = e / C4, c4 = e - px * C4;
-                    *reinterpret_cast<float4*>(xt + (lo - (r0 - 2) + rr) * g.RSx + (px + 1) * g.PSx + 4 * c4) = xv[k];
-                }
+                if (tid + 512 * k < n4) *reinterpret_cast<float4*>(xt + (lo - (r0 - 2) + rr) * g.RSx + (px + 1) * g.PSx + 4 * c4) = xv[k];
+                c4 += dc4; px += dpx;
+                if (c4 >= C4) { c4 -= C4; px++; }
+                while (px >= W) { px -= W; rr++; }
             }
             for (int s = 0; s < g.RB + 4; s++) {  // uniform
                 const int iy = r0 - 2 + s;
@@ -148,7 +163,9 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
             }
         }
         if (item + (int)gridDim.x < total) prefetch(item + gridDim.x);  // the next band's rows travel under this band's work
+        MI_DB_STAMP(2)
         wg_barrier();
+        MI_DB_STAMP(3)
         // ---- stage 1: a on rows [r0 - 1, r0 + RB + 1): 32-pixel groups round-robin over the waves
         {
             const int npx = (g.RB + 2) * W, ngr = (npx + 31) >> 5;
@@ -176,7 +193,9 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
                 }
             }
         }
+        MI_DB_STAMP(4)
         wg_barrier();
+        MI_DB_STAMP(5)
         // ---- stage 2: y on rows [r0, r0 + RB) inside the image
         {
             const int rows = min(g.RB, a.H - r0), npx = rows * W, ngr = (npx + 31) >> 5;
@@ -204,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
                     }
             }
         }
+        MI_DB_STAMP(6)
         item += gridDim.x;
         if (item >= total) break;
         wg_barrier();  // the next band overwrites both tensors
@@ -281,6 +301,10 @@ int dblock_const_floats(int C, int Cm) {
 int launch_dblock(const DblockArgs& a, void* stream) {
     DblockGeom g;
     if (!make_dblock_geom(a, &g)) return (int)hipErrorInvalidValue;
+#ifdef MI_DBLOCK_STAMPS
+    static const int only_h = getenv("MI_DB_H") ? atoi(getenv("MI_DB_H")) : 0;  // stamp the launches on frames of this height only
+    g.stamps = (only_h == 0 || a.H == only_h) ? g_dblock_stamps : nullptr;
+#endif
     hipStream_t s = (hipStream_t)stream;
     switch ((a.C + 31) / 32) {
         case 1: return launch_dblock_inst<1>(a, g, s);
@@ -292,3 +316,8 @@ int launch_dblock(const DblockArgs& a, void* stream) {
 }
 
 }  // namespace mi
+
+#ifdef MI_DBLOCK_STAMPS
+// stamps build only (tools/dblock_stamps.py)
+extern "C" void mi_debug_set_dblock_stamps(unsigned long long* p) { mi::g_dblock_stamps = p; }
+#endif
