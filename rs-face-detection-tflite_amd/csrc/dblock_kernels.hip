@@ -206,14 +206,16 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
                 df32x16 D[MT];
                 contract(at + la * g.RSa + ox * g.PSa, g.RSa, g.PSa, g.Cmp, nch2, cst + o_wdw2, cst + o_bdw2, w2L, D, std::integral_constant<int, MT>{});
                 const float* xs = xt + (la + 2) * g.RSx + (ox + 1) * g.PSx;  // the skip: x at this pixel
-                float* yo = a.out + (long)frame * a.out_fs + ((long)(r0 + la) * W + ox) * a.C;
+                float* yo = a.out + (long)frame * a.out_fs + ((long)(r0 + la) * W + ox) * a.Co;
 #pragma unroll
                 for (int m = 0; m < MT; m++)
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++) {
                         const int ch = 32 * m + 8 * gq + 4 * h;
-                        if (ch >= a.C || !valid) continue;
-                        const float4 bb = dld4(cst + o_b2 + ch), sl = dld4(cst + o_sl2 + ch), sk = dld4(xs + ch);
+                        if (ch >= a.Co || !valid) continue;
+                        const float4 bb = dld4(cst + o_b2 + ch), sl = dld4(cst + o_sl2 + ch);
+                        float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);  // channels above C: the zero channel-pad of the skip
+                        if (ch < a.C) sk = dld4(xs + ch);
                         float4 v = make_float4(D[m][4 * gq] + bb.x + sk.x, D[m][4 * gq + 1] + bb.y + sk.y, D[m][4 * gq + 2] + bb.z + sk.z, D[m][4 * gq + 3] + bb.w + sk.w);
                         v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi2);
                         v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi2);
@@ -233,11 +235,12 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
 bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
     DblockGeom g{};
     if (a.C % 8 || a.C < 8 || a.C > 128 || a.Cm % 4 || a.Cm < 4 || a.Cm > 32 || a.H < 1 || a.W < 2 || a.B < 1) return false;
+    if (a.Co < a.C || a.Co > 128 || a.Co % 4) return false;
     g.Cp = a.C;
     g.Cmp = (a.Cm + 7) & ~7;
     g.PSx = g.Cp + 4; g.RSx = (a.W + 2) * g.PSx;
     g.PSa = g.Cmp + 4; g.RSa = (a.W + 2) * g.PSa;
-    const int MT = (a.C + 31) / 32;
+    const int MT = (a.Co + 31) / 32;
     g.cfl = 10 * g.Cp + 64 + 10 * g.Cmp + 64 * MT;
     const int wfl = 32 * g.Cp + 32 * MT * g.Cmp;
     // rows per band: as many as LDS and the prefetch registers hold (fewer bands = less halo work)
@@ -293,8 +296,8 @@ bool dblock_kernel_supports(const DblockArgs& a) {
     return make_dblock_geom(a, &g);
 }
 
-int dblock_const_floats(int C, int Cm) {
-    const int Cmp = (Cm + 7) & ~7, MT = (C + 31) / 32;
+int dblock_const_floats(int C, int Cm, int Co) {
+    const int Cmp = (Cm + 7) & ~7, MT = (Co + 31) / 32;
     return 10 * C + 64 + 10 * Cmp + 64 * MT;
 }
 
@@ -306,7 +309,7 @@ int launch_dblock(const DblockArgs& a, void* stream) {
     g.stamps = (only_h == 0 || a.H == only_h) ? g_dblock_stamps : nullptr;
 #endif
     hipStream_t s = (hipStream_t)stream;
-    switch ((a.C + 31) / 32) {
+    switch ((a.Co + 31) / 32) {
         case 1: return launch_dblock_inst<1>(a, g, s);
         case 2: return launch_dblock_inst<2>(a, g, s);
         case 3: return launch_dblock_inst<3>(a, g, s);

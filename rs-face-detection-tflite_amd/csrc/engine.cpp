@@ -186,11 +186,11 @@ void Model::rebuild() {
         if (n.kind == Node::Resident && n.dblock) {
             // double block (dblock_kernels.hip): both pointwise matrices in the block kernel's packing, one blob of small constants
             const Node &pa = n.members[0], &pb = n.members[1];
-            const int C = g.tensors[pa.in[0]].shape[3], Cm = g.tensors[pa.out].shape[3], Cmp = (Cm + 7) & ~7, MT = (C + 31) / 32;
+            const int C = g.tensors[pa.in[0]].shape[3], Cm = g.tensors[pa.out].shape[3], Co = g.tensors[pb.out].shape[3], Cmp = (Cm + 7) & ~7, MT = (Co + 31) / 32;
             MemberOff ma, mb;
             ma.w2 = pack_pw(pa.w2);
             mb.w2 = pack_pw(pb.w2);
-            std::vector<float> cb(static_cast<size_t>(dblock_const_floats(C, Cm)), 0.f);
+            std::vector<float> cb(static_cast<size_t>(dblock_const_floats(C, Cm, Co)), 0.f);
             auto slope = [&](const Node& m, int c) { return m.act == ACT_PRELU ? g.tensors[m.alpha].f32[static_cast<size_t>(c)] : (m.act == ACT_NONE ? 1.f : 0.f); };
             size_t o = 0;
             for (int tap = 0; tap < 9; tap++)
@@ -205,7 +205,7 @@ void Model::rebuild() {
             o += static_cast<size_t>(9) * Cmp;
             for (int c = 0; c < Cm; c++) cb[o + c] = pb.b >= 0 ? g.tensors[pb.b].f32[static_cast<size_t>(c)] : 0.f;
             o += static_cast<size_t>(Cmp);
-            for (int c = 0; c < C; c++) { cb[o + c] = pb.b2 >= 0 ? g.tensors[pb.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + static_cast<size_t>(32) * MT + c] = slope(pb, c); }
+            for (int c = 0; c < Co; c++) { cb[o + c] = pb.b2 >= 0 ? g.tensors[pb.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + static_cast<size_t>(32) * MT + c] = slope(pb, c); }
             ma.strip = put(cb);
             chain_off_[i].push_back(ma);
             chain_off_[i].push_back(mb);
@@ -685,7 +685,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 if (n.dblock) {
                     DblockArgs a;
                     a.in = ip; a.in_fs = in_fs; a.out = op; a.out_fs = out_fs;
-                    a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Cm = g.tensors[n.members[0].out].shape[3];
+                    a.B = F; a.H = si[1]; a.W = si[2]; a.C = si[3]; a.Cm = g.tensors[n.members[0].out].shape[3]; a.Co = so[3];
                     a.w1 = d_weights_ + chain_off_[i][0].w2;
                     a.w2 = d_weights_ + chain_off_[i][1].w2;
                     a.consts = d_weights_ + chain_off_[i][0].strip;

@@ -281,19 +281,20 @@ struct BneckArgs {
     BneckBlock blocks[kMaxBneck];
 };
 // ---- full_range's double BlazeBlock as one launch (dblock_kernels.hip):
-//   a = act1(W1 . (DW3x3(x) + b_dw1) + b1) (C -> Cm);  y = act2(W2 . (DW3x3(a) + b_dw2) + b2 + x) (Cm -> C)
+//   a = act1(W1 . (DW3x3(x) + b_dw1) + b1) (C -> Cm);  y = act2(W2 . (DW3x3(a) + b_dw2) + b2 + pad(x)) (Cm -> Co >= C)
 struct DblockArgs {
     const float* in = nullptr;
     float* out = nullptr;
     long in_fs = 0, out_fs = 0;
     int B = 0, H = 0, W = 0, C = 0, Cm = 0;
+    int Co = 0;                     // output channels >= C (the skip is x zero-padded to Co channels, as where full_range widens: 48 -> 16 -> 64)
     const float* consts = nullptr;  // dblock_const_floats(): [dw1 taps 9 x C][b_dw1 C][b1 32][slope1 32][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
     const float* w1 = nullptr;      // block kernel's A-fragment packing of W1 [Cm][C] (one 32-row tile)
     const float* w2 = nullptr;      // ... of W2 [C][Cm] (MT tiles, contraction padded to Cmp = roundup8(Cm))
     float hi1 = 0.f, hi2 = 0.f;
 };
 bool dblock_kernel_supports(const DblockArgs& a);
-int dblock_const_floats(int C, int Cm);
+int dblock_const_floats(int C, int Cm, int Co);
 int launch_dblock(const DblockArgs& a, void* stream);
 
 bool bneck_kernel_supports(const BneckArgs& a);

@@ -681,12 +681,13 @@ size_t build_dblock(const Graph& g, const std::vector<Node>& ns, size_t i, Node*
         if (std::find(ns[q].in.begin(), ns[q].in.end(), a.out) != ns[q].in.end() || ns[q].res == a.out) return 0;  // a has one reader
     }
     const auto &sx = g.tensors[a.in[0]].shape, &sa = g.tensors[a.out].shape, &sy = g.tensors[b.out].shape;
-    if (sx.size() != 4 || sa.size() != 4 || sy != sx || sa[1] != sx[1] || sa[2] != sx[2]) return 0;
+    if (sx.size() != 4 || sa.size() != 4 || sy.size() != 4 || sy[1] != sx[1] || sy[2] != sx[2] || sy[3] < sx[3] || sa[1] != sx[1] || sa[2] != sx[2]) return 0;
     if (sx[1] * sx[2] <= 256) return 0;  // small frames: the per-block launches with their tiles spread over the chip do better
     DblockArgs da;
     da.in = reinterpret_cast<const float*>(0x1000); da.out = reinterpret_cast<float*>(0x2000);
     da.in_fs = da.out_fs = static_cast<long>(g.tensors[a.in[0]].elems());
-    da.B = 1; da.H = sx[1]; da.W = sx[2]; da.C = sx[3]; da.Cm = sa[3];
+    da.B = 1; da.H = sx[1]; da.W = sx[2]; da.C = sx[3]; da.Cm = sa[3]; da.Co = sy[3];
+    da.out_fs = static_cast<long>(g.tensors[b.out].elems());
     da.consts = da.w1 = da.w2 = reinterpret_cast<const float*>(0x3000);
     if (!dblock_kernel_supports(da)) return 0;
     Node r;

@@ -222,6 +222,13 @@ class GraphBuilder:
         y = self.conv(self.dw(a), c)
         return self.relu(self.add(y, x))
 
+    def double_block_widen(self, x, cm, co):
+        """full_range where it widens without down-sampling: (DW3x3 -> PW C -> cm, ReLU), (DW3x3 -> PW cm -> co) + pad(x), ReLU."""
+        c = self.shape(x)[3]
+        a = self.relu(self.conv(self.dw(x), cm))
+        y = self.conv(self.dw(a), co)
+        return self.relu(self.add(y, self.pad_channels(x, co - c)))
+
     def finish(self):
         codes = sorted({op[0] for op in self.ops})
         fb = _FB()
@@ -285,6 +292,17 @@ def back_like(seed, size, c0=24, n1=3, n2=3):
     return g.finish()
 
 
+def full_widen(seed, h, w, c=24, cm=8, co=40):
+    """double blocks on a non-square frame whose row bands end ragged, one of them widening (skip zero-padded to co channels)."""
+    g = GraphBuilder(seed, [1, h, w, 3])
+    x = g.relu(g.conv(g.input, c, 3, 2))
+    x = g.double_block(x, cm)
+    x = g.double_block_widen(x, cm + 4, co)
+    x = g.double_block(x, 12)
+    g.outputs = [g.conv(x, 5)]
+    return g.finish()
+
+
 def full_like(seed, size, c=32, cm=12):
     """stem 3x3 s2 -> double blocks at (size/2)^2 x c -> stride-2 double block to 2c -> double blocks -> pointwise head."""
     g = GraphBuilder(seed, [1, size, size, 3])
@@ -334,6 +352,7 @@ CASES = {
     "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads
     "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
     "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames
+    "full_widen_70x44": (lambda: full_widen(33, 70, 44), 70, 44),                           # 35 x 22 frames: ragged bands, widening double block
     "full_64": (lambda: full_like(31, 64), 64, 64),                                        # double blocks, odd middle widths
     "full_80_c48": (lambda: full_like(32, 80, 48, 20), 80, 80),
 }
