@@ -39,6 +39,7 @@ constexpr int kDbPrefetch = 12;  // float4 registers per thread for the next ban
 
 struct DblockGeom {
     int RB, bands;            // output rows per band, bands per frame
+    int pair1;                // stage 1 computes two rows per lane (worth it when it shortens the busiest wave's share)
     int Cp, Cmp;              // channel counts padded to 8
     int PSx, RSx, PSa, RSa;   // LDS pixel / row strides (floats)
     int off_a, off_c, off_w1, off_w2;  // LDS offsets (floats): a tensor, constants, the two pointwise matrices
@@ -166,8 +167,10 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
         MI_DB_STAMP(2)
         wg_barrier();
         MI_DB_STAMP(3)
-        // ---- stage 1: a on rows [r0 - 1, r0 + RB + 1): 32-pixel groups round-robin over the waves
-        {
+        // ---- stage 1: a on rows [r0 - 1, r0 + RB + 1).  A lane computes TWO vertically adjacent pixels (RB is even): the 4 x 3 window
+        // they share is 12 LDS reads instead of 18, the nine depthwise taps are read once for both — the LDS pipe bounds this stage
+        // (per channel chunk and pixel: 9 + 9 + 2 reads before, 6 + 4.5 + 1 now).  Groups of 32 column positions x 2 rows, round-robin.
+        if (!g.pair1) {  // few groups (narrow frames): one pixel per lane keeps more waves busy
             const int npx = (g.RB + 2) * W, ngr = (npx + 31) >> 5;
             for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
                 const int q = grp * 32 + pl;
@@ -188,8 +191,69 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
                     v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi1);
                     v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi1);
                     v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi1);
-                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the image are the second depthwise conv's zero padding
+                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(dst + ch) = v;
+                }
+            }
+        } else {
+            const int prows = (g.RB + 2) >> 1, npq = prows * W, ngr = (npq + 31) >> 5;
+            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
+                const int qq = grp * 32 + pl;
+                const bool valid = qq < npq;
+                const int pr = valid ? qq / W : 0, ox = valid ? qq - (qq / W) * W : 0, la0 = 2 * pr;
+                const float* t0 = xt + la0 * g.RSx + ox * g.PSx;  // tap rows la0 .. la0 + 3
+                df32x16 D0, D1;
+#pragma unroll
+                for (int e = 0; e < 16; e++) { D0[e] = 0.f; D1[e] = 0.f; }
+                for (int j = 0; j < nch1; j++) {
+                    const int c0 = h * Ch + 4 * j;
+                    float4 wq[9];
+#pragma unroll
+                    for (int t = 0; t < 9; t++) wq[t] = dld4(cst + t * g.Cp + c0);
+                    const float4 bb = dld4(cst + o_bdw1 + c0);
+                    float4 d[4][3];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) d[r][kx] = dld4(t0 + r * g.RSx + kx * g.PSx + c0);
+                    float4 bf0 = bb, bf1 = bb;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const float4 w = wq[ky * 3 + kx], da = d[ky][kx], db = d[ky + 1][kx];
+                            bf0.x = fmaf(da.x, w.x, bf0.x); bf0.y = fmaf(da.y, w.y, bf0.y); bf0.z = fmaf(da.z, w.z, bf0.z); bf0.w = fmaf(da.w, w.w, bf0.w);
+                            bf1.x = fmaf(db.x, w.x, bf1.x); bf1.y = fmaf(db.y, w.y, bf1.y); bf1.z = fmaf(db.z, w.z, bf1.z); bf1.w = fmaf(db.w, w.w, bf1.w);
+                        }
+                    const float4 av = dld4(w1L + (j * 64 + lane) * 4);
+                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf0.x, D0, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf1.x, D1, 0, 0, 0);
+                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf0.y, D0, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf1.y, D1, 0, 0, 0);
+                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf0.z, D0, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf1.z, D1, 0, 0, 0);
+                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf0.w, D0, 0, 0, 0);
+                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf1.w, D1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int la = la0 + rr, iy = r0 - 1 + la;
+                    const bool inside = iy >= 0 && iy < a.H;
+                    float* dst = at + la * g.RSa + (ox + 1) * g.PSa;
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int ch = 8 * gq + 4 * h;
+                        if (ch >= g.Cmp || !valid) continue;
+                        const float4 bb = dld4(cst + o_b1 + ch), sl = dld4(cst + o_sl1 + ch);
+                        float4 v = rr == 0 ? make_float4(D0[4 * gq] + bb.x, D0[4 * gq + 1] + bb.y, D0[4 * gq + 2] + bb.z, D0[4 * gq + 3] + bb.w)
+                                           : make_float4(D1[4 * gq] + bb.x, D1[4 * gq + 1] + bb.y, D1[4 * gq + 2] + bb.z, D1[4 * gq + 3] + bb.w);
+                        v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi1);
+                        v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi1);
+                        v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi1);
+                        v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi1);
+                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the image are the second depthwise conv's zero padding
+                        *reinterpret_cast<float4*>(dst + ch) = v;
+                    }
                 }
             }
         }
@@ -251,8 +315,18 @@ bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
         if (fl * 4 <= 160 * 1024 - 256 && n4 <= (long)kDbPrefetch * 512) { RB = r; break; }
     }
     if (RB < 2) return false;
-    g.bands = (a.H + RB - 1) / RB;
-    g.RB = (a.H + g.bands - 1) / g.bands;  // even bands
+    // stage 1 with two rows per lane needs an even band height; worth it when it shortens the busiest wave's share (a pair group
+    // costs about 1.3 single groups) and giving up an odd row does not cost a short band a third of its height
+    g.pair1 = 0;
+    if (RB % 2 == 0 || RB >= 5) {
+        const int RBe = RB & ~1, bands = (a.H + RBe - 1) / RBe, rb = (((a.H + bands - 1) / bands) + 1) & ~1;
+        const int single = ((rb + 2) * a.W + 31) / 32, pairs = ((rb + 2) / 2 * a.W + 31) / 32;
+        if (13 * ((pairs + 7) / 8) < 10 * ((single + 7) / 8)) { g.pair1 = 1; g.bands = bands; g.RB = rb; }
+    }
+    if (!g.pair1) {
+        g.bands = (a.H + RB - 1) / RB;
+        g.RB = (a.H + g.bands - 1) / g.bands;  // bands of equal height
+    }
     int off = (g.RB + 4) * g.RSx;
     off = (off + 3) & ~3;
     g.off_a = off; off += (g.RB + 2) * g.RSa; off = (off + 3) & ~3;
