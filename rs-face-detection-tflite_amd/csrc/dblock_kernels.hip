@@ -39,7 +39,7 @@ constexpr int kDbPrefetch = 12;  // float4 registers per thread for the next ban
 
 struct DblockGeom {
     int RB, bands;            // output rows per band, bands per frame
-    int pair1;                // stage 1 computes two rows per lane (worth it when it shortens the busiest wave's share)
+    int pair1, pair2;         // stage 1 / 2 computes two rows per lane (worth it when it shortens the busiest wave's share)
     int Cp, Cmp;              // channel counts padded to 8
     int PSx, RSx, PSa, RSa;   // LDS pixel / row strides (floats)
     int off_a, off_c, off_w1, off_w2;  // LDS offsets (floats): a tensor, constants, the two pointwise matrices
@@ -54,8 +54,8 @@ unsigned long long* g_dblock_stamps = nullptr;
 #define MI_DB_STAMP(k)
 #endif
 
-// constants blob (floats): [dw1 taps 9 x Cp][b_dw1 Cp][b1 32][slope1 32][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
-template <int MT>
+// constants blob (floats): [dw1 taps 9 x Cp][b_dw1 Cp][b1 32 MTA][slope1 32 MTA][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
+template <int MT, int MTA>
 __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xt = lds;               // x: [(RB + 4)][(W + 2)][PSx], row 0 = image row r0 - 2
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
     const int pl = lane & 31, h = lane >> 5;
     const int W = a.W, C4 = a.C >> 2;
     const int Ch = g.Cp >> 1, Chm = g.Cmp >> 1, nch1 = Ch >> 2, nch2 = Chm >> 2;
-    const int o_bdw1 = 9 * g.Cp, o_b1 = 10 * g.Cp, o_sl1 = o_b1 + 32, o_wdw2 = o_sl1 + 32, o_bdw2 = o_wdw2 + 9 * g.Cmp, o_b2 = o_bdw2 + g.Cmp, o_sl2 = o_b2 + 32 * MT;
+    const int o_bdw1 = 9 * g.Cp, o_b1 = 10 * g.Cp, o_sl1 = o_b1 + 32 * MTA, o_wdw2 = o_sl1 + 32 * MTA, o_bdw2 = o_wdw2 + 9 * g.Cmp, o_b2 = o_bdw2 + g.Cmp, o_sl2 = o_b2 + 32 * MT;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int total = a.B * g.bands;
     // LDS-only workgroup barrier: __syncthreads() would also wait for the next band's rows and for this band's stores
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
     for (int i = tid; i < ((g.RB + 4) * g.RSx) >> 2; i += 512) reinterpret_cast<float4*>(xt)[i] = zero4;
     for (int i = tid; i < ((g.RB + 2) * g.RSa) >> 2; i += 512) reinterpret_cast<float4*>(at)[i] = zero4;
     for (int i = tid; i < g.cfl; i += 512) lds[g.off_c + i] = a.consts[i];
-    for (int i = tid; i < (32 * g.Cp) >> 2; i += 512) reinterpret_cast<float4*>(lds + g.off_w1)[i] = dld4(a.w1 + 4 * i);
+    for (int i = tid; i < (32 * MTA * g.Cp) >> 2; i += 512) reinterpret_cast<float4*>(lds + g.off_w1)[i] = dld4(a.w1 + 4 * i);
     for (int i = tid; i < (32 * MT * g.Cmp) >> 2; i += 512) reinterpret_cast<float4*>(lds + g.off_w2)[i] = dld4(a.w2 + 4 * i);
     int item = blockIdx.x;
     prefetch(item);
@@ -136,6 +136,110 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
         }
     };
 
+    // One stage over the 32-pixel groups of `nrows` output rows (local row la reads the source tensor's rows la .. la + 2):
+    //   out = act( W . (DW3x3(src) + b_dw) + bias + skip )
+    // skip (or null): tensor K, the output pixel's own position at K's local row la + krow, channels < Ck.  TOLDS: the result goes to the
+    // LDS tensor dstL (local row la; zero where the image row img0 + la lies outside the image), else to the frame in global memory.
+    // pair: a lane computes TWO vertically adjacent pixels — the 4 x 3 window they share is 12 LDS reads instead of 18 and the nine
+    // depthwise taps are read once for both; the LDS pipe bounds these stages (per channel chunk and pixel 9 + 9 + 2 reads, paired 6 + 4.5 + 1).
+    auto stage = [&](auto NTc, auto TOLDSc, auto PAIROKc, bool pair, int nrows, int img0, const float* S, int RSs, int PSs, int Cpad, int nchk, const float* wdw,
+                     const float* bdw, const float* wL, const float* bias, const float* slope, float hi, int Cout, const float* K, int RSk, int PSk,
+                     int krow, int Ck, float* dstL, float* dstG) {
+        constexpr int NT = decltype(NTc)::value;
+        constexpr bool TOLDS = decltype(TOLDSc)::value;
+        const int Chh = Cpad >> 1;
+        auto finish = [&](const df32x16 (&D)[NT], int la, int ox, bool valid) {
+            const int iy = img0 + la;
+            const bool inside = iy >= 0 && iy < a.H;
+            const float* ks = K ? K + (la + krow) * RSk + (ox + 1) * PSk : nullptr;
+            float* dl = TOLDS ? dstL + la * g.RSa + (ox + 1) * g.PSa : nullptr;
+            float* dg = TOLDS ? nullptr : dstG + ((long)la * W + ox) * Cout;
+#pragma unroll
+            for (int m = 0; m < NT; m++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int ch = 32 * m + 8 * gq + 4 * h;
+                    if (ch >= (TOLDS ? g.Cmp : Cout) || !valid) continue;
+                    const float4 bb = dld4(bias + ch), sl = dld4(slope + ch);
+                    float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);  // channels above Ck: the zero channel-pad of the skip
+                    if (ks && ch < Ck) sk = dld4(ks + ch);
+                    float4 v = make_float4(D[m][4 * gq] + bb.x + sk.x, D[m][4 * gq + 1] + bb.y + sk.y, D[m][4 * gq + 2] + bb.z + sk.z, D[m][4 * gq + 3] + bb.w + sk.w);
+                    v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), hi);
+                    v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), hi);
+                    v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), hi);
+                    v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), hi);
+                    if (TOLDS) {
+                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the image are the next depthwise conv's zero padding
+                        *reinterpret_cast<float4*>(dl + ch) = v;
+                    } else {
+                        *reinterpret_cast<float4*>(dg + ch) = v;
+                    }
+                }
+        };
+        constexpr bool PAIROK = decltype(PAIROKc)::value;  // the two-row form exists for <= 2 output tiles (accumulators)
+        if (!PAIROK || !pair) {
+            const int npx = nrows * W, ngr = (npx + 31) >> 5;
+            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
+                const int q = grp * 32 + pl;
+                const bool valid = q < npx;
+                const int la = valid ? q / W : 0, ox = valid ? q - (q / W) * W : 0;
+                df32x16 D[NT];
+                contract(S + la * RSs + ox * PSs, RSs, PSs, Cpad, nchk, wdw, bdw, wL, D, NTc);
+                finish(D, la, ox, valid);
+            }
+        } else if constexpr (PAIROK) {
+            const int prows = (nrows + 1) >> 1, npq = prows * W, ngr = (npq + 31) >> 5;
+            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
+                const int qq = grp * 32 + pl;
+                const bool vq = qq < npq;
+                const int pr = vq ? qq / W : 0, ox = vq ? qq - (qq / W) * W : 0, la0 = 2 * pr;
+                const float* t0 = S + la0 * RSs + ox * PSs;  // tap rows la0 .. la0 + 3
+                df32x16 D0[NT], D1[NT];
+#pragma unroll
+                for (int m = 0; m < NT; m++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) { D0[m][e] = 0.f; D1[m][e] = 0.f; }
+                for (int j = 0; j < nchk; j++) {
+                    const int c0 = h * Chh + 4 * j;
+                    const float4 bb = dld4(bdw + c0);
+                    float4 bf0 = bb, bf1 = bb;
+                    // data row r feeds tap row r of the upper pixel and tap row r - 1 of the lower one (same tap order as the one-row form)
+                    float4 wprev[3];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float4 d[3], wr[3];
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            d[kx] = dld4(t0 + r * RSs + kx * PSs + c0);
+                            if (r < 3) wr[kx] = dld4(wdw + (r * 3 + kx) * Cpad + c0);
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            if (r < 3) { bf0.x = fmaf(d[kx].x, wr[kx].x, bf0.x); bf0.y = fmaf(d[kx].y, wr[kx].y, bf0.y); bf0.z = fmaf(d[kx].z, wr[kx].z, bf0.z); bf0.w = fmaf(d[kx].w, wr[kx].w, bf0.w); }
+                            if (r > 0) { bf1.x = fmaf(d[kx].x, wprev[kx].x, bf1.x); bf1.y = fmaf(d[kx].y, wprev[kx].y, bf1.y); bf1.z = fmaf(d[kx].z, wprev[kx].z, bf1.z); bf1.w = fmaf(d[kx].w, wprev[kx].w, bf1.w); }
+                        }
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) wprev[kx] = wr[kx];
+                    }
+#pragma unroll
+                    for (int m = 0; m < NT; m++) {
+                        const float4 av = dld4(wL + ((m * nchk + j) * 64 + lane) * 4);
+                        D0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf0.x, D0[m], 0, 0, 0);
+                        D1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf1.x, D1[m], 0, 0, 0);
+                        D0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf0.y, D0[m], 0, 0, 0);
+                        D1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf1.y, D1[m], 0, 0, 0);
+                        D0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf0.z, D0[m], 0, 0, 0);
+                        D1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf1.z, D1[m], 0, 0, 0);
+                        D0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf0.w, D0[m], 0, 0, 0);
+                        D1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf1.w, D1[m], 0, 0, 0);
+                    }
+                }
+                finish(D0, la0, ox, vq);
+                finish(D1, la0 + 1, ox, vq && la0 + 1 < nrows);
+            }
+        }
+    };
+
     MI_DB_STAMP(0)
     for (;;) {
         int frame, r0, lo, hi;
@@ -167,128 +271,16 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
         MI_DB_STAMP(2)
         wg_barrier();
         MI_DB_STAMP(3)
-        // ---- stage 1: a on rows [r0 - 1, r0 + RB + 1).  A lane computes TWO vertically adjacent pixels (RB is even): the 4 x 3 window
-        // they share is 12 LDS reads instead of 18, the nine depthwise taps are read once for both — the LDS pipe bounds this stage
-        // (per channel chunk and pixel: 9 + 9 + 2 reads before, 6 + 4.5 + 1 now).  Groups of 32 column positions x 2 rows, round-robin.
-        if (!g.pair1) {  // few groups (narrow frames): one pixel per lane keeps more waves busy
-            const int npx = (g.RB + 2) * W, ngr = (npx + 31) >> 5;
-            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
-                const int q = grp * 32 + pl;
-                const bool valid = q < npx;
-                const int la = valid ? q / W : 0, ox = valid ? q - (q / W) * W : 0;
-                const int iy = r0 - 1 + la;
-                float* dst = at + la * g.RSa + (ox + 1) * g.PSa;
-                df32x16 D[1];
-                contract(xt + la * g.RSx + ox * g.PSx, g.RSx, g.PSx, g.Cp, nch1, cst, cst + o_bdw1, w1L, D, std::integral_constant<int, 1>{});
-                const bool inside = iy >= 0 && iy < a.H;
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int ch = 8 * gq + 4 * h;
-                    if (ch >= g.Cmp || !valid) continue;
-                    const float4 bb = dld4(cst + o_b1 + ch), sl = dld4(cst + o_sl1 + ch);
-                    float4 v = make_float4(D[0][4 * gq] + bb.x, D[0][4 * gq + 1] + bb.y, D[0][4 * gq + 2] + bb.z, D[0][4 * gq + 3] + bb.w);
-                    v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi1);
-                    v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi1);
-                    v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi1);
-                    v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi1);
-                    if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(dst + ch) = v;
-                }
-            }
-        } else {
-            const int prows = (g.RB + 2) >> 1, npq = prows * W, ngr = (npq + 31) >> 5;
-            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
-                const int qq = grp * 32 + pl;
-                const bool valid = qq < npq;
-                const int pr = valid ? qq / W : 0, ox = valid ? qq - (qq / W) * W : 0, la0 = 2 * pr;
-                const float* t0 = xt + la0 * g.RSx + ox * g.PSx;  // tap rows la0 .. la0 + 3
-                df32x16 D0, D1;
-#pragma unroll
-                for (int e = 0; e < 16; e++) { D0[e] = 0.f; D1[e] = 0.f; }
-                for (int j = 0; j < nch1; j++) {
-                    const int c0 = h * Ch + 4 * j;
-                    float4 wq[9];
-#pragma unroll
-                    for (int t = 0; t < 9; t++) wq[t] = dld4(cst + t * g.Cp + c0);
-                    const float4 bb = dld4(cst + o_bdw1 + c0);
-                    float4 d[4][3];
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-#pragma unroll
-                        for (int kx = 0; kx < 3; kx++) d[r][kx] = dld4(t0 + r * g.RSx + kx * g.PSx + c0);
-                    float4 bf0 = bb, bf1 = bb;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                        for (int kx = 0; kx < 3; kx++) {
-                            const float4 w = wq[ky * 3 + kx], da = d[ky][kx], db = d[ky + 1][kx];
-                            bf0.x = fmaf(da.x, w.x, bf0.x); bf0.y = fmaf(da.y, w.y, bf0.y); bf0.z = fmaf(da.z, w.z, bf0.z); bf0.w = fmaf(da.w, w.w, bf0.w);
-                            bf1.x = fmaf(db.x, w.x, bf1.x); bf1.y = fmaf(db.y, w.y, bf1.y); bf1.z = fmaf(db.z, w.z, bf1.z); bf1.w = fmaf(db.w, w.w, bf1.w);
-                        }
-                    const float4 av = dld4(w1L + (j * 64 + lane) * 4);
-                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf0.x, D0, 0, 0, 0);
-                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bf1.x, D1, 0, 0, 0);
-                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf0.y, D0, 0, 0, 0);
-                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bf1.y, D1, 0, 0, 0);
-                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf0.z, D0, 0, 0, 0);
-                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bf1.z, D1, 0, 0, 0);
-                    D0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf0.w, D0, 0, 0, 0);
-                    D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bf1.w, D1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int rr = 0; rr < 2; rr++) {
-                    const int la = la0 + rr, iy = r0 - 1 + la;
-                    const bool inside = iy >= 0 && iy < a.H;
-                    float* dst = at + la * g.RSa + (ox + 1) * g.PSa;
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        const int ch = 8 * gq + 4 * h;
-                        if (ch >= g.Cmp || !valid) continue;
-                        const float4 bb = dld4(cst + o_b1 + ch), sl = dld4(cst + o_sl1 + ch);
-                        float4 v = rr == 0 ? make_float4(D0[4 * gq] + bb.x, D0[4 * gq + 1] + bb.y, D0[4 * gq + 2] + bb.z, D0[4 * gq + 3] + bb.w)
-                                           : make_float4(D1[4 * gq] + bb.x, D1[4 * gq + 1] + bb.y, D1[4 * gq + 2] + bb.z, D1[4 * gq + 3] + bb.w);
-                        v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi1);
-                        v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi1);
-                        v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi1);
-                        v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi1);
-                        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);  // rows outside the image are the second depthwise conv's zero padding
-                        *reinterpret_cast<float4*>(dst + ch) = v;
-                    }
-                }
-            }
-        }
+        // ---- stage 1: a on rows [r0 - 1, r0 + RB + 1) (rows outside the image: zeros)
+        stage(std::integral_constant<int, MTA>{}, std::true_type{}, std::true_type{}, g.pair1 != 0, g.RB + 2, r0 - 1, xt, g.RSx, g.PSx, g.Cp, nch1, cst, cst + o_bdw1, w1L,
+              cst + o_b1, cst + o_sl1, a.hi1, a.Cm, a.skip1 ? xt : nullptr, g.RSx, g.PSx, 1, a.C, at, nullptr);
         MI_DB_STAMP(4)
         wg_barrier();
         MI_DB_STAMP(5)
-        // ---- stage 2: y on rows [r0, r0 + RB) inside the image
-        {
-            const int rows = min(g.RB, a.H - r0), npx = rows * W, ngr = (npx + 31) >> 5;
-            for (int grp = wave; grp < ngr; grp += 8) {  // wave-uniform
-                const int q = grp * 32 + pl;
-                const bool valid = q < npx;
-                const int la = valid ? q / W : 0, ox = valid ? q - (q / W) * W : 0;
-                df32x16 D[MT];
-                contract(at + la * g.RSa + ox * g.PSa, g.RSa, g.PSa, g.Cmp, nch2, cst + o_wdw2, cst + o_bdw2, w2L, D, std::integral_constant<int, MT>{});
-                const float* xs = xt + (la + 2) * g.RSx + (ox + 1) * g.PSx;  // the skip: x at this pixel
-                float* yo = a.out + (long)frame * a.out_fs + ((long)(r0 + la) * W + ox) * a.Co;
-#pragma unroll
-                for (int m = 0; m < MT; m++)
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        const int ch = 32 * m + 8 * gq + 4 * h;
-                        if (ch >= a.Co || !valid) continue;
-                        const float4 bb = dld4(cst + o_b2 + ch), sl = dld4(cst + o_sl2 + ch);
-                        float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);  // channels above C: the zero channel-pad of the skip
-                        if (ch < a.C) sk = dld4(xs + ch);
-                        float4 v = make_float4(D[m][4 * gq] + bb.x + sk.x, D[m][4 * gq + 1] + bb.y + sk.y, D[m][4 * gq + 2] + bb.z + sk.z, D[m][4 * gq + 3] + bb.w + sk.w);
-                        v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi2);
-                        v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi2);
-                        v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi2);
-                        v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi2);
-                        *reinterpret_cast<float4*>(yo + ch) = v;
-                    }
-            }
-        }
+        // ---- stage 2: y on rows [r0, r0 + RB) inside the image; its skip is x (double block) or a (a pair of BlazeBlocks)
+        stage(std::integral_constant<int, MT>{}, std::false_type{}, std::integral_constant<bool, (MT <= 2)>{}, g.pair2 != 0, min(g.RB, a.H - r0), r0, at, g.RSa, g.PSa, g.Cmp, nch2, cst + o_wdw2, cst + o_bdw2, w2L,
+              cst + o_b2, cst + o_sl2, a.hi2, a.Co, a.skip2_from_a ? at : xt, a.skip2_from_a ? g.RSa : g.RSx, a.skip2_from_a ? g.PSa : g.PSx, a.skip2_from_a ? 1 : 2,
+              a.skip2_from_a ? a.Cm : a.C, nullptr, a.out + (long)frame * a.out_fs + (long)r0 * W * a.Co);
         MI_DB_STAMP(6)
         item += gridDim.x;
         if (item >= total) break;
@@ -298,15 +290,18 @@ __global__ __launch_bounds__(512, 2) void dblock_kernel(DblockArgs a, DblockGeom
 
 bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
     DblockGeom g{};
-    if (a.C % 8 || a.C < 8 || a.C > 128 || a.Cm % 4 || a.Cm < 4 || a.Cm > 32 || a.H < 1 || a.W < 2 || a.B < 1) return false;
-    if (a.Co < a.C || a.Co > 128 || a.Co % 4) return false;
+    if (a.C % 8 || a.C < 8 || a.C > 128 || a.Cm % 4 || a.Cm < 4 || a.Cm > 64 || a.H < 1 || a.W < 2 || a.B < 1) return false;
+    if (a.Co > 128 || a.Co % 4) return false;
+    if (a.skip2_from_a ? a.Co != a.Cm : a.Co < a.C) return false;
+    if (a.skip1 && a.Cm != a.C) return false;
     g.Cp = a.C;
     g.Cmp = (a.Cm + 7) & ~7;
     g.PSx = g.Cp + 4; g.RSx = (a.W + 2) * g.PSx;
     g.PSa = g.Cmp + 4; g.RSa = (a.W + 2) * g.PSa;
-    const int MT = (a.Co + 31) / 32;
-    g.cfl = 10 * g.Cp + 64 + 10 * g.Cmp + 64 * MT;
-    const int wfl = 32 * g.Cp + 32 * MT * g.Cmp;
+    const int MT = (a.Co + 31) / 32, MTA = (a.Cm + 31) / 32;
+    if (MTA == 2 && MT != 2) return false;  // instantiated: one stage-1 tile with 1 .. 4 stage-2 tiles, or two and two
+    g.cfl = 10 * g.Cp + 64 * MTA + 10 * g.Cmp + 64 * MT;
+    const int wfl = 32 * MTA * g.Cp + 32 * MT * g.Cmp;
     // rows per band: as many as LDS and the prefetch registers hold (fewer bands = less halo work)
     int RB = 0;
     for (int r = std::min(a.H, 32); r >= 1; r--) {
@@ -327,11 +322,15 @@ bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
         g.bands = (a.H + RB - 1) / RB;
         g.RB = (a.H + g.bands - 1) / g.bands;  // bands of equal height
     }
+    {
+        const int single = (g.RB * a.W + 31) / 32, pairs = ((g.RB + 1) / 2 * a.W + 31) / 32;
+        g.pair2 = MT <= 2 && 13 * ((pairs + 7) / 8) < 10 * ((single + 7) / 8);  // the accumulators of 2 x 2 tiles fit, those of 2 x 4 do not
+    }
     int off = (g.RB + 4) * g.RSx;
     off = (off + 3) & ~3;
     g.off_a = off; off += (g.RB + 2) * g.RSa; off = (off + 3) & ~3;
     g.off_c = off; off += (g.cfl + 3) & ~3;
-    g.off_w1 = off; off += 32 * g.Cp;
+    g.off_w1 = off; off += 32 * MTA * g.Cp;
     g.off_w2 = off; off += 32 * MT * g.Cmp;
     g.lds_bytes = off * 4;
     if (g.lds_bytes > 160 * 1024 - 256) return false;
@@ -350,9 +349,9 @@ int dblock_cu_count() {
     return n;
 }
 
-template <int MT>
+template <int MT, int MTA>
 int launch_dblock_inst(const DblockArgs& a, const DblockGeom& g, hipStream_t s) {
-    auto kern = dblock_kernel<MT>;
+    auto kern = dblock_kernel<MT, MTA>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -371,8 +370,8 @@ bool dblock_kernel_supports(const DblockArgs& a) {
 }
 
 int dblock_const_floats(int C, int Cm, int Co) {
-    const int Cmp = (Cm + 7) & ~7, MT = (Co + 31) / 32;
-    return 10 * C + 64 + 10 * Cmp + 64 * MT;
+    const int Cmp = (Cm + 7) & ~7, MT = (Co + 31) / 32, MTA = (Cm + 31) / 32;
+    return 10 * C + 64 * MTA + 10 * Cmp + 64 * MT;
 }
 
 int launch_dblock(const DblockArgs& a, void* stream) {
@@ -383,11 +382,12 @@ int launch_dblock(const DblockArgs& a, void* stream) {
     g.stamps = (only_h == 0 || a.H == only_h) ? g_dblock_stamps : nullptr;
 #endif
     hipStream_t s = (hipStream_t)stream;
+    if ((a.Cm + 31) / 32 == 2) return launch_dblock_inst<2, 2>(a, g, s);
     switch ((a.Co + 31) / 32) {
-        case 1: return launch_dblock_inst<1>(a, g, s);
-        case 2: return launch_dblock_inst<2>(a, g, s);
-        case 3: return launch_dblock_inst<3>(a, g, s);
-        case 4: return launch_dblock_inst<4>(a, g, s);
+        case 1: return launch_dblock_inst<1, 1>(a, g, s);
+        case 2: return launch_dblock_inst<2, 1>(a, g, s);
+        case 3: return launch_dblock_inst<3, 1>(a, g, s);
+        case 4: return launch_dblock_inst<4, 1>(a, g, s);
     }
     return (int)hipErrorInvalidValue;
 }

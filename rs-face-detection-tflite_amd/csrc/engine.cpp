@@ -186,7 +186,7 @@ void Model::rebuild() {
         if (n.kind == Node::Resident && n.dblock) {
             // double block (dblock_kernels.hip): both pointwise matrices in the block kernel's packing, one blob of small constants
             const Node &pa = n.members[0], &pb = n.members[1];
-            const int C = g.tensors[pa.in[0]].shape[3], Cm = g.tensors[pa.out].shape[3], Co = g.tensors[pb.out].shape[3], Cmp = (Cm + 7) & ~7, MT = (Co + 31) / 32;
+            const int C = g.tensors[pa.in[0]].shape[3], Cm = g.tensors[pa.out].shape[3], Co = g.tensors[pb.out].shape[3], Cmp = (Cm + 7) & ~7, MT = (Co + 31) / 32, MTA = (Cm + 31) / 32;
             MemberOff ma, mb;
             ma.w2 = pack_pw(pa.w2);
             mb.w2 = pack_pw(pb.w2);
@@ -198,8 +198,8 @@ void Model::rebuild() {
             o += static_cast<size_t>(9) * C;
             for (int c = 0; c < C; c++) cb[o + c] = pa.b >= 0 ? g.tensors[pa.b].f32[static_cast<size_t>(c)] : 0.f;
             o += static_cast<size_t>(C);
-            for (int c = 0; c < Cm; c++) { cb[o + c] = pa.b2 >= 0 ? g.tensors[pa.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + 32 + c] = slope(pa, c); }
-            o += 64;
+            for (int c = 0; c < Cm; c++) { cb[o + c] = pa.b2 >= 0 ? g.tensors[pa.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + static_cast<size_t>(32) * MTA + c] = slope(pa, c); }
+            o += static_cast<size_t>(64) * MTA;
             for (int tap = 0; tap < 9; tap++)
                 for (int c = 0; c < Cm; c++) cb[o + static_cast<size_t>(tap) * Cmp + c] = g.tensors[pb.w].f32[static_cast<size_t>(tap) * Cm + c];
             o += static_cast<size_t>(9) * Cmp;
@@ -691,6 +691,8 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     a.consts = d_weights_ + chain_off_[i][0].strip;
                     a.hi1 = n.members[0].act == ACT_RELU6 ? 6.f : INFINITY;
                     a.hi2 = n.members[1].act == ACT_RELU6 ? 6.f : INFINITY;
+                    a.skip1 = n.members[0].res >= 0;                       // two plain BlazeBlocks: each adds its own input
+                    a.skip2_from_a = n.members[1].res == n.members[0].out;
                     rc = launch_dblock(a, s);
                     break;
                 }

@@ -288,8 +288,10 @@ struct DblockArgs {
     long in_fs = 0, out_fs = 0;
     int B = 0, H = 0, W = 0, C = 0, Cm = 0;
     int Co = 0;                     // output channels >= C (the skip is x zero-padded to Co channels, as where full_range widens: 48 -> 16 -> 64)
-    const float* consts = nullptr;  // dblock_const_floats(): [dw1 taps 9 x C][b_dw1 C][b1 32][slope1 32][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
-    const float* w1 = nullptr;      // block kernel's A-fragment packing of W1 [Cm][C] (one 32-row tile)
+    int skip1 = 0;                  // a pair of plain BlazeBlocks instead: stage 1 adds x as well (Cm == C) ...
+    int skip2_from_a = 0;           // ... and stage 2's skip is a, the first block's output (Co == Cm)
+    const float* consts = nullptr;  // dblock_const_floats(): [dw1 taps 9 x C][b_dw1 C][b1 32 MTA][slope1 32 MTA][dw2 taps 9 x Cmp][b_dw2 Cmp][b2 32 MT][slope2 32 MT]
+    const float* w1 = nullptr;      // block kernel's A-fragment packing of W1 [Cm][C] (MTA = ceil(Cm / 32) tiles)
     const float* w2 = nullptr;      // ... of W2 [C][Cm] (MT tiles, contraction padded to Cmp = roundup8(Cm))
     float hi1 = 0.f, hi2 = 0.f;
 };

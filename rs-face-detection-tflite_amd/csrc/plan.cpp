@@ -673,8 +673,14 @@ size_t build_dblock(const Graph& g, const std::vector<Node>& ns, size_t i, Node*
     auto dw_block = [](const Node& n) {
         return n.kind == Node::Block && n.w >= 0 && n.KH == 3 && n.KW == 3 && n.sh == 1 && n.sw == 1 && n.padding == Padding::Same && n.ept < 0 && n.epl < 0 && n.in.size() == 1;
     };
-    if (!dw_block(a) || !dw_block(b) || a.res >= 0 || b.in[0] != a.out) return 0;
-    if (b.res != a.in[0] || b.res_mode != RES_DIRECT || b.res_after) return 0;
+    if (!dw_block(a) || !dw_block(b) || b.in[0] != a.out) return 0;
+    // either the double block (no skip on the first half, the second half's skip is x) or two plain BlazeBlocks in a row (each adds its own input)
+    const bool blaze_pair = a.res == a.in[0] && a.res_mode == RES_DIRECT && !a.res_after && b.res == a.out && b.res_mode == RES_DIRECT && !b.res_after;
+    const bool dbl = a.res < 0 && b.res == a.in[0] && b.res_mode == RES_DIRECT && !b.res_after;
+    // (the pair form is measured slower than two block-kernel launches — BackCamera 32x32x48: 0.107 against 2 x 0.040 ms, both stages are
+    // heavy and the recomputed halo rows cost more than the saved round trip — and stays off unless asked for)
+    static const bool pairs_on = getenv("MI_BLAZE_PAIRS") != nullptr;  // development aid
+    if (!dbl && !(blaze_pair && pairs_on)) return 0;
     if (std::find(g.outputs.begin(), g.outputs.end(), a.out) != g.outputs.end()) return 0;
     for (size_t q = 0; q < ns.size(); q++) {
         if (q == i + 1) continue;
@@ -687,6 +693,7 @@ size_t build_dblock(const Graph& g, const std::vector<Node>& ns, size_t i, Node*
     da.in = reinterpret_cast<const float*>(0x1000); da.out = reinterpret_cast<float*>(0x2000);
     da.in_fs = da.out_fs = static_cast<long>(g.tensors[a.in[0]].elems());
     da.B = 1; da.H = sx[1]; da.W = sx[2]; da.C = sx[3]; da.Cm = sa[3]; da.Co = sy[3];
+    da.skip1 = blaze_pair; da.skip2_from_a = blaze_pair;
     da.out_fs = static_cast<long>(g.tensors[b.out].elems());
     da.consts = da.w1 = da.w2 = reinterpret_cast<const float*>(0x3000);
     if (!dblock_kernel_supports(da)) return 0;
@@ -1219,7 +1226,7 @@ std::string Plan::describe() const {
                 os << " x" << n.members.size() << " blocks, " << (si[1] * si[2] <= 256 ? "frame resident in LDS" : "row-pipelined through LDS")
                    << (n.members.back().sh == 2 ? " (stride-2 tail)" : "") << (n.head_nodes.empty() ? "" : ", " + std::to_string(n.head_nodes.size()) + " output heads");
         if (n.kind == Node::Resident && n.dblock) {
-            os << " double block (" << graph.tensors[n.members[0].in[0]].shape[3] << " -> " << graph.tensors[n.members[0].out].shape[3] << " -> " << graph.tensors[n.members[1].out].shape[3]
+            os << (n.members[0].res >= 0 ? " two BlazeBlocks (" : " double block (") << graph.tensors[n.members[0].in[0]].shape[3] << " -> " << graph.tensors[n.members[0].out].shape[3] << " -> " << graph.tensors[n.members[1].out].shape[3]
                << " channels), walking row bands, narrow tensor in LDS";
         } else if (n.kind == Node::Resident && n.bneck) {
             os << " x" << n.members.size() / 2 << " bottleneck blocks, wide tensor in registers, " << (n.res_bands > 1 ? std::to_string(n.res_bands) + " row bands" : std::string("frame resident"));
