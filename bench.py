@@ -4,6 +4,7 @@
     python bench.py                      # N = 1, configs[1] of BASELINE.json (the headline)
     python bench.py --gpus 8             # starts 8 ranks itself (one process per GPU, RCCL) and prints rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8
+    python bench.py --config 1           # ShortRange / FrontCamera 128x128, 256 frames/GPU (configs[0]'s model, batched)
     python bench.py --config 3           # FaceLandmark 192x192, 512 ROIs/GPU           (configs[2])
     python bench.py --config 5 --gpus 8  # full_range -> mesh -> 2 x iris, 128 frames/GPU (configs[4])
 
@@ -43,24 +44,51 @@ def _free_port():
     return p
 
 
+def kfd_gpu_nodes():
+    """Number of GPU nodes the kernel driver lists, read from sysfs text files (no HIP, no amdsmi, no torch): a KFD topology
+    node with simd_count > 0 is a GPU (CPU nodes have 0).  None when the topology is not readable (no driver, a container
+    that hides /sys/class/kfd)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    count, readable = 0, 0
+    for node in nodes:
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue                    # a node the device cgroup hides from this container
+        readable += 1
+        if int(props.get("simd_count", "0")) > 0:
+            count += 1
+    return count if readable else None
+
+
 def launch_ranks(args, argv):
-    """`python bench.py --gpus N` without an external launcher: this process makes NO GPU call (torch.cuda.device_count()
-    only counts), starts N fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, lets rank 0 print the
-    JSON line on the inherited stdout and exits with the first non-zero child status."""
+    """`python bench.py --gpus N` without an external launcher.  This process never imports torch and makes no HIP / amdsmi call
+    (a process that has touched the GPU must not start other programs on this pool): it reads the KFD topology from sysfs only
+    to refuse early, starts N fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, lets rank 0 print the
+    JSON line on the inherited stdout, and exits with the first non-zero child status after relaying that rank's stderr tail.
+    Every child checks `torch.cuda.device_count() >= WORLD_SIZE` itself (exit status 2) before it touches a device."""
+    import tempfile
     n = args.gpus
     if not args.rehearse:
-        import torch
-        visible = torch.cuda.device_count()
-        if visible < n:
-            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run a smaller job under that label\n" % (n, visible))
+        nodes = kfd_gpu_nodes()
+        if nodes is not None and nodes < n:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run a smaller job under that label\n" % (n, nodes))
             return 2
     env = dict(os.environ)
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    procs = []
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), BENCH_SPAWNED="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs, logs = [], []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
-    rc = 0
+        log = tempfile.TemporaryFile(mode="w+")
+        logs.append(log)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e, stderr=log))
+    rc, failed = 0, None
     deadline = time.time() + 3600
     alive = list(procs)
     while alive and time.time() < deadline:
@@ -70,13 +98,20 @@ def launch_ranks(args, argv):
                 continue
             alive.remove(p)
             if code != 0 and rc == 0:
-                rc = code
+                rc, failed = code, procs.index(p)
                 for q in alive:        # a rank died: the others would wait at the next barrier for ever
                     q.terminate()
         time.sleep(0.05)
     for p in alive:
         p.kill()
         rc = rc or 1
+    for r, log in enumerate(logs):     # the dead rank's stderr tail first, then whatever the others said (warnings)
+        log.seek(0)
+        text = log.read()
+        if text and (failed is None or r == failed):
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in text[-4000:].splitlines()))
+        log.close()
+    sys.stderr.write("bench.py launcher: %d rank(s), status %d, torch imported in the launcher: %s\n" % (n, rc, "torch" in sys.modules))
     return rc
 
 
@@ -90,14 +125,17 @@ def make_frames(batch, seed, size=256):
     """SURVEY.md §8d config 2 frame mix: 50% U(-1,1) noise, 50% face-bearing (committed man-face tensor with a seeded
     +-32 px roll and 0.8-1.2 gain) so that NMS sees real candidates."""
     import numpy as np
-    face = (_gold()["man_back_u8"].astype(np.float64) * 2.0 / 255.0 - 1.0).astype(np.float32)
+    u8 = _gold()["man_back_u8"].astype(np.float64)
+    if size == 128:   # config 1 (front / short, 128x128): the same picture, 2x2 box-filtered; the roll scales with the frame
+        u8 = u8.reshape(128, 2, 128, 2, 3).mean(axis=(1, 3))
+    face = (u8 * 2.0 / 255.0 - 1.0).astype(np.float32)
     rs = np.random.RandomState(seed)
     x = np.empty((batch, size, size, 3), np.float32)
     for b in range(batch):
         if b % 2 == 0:
             x[b] = rs.uniform(-1, 1, (size, size, 3)).astype(np.float32)
         else:
-            dy, dx = int(rs.randint(-32, 33)), int(rs.randint(-32, 33))
+            dy, dx = int(rs.randint(-size // 8, size // 8 + 1)), int(rs.randint(-size // 8, size // 8 + 1))
             x[b] = np.clip(np.roll(face, (dy, dx), axis=(0, 1)) * np.float32(rs.uniform(0.8, 1.2)), -1, 1)
     return x
 
@@ -127,11 +165,32 @@ def make_rgb_frames(batch, seed, size=192):
 
 
 # ------------------------------------------------------------------------------------------------- CPU baseline (oracle = port)
-def cpu_baseline(x_host, threads):
+def usable_cpus():
+    """Host threads this process may actually run on: the scheduler affinity mask, cut down by a cgroup CPU quota if one is set
+    (os.cpu_count() reports the whole host, which a 1-GPU box shares with seven others)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            fields = open(path).read().split()
+            quota = int(fields[0]) if fields[0] != "max" else -1
+            period = int(fields[1]) if len(fields) > 1 else int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = max(1, min(n, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+CPU_THREADS_NOTE = ("threads = min(usable CPUs (affinity mask and cgroup quota), frames in the batch); one frame per thread, as "
+                    "the reference runs TFLite single-threaded per image")
+
+
+def cpu_baseline(x_host, threads, model_file="face_detection_back.tflite", kind="FD_BACK"):
     """The oracle (CPU port of the same graph + glue) on the GPU box's host cores, bounded sample: all cores over frames."""
     from oracle import pyoracle as po
-    om = po.Model(os.path.join(ROOT, "models", "face_detection_back.tflite"))
-    anchors = po.ssd_anchors(po.FD_BACK)
+    om = po.Model(os.path.join(ROOT, "models", model_file))
+    anchors = po.ssd_anchors(getattr(po, kind))
+    scale = float(x_host.shape[1])
     n = min(len(x_host), max(threads, 64))
     om.run(x_host[: min(n, threads)], nthreads=threads)  # warm (page-in, thread pool)
     t0 = time.time()
@@ -139,25 +198,27 @@ def cpu_baseline(x_host, threads):
     while time.time() - t0 < 10.0:
         rb, rs = om.run(x_host[:n], nthreads=threads)
         for f in range(n):
-            po.fd_postprocess(rb[f], rs[f], anchors, 256.0)
+            po.fd_postprocess(rb[f], rs[f], anchors, scale)
         frames += n
     dt = time.time() - t0
     return {"value": round(frames / dt, 1), "unit": "faces/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": "%d frames of the same batch (net + decode + NMS), C oracle, OpenMP over frames, %.1f s" % (frames, dt)}
+            "sample": "%d frames of the same batch (net + decode + NMS), C oracle, OpenMP over frames, %.1f s" % (frames, dt),
+            "threads_note": CPU_THREADS_NOTE}
 
 
-def cpu_baseline_1thread(x_host):
+def cpu_baseline_1thread(x_host, model_file="face_detection_back.tflite", kind="FD_BACK"):
     """The reference's own operating point (face_detection.rs:207-210: one image per call, one thread, the interpreter
     rebuilt inside every call): model parse + run + post-processing per frame, one thread."""
     from oracle import pyoracle as po
-    path = os.path.join(ROOT, "models", "face_detection_back.tflite")
-    anchors = po.ssd_anchors(po.FD_BACK)
+    path = os.path.join(ROOT, "models", model_file)
+    anchors = po.ssd_anchors(getattr(po, kind))
+    scale = float(x_host.shape[1])
     t0 = time.time()
     frames = 0
     while time.time() - t0 < 8.0:
         om = po.Model(path)                                    # InterpreterBuilder::build + allocate_tensors, per call
         rb, rs = om.run(x_host[frames % len(x_host)][None], nthreads=1)
-        po.fd_postprocess(rb[0], rs[0], anchors, 256.0)
+        po.fd_postprocess(rb[0], rs[0], anchors, scale)
         frames += 1
     dt = time.time() - t0
     return {"value": round(frames / dt, 2), "unit": "faces/s", "cores": 1, "kind": "port",
@@ -222,9 +283,10 @@ def roofline_of(records, workload_tag):
 
 
 # ------------------------------------------------------------------------------------------------- one rank
-MODEL_FILES = {2: ["face_detection_back.tflite"], 3: ["face_landmark.tflite"],
+MIN_TIMED_S = 0.5
+MODEL_FILES = {1: ["face_detection_short_range.tflite"], 2: ["face_detection_back.tflite"], 3: ["face_landmark.tflite"],
                5: ["face_detection_full_range.tflite", "face_landmark.tflite", "iris_landmark.tflite"]}
-DEFAULT_BATCH = {2: 256, 3: 512, 5: 128}
+DEFAULT_BATCH = {1: 256, 2: 256, 3: 512, 5: 128}
 
 
 def rehearse(args, rank, world):
@@ -270,6 +332,9 @@ def run_rank(args):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.rehearse:
         return rehearse(args, rank, world)
+    if torch.cuda.device_count() < world:     # every rank checks for itself, before anything touches a device
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to run a smaller job under that label\n" % (world, torch.cuda.device_count()))
+        raise SystemExit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -295,9 +360,11 @@ def run_rank(args):
     stream = torch.cuda.Stream(device=device)
     sp = stream.cuda_stream
     x_host = None
-    if args.config == 2:
-        fd = mi.FaceDetection(mi.FaceDetectionModel.BackCamera, device=local_rank, model_bytes=blobs[0])
-        models, tag = [(fd.model, None)], "back256_b%d" % B
+    if args.config in (1, 2):
+        size = 256 if args.config == 2 else 128
+        kind = mi.FaceDetectionModel.BackCamera if args.config == 2 else mi.FaceDetectionModel.Short
+        fd = mi.FaceDetection(kind, device=local_rank, model_bytes=blobs[0])
+        models, tag = [(fd.model, None)], ("back256_b%d" if args.config == 2 else "short128_b%d") % B
         for key in ("fuse", "chunk", "lanes", "heads"):
             if getattr(args, key) is not None:
                 fd.model.set_option(key, getattr(args, key))
@@ -305,7 +372,7 @@ def run_rank(args):
             k, v = kv.split("=")
             fd.model.set_option(k, int(v))
         cap = 16
-        x_host = make_frames(B, seed=rank)
+        x_host = make_frames(B, seed=rank, size=size)
         x = torch.from_numpy(x_host).to(device)
         out = torch.zeros((B, cap, 17), dtype=torch.float32, device=device)
         counts = torch.zeros((B,), dtype=torch.int32, device=device)
@@ -316,9 +383,14 @@ def run_rank(args):
             if L.mi_fd_infer_tensor(h, xp, B, None, op, cap, cp, mi.MI_MEM_DEVICE, spp) != 0:
                 raise RuntimeError(L.mi_last_error().decode())
         found = lambda: int((counts > 0).sum().item())
-        metric, unit = "faces/sec at batch=256 (256x256 back-camera) per GPU", "faces/s"
-        workload = ("BackCamera BlazeFace 256x256, batch=%d frames/GPU, net + SSD decode + sigmoid + weighted NMS (configs[1]%s); "
-                    "50%% noise / 50%% face-bearing frames, inputs resident in HBM" % (B, ", sharded as configs[3]" if world > 1 else ""))
+        if args.config == 2:
+            metric, unit = "faces/sec at batch=256 (256x256 back-camera) per GPU", "faces/s"
+            workload = ("BackCamera BlazeFace 256x256, batch=%d frames/GPU, net + SSD decode + sigmoid + weighted NMS (configs[1]%s); "
+                        "50%% noise / 50%% face-bearing frames, inputs resident in HBM" % (B, ", sharded as configs[3]" if world > 1 else ""))
+        else:
+            metric, unit = "faces/sec at batch=256 (128x128 short-range / front-camera) per GPU", "faces/s"
+            workload = ("ShortRange (= FrontCamera bytes) BlazeFace 128x128, batch=%d frames/GPU, net + SSD decode + sigmoid + weighted NMS "
+                        "(configs[0]'s model on north_star's 128x128 batch); 50%% noise / 50%% face-bearing frames, inputs resident in HBM" % B)
         models[0] = (fd.model, x)
         keep = fd
     elif args.config == 3:
@@ -367,6 +439,24 @@ def run_rank(args):
     elapsed = time.perf_counter() - t0
     elapsed = mdist.max_over_ranks(elapsed, dist, device)
     n_found = found()
+    # ---- the same K-step window again until >= MIN_TIMED_S of device time has been sampled (the first window above stays the
+    # reported one: `ms_per_step` and `value`); median / min over all windows go into extra keys.  The number of windows is
+    # decided from rank 0's clock and shared, so every rank runs the same count.
+    windows = [elapsed]
+    n_extra = max(4, int(MIN_TIMED_S / max(elapsed, 1e-6)) + 1) if not args.single_window else 0
+    n_extra = int(mdist.max_over_ranks(float(min(n_extra, 2000)), dist, device))
+    for _ in range(n_extra):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        windows.append(time.perf_counter() - t0)
+    if dist and n_extra:
+        windows = [mdist.max_over_ranks(w, dist, device) for w in windows[:1]] + \
+                  [float(v) for v in mdist.max_over_ranks_vec(windows[1:], dist, device)]
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events between launches on the launch stream (eager replays of the same plans on
@@ -379,16 +469,22 @@ def run_rank(args):
             "metric": metric, "value": round(value, 1), "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timing": {"windows": len(windows), "steps_per_window": args.steps, "timed_s": round(sum(windows), 4),
+                       "ms_per_step_median": round(sorted(windows)[len(windows) // 2] / args.steps * 1e3, 4),
+                       "ms_per_step_min": round(min(windows) / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(max(windows) / args.steps * 1e3, 4),
+                       "note": "ms_per_step / value = the first window (the driver's K steps); the others repeat it"},
             "config": {"workload": workload, "global_batch": world * B, "frames_with_faces": n_found,
                        "parallelism": "frames sharded %d/GPU, one process per GPU, no data-path collective" % B,
                        "weight_broadcast_ms": round(bcast_ms, 3), "weight_broadcast_bytes": sum(len(b) for b in blobs),
                        "plan": " | ".join(m.describe().splitlines()[0] for m, _ in models)},
             "roofline": roofline_of(recs, tag),
         }
-        if not args.no_cpu_baseline and world == 1 and args.config == 2:  # CPU baseline: rank 0 at N = 1 only
-            threads = min(os.cpu_count() or 1, 64)
-            result["cpu_baseline"] = cpu_baseline(x_host, threads)
-            result["cpu_baseline_1thread"] = cpu_baseline_1thread(x_host)
+        if not args.no_cpu_baseline and world == 1 and args.config in (1, 2):  # CPU baseline: rank 0 at N = 1 only
+            threads = max(1, min(usable_cpus(), B))
+            mf, kd = MODEL_FILES[args.config][0], ("FD_BACK" if args.config == 2 else "FD_SHORT")
+            result["cpu_baseline"] = cpu_baseline(x_host, threads, mf, kd)
+            result["cpu_baseline_1thread"] = cpu_baseline_1thread(x_host, mf, kd)
     keep.close()
     if dist:
         dist.barrier()
@@ -402,8 +498,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5], help="BASELINE config: 2 = headline (4 with --gpus N), 3 = face mesh, 5 = pipeline")
-    ap.add_argument("--batch", type=int, default=None, help="units per GPU (default 256 / 512 / 128 for config 2 / 3 / 5)")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 5],
+                    help="BASELINE config: 2 = headline (4 with --gpus N), 1 = short-range / front 128x128 batch, 3 = face mesh, 5 = pipeline")
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU (default 256 / 256 / 512 / 128 for config 1 / 2 / 3 / 5)")
+    ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (one child process)")
+    ap.add_argument("--single-window", action="store_true", help="time the K steps once only (no repeated windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing over gloo (no kernels)")
     ap.add_argument("--fuse", type=int, default=None)
@@ -414,7 +513,7 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.rehearse):
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.rehearse or args.spawn):
         sys.exit(launch_ranks(args, sys.argv[1:]))
     run_rank(args)
 

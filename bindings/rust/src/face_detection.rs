@@ -38,10 +38,17 @@ impl FaceDetection {
         Ok(FaceDetection { handle })
     }
 
-    /// `infer(&self, image, roi) -> Result<Vec<Detection>>` — face_detection.rs:205-267: image_to_tensor (letterbox to the
+    /// `infer(&self, image: &Mat, roi) -> Result<Vec<Detection>>` — face_detection.rs:205-267.  `image` is anything that turns
+    /// into an `Image` view: `&Mat` (feature `opencv`), `&RgbImage`, `&Image` or an `Image` — so the reference's call
+    /// `face_detection.infer(&mat, None)` compiles unchanged.  Flow: image_to_tensor (letterbox to the
     /// model size, [-1, 1]) -> network -> decode_boxes -> sigmoid -> threshold -> weighted NMS -> letterbox removal, all on
     /// the GPU.  Detections come back in descending head-score order, normalised to the picture.
-    pub fn infer(&self, image: &Image, roi: Option<Rect>) -> Result<Vec<Detection>, Error> {
+    pub fn infer<'a, I>(&self, image: I, roi: Option<Rect>) -> Result<Vec<Detection>, Error>
+    where
+        I: TryInto<Image<'a>>,
+        I::Error: Into<Error>,
+    {
+        let image: Image<'a> = image.try_into().map_err(Into::into)?;
         let c_roi = roi.map(|r| r.to_mi());
         let mut cap = 64usize;
         loop {
@@ -64,6 +71,13 @@ impl FaceDetection {
     pub fn infer_tensor(&self, input: &[f32], batch: usize, padding: &[[f64; 4]], cap_per_frame: usize) -> Result<Vec<Vec<Detection>>, Error> {
         if !padding.is_empty() && padding.len() != batch {
             return Err(Error::msg("padding must be empty or hold one entry per frame"));
+        }
+        // the C side reads batch * H * W * 3 floats: a shorter slice must never reach it from safe code
+        let (mut w, mut h) = (0i32, 0i32);
+        check(unsafe { ffi::mi_fd_input_size(self.handle, &mut w, &mut h) })?;
+        let need = batch.checked_mul(w as usize * h as usize * 3).ok_or_else(|| Error::msg("batch too large"))?;
+        if batch == 0 || batch > i32::MAX as usize || cap_per_frame == 0 || cap_per_frame > i32::MAX as usize || input.len() != need {
+            return Err(Error::msg(format!("input must hold batch x {} x {} x 3 floats ({}), got {}", h, w, need, input.len())));
         }
         let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; batch * cap_per_frame];
         let mut counts = vec![0i32; batch];

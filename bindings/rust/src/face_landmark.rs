@@ -40,7 +40,12 @@ impl FaceLandmark {
 
     /// `infer(&self, image, roi) -> Result<Vec<Landmark>>` — face_landmark.rs:232-306: rotated-ROI warp to 192x192 in [0, 1],
     /// network, face flag (`sigmoid(flag) <= 0.5` gives the empty `Vec`, 292-296), `project_landmarks` back to the picture.
-    pub fn infer(&self, image: &Image, roi: Option<Rect>) -> Result<Vec<Landmark>, Error> {
+    pub fn infer<'a, I>(&self, image: I, roi: Option<Rect>) -> Result<Vec<Landmark>, Error>
+    where
+        I: TryInto<Image<'a>>,
+        I::Error: Into<Error>,
+    {
+        let image: Image<'a> = image.try_into().map_err(Into::into)?;
         let c_roi = roi.map(|r| r.to_mi());
         let mut out = vec![ffi::mi_landmark::default(); ffi::MI_NUM_FACE_LANDMARKS];
         let mut n: i32 = 0;

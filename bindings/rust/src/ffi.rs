@@ -52,6 +52,7 @@ extern "C" {
     pub fn mi_fd_create(kind: c_int, model_dir: *const c_char, device: c_int, out: *mut *mut mi_fd) -> c_int;
     pub fn mi_fd_create_from_bytes(kind: c_int, tflite: *const u8, nbytes: usize, device: c_int, out: *mut *mut mi_fd) -> c_int;
     pub fn mi_fd_free(h: *mut mi_fd);
+    pub fn mi_fd_input_size(h: *const mi_fd, width: *mut c_int, height: *mut c_int) -> c_int;
     pub fn mi_fd_infer_image(h: *mut mi_fd, rgb: *const u8, width: c_int, height: c_int, stride: c_int, roi: *const mi_rect,
                              out: *mut mi_detection, cap: c_int, count: *mut c_int) -> c_int;
     pub fn mi_fd_infer_tensor(h: *mut mi_fd, input: *const c_float, batch: c_int, padding: *const c_double, out: *mut mi_detection,

@@ -61,7 +61,12 @@ impl IrisLandmark {
 
     /// `infer(&self, image, roi, is_right_eye) -> Result<IrisResults>` — iris_landmark.rs:158-248: letterboxed ROI warp to
     /// 64x64 in [0, 1] (flipped for the right eye), network, both outputs projected back (x mirrored for the right eye).
-    pub fn infer(&self, image: &Image, roi: Option<Rect>, is_right_eye: Option<bool>) -> Result<IrisResults, Error> {
+    pub fn infer<'a, I>(&self, image: I, roi: Option<Rect>, is_right_eye: Option<bool>) -> Result<IrisResults, Error>
+    where
+        I: TryInto<Image<'a>>,
+        I::Error: Into<Error>,
+    {
+        let image: Image<'a> = image.try_into().map_err(Into::into)?;
         let c_roi = roi.map(|r| r.to_mi());
         let mut contour = vec![ffi::mi_landmark::default(); ffi::MI_NUM_EYE_LANDMARKS];
         let mut iris = vec![ffi::mi_landmark::default(); ffi::MI_NUM_IRIS_LANDMARKS];

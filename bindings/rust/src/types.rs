@@ -182,25 +182,57 @@ impl IrisResults {
 }
 
 /// Borrowed 8UC3 **RGB** picture — the role `&opencv::core::Mat` plays in the reference (utils.rs:8-21).  `stride` = bytes
-/// per row (>= 3 * width); a strided view such as a `Mat` ROI is fine.
+/// per row (>= 3 * width); a strided view such as a `Mat` ROI is fine.  The fields are private: the only way to make one is
+/// `Image::new` (or a `TryFrom` below), which checks the buffer against the geometry, so the C library never reads past
+/// `data` on behalf of safe code.
 #[derive(Debug, Clone, Copy)]
 pub struct Image<'a> {
-    pub data: &'a [u8],
-    pub width: i32,
-    pub height: i32,
-    pub stride: i32,
+    pub(crate) data: &'a [u8],
+    pub(crate) width: i32,
+    pub(crate) height: i32,
+    pub(crate) stride: i32,
 }
 
 impl<'a> Image<'a> {
     pub fn new(data: &'a [u8], width: i32, height: i32, stride: i32) -> Result<Image<'a>, anyhow::Error> {
-        if width <= 0 || height <= 0 || stride < 3 * width {
+        if width <= 0 || height <= 0 || (stride as i64) < 3 * width as i64 {
             return Err(anyhow::Error::msg("bad image geometry"));
         }
-        let need = (height as usize - 1) * stride as usize + 3 * width as usize;
+        let need = (height as usize - 1)
+            .checked_mul(stride as usize)
+            .and_then(|v| v.checked_add(3 * width as usize))
+            .ok_or_else(|| anyhow::Error::msg("image geometry overflows"))?;
         if data.len() < need {
             return Err(anyhow::Error::msg("image buffer shorter than its geometry"));
         }
         Ok(Image { data, width, height, stride })
+    }
+    pub fn data(&self) -> &'a [u8] {
+        self.data
+    }
+    pub fn width(&self) -> i32 {
+        self.width
+    }
+    pub fn height(&self) -> i32 {
+        self.height
+    }
+    pub fn stride(&self) -> i32 {
+        self.stride
+    }
+}
+
+/// `infer(&image, ..)` with an `Image` view: the generic `infer<I: TryInto<Image>>` takes it by reference like a `&Mat`.
+impl<'a, 'b> From<&'b Image<'a>> for Image<'a> {
+    fn from(v: &'b Image<'a>) -> Image<'a> {
+        *v
+    }
+}
+
+impl<'a> TryFrom<&'a crate::utils::RgbImage> for Image<'a> {
+    type Error = anyhow::Error;
+    /// the picture `convert_image_to_mat` returns, passed to `infer` by reference as the reference passes its `&Mat`
+    fn try_from(m: &'a crate::utils::RgbImage) -> Result<Image<'a>, anyhow::Error> {
+        Image::new(m.data(), m.width(), m.height(), 3 * m.width())
     }
 }
 

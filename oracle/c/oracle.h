@@ -5,13 +5,20 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing in the product path
  * (rs-face-detection-tflite_amd/) may include, link or call anything declared here.
  *
- * PARITY UNPINNED: the reference (okieraised/rs-face-detection-tflite @ 2024-10-16) cannot be built in this
- * image (no Rust toolchain, no TensorFlow-Lite, no OpenCV) and its tests hold no numeric assertions
- * (SURVEY.md §4, §8c).  The only result pins are the rendered PNGs in assets/ (checked to ±2 px by
- * tests/test_pins.py).  The network arithmetic lives in a third-party dependency that is absent from
- * /root/reference: the `tflite` crate 0.9.8 (Cargo.toml:14, Cargo.lock:1502-1505), which wraps Google's
- * TensorFlow-Lite C++ runtime; interp.c restates the published float builtin-kernel semantics and is
- * cross-checked against an independent torch-CPU evaluation (oracle/np/evaluate.py).
+ * PARITY PIN: the reference (okieraised/rs-face-detection-tflite @ 2024-10-16) cannot be built in this image (no Rust
+ * toolchain, no TensorFlow-Lite, no OpenCV: no oracle/_ref) and its tests hold no numeric assertions.
+ * What its tests DO hold is the output of its own run on test_data/man.jpg (BackCamera -> mesh -> iris) rendered into three
+ * PNGs under assets/.  This oracle's results on man.jpg, drawn by the restated renderer (oracle/render.py), reproduce the
+ * annotation pixels of all three PNGs exactly — 552 + 2414 + 150 pixels, 0 mismatches (tests/test_pins.py) — which pins
+ * 4 + 936 + 60 truncated pixel coordinates of the reference's own TFLite + OpenCV run (every truncation lands on the same
+ * integer, i.e. agreement to < 1 px absolutely and about 0.005 px statistically).  That is the resolution of the pin: it is
+ * not a float-level pin, and it covers the BackCamera detector, the 468 mesh points (x, y) and the first 15 contour points
+ * of each eye on ONE picture.  NOT pinned by any reference-held fixture (none exists): the Front / Short / Full / FullSparse
+ * detectors, the 5 iris points and contour points 15-70, every z and every score — those rest on this dtype-for-dtype
+ * restatement and on the independent second evaluation (oracle/np/evaluate.py), which agree bit for bit on five graphs.
+ * The network arithmetic lives in a third-party dependency that is absent from /root/reference: the `tflite` crate 0.9.8
+ * (Cargo.toml:14, Cargo.lock:1502-1505), which wraps Google's TensorFlow-Lite C++ runtime; interp.c restates the published
+ * float builtin-kernel semantics.
  *
  * Every function cites the reference file:line it follows (paths relative to /root/reference).
  */

@@ -9,7 +9,8 @@ What it stands in for: the third-party TensorFlow-Lite runtime behind the `tflit
 iris_landmark.rs:203).  The runtime's source is not under /root/reference; op semantics follow the published TFLite
 builtin float kernels.
 
-PARITY UNPINNED: the reference's tests hold no numeric assertions for this path.
+Pin: the reference's tests hold no numeric assertions for this path; the C oracle this module cross-checks is
+pinned by the reference's rendered PNGs on man.jpg, pixel for pixel (tests/test_pins.py, oracle/c/oracle.h).
 """
 from __future__ import annotations
 

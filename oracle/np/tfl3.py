@@ -8,7 +8,8 @@ The reference never parses these files itself: it hands them to the third-party 
 face_landmark.rs:216, iris_landmark.rs:150).  The field indices below follow the published TFLite
 schema v3 (schema.fbs) — see SURVEY.md Appendix B, verified there against all seven shipped graphs.
 
-PARITY UNPINNED: the reference's tests hold no numeric assertions for this path.
+Pin: the reference's tests hold no numeric assertions for this path; the C oracle this module cross-checks is
+pinned by the reference's rendered PNGs on man.jpg, pixel for pixel (tests/test_pins.py, oracle/c/oracle.h).
 """
 from __future__ import annotations
 

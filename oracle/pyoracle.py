@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE — ctypes binding of the C oracle (oracle/liboracle.so, see oracle/c/oracle.h).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product path
-(rs-face-detection-tflite_amd/) never does.  PARITY UNPINNED (see oracle/c/oracle.h).
+(rs-face-detection-tflite_amd/) never does.  Pinned by the reference's own rendered PNGs, pixel for pixel, on man.jpg
+(tests/test_pins.py); what that pin covers and what it does not is stated in oracle/c/oracle.h.
 """
 from __future__ import annotations
 

@@ -332,8 +332,13 @@ Graph parse_tflite(const uint8_t* data, size_t size) {
         op.op = static_cast<BuiltinOp>(op.raw_code);
         op.inputs = o.ints(1);
         op.outputs = o.ints(2);
-        for (int t : op.inputs)  // -1 = optional input absent; anything below is malformed
-            if (t < -1 || t >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tflite: tensor index out of range");
+        for (size_t k = 0; k < op.inputs.size(); k++) {
+            // -1 = optional input absent: only the bias slot of a convolution is optional in the operators taken here; a -1
+            // anywhere else (an activation, a filter, PAD's paddings ...) is a malformed model, refused before any g.tensors[t]
+            int t = op.inputs[k];
+            bool optional_slot = k >= 2 && (op.op == BuiltinOp::Conv2D || op.op == BuiltinOp::DepthwiseConv2D);
+            if (t < (optional_slot ? -1 : 0) || t >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tflite: tensor index out of range");
+        }
         for (int t : op.outputs)
             if (t < 0 || t >= static_cast<int>(g.tensors.size())) throw std::runtime_error("tflite: tensor index out of range");
         if (op.outputs.empty()) throw std::runtime_error("tflite: operator without outputs");

@@ -40,6 +40,16 @@ def max_over_ranks(seconds: float, dist, device) -> float:
     return float(t.item())
 
 
+def max_over_ranks_vec(seconds, dist, device):
+    """Element-wise max over ranks of a list of timings (one all-reduce)."""
+    import torch
+    if dist is None or dist.get_world_size() == 1 or not len(seconds):
+        return list(seconds)
+    t = torch.tensor(list(seconds), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.tolist()
+
+
 def gather_counts(counts, dist, device):
     """Optional result collection: per-rank detection counts -> list over ranks (fixed-size records, no padding issue)."""
     import torch

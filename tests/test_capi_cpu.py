@@ -148,3 +148,38 @@ def test_rust_shim_declarations_match_the_header():
         text = re.sub(r'"(?:[^"\\]|\\.)*"', '""', text)
         for a, b in ("{}", "()", "[]"):
             assert text.count(a) == text.count(b), (f, a)
+
+
+def test_absent_operand_is_refused_not_dereferenced(mi):
+    """-1 ("optional input absent") is legal only in a convolution's bias slot.  A model with -1 as an activation,
+    filter, skip, slope or paddings operand must end in MI_EMODEL from the parser — the lowering indexes g.tensors[operand]."""
+    import synth_tflite as st
+
+    def graph(mutate=None):
+        gb = st.GraphBuilder(3, [1, 16, 16, 8])
+        x = gb.blaze_block(gb.input, 8)
+        x = gb.prelu(gb.conv(x, 8))
+        x = gb.blaze_block(x, 16, stride=2)       # max-pool + channel PAD on the skip
+        gb.outputs = [x]
+        ops = list(gb.ops)
+        if mutate:
+            mutate(gb.ops)
+        return gb.finish(), ops
+
+    blob, ops = graph()
+    mi.plan_describe(blob, 5)                     # the unmodified graph lowers
+    refused = accepted = 0
+    for i, op in enumerate(ops):
+        for slot in range(len(op[1])):
+            def mutate(ops_, i=i, slot=slot):
+                code, ins, outs, tag, opt = ops_[i]
+                ops_[i] = (code, [(-1 if k == slot else t) for k, t in enumerate(ins)], outs, tag, opt)
+            bias_slot = slot == 2 and op[0] in (st.CONV_2D, st.DEPTHWISE_CONV_2D)
+            try:
+                mi.plan_describe(graph(mutate)[0], 5)
+                assert bias_slot, "operand %d of op %d (builtin %d) absent, yet the model was accepted" % (slot, i, op[0])
+                accepted += 1
+            except mi.MiError:
+                assert not bias_slot
+                refused += 1
+    assert refused >= len(ops) and accepted >= 4

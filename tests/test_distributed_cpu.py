@@ -90,6 +90,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "3", "--config", str(cfg)],
                            capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
+        assert "torch imported in the launcher: False" in r.stderr      # the parent never loads torch (so it cannot touch HIP)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1                                     # exactly one JSON line, from rank 0
         out = json.loads(lines[0])
@@ -102,7 +103,28 @@ def test_bench_launches_its_own_ranks(tmp_path):
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode == 2 and "visible" in r.stderr
+        assert "torch imported in the launcher: False" in r.stderr or "[rank" not in r.stderr   # refused by sysfs count or by the ranks
     # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--rehearse"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_launcher_parent_stays_clear_of_torch_and_hip():
+    """The process that starts the ranks must not have initialised the GPU: it may not even import torch (whose device count can
+    fall through to hipGetDeviceCount).  Importing bench.py and running its launcher (one rehearsal rank through --spawn) leaves
+    torch, numpy and ctypes-loaded HIP libraries out of the parent."""
+    import subprocess
+    import sys
+    code = ("import sys, argparse; sys.path.insert(0, %r); import bench; "
+            "assert 'torch' not in sys.modules and 'numpy' not in sys.modules; "
+            "n = bench.kfd_gpu_nodes(); assert n is None or n >= 0; "
+            "a = argparse.Namespace(gpus=1, rehearse=True); "
+            "rc = bench.launch_ranks(a, ['--gpus', '1', '--rehearse', '--spawn', '--steps', '2']); "
+            "assert rc == 0, rc; assert 'torch' not in sys.modules and 'numpy' not in sys.modules; "
+            "maps = open('/proc/self/maps').read(); assert 'libamdhip64' not in maps and 'libhsa-runtime' not in maps and 'libamd_smi' not in maps; "
+            "print('clean')") % ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
+    assert '"n_gpus": 1' in r.stdout
