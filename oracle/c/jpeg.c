@@ -25,6 +25,8 @@ typedef struct {
     uint32_t bitbuf;
     int bits;
     int marker;  /* a marker met inside the entropy-coded data (0 = none) */
+    int fake;    /* the byte in bitbuf is padding behind a marker / the end of the data, not stream data */
+    int insufficient; /* a padding bit was consumed: jdhuff.c's insufficient_data (the MCUs that follow stay zero) */
 } bitreader;
 
 typedef struct {
@@ -63,18 +65,21 @@ static void build_huff(hufftab *h) { /* T.81 Annex C / F.2.2.3 */
 static int get_bit(bitreader *br) {
     if (br->bits == 0) {
         int byte = 0;
+        br->fake = 1;
         if (br->marker == 0 && br->p < br->end) {
+            br->fake = 0;
             byte = *br->p++;
             if (byte == 0xFF) {
                 int nx = br->p < br->end ? *br->p : 0xD9;
                 if (nx == 0x00) br->p++;             /* stuffed zero */
-                else { br->marker = nx; byte = 0; br->p--; } /* marker: feed zeros from here on (libjpeg does the same) */
+                else { br->marker = nx; byte = 0; br->p--; br->fake = 1; } /* marker: feed zeros from here on (libjpeg does the same) */
             }
         }
         br->bitbuf = (uint32_t)byte;
         br->bits = 8;
     }
     br->bits--;
+    if (br->fake) br->insufficient = 1; /* jdhuff.c jpeg_fill_bit_buffer: "if (nbits > bits_left) ... insufficient_data = TRUE" */
     return (int)((br->bitbuf >> br->bits) & 1);
 }
 static int get_bits(bitreader *br, int n) {
@@ -247,17 +252,21 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
                 comp[c].plane = (uint8_t *)malloc((size_t)comp[c].bw * comp[c].bh * 64);
                 if (!comp[c].coef || !comp[c].plane) goto done;
             }
-            bitreader br = {data + i + 2 + len, data + n, 0, 0, 0};
+            bitreader br = {data + i + 2 + len, data + n, 0, 0, 0, 0, 0};
             int mcus = 0;
             for (int my = 0; my < mcuy; my++)
                 for (int mx = 0; mx < mcux; mx++) {
                     if (restart && mcus > 0 && mcus % restart == 0) { /* RSTn: byte-align, skip the marker, reset the predictors */
                         br.bits = 0;
-                        if (br.marker >= 0xD0 && br.marker <= 0xD7) { br.p += 2; br.marker = 0; }              /* already met by the bit reader */
-                        else if (br.marker == 0 && br.p + 1 < br.end && br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7) br.p += 2;
+                        if (br.marker >= 0xD0 && br.marker <= 0xD7) { br.p += 2; br.marker = 0; br.insufficient = 0; } /* already met by the bit reader */
+                        else if (br.marker == 0 && br.p + 1 < br.end && br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7) { br.p += 2; br.insufficient = 0; }
                         for (int c = 0; c < ncomp; c++) comp[c].pred = 0;
                     }
                     mcus++;
+                    /* jdhuff.c decode_mcu: "If we've run out of data, just leave the MCU set to zeroes": the MCU in which the data
+                     * ran out is finished on padding zeros, the ones behind it are not decoded (uniform grey) until a restart
+                     * marker is found again (process_restart clears the flag only then) */
+                    if (br.insufficient) continue;
                     for (int c = 0; c < ncomp; c++)
                         for (int by = 0; by < comp[c].v; by++)
                             for (int bx = 0; bx < comp[c].h; bx++) {

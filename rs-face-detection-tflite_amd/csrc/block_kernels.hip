@@ -44,15 +44,7 @@ namespace {
 
 constexpr int kPrefetch = 8;          // float4 registers per thread for the next step's rows
 constexpr int kALdsMax = 40 * 1024;   // pointwise weights are staged in LDS when they fit in this many bytes
-// compute units of the current device (MI355X: 256); asked once, 256 when no device answers (host-only planning)
-static int cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
+static int cu_count() { return device_cu_count(); }  // launch.hpp: per device
 
 int lds_budget() {
     static const int v = getenv("MI_BLOCK_LDS") ? atoi(getenv("MI_BLOCK_LDS")) : 80 * 1024;  // tuning aid
@@ -584,12 +576,7 @@ bool make_geom(const BlockArgs& a, BlockGeom* out) {
 template <int MTG, int S, int KS, int PG, bool SLOW, int CPT, bool ALDS>
 int launch_inst4(const BlockArgs& a, const BlockGeom& g, hipStream_t s) {
     auto kern = block_kernel<MTG, S, KS, PG, SLOW, CPT, ALDS>;
-    static bool configured = false;  // one attribute call per instantiation (one GPU per process here)
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     return (int)launch_kernel(kern, dim3((unsigned)(a.B * g.bands * g.nsplit)), dim3(256), (size_t)g.lds_bytes, s, a, g);
 }
 

@@ -396,24 +396,12 @@ bool make_bneck_geom(const BneckArgs& a, BneckGeom* out) {
     return true;
 }
 
-int bneck_cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
+int bneck_cu_count() { return device_cu_count(); }  // launch.hpp: per device
 
 template <int MT, int MTA, bool WL>
 int launch_bneck_inst(const BneckArgs& a, const BneckGeom& g, hipStream_t s) {
     auto kern = bneck_kernel<MT, MTA, WL>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     // row bands: one workgroup per CU walks over its share of the bands (the next band's x in flight under the current band's MFMAs)
     unsigned grid = (unsigned)(a.B * a.bands);
     if (WL) grid = std::min(grid, (unsigned)bneck_cu_count());  // walking kernels: one workgroup per CU

@@ -507,12 +507,7 @@ bool make_chain_geom(const ChainArgs& a, ChainGeom* out) {
 template <int MT, bool SPLIT>
 int launch_chain_inst(const ChainArgs& a, const ChainGeom& g, hipStream_t s) {
     auto kern = chain_kernel<MT, SPLIT>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     return (int)launch_kernel(kern, dim3((unsigned)a.B), dim3(512), (size_t)g.lds_bytes, s, a, g);
 }
 

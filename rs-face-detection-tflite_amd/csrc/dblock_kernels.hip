@@ -340,24 +340,12 @@ bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
     return true;
 }
 
-int dblock_cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
+int dblock_cu_count() { return device_cu_count(); }  // launch.hpp: per device
 
 template <int MT, int MTA>
 int launch_dblock_inst(const DblockArgs& a, const DblockGeom& g, hipStream_t s) {
     auto kern = dblock_kernel<MT, MTA>;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     const unsigned grid = (unsigned)std::min<long>((long)a.B * g.bands, dblock_cu_count());
     return (int)launch_kernel(kern, dim3(grid), dim3(512), (size_t)g.lds_bytes, s, a, g);
 }

@@ -28,7 +28,9 @@ struct Huff {
         present = false;
         std::memset(look, 0, sizeof look);
         for (int l = 1; l <= 16; l++) {
-            if (code + counts[l] > (1 << l)) return false;
+            // jdhuff.c jpeg_make_d_derived_tbl: after the codes of length l "code is now 1 more than the last code used ...
+            // it must still fit in si bits, since no code is allowed to be all ones": code + counts[l] >= 2^l is a bad table
+            if (counts[l] && code + counts[l] >= (1 << l)) return false;
             valoff[l] = k - code;
             for (int i = 0; i < counts[l]; i++, code++, k++)
                 if (l <= kLook)
@@ -46,16 +48,19 @@ struct Bits {
     const uint8_t *p, *end;
     uint64_t buf = 0;
     int n = 0;
+    int real = 0;               // how many of the n buffered bits are stream data (the rest is padding behind a marker / the end)
+    bool insufficient = false;  // a padding bit was consumed: jdhuff.c's insufficient_data
     bool hit_marker = false;
     void fill() {  // keep at least 32 bits; past a marker (or the end) the stream reads as zeros, like libjpeg
         while (n <= 56) {
             unsigned byte = 0;
             if (!hit_marker && p < end) {
                 byte = *p++;
+                real += 8;
                 if (byte == 0xFF) {
                     unsigned nx = p < end ? *p : 0xD9u;
                     if (nx == 0) p++;
-                    else { hit_marker = true; byte = 0; p--; }
+                    else { hit_marker = true; byte = 0; p--; real -= 8; }
                 }
             }
             buf |= static_cast<uint64_t>(byte) << (56 - n);
@@ -63,7 +68,10 @@ struct Bits {
         }
     }
     unsigned peek(int k) { return static_cast<unsigned>(buf >> (64 - k)); }
-    void skip(int k) { buf <<= k; n -= k; }
+    void skip(int k) {
+        buf <<= k; n -= k;
+        if ((real -= k) < 0) { real = 0; insufficient = true; }
+    }
     int get(int k) {
         if (k == 0) return 0;
         if (n < k) fill();
@@ -87,10 +95,10 @@ struct Bits {
         skip(16);
         return 0;  // corrupt stream: libjpeg warns and substitutes 0
     }
-    void restart() {  // byte-align and step over RSTn
-        n = 0; buf = 0;
-        if (hit_marker) { if (p + 1 < end && p[1] >= 0xD0 && p[1] <= 0xD7) { p += 2; hit_marker = false; } }
-        else if (p + 1 < end && p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) p += 2;
+    void restart() {  // byte-align and step over RSTn; data found again ends the run of skipped MCUs (jdhuff.c process_restart)
+        n = 0; buf = 0; real = 0;
+        if (hit_marker) { if (p + 1 < end && p[1] >= 0xD0 && p[1] <= 0xD7) { p += 2; hit_marker = false; insufficient = false; } }
+        else if (p + 1 < end && p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) { p += 2; insufficient = false; }
     }
 };
 
@@ -216,9 +224,12 @@ void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
         cp.coef_off = total;
         total += static_cast<size_t>(cp.bw) * cp.bh * 64;
     }
-    // every block costs at least two bits of entropy-coded data (one DC and one AC symbol): a header that promises more
-    // blocks than the remaining bytes can hold is refused before its coefficient buffer is allocated
-    if (total / 64 > 4 * (n - ecs) + 64) bad("truncated stream (fewer entropy-coded bytes than the frame header needs)");
+    // A short entropy-coded segment is NOT an error (libjpeg pads it with zeros, warns and returns a picture whose tail is grey:
+    // the `insufficient` flag below).  What is refused is the allocation bomb: a few header bytes that promise a huge frame.
+    // Every block costs at least two bits of entropy-coded data (one DC and one AC symbol); a header asking for more than 32 MiB
+    // of coefficients that the remaining bytes cannot possibly hold is refused before the buffer is allocated.
+    if (total * sizeof(int16_t) > (32u << 20) && total / 64 > 4 * (n - ecs) + 64)
+        bad("truncated stream (fewer entropy-coded bytes than the frame header needs)");
     f.coef.assign(total, 0);
     Bits br{data + ecs, data + n};
     int pred[3] = {0, 0, 0};
@@ -230,6 +241,7 @@ void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
                 pred[0] = pred[1] = pred[2] = 0;
             }
             mcus++;
+            if (br.insufficient) continue;  // jdhuff.c decode_mcu: out of data -> "leave the MCU set to zeroes" until a restart marker is found
             for (int c = 0; c < f.ncomp; c++) {
                 const JpegComponent& cp = f.comp[c];
                 const Huff &hd = p.dc[cp.td], &ha = p.ac[cp.ta];

@@ -15,7 +15,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
+#include <mutex>
+#include <set>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -77,6 +80,34 @@ inline hipError_t launch_kernel(void (*kern)(KArgs...), dim3 grid, dim3 block, s
     }
     hipLaunchKernelGGL(kern, grid, block, shmem, s, std::forward<Args>(args)...);
     return hipGetLastError();
+}
+
+// Per-device launcher state.  A process may hold handles on several devices (every mi_*_create takes a device ordinal) and
+// call them from several threads, so nothing here is a plain function-local flag.
+
+// compute units of the CURRENT device (MI355X: 256); 256 when no device answers (host-only planning: mi_plan_describe)
+inline int device_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if ((v = cache[dev].load(std::memory_order_relaxed)) > 0) return v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize = the CU's 160 KB) once per (kernel, device)
+inline hipError_t allow_full_lds(const void* func) {
+    static std::mutex m;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(m);
+    if (done.count({func, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({func, dev});
+    return e;
 }
 
 inline hipError_t record_event(hipEvent_t ev, hipStream_t s) {

@@ -367,6 +367,7 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
             int K = 1, sh = 1;
             if (n.kind == Node::Conv) {
                 if (n.KH != n.KW || n.res >= 0) return false;
+                if (n.ept >= 0 || n.epl >= 0) return false;  // a folded spatial PAD: the k x k stride-k gather has no border
                 K = n.KH; sh = n.sh;
                 const bool whole = H == K && W == K;  // the window is the frame: one output pixel whatever the stride
                 if (!whole && (n.sh != K || n.sw != K || H % K || W % K)) return false;
@@ -761,7 +762,36 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
 
 }  // namespace
 
+namespace {
+Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads);
+
+// The chain's output heads and the batch-GEMM heads are chosen before storage exists (placeholder pointers, 16-byte aligned); the
+// kernels need the real views 16-byte aligned with frame strides that are multiples of 4 floats.  A head whose slice of a
+// concatenated output starts at an odd offset (e.g. 15 x 15 anchors) fails that: such a graph is lowered again without them.
+bool head_views_aligned(const Plan& plan) {
+    auto aligned = [&](int t) {
+        if (t < 0) return true;
+        const Storage& s = plan.storage[t];
+        return (s.offset & 3) == 0 && (s.frame_stride & 3) == 0;
+    };
+    for (const Node& n : plan.nodes) {
+        if (n.kind == Node::Chain)
+            for (const Node& h : n.head_nodes)
+                if (!aligned(h.out)) return false;
+        if (n.kind == Node::Conv && n.gemm_head && !(aligned(n.out) && aligned(n.in[0]))) return false;
+    }
+    return true;
+}
+}  // namespace
+
 Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes) {
+    Plan plan = build_plan_impl(graph, fuse_level, pipe_max_opt, res_budget_bytes, true);
+    if (head_views_aligned(plan)) return plan;
+    return build_plan_impl(std::move(graph), fuse_level, pipe_max_opt, res_budget_bytes, false);
+}
+
+namespace {
+Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads) {
     Plan plan;
     plan.graph = std::move(graph);
     plan.fuse_level = fuse_level;
@@ -968,7 +998,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
                 const int t = src == 0 ? tout : t_post;
                 if (t < 0) continue;
                 std::vector<size_t> hs = heads_on(t, next);
-                if (hs.empty() || hs.size() > 2) continue;
+                if (!fuse_heads || hs.empty() || hs.size() > 2) continue;
                 // a = the head whose channel count is a multiple of 4 (the regressors), b = the other one
                 auto co = [&](size_t k) { return g.tensors[plan.nodes[k].out].shape.back(); };
                 size_t ka = hs[0], kb = hs.size() > 1 ? hs[1] : static_cast<size_t>(-1);
@@ -1070,7 +1100,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
             if (si.size() != 4 || so.size() != 4 || si[1] != n.KH || si[2] != n.KW || so[1] != 1 || so[2] != 1) continue;
             if (n.padding != Padding::Valid && !(n.KH == 1 && n.KW == 1)) continue;
             if (si[1] * si[2] < 2) continue;  // 1x1 frames: pointwise, the stage programs / block kernels have them
-            n.gemm_head = head_gemm_supports(n.KH * n.KW * si[3], so[3]);
+            n.gemm_head = fuse_heads && head_gemm_supports(n.KH * n.KW * si[3], so[3]);
         }
     }
 
@@ -1198,6 +1228,7 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
     (void)same_pad;
     return plan;
 }
+}  // namespace
 
 std::string Plan::describe() const {
     static const char* kinds[] = {"conv", "dw", "block", "add", "act", "maxpool", "pad", "reshape", "concat", "resize", "d2s", "chain", "resident"};

@@ -462,12 +462,7 @@ int resident_const_floats(const ResStage& st) {
 
 int launch_resident(const ResLaunch& a, void* stream) {
     if (!a.prog || a.nstages < 1 || a.B < 1 || a.bands < 1 || a.lds_bytes > 160 * 1024 || a.const_floats > kResConstMax) return (int)hipErrorInvalidValue;
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resident_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(resident_kernel)); e != hipSuccess) return (int)e;
     return (int)launch_kernel(resident_kernel, dim3((unsigned)(a.B * a.bands)), dim3(512), (size_t)a.lds_bytes, (hipStream_t)stream, a.prog, a.nstages,
                               a.const_off, a.const_floats, a.bands, a.bases,
 #ifdef MI_RES_STAMPS

@@ -1106,12 +1106,7 @@ int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
     const bool two = pa.rows_per_step == 2;
     auto kern = two ? strip_pipe2_kernel<CQ, KB, RELU, NH2> : strip_pipe_kernel<CQ, KB, RELU, NH2>;
     const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + (two ? 10 : 6) * K::BUF_F) * 4;
-    static bool configured[2] = {false, false};
-    if (!configured[two]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured[two] = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     const int wgs = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
     return (int)launch_kernel(kern, dim3((unsigned)wgs), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds_bytes, s, pa);
 }
@@ -1147,12 +1142,7 @@ int launch_strip_inst(const BlockArgs& a, hipStream_t s) {
     sa.stamps = g_strip_stamps;
     const long waves = (long)a.B * sa.strips * sa.bands;
     const size_t lds_bytes = (size_t)4 * K::WAVE_F * 4;  // 4 waves x 2 row buffers
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     return (int)launch_kernel(kern, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_bytes, s, sa);
 }
 

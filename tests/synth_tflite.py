@@ -265,7 +265,7 @@ def iris_like(seed, h, w, c=64, cm=32, pairs=2, down=True):
     return g.finish()
 
 
-def back_like(seed, size, c0=24, n1=3, n2=3):
+def back_like(seed, size, c0=24, n1=3, n2=3, coarse_first=False):
     """stem 5x5 s2 -> n1 BlazeBlocks(c0) -> s2 block to 2 c0 -> n2 blocks -> s2 block to 4 c0 -> 3 blocks -> s2 block -> 2 blocks; SSD-style
     heads on the last two resolutions, reshaped and concatenated like the detectors' outputs."""
     g = GraphBuilder(seed, [1, size, size, 3])
@@ -284,7 +284,7 @@ def back_like(seed, size, c0=24, n1=3, n2=3):
         x = g.blaze_block(x)
     b = x
     regs, clss = [], []
-    for t, anchors in ((a, 2), (b, 6)):
+    for t, anchors in (((b, 6), (a, 2)) if coarse_first else ((a, 2), (b, 6))):   # coarse_first: concatenated in the other order
         n, h, w, _ = g.shape(t)
         clss.append(g.reshape(g.conv(t, anchors), [1, h * w * anchors, 1]))
         regs.append(g.reshape(g.conv(t, anchors * 16), [1, h * w * anchors, 16]))
@@ -349,6 +349,7 @@ CASES = {
     "iris_24x24_fallback": (lambda: iris_like(14, 48, 48, 64, 32, 1), 48, 48),            # band rows do not tile 32-pixel groups: stage programs
     "back_96": (lambda: back_like(21, 96), 96, 96),                                        # chains at 12x12x96 / 6x6x96 with edges and heads
     "back_160_c16": (lambda: back_like(22, 160, 16, 2, 4), 160, 160),                      # 16-channel pipelines, 20x20 / 10x10 chains
+    "back_48_odd_head_slices": (lambda: back_like(24, 48, coarse_first=True), 48, 48),     # 3x3 heads first: the 6x6 classifier's slice of the concatenation starts at float 54 (not 16-byte aligned)
     "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads
     "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
     "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames

@@ -510,6 +510,45 @@ def test_batch256_properties(gpu, gold):
     fd.close()
 
 
+def test_config2_batch256_originals_vs_oracle(gpu, oracle, gold):
+    """BASELINE config 2 at full size, oracle-checked: 256 frames = 8 distinct frames (four face-bearing:
+    plain, mirrored, rolled, dimmed; four noise) repeated 32 times in a shuffled order.  Every copy must reproduce its original
+    bit for bit (frames are independent whatever workgroup / strip / band they land in), and the 8 originals are compared with
+    the oracle detection by detection.  The same for BASELINE config 1's batch (ShortRange, 128x128)."""
+    torch = pytest.importorskip("torch")
+    for kind, name, size, okind in ((gpu.FaceDetectionModel.BackCamera, "back", 256, oracle.FD_BACK), (gpu.FaceDetectionModel.Short, "short", 128, oracle.FD_SHORT)):
+        fd = gpu.FaceDetection(kind)
+        rs = np.random.RandomState(9)
+        u8 = gold["man_back_u8"].astype(np.float64)
+        if size == 128:
+            u8 = u8.reshape(128, 2, 128, 2, 3).mean(axis=(1, 3))
+        face = (u8 * 2.0 / 255.0 - 1.0).astype(np.float32)
+        base = np.stack([face, face[:, ::-1].copy(), np.roll(face, (size // 9, -size // 12), axis=(0, 1)), face * np.float32(0.8)] +
+                        [rs.uniform(-1, 1, face.shape).astype(np.float32) for _ in range(4)])
+        order = rs.permutation(256) % 8
+        out, counts = fd.infer_tensor(torch.from_numpy(base[order]).cuda(), cap=16)
+        torch.cuda.synchronize()
+        out, counts = out.cpu().numpy(), counts.cpu().numpy()
+        first = {int(k): int(np.where(order == k)[0][0]) for k in range(8)}
+        for i in range(256):
+            j = first[int(order[i])]
+            assert counts[i] == counts[j]
+            np.testing.assert_array_equal(out[i, : counts[i]], out[j, : counts[j]])
+        om = oracle.Model(model_path(name))
+        rb, rsc = om.run(base, nthreads=8)
+        anchors = oracle.ssd_anchors(okind)
+        found = 0
+        for k in range(8):
+            want = oracle.fd_postprocess(rb[k], rsc[k], anchors, float(size))
+            j = first[k]
+            assert counts[j] == len(want), (name, k, counts[j], len(want))
+            if len(want):
+                np.testing.assert_allclose(out[j, : len(want)], want, atol=2e-5)
+                found += 1
+        assert found >= 4            # the four face-bearing originals carry a detection
+        fd.close()
+
+
 def test_config3_landmark_batch512_properties(gpu, oracle, gold):
     """BASELINE config 3 at full size (512 ROIs 192x192 through the face-mesh net + projection + face flag): the batch is 8
     distinct ROIs repeated 64 times in a shuffled order, so every copy must reproduce its original bit for bit (frames are

@@ -65,6 +65,8 @@ def test_malformed_huffman_tables_and_sizes_are_refused(mi, oracle):
     bad = ([200] + [0] * 15,            # 200 codes of length 1
            [0, 5] + [0] * 14,           # 5 codes of length 2
            [2, 1] + [0] * 14,           # both 1-bit codes used, then one more
+           [2] + [0] * 15,              # both 1-bit codes used: the second is all ones (jdhuff.c: "no code is allowed to be all ones")
+           [1, 1, 2] + [0] * 13,        # complete tree: its last code is 111
            [1] * 15 + [250])            # the last length overflows 16 bits
     good = ([0] * 8 + [255] + [0] * 7,  # 255 codes of length 9 fit
             [1] * 16)
@@ -95,6 +97,35 @@ def test_gpu_decode_is_bit_exact(mi, oracle, rel):
     assert hashlib.sha256(got.tobytes()).hexdigest() == PINS[rel]["sha256"]
     dev = mi.convert_image_to_mat(data, to_device=True)            # pixels stay in HBM
     np.testing.assert_array_equal(dev.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rel", ["man.jpg", "jpeg/c420_rst3.jpg", "jpeg/c444_rstrow.jpg", "jpeg/grey.jpg"])
+def test_short_entropy_segment_decodes_like_libjpeg(mi, oracle, rel):
+    """A picture cut off inside its entropy-coded data is not an error for libjpeg (hence for cv::imdecode, utils.rs:10): the MCU in
+    which the data runs out is finished on padding zeros, the MCUs behind it stay zero = grey (jdhuff.c: insufficient_data), and with
+    restart markers decoding resumes at the next marker found.  Product and checker agree byte for byte on cut and on holed files;
+    only a header that promises more than 32 MiB of coefficients the remaining bytes cannot hold is refused (allocation bomb)."""
+    data = _bytes(rel)
+    full = oracle.jpeg_decode_rgb(data)
+    for frac in (0.35, 0.6, 0.9):
+        cut = data[: int(len(data) * frac)]
+        want = oracle.jpeg_decode_rgb(cut)
+        got = mi.convert_image_to_mat(cut)
+        np.testing.assert_array_equal(got, want)
+        assert got.shape == full.shape and not np.array_equal(got, full)
+        H = got.shape[0]
+        assert np.array_equal(got[: H // 8], full[: H // 8])         # the rows decoded before the cut are the picture's
+        assert (got[-4:] == got[-1, -1]).all()                        # the tail is uniform
+    # a hole (bytes zeroed) in the middle of a file with restart markers: decoding picks up again behind it
+    if "rst" in rel:
+        holed = bytearray(data)
+        a = len(data) // 2
+        holed[a: a + 40] = bytes(40)
+        np.testing.assert_array_equal(mi.convert_image_to_mat(bytes(holed)), oracle.jpeg_decode_rgb(bytes(holed)))
+    bomb = b"\xff\xd8" + _segment(0xC0, bytes([8, 0x2E, 0xE0, 0x2E, 0xE0, 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])) + data[2:400]
+    with pytest.raises(mi.MiError):
+        mi.convert_image_to_mat(bomb)
 
 
 @pytest.mark.gpu
