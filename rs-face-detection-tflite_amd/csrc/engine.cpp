@@ -318,6 +318,11 @@ void Model::rebuild() {
                 strip_pack_consts(ws[3], g.tensors[n.w].f32.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, g.tensors[n.w2].f32.data(),
                                   n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
                 node_strip_[i] = put(sc);
+            } else if (n.w >= 0 && n.sh == 1 && n.sw == 1 && n.padding == Padding::Same && mstrip_shape_ok(ws[3], ws[0]) && g.tensors[n.out].shape[2] == 32) {
+                std::vector<float> sc(static_cast<size_t>(mstrip_consts_floats(ws[3])));
+                mstrip_pack_consts(ws[3], g.tensors[n.w].f32.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, g.tensors[n.w2].f32.data(),
+                                   n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
+                node_strip_[i] = put(sc);
             }
         }
     }
@@ -834,8 +839,9 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.ep = ep;
                 a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
                 const bool strip = strip_ && strip_kernel_supports(a);
-                if (labels) { char buf[96]; labels->back() = strip ? strip_kernel_label(a, buf, sizeof buf) : block_kernel_label(a, buf, sizeof buf); }
-                rc = strip ? launch_strip(a, s) : launch_block(a, s);
+                const bool mstrip = strip_ && !strip && mstrip_kernel_supports(a);
+                if (labels) { char buf[96]; labels->back() = strip ? strip_kernel_label(a, buf, sizeof buf) : (mstrip ? mstrip_kernel_label(a, buf, sizeof buf) : block_kernel_label(a, buf, sizeof buf)); }
+                rc = strip ? launch_strip(a, s) : (mstrip ? launch_mstrip(a, s) : launch_block(a, s));
                 break;
             }
             default: {

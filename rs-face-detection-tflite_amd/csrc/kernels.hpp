@@ -251,6 +251,14 @@ bool strip_shape_ok(int C, int Co);
 int strip_consts_floats(int C);
 void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
 const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
+// mstrip_kernels.hip: stride-1 blocks with C = Co = 48 on 32-pixel-wide frames: depthwise stage in the MFMA operand layout, pointwise
+// conv on v_mfma_f32_16x16x4_f32 with resident weights (constants blob through BlockArgs::w_strip)
+int launch_mstrip(const BlockArgs& a, void* stream);
+bool mstrip_kernel_supports(const BlockArgs& a);
+bool mstrip_shape_ok(int C, int Co);
+int mstrip_consts_floats(int C);
+void mstrip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
+const char* mstrip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
 // row-pipelined chain of 2..4 strip-eligible blocks (blocks[k+1].in == blocks[k].out, which never reaches HBM)
 bool strip_pipe_supports(const BlockArgs* blocks, int n);
 bool strip_pipe_shape_ok(int C, int W);  // host-only shape tests for the planner

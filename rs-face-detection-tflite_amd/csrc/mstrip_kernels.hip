@@ -95,31 +95,11 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
     const int kq = lane >> 4, p = lane & 15;
     float* wgc = lds;                                   // [A_F] A operands, [C] bias, [C] slopes
     float* img = lds + K::WG_F + wave * NBUF * IMG_F;   // this wave's row images
-    // ---- workgroup constants into LDS (the only workgroup-level synchronisation of the kernel)
-    for (int i = threadIdx.x; i < K::A_F / 4; i += 256) reinterpret_cast<float4*>(wgc)[i] = reinterpret_cast<const float4*>(a.consts + K::OFF_A)[i];
-    for (int i = threadIdx.x; i < 2 * C; i += 256) wgc[K::A_F + i] = a.consts[K::OFF_BIAS + i];
-    // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers
-    float tap[CK][9];
-    {
-        const float* tp = a.consts + K::OFF_TAP + kq * 12;   // dword loads: nothing but the 108 values is ever live
-#pragma unroll
-        for (int ks = 0; ks < CK; ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) tap[ks][t] = tp[ks * 48 + t];
-        // the taps are in their registers before the first LDS-DMA is issued: the compiler counts only its own loads when it
-        // places vmcnt waits, and the row loop's DMA instructions (inline asm) would make its counts wrong
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < CK; ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap[ks][t]));
-    }
-    __syncthreads();
     // unit = (band, frame): the four waves of a workgroup take four consecutive frames of one band; bands of a frame are B
     // units = B / 4 workgroup ids apart (the same XCD when B % 32 == 0: their shared halo rows meet in one L2)
     const int unit = blockIdx.x * 4 + wave;
     const int band = unit / a.B, b = unit - band * a.B;
-    if (band >= a.bands) return;  // whole wave
+    const bool active = band < a.bands;  // whole wave; an idle wave still helps with the constants and meets the barrier
     const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
     const float* in = a.in + (long)b * a.in_fs;
 
@@ -167,6 +147,32 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
         for (int bi = 0; bi < NBUF; bi++) *reinterpret_cast<float4*>(img + bi * IMG_F + col * 33 * PS + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
+    // the first two rows are on their way while the constants below are fetched
+    if (active) {
+        issue_row(y0 - 1, 0);
+        issue_row(y0, 1);
+    }
+    // ---- workgroup constants into LDS (the only workgroup-level synchronisation of the kernel)
+    for (int i = threadIdx.x; i < K::A_F / 4; i += 256) reinterpret_cast<float4*>(wgc)[i] = reinterpret_cast<const float4*>(a.consts + K::OFF_A)[i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) wgc[K::A_F + i] = a.consts[K::OFF_BIAS + i];
+    // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers
+    float tap[CK][9];
+    {
+        const float* tp = a.consts + K::OFF_TAP + kq * 12;   // dword loads: nothing but the 108 values is ever live
+#pragma unroll
+        for (int ks = 0; ks < CK; ks++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) tap[ks][t] = tp[ks * 48 + t];
+        // the taps are in their registers before the row loop starts: the compiler counts only its own loads when it places vmcnt
+        // waits, and the loop's DMA instructions (inline asm) would make its counts wrong (this also lands the two prologue rows)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < CK; ks++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap[ks][t]));
+    }
+    __syncthreads();
+    if (!active) return;
     // ---- per-lane addresses
     const float* xme = img + p * PS + kq;                       // B layout: left neighbour (image pixel p = x - 1 + 1) of pixel p, channel kq
     const float* sme = img + (1 + p) * PS + 4 * kq;             // D layout: centre pixel p, channels 4 kq .. 4 kq + 3 of a 16-channel tile
@@ -308,8 +314,6 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
         __builtin_amdgcn_s_waitcnt(0xC07F);  // ... and has returned (LDS-DMA writes are not ordered behind this wave's earlier reads)
         if (r + 2 <= y1) issue_row(r + 2, bi);
     };
-    issue_row(y0 - 1, 0);
-    issue_row(y0, 1);
     step(std::false_type{}, y0 - 1, accA, accB);
     step(std::false_type{}, y0, accB, accA);
     for (int r = y0 + 1; r <= y1; r += 2) {

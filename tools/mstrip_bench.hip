@@ -1,8 +1,7 @@
-// Development harness for the wide strip kernel (wide_kernels.hip): checks it against the LDS-ring block kernel on the
-// 32x32x48 layer shape, times both, and times a run of `nb` dependent blocks (BackCamera has seven in a row).
-// Build: tools/build_wide_bench.sh [TAG -DFLAG ...]   Run: tools/bin/bb_wide [B H act has_res nb]
+// Development harness for mstrip_kernel (mstrip_kernels.hip): checks it against the LDS-ring block kernel on the 32x32x48 layer
+// shape, times both, and times a run of `nb` dependent blocks (BackCamera has seven in a row).
+// Build: tools/build_mstrip_bench.sh [TAG -DFLAG ...]   Run: tools/bin/bb_mstrip [B H act has_res nb]
 #include "../rs-face-detection-tflite_amd/csrc/block_kernels.hip"
-#include "../rs-face-detection-tflite_amd/csrc/wide_kernels.hip"
 #include "../rs-face-detection-tflite_amd/csrc/mstrip_kernels.hip"
 
 #include <cmath>
@@ -19,9 +18,9 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 32;
     int act = argc > 3 ? atoi(argv[3]) : ACT_RELU, has_res = argc > 4 ? atoi(argv[4]) : 1, nb = argc > 5 ? atoi(argv[5]) : 7;
     const int C = 48, Co = 48, W = 32;
-    const bool ms = getenv("MI_BENCH_KERNEL") == nullptr || getenv("MI_BENCH_KERNEL")[0] == 'm';  // mstrip (default) or wide
-    auto supports = [&](const BlockArgs& x) { return ms ? mstrip_kernel_supports(x) : wide_kernel_supports(x); };
-    auto launch = [&](const BlockArgs& x, hipStream_t st) { return ms ? launch_mstrip(x, st) : launch_wide(x, st); };
+    const bool ms = true;
+    auto supports = [&](const BlockArgs& x) { return mstrip_kernel_supports(x); };
+    auto launch = [&](const BlockArgs& x, hipStream_t st) { return launch_mstrip(x, st); };
     size_t n = (size_t)B * H * W * C;
     float *din, *dout, *dref;
     CK(hipMalloc(&din, n * 4)); CK(hipMalloc(&dout, n * 4)); CK(hipMalloc(&dref, n * 4));
@@ -34,7 +33,7 @@ int main(int argc, char** argv) {
     float* tmp[2]; CK(hipMalloc(&tmp[0], n * 4)); CK(hipMalloc(&tmp[1], n * 4));
     for (int k = 0; k < nb; k++) {
         int Cp, Cop; block_weight_dims(C, Co, &Cp, &Cop);
-        std::vector<float> w(9 * C), bdw(C), bias(C), alpha(C), pw((size_t)Co * C), packed((size_t)Cop * Cp, 0.f), sc(ms ? mstrip_consts_floats(C) : wide_consts_floats(C));
+        std::vector<float> w(9 * C), bdw(C), bias(C), alpha(C), pw((size_t)Co * C), packed((size_t)Cop * Cp, 0.f), sc(mstrip_consts_floats(C));
         for (auto& v : w) v = 0.3f * rnd(seed);
         for (auto& v : bdw) v = 0.1f * rnd(seed);
         for (auto& v : bias) v = 0.1f * rnd(seed);
@@ -45,8 +44,7 @@ int main(int argc, char** argv) {
             int o = mt * 32 + (l & 31), c = (l >> 5) * Ch + 4 * j + e;
             if (o < Co && c < C) packed[(((size_t)mt * (Ch / 4) + j) * 64 + l) * 4 + e] = pw[(size_t)o * C + c];
         }
-        if (ms) mstrip_pack_consts(C, w.data(), bdw.data(), pw.data(), bias.data(), alpha.data(), act, sc.data());
-        else wide_pack_consts(C, w.data(), bdw.data(), pw.data(), bias.data(), alpha.data(), act, sc.data());
+        mstrip_pack_consts(C, w.data(), bdw.data(), pw.data(), bias.data(), alpha.data(), act, sc.data());
         float *dw, *db, *dpw, *dbp, *dal, *dst;
         up(&dw, w); up(&db, bdw); up(&dpw, packed); up(&dbp, bias); up(&dal, alpha); up(&dst, sc);
         BlockArgs a;
