@@ -55,6 +55,7 @@ struct MstripArgs {
     int bands, band_rows;
     int has_res;
     float hi;              // upper clamp of the activation (6 for ReLU6, +inf otherwise)
+    unsigned long long* stamps;  // diagnostic builds only (MI_MSTRIP_STAMPS): 8 accumulators per wave
 };
 
 template <int CK>   // k-steps: C = 4 * CK channels in and out (CK % 4 == 0: whole 16-channel output tiles)
@@ -69,7 +70,7 @@ struct MK {
     static_assert((16 * PS) % 64 == 0 && 16 * PS / 64 < 256, "ds_read2st64_b32 reaches the second pixel tile");
     // constants blob (floats): A operands [CK][MT][64] | taps [CK][4][12] | bias [C] | slopes [C]
     static constexpr int OFF_A = 0, A_F = CK * MT * 64, OFF_TAP = A_F, TAP_F = CK * 48, OFF_BIAS = OFF_TAP + TAP_F, OFF_SLOPE = OFF_BIAS + C, TOTAL = OFF_SLOPE + C;
-    static constexpr int WG_F = A_F + 2 * C;   // LDS floats shared by a workgroup: A operands, bias, slopes
+    static constexpr int WG_F = A_F + 2 * C + TAP_F;   // LDS floats shared by a workgroup: A operands, bias, slopes, taps (read once)
     static constexpr int NBUF = 2;
 };
 
@@ -90,6 +91,12 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
     using K = MK<CK>;
     constexpr int C = K::C, MT = K::MT, PS = K::PS, QP = K::QP, IMG_F = K::IMG_F, NLD = K::NLD, NBUF = K::NBUF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef MI_MSTRIP_STAMPS
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#define MI_MSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_MSTAMP(k)
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kq = lane >> 4, p = lane & 15;
@@ -147,32 +154,41 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
         for (int bi = 0; bi < NBUF; bi++) *reinterpret_cast<float4*>(img + bi * IMG_F + col * 33 * PS + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // the first two rows are on their way while the constants below are fetched
-    if (active) {
-        issue_row(y0 - 1, 0);
-        issue_row(y0, 1);
-    }
+    // the first row is on its way while the constants below are fetched
+    if (active) issue_row(y0 - 1, 0);
+    MI_MSTAMP(5)
     // ---- workgroup constants into LDS (the only workgroup-level synchronisation of the kernel)
     for (int i = threadIdx.x; i < K::A_F / 4; i += 256) reinterpret_cast<float4*>(wgc)[i] = reinterpret_cast<const float4*>(a.consts + K::OFF_A)[i];
     for (int i = threadIdx.x; i < 2 * C; i += 256) wgc[K::A_F + i] = a.consts[K::OFF_BIAS + i];
-    // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers
+    for (int i = threadIdx.x; i < K::TAP_F / 4; i += 256) reinterpret_cast<float4*>(wgc + K::A_F + 2 * C)[i] = reinterpret_cast<const float4*>(a.consts + K::OFF_TAP)[i];
+    // The second row goes out behind the constants, and only it may still be in flight when the row loop starts (vector-memory
+    // operations retire in issue order): the compiler counts only its own loads when it places vmcnt waits — always safe, since a
+    // counted wait also covers everything older — but the loop's own counted waits assume that nothing else is outstanding.
+    if (active) issue_row(y0, 1);
+    if (active) mwait_vm<NLD>(); else mwait_vm<0>();
+    MI_MSTAMP(6)
+    // raw barrier behind an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. wait for the second row
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
     float tap[CK][9];
     {
-        const float* tp = a.consts + K::OFF_TAP + kq * 12;   // dword loads: nothing but the 108 values is ever live
+        const float4* tp = reinterpret_cast<const float4*>(wgc + K::A_F + 2 * C) + kq * 3;
 #pragma unroll
-        for (int ks = 0; ks < CK; ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) tap[ks][t] = tp[ks * 48 + t];
-        // the taps are in their registers before the row loop starts: the compiler counts only its own loads when it places vmcnt
-        // waits, and the loop's DMA instructions (inline asm) would make its counts wrong (this also lands the two prologue rows)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int ks = 0; ks < CK; ks++) {
+            const float4 t0 = tp[ks * 12], t1 = tp[ks * 12 + 1], t2 = tp[ks * 12 + 2];
+            tap[ks][0] = t0.x; tap[ks][1] = t0.y; tap[ks][2] = t0.z; tap[ks][3] = t0.w;
+            tap[ks][4] = t1.x; tap[ks][5] = t1.y; tap[ks][6] = t1.z; tap[ks][7] = t1.w;
+            tap[ks][8] = t2.x;
+        }
 #pragma unroll
         for (int ks = 0; ks < CK; ks++)
 #pragma unroll
             for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap[ks][t]));
     }
-    __syncthreads();
     if (!active) return;
+    MI_MSTAMP(0)
     // ---- per-lane addresses
     const float* xme = img + p * PS + kq;                       // B layout: left neighbour (image pixel p = x - 1 + 1) of pixel p, channel kq
     const float* sme = img + (1 + p) * PS + 4 * kq;             // D layout: centre pixel p, channels 4 kq .. 4 kq + 3 of a 16-channel tile
@@ -186,18 +202,21 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
 
     // D <- bias + skip for the output row whose centre input row sits in image bi (called at the end of that row's step)
     auto init_D = [&](int bi) {
+        float4 bs[MT], x[MT][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const float4 bs = *reinterpret_cast<const float4*>(wgc + K::A_F + 16 * mt + 4 * kq);
+        for (int mt = 0; mt < MT; mt++) bs[mt] = *reinterpret_cast<const float4*>(wgc + K::A_F + 16 * mt + 4 * kq);
+        if (a.has_res) {  // wave-uniform; one branch around all six reads (per tile, each read would be waited for on its own)
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                if (a.has_res) {  // wave-uniform
-                    const float4 x = *reinterpret_cast<const float4*>(sme + bi * IMG_F + 16 * nt * PS + 16 * mt);
-                    D[mt][nt] = f32x4{x.x + bs.x, x.y + bs.y, x.z + bs.z, x.w + bs.w};
-                } else {
-                    D[mt][nt] = f32x4{bs.x, bs.y, bs.z, bs.w};
-                }
-            }
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) x[mt][nt] = *reinterpret_cast<const float4*>(sme + bi * IMG_F + 16 * nt * PS + 16 * mt);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) D[mt][nt] = f32x4{x[mt][nt].x + bs[mt].x, x[mt][nt].y + bs[mt].y, x[mt][nt].z + bs[mt].z, x[mt][nt].w + bs[mt].w};
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) D[mt][0] = D[mt][1] = f32x4{bs[mt].x, bs[mt].y, bs[mt].z, bs[mt].w};
         }
     };
     typedef __attribute__((address_space(1))) char gchar;
@@ -304,15 +323,19 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
         wait_row(t);
         fix_row(r, bi);
         mwave_sync();
+        MI_MSTAMP(1)
         row(emit, bi, aPN, aC);
+        MI_MSTAMP(2)
         __builtin_amdgcn_sched_barrier(0);  // (fences: the old and the new accumulator tiles are never live together)
         if constexpr (decltype(emit)::value) epilogue(r - 1);
+        MI_MSTAMP(3)
         __builtin_amdgcn_sched_barrier(0);
         init_D(bi);     // output row r starts from bias + its skip, the centre pixels of input row r
         __builtin_amdgcn_sched_barrier(0);
         mwave_sync();   // every read of image bi is issued before the DMA below overwrites it
         __builtin_amdgcn_s_waitcnt(0xC07F);  // ... and has returned (LDS-DMA writes are not ordered behind this wave's earlier reads)
         if (r + 2 <= y1) issue_row(r + 2, bi);
+        MI_MSTAMP(4)
     };
     step(std::false_type{}, y0 - 1, accA, accB);
     step(std::false_type{}, y0, accB, accA);
@@ -321,6 +344,10 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
         if (r + 1 > y1) break;
         step(std::true_type{}, r + 1, accB, accA);
     }
+#ifdef MI_MSTRIP_STAMPS
+    if (a.stamps && lane == 0)
+        for (int k = 0; k < 7; k++) a.stamps[(long)unit * 8 + k] = st_acc[k];
+#endif
 }
 
 }  // namespace
@@ -339,6 +366,10 @@ bool mstrip_kernel_supports(const BlockArgs& a) {
         if (a.ep.res_after) return false;
         if (a.ep.res_mode != RES_DIRECT || a.ep.res != a.in || a.ep.res_fs != a.in_fs || a.ep.res_C != a.C) return false;
     }
+    // a wave walks its band row by row (six dependent steps at four rows): below about one wave per SIMD over the chip the launch is
+    // latency-bound and the block kernel's wider workgroups finish sooner (B = 5: 14.3 against 11 us)
+    static const int min_b = getenv("MI_MSTRIP_MIN_B") ? atoi(getenv("MI_MSTRIP_MIN_B")) : 32;
+    if (a.B < min_b) return false;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return aligned16(a.in) && aligned16(a.out) && !(a.in_fs & 3) && !(a.out_fs & 3);
 }
@@ -372,9 +403,12 @@ const char* mstrip_kernel_label(const BlockArgs& a, char* buf, size_t cap) {
     return buf;
 }
 
+unsigned long long* g_mstrip_stamps = nullptr;  // set by the development harness (MI_MSTRIP_STAMPS builds)
+
 int launch_mstrip(const BlockArgs& a, void* stream) {
     using K = MK<12>;
     MstripArgs ma;
+    ma.stamps = g_mstrip_stamps;
     ma.in = a.in; ma.out = a.out; ma.consts = a.w_strip; ma.in_fs = a.in_fs; ma.out_fs = a.out_fs;
     ma.B = a.B; ma.H = a.H;
     // bands: about eight waves per CU over the chip; a band costs two priming rows of depthwise work and two halo rows of input

@@ -173,6 +173,32 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
     m.close()
 
 
+def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
+    """BackCamera's seven 32x32x48 blocks run on mstrip_kernel (depthwise stage in the MFMA operand layout, pointwise conv on
+    v_mfma_f32_16x16x4_f32) from 32 frames per launch on; below that the LDS-ring block kernel takes them.  An odd batch of 35 frames
+    (the last workgroup has one live wave) against the oracle frame by frame, against the block-kernel path ("strip" = 0), and frame
+    7 alone (block kernel: batch 1) against frame 7 inside the batch."""
+    m = gpu.Model(model_path("back"))
+    x = seeded_input("back", 35, 4711, m.input_dims[1:3])
+    x[5] = 0.0                       # an all-zero frame: biases only
+    x[9, :, :128] = -1.0             # half-saturated frame
+    outs = [o.copy() for o in m.run(x)]
+    labels = {r["kernel"] for r in m.profile(__import__("torch").from_numpy(x).cuda(), reps=1)}
+    assert any(k.startswith("mstrip_kernel") for k in labels), labels
+    om = oracle.Model(model_path("back"))
+    refs = om.run(x, nthreads=8)
+    for o, r in zip(outs, refs):
+        _raw_close(o, r)
+    for o, r in zip(m.run(x[7:8]), outs):
+        _raw_close(o[0], r[7])
+    m.set_option("strip", 0)
+    labels0 = {r["kernel"] for r in m.profile(__import__("torch").from_numpy(x).cuda(), reps=1)}
+    assert not any(k.startswith("mstrip_kernel") for k in labels0)
+    for o, r in zip(m.run(x), outs):
+        _raw_close(o, r)
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))

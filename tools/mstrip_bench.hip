@@ -87,5 +87,21 @@ int main(int argc, char** argv) {
         printf("%s x%d B %d %dx%d C %d : %.4f ms (%.4f per block)  %.1f GB/s  %.1f TFLOP/s algorithmic\n", which ? (ms ? "mstrip" : "wide ") : "block", nb, B, H, W, C, ms, ms / nb,
                2.0 * n * 4 * nb / ms / 1e6, 2.0 * B * H * W * C * (9.0 + Co) * nb / ms / 1e9);
     }
+#ifdef MI_MSTRIP_STAMPS
+    {
+        const size_t nw = (size_t)B * 64;  // upper bound of units (bands <= H)
+        unsigned long long* dstp; CK(hipMalloc(&dstp, nw * 64)); CK(hipMemset(dstp, 0, nw * 64));
+        g_mstrip_stamps = dstp;
+        launch(blk[0], s); CK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(nw * 8);
+        CK(hipMemcpy(h.data(), dstp, nw * 64, hipMemcpyDeviceToHost));
+        double acc[7] = {0}, tot = 0; size_t units = 0;
+        for (size_t i = 0; i < nw; i++) { if (!h[i * 8 + 2]) continue; units++; for (int k = 0; k < 7; k++) acc[k] += h[i * 8 + k]; }
+        for (int k = 0; k < 7; k++) tot += acc[k];
+        const char* nm[7] = {"startup: barrier", "wait-dma+fix", "row (dw+mfma)", "epilogue", "init+dma-issue", "startup: dma issue", "startup: consts+taps+landed"};
+        for (int k = 0; k < 7; k++) printf("  %-28s %5.1f%%  %9.0f ticks/wave\n", nm[k], 100 * acc[k] / tot, acc[k] / units);
+        printf("  total %.0f ticks per wave over %zu waves\n", tot / units, units);
+    }
+#endif
     return bad ? 2 : 0;
 }
