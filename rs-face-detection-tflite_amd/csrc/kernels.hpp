@@ -70,7 +70,6 @@ struct BlockArgs {
     const float* b_dw = nullptr;
     const float* w_pw = nullptr;  // [Cop][Cp] row-major (out channel major), zero padded: Cp = C up to 4, Cop = Co up to 16/32
     const float* w_strip = nullptr;  // strip_pack_consts() blob when the shape qualifies for strip_kernels.hip, else null
-    const float* w_mfma = nullptr;   // mpipe_pack_consts() blob (MFMA operand layout) when the shape qualifies for mpipe_kernels.hip, else null
     float* out = nullptr;
     long in_fs = 0, out_fs = 0;
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0;
@@ -270,14 +269,6 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream);
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
 int strip_pipe_rows_per_step(int H, int hint = 0);
 int launch_chain(const ChainArgs& a, void* stream);
-// mpipe_kernels.hip: row-pipelined chain of 2..4 stride-1 blocks with C = Co = 24 at W = 64 / 128, pointwise convs on
-// v_mfma_f32_16x16x4_f32 with resident weights (constants through BlockArgs::w_mfma)
-bool mpipe_supports(const BlockArgs* blocks, int n);
-bool mpipe_shape_ok(int C, int Co);
-int mpipe_consts_floats(int C);
-void mpipe_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
-int launch_mpipe(const BlockArgs* blocks, int n, void* stream);
-const char* mpipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap);
 
 // ---- bottleneck blocks with the wide tensor in registers (bneck_kernels.hip):
 //   r = act1(W1 . x + b1) (C -> Cm);  y = act2(W2 . (DW3x3(r) + b_dw) + b2 + x) (Cm -> C)
