@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <map>
 #include <sstream>
+#include <functional>
 #include <stdexcept>
 
 namespace mi {
@@ -791,10 +792,171 @@ Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_by
 }
 
 namespace {
+// Activation tensors whose channel count is not a multiple of 4 (front / short-range: 36 -> 42 -> 48) keep their layers off every
+// fused kernel (float4 pixels everywhere).  Such a tensor — together with everything tied to it by channel-preserving operators
+// (depthwise conv, ADD, RELU / PRELU, MAX_POOL) — is widened to the next multiple of 4 with channels that are exactly zero: the
+// producing convolution gets zero filter rows and biases, depthwise stages zero taps and biases, PRELU a zero slope, consuming
+// convolutions zero filter columns, and channel PADs on either side (zeros appended at the high end) append
+// or remove correspondingly fewer / more.  Every real channel computes what it computed before, bit for bit.  Classes that touch a
+// graph input / output or an operator not listed here are left alone.
+void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<int>* logical_C) {
+    const int NT = static_cast<int>(g.tensors.size());
+    logical_elems->resize(NT);
+    logical_C->resize(NT);
+    for (int t = 0; t < NT; t++) {
+        (*logical_elems)[t] = static_cast<double>(g.tensors[t].elems());
+        (*logical_C)[t] = g.tensors[t].shape.empty() ? 0 : g.tensors[t].shape.back();
+    }
+    // Untrusted graphs reach this pass before the lowering has checked them: anything that is not the plain, consistent form
+    // handled below leaves the graph as it is (and to the lowering's own error messages).
+    for (const OpInfo& op : g.ops) {
+        if (op.inputs.empty() || op.outputs.empty()) return;
+        auto cst = [&](int t, size_t rank) {
+            return t >= 0 && g.tensors[t].is_const && g.tensors[t].shape.size() == rank && g.tensors[t].f32.size() == g.tensors[t].elems() && g.tensors[t].elems() > 0;
+        };
+        auto r4 = [&](int t) { return t >= 0 && !g.tensors[t].is_const && g.tensors[t].shape.size() == 4 && g.tensors[t].shape.back() > 0; };
+        const int in = op.inputs[0], out = op.outputs[0];
+        if (op.op == BuiltinOp::Conv2D || op.op == BuiltinOp::DepthwiseConv2D) {
+            if (op.inputs.size() < 2 || !r4(in) || !r4(out) || !cst(op.inputs[1], 4)) return;
+            const auto& ws = g.tensors[op.inputs[1]].shape;
+            const int Ci = g.tensors[in].shape.back(), Co = g.tensors[out].shape.back();
+            if (op.op == BuiltinOp::Conv2D ? (ws[0] != Co || ws[3] != Ci) : (ws[0] != 1 || ws[3] != Ci || Ci != Co)) return;
+            if (op.inputs.size() > 2 && op.inputs[2] >= 0 && !(cst(op.inputs[2], 1) && g.tensors[op.inputs[2]].shape[0] == Co)) return;
+        } else if (op.op == BuiltinOp::Prelu) {
+            if (op.inputs.size() < 2 || !r4(in) || !r4(out)) return;
+            const TensorInfo& al = g.tensors[op.inputs[1]];
+            if (!al.is_const || al.shape.empty() || al.f32.size() != al.elems() || static_cast<int>(al.elems()) != g.tensors[in].shape.back() ||
+                al.shape.back() != g.tensors[in].shape.back()) return;
+        } else if (op.op == BuiltinOp::Pad) {
+            if (op.inputs.size() < 2 || op.inputs[1] < 0 || !g.tensors[op.inputs[1]].is_const) return;
+        } else if (op.op == BuiltinOp::Add) {
+            if (op.inputs.size() < 2 || op.inputs[1] < 0) return;
+        }
+    }
+    for (int t = 0; t < NT; t++)
+        if (!g.tensors[t].is_const && g.tensors[t].shape.empty()) return;
+    std::vector<int> parent(NT);
+    for (int t = 0; t < NT; t++) parent[t] = t;
+    std::function<int(int)> find = [&](int t) { return parent[t] == t ? t : parent[t] = find(parent[t]); };
+    auto unite = [&](int a, int b) { if (a >= 0 && b >= 0) parent[find(a)] = find(b); };
+    auto act = [&](int t) { return t >= 0 && t < NT && !g.tensors[t].is_const; };
+    for (const OpInfo& op : g.ops) {
+        switch (op.op) {
+            case BuiltinOp::DepthwiseConv2D: case BuiltinOp::Relu: case BuiltinOp::Prelu: case BuiltinOp::MaxPool2D:
+                unite(op.inputs.at(0), op.outputs.at(0));
+                break;
+            case BuiltinOp::Add:
+                unite(op.inputs.at(0), op.outputs.at(0));
+                if (act(op.inputs.at(1))) unite(op.inputs.at(1), op.outputs.at(0));
+                break;
+            default: break;
+        }
+    }
+    std::vector<char> bad(NT, 0);  // per class root
+    auto mark = [&](int t) { if (act(t)) bad[find(t)] = 1; };
+    for (int t : g.inputs) mark(t);
+    for (int t : g.outputs) mark(t);
+    for (int t = 0; t < NT; t++)
+        if (act(t) && g.tensors[t].shape.size() != 4) mark(t);
+    for (const OpInfo& op : g.ops) {
+        const bool conv = op.op == BuiltinOp::Conv2D;
+        switch (op.op) {
+            case BuiltinOp::Conv2D: case BuiltinOp::DepthwiseConv2D: case BuiltinOp::Relu: case BuiltinOp::MaxPool2D:
+                break;
+            case BuiltinOp::Prelu:
+                if (!g.tensors[op.inputs.at(1)].is_const) mark(op.inputs[0]);
+                break;
+            case BuiltinOp::Add:
+                if (!act(op.inputs.at(1))) mark(op.inputs[0]);  // constant addend: not handled
+                break;
+            case BuiltinOp::Pad: {
+                const auto& pd = g.tensors[op.inputs.at(1)].i32;
+                bool channel_only = pd.size() == 8;
+                for (size_t k = 0; k < 7 && channel_only; k++) channel_only = pd[k] == 0;
+                if (!channel_only) { mark(op.inputs[0]); mark(op.outputs[0]); }
+                break;
+            }
+            default:  // RESHAPE, CONCATENATION, RESIZE_BILINEAR, DEPTH_TO_SPACE ...: the channel count is part of their meaning
+                for (int t : op.inputs) mark(t);
+                for (int t : op.outputs) mark(t);
+                break;
+        }
+        (void)conv;
+    }
+    auto padded = [&](int t) {  // new channel count of activation tensor t (unchanged when its class is left alone)
+        const int C = g.tensors[t].shape.back();
+        return (act(t) && g.tensors[t].shape.size() == 4 && !bad[find(t)] && (C & 3)) ? (C + 3) & ~3 : C;
+    };
+    // a channel PAD that consumes a widened tensor must have room for the extra channels
+    for (const OpInfo& op : g.ops)
+        if (op.op == BuiltinOp::Pad) {
+            const int in = op.inputs.at(0), out = op.outputs.at(0);
+            if (padded(out) - padded(in) < 0) { mark(in); mark(out); }
+        }
+    std::vector<int> newC(NT);
+    bool any = false;
+    for (int t = 0; t < NT; t++) {
+        newC[t] = act(t) ? padded(t) : 0;
+        any |= act(t) && newC[t] != g.tensors[t].shape.back();
+    }
+    if (!any) return;
+    auto clone_const = [&](int t) {  // constants may be shared between operators: every change goes to a private copy
+        g.tensors.push_back(g.tensors[t]);
+        logical_elems->push_back((*logical_elems)[t]);
+        logical_C->push_back((*logical_C)[t]);
+        return static_cast<int>(g.tensors.size()) - 1;
+    };
+    auto widen_last = [&](int t, int Cn) {  // [..., C] -> [..., Cn], zeros appended (filters [*,kh,kw,I], taps [1,kh,kw,C], bias / alpha [C])
+        TensorInfo& ti = g.tensors[t];
+        const int C = ti.shape.back();
+        const size_t rows = ti.elems() / static_cast<size_t>(C);
+        std::vector<float> w(rows * Cn, 0.f);
+        for (size_t r = 0; r < rows; r++)
+            for (int c = 0; c < C; c++) w[r * Cn + c] = ti.f32[r * C + c];
+        ti.f32 = std::move(w);
+        ti.shape.back() = Cn;
+    };
+    auto widen_first = [&](int t, int On) {  // [O, ...] -> [On, ...], zero filters appended
+        TensorInfo& ti = g.tensors[t];
+        const size_t per = ti.elems() / static_cast<size_t>(ti.shape[0]);
+        ti.f32.resize(per * On, 0.f);
+        ti.shape[0] = On;
+    };
+    for (OpInfo& op : g.ops) {
+        const int in = op.inputs.at(0), out = op.outputs.at(0);
+        const int Ci = act(in) ? g.tensors[in].shape.back() : 0, Co = g.tensors[out].shape.back();
+        const int Cin = act(in) ? newC[in] : 0, Con = newC[out];
+        if (op.op == BuiltinOp::Conv2D) {
+            if (Cin != Ci || Con != Co) {
+                op.inputs[1] = clone_const(op.inputs[1]);
+                if (Cin != Ci) widen_last(op.inputs[1], Cin);
+                if (Con != Co) widen_first(op.inputs[1], Con);
+            }
+            if (Con != Co && op.inputs.size() > 2 && op.inputs[2] >= 0) { op.inputs[2] = clone_const(op.inputs[2]); widen_last(op.inputs[2], Con); }
+        } else if (op.op == BuiltinOp::DepthwiseConv2D && Con != Co) {
+            op.inputs[1] = clone_const(op.inputs[1]);
+            widen_last(op.inputs[1], Con);
+            if (op.inputs.size() > 2 && op.inputs[2] >= 0) { op.inputs[2] = clone_const(op.inputs[2]); widen_last(op.inputs[2], Con); }
+        } else if (op.op == BuiltinOp::Prelu && Con != Co) {
+            op.inputs[1] = clone_const(op.inputs[1]);
+            widen_last(op.inputs[1], Con);
+        } else if (op.op == BuiltinOp::Pad && (Cin != Ci || Con != Co)) {
+            op.inputs[1] = clone_const(op.inputs[1]);
+            g.tensors[op.inputs[1]].i32[7] = Con - Cin;
+        }
+    }
+    for (int t = 0; t < NT; t++)
+        if (act(t)) g.tensors[t].shape.back() = newC[t];
+}
+
 Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads) {
     Plan plan;
     plan.graph = std::move(graph);
     plan.fuse_level = fuse_level;
+    // algorithmic sizes (traffic / MAC figures of the plan) are those of the graph as stored, whatever padding the lowering adds
+    std::vector<double> logical_elems;
+    std::vector<int> logical_C;
+    if (fuse_level >= 2) pad_odd_channels(plan.graph, &logical_elems, &logical_C);  // (the op-by-op levels take any channel count)
     Graph& g = plan.graph;
     std::vector<Node> nodes;
     for (size_t oi = 0; oi < g.ops.size(); oi++) {
@@ -1186,7 +1348,8 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
     // ---- algorithmic traffic / MACs of the plan as launched (per frame)
     double bytes = 0, macs = 0;
     for (const Node& n : plan.nodes) {
-        auto elems = [&](int t) { return t >= 0 ? static_cast<double>(g.tensors[t].elems()) : 0.0; };
+        auto elems = [&](int t) { return t < 0 ? 0.0 : (static_cast<size_t>(t) < logical_elems.size() ? logical_elems[t] : static_cast<double>(g.tensors[t].elems())); };
+        auto LC = [&](int t) { return static_cast<size_t>(t) < logical_C.size() ? logical_C[t] : g.tensors[t].shape.back(); };
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
         for (int t : n.in) bytes += 4 * elems(t);
         bytes += 4 * elems(n.out);
@@ -1195,9 +1358,9 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
             for (const Node& m : n.members) {
                 for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) bytes += 4 * elems(c);
                 const auto& so2 = g.tensors[m.out].shape;
-                const int Cm = g.tensors[m.in[0]].shape[3];
+                const int Cm = LC(m.in[0]);
                 if (m.kind == Node::Conv) macs += elems(m.out) * m.KH * m.KW * Cm;
-                else macs += static_cast<double>(so2[1]) * so2[2] * Cm * ((m.w >= 0 ? 9 : 0) + so2[3]);
+                else macs += static_cast<double>(so2[1]) * so2[2] * Cm * ((m.w >= 0 ? 9 : 0) + LC(m.out));
             }
             continue;
         }
@@ -1205,22 +1368,22 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
             for (const Node& m : n.members) {
                 for (int c : {m.w, m.b, m.w2, m.b2, m.alpha}) bytes += 4 * elems(c);
                 const auto& so2 = g.tensors[m.out].shape;
-                macs += static_cast<double>(so2[1]) * so2[2] * g.tensors[m.in[0]].shape[3] * (9 + so2[3]);
+                macs += static_cast<double>(so2[1]) * so2[2] * LC(m.in[0]) * (9 + LC(m.out));
             }
             for (const Node& m : n.head_nodes) {
                 for (int c : {m.w, m.b, m.w2, m.b2}) bytes += 4 * elems(c);
-                macs += elems(m.out) * g.tensors[m.in[0]].shape[3];
+                macs += elems(m.out) * LC(m.in[0]);
             }
             continue;
         }
         if (n.res >= 0 && !(n.kind == Node::Block && n.res == n.in[0])) bytes += 4 * elems(n.res);
         for (int c : {n.w, n.b, n.w2, n.b2, n.alpha}) bytes += 4 * elems(c);
         const auto& so = g.tensors[n.out].shape;
-        if (n.kind == Node::Conv) macs += elems(n.out) * n.KH * n.KW * g.tensors[n.in[0]].shape[3];
+        if (n.kind == Node::Conv) macs += elems(n.out) * n.KH * n.KW * LC(n.in[0]);
         if (n.kind == Node::Dw) macs += elems(n.out) * n.KH * n.KW;
         if (n.kind == Node::Block) {
-            int C = g.tensors[n.in[0]].shape[3];
-            macs += static_cast<double>(so[1]) * so[2] * C * ((n.w >= 0 ? n.KH * n.KW : 0) + so[3]);
+            int C = LC(n.in[0]);
+            macs += static_cast<double>(so[1]) * so[2] * C * ((n.w >= 0 ? n.KH * n.KW : 0) + LC(n.out));
         }
     }
     plan.bytes_per_frame = bytes;

@@ -292,6 +292,22 @@ def back_like(seed, size, c0=24, n1=3, n2=3, coarse_first=False):
     return g.finish()
 
 
+def front_like(seed, size, act="relu"):
+    """The front / short-range detector's habit of growing by channel PADs on the skip, with widths that are not multiples of 4:
+    24 -> 30 -> 42 at size/2, stride 2 to 54 (max-pool + PAD skip), 54 -> 58 -> 58, 1x1 head.  The lowering widens the 30 / 42 /
+    54 / 58-channel tensors to 32 / 44 / 56 / 60 with zero channels (plan.cpp pad_odd_channels) so the fused kernels take them."""
+    g = GraphBuilder(seed, [1, size, size, 3])
+    x = g.relu(g.conv(g.input, 24, 5, 2))
+    x = g.blaze_block(x, 30, act=act)
+    x = g.blaze_block(x, 42, act=act)
+    x = g.blaze_block(x, 54, 2, act=act)
+    x = g.blaze_block(x, 58, act=act)
+    x = g.blaze_block(x, act=act)
+    n, h, w, _ = g.shape(x)
+    g.outputs = [g.reshape(g.conv(x, 6), [1, h * w * 6, 1]), g.reshape(g.conv(x, 32), [1, h * w * 2, 16])]
+    return g.finish()
+
+
 def full_widen(seed, h, w, c=24, cm=8, co=40):
     """double blocks on a non-square frame whose row bands end ragged, one of them widening (skip zero-padded to co channels)."""
     g = GraphBuilder(seed, [1, h, w, 3])
@@ -350,6 +366,8 @@ CASES = {
     "back_96": (lambda: back_like(21, 96), 96, 96),                                        # chains at 12x12x96 / 6x6x96 with edges and heads
     "back_160_c16": (lambda: back_like(22, 160, 16, 2, 4), 160, 160),                      # 16-channel pipelines, 20x20 / 10x10 chains
     "back_48_odd_head_slices": (lambda: back_like(24, 48, coarse_first=True), 48, 48),     # 3x3 heads first: the 6x6 classifier's slice of the concatenation starts at float 54 (not 16-byte aligned)
+    "front_64_odd_widths": (lambda: front_like(25, 64), 64, 64),                            # 30 / 42 / 54 / 58 channels: zero-padded to multiples of 4 at lowering
+    "front_48_odd_widths_prelu": (lambda: front_like(26, 48, "prelu"), 48, 48),            # the same with PReLU slopes to pad
     "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads
     "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
     "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames
