@@ -73,8 +73,7 @@ def synth_models(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("case", ["iris_32x20_ragged_bands", "iris_16x16_c64_run", "iris_12x20_c128", "iris_24x24_fallback", "back_96", "back_160_c16",
-                                  "back_128_c32", "mesh_160", "mesh_96_c24", "full_64", "full_80_c48", "full_widen_70x44"])
+@pytest.mark.parametrize("case", sorted(__import__("synth_tflite").CASES))
 @pytest.mark.parametrize("fuse", [0, 2, 3, 4, 5])
 def test_synthetic_graphs_vs_oracle(gpu, oracle, synth_models, case, fuse):
     """The reference graphs' operator chains on OTHER shapes (ragged row bands, partial pixel groups, odd channel counts, chains with
