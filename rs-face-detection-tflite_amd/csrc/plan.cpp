@@ -776,10 +776,14 @@ bool head_views_aligned(const Plan& plan) {
         return (s.offset & 3) == 0 && (s.frame_stride & 3) == 0;
     };
     for (const Node& n : plan.nodes) {
+        // chain heads: the head with Co % 4 == 0 of a pair is stored as float4 (chain_kernel_supports: out_a, out_a_fs); its partner
+        // (the classifier, 2 / 6 channels) is stored float by float and may start anywhere
         if (n.kind == Node::Chain)
-            for (const Node& h : n.head_nodes)
-                if (!aligned(h.out)) return false;
-        if (n.kind == Node::Conv && n.gemm_head && !(aligned(n.out) && aligned(n.in[0]))) return false;
+            for (const Node::HeadPair& hp : n.head_pairs)
+                if (!aligned(n.head_nodes[static_cast<size_t>(hp.a)].out)) return false;
+        // batch GEMM heads read their input as float4 (launch_head_gemm: in, in_fs); the output is stored float by float (the face
+        // flag is one float per frame)
+        if (n.kind == Node::Conv && n.gemm_head && !aligned(n.in[0])) return false;
     }
     return true;
 }

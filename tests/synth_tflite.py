@@ -365,7 +365,7 @@ CASES = {
     "iris_24x24_fallback": (lambda: iris_like(14, 48, 48, 64, 32, 1), 48, 48),            # band rows do not tile 32-pixel groups: stage programs
     "back_96": (lambda: back_like(21, 96), 96, 96),                                        # chains at 12x12x96 / 6x6x96 with edges and heads
     "back_160_c16": (lambda: back_like(22, 160, 16, 2, 4), 160, 160),                      # 16-channel pipelines, 20x20 / 10x10 chains
-    "back_48_odd_head_slices": (lambda: back_like(24, 48, coarse_first=True), 48, 48),     # 3x3 heads first: the 6x6 classifier's slice of the concatenation starts at float 54 (not 16-byte aligned)
+    "back_48_odd_head_slices": (lambda: back_like(24, 48, coarse_first=True), 48, 48),     # 3x3 heads first: the 6x6 classifier's slice of the concatenation starts at float 54 (not 16-byte aligned: stored float by float by the chain's fused heads)
     "front_64_odd_widths": (lambda: front_like(25, 64), 64, 64),                            # 30 / 42 / 54 / 58 channels: zero-padded to multiples of 4 at lowering
     "front_48_odd_widths_prelu": (lambda: front_like(26, 48, "prelu"), 48, 48),            # the same with PReLU slopes to pad
     "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads

@@ -1,29 +1,30 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the bench lines of configs 2 / 3 / 5, the per-launch event lists, and the rocprofv3 passes
+# Runs on the GPU box (via gpurun): the bench lines of configs 1 / 2 / 3 / 5, the per-launch event lists, and the rocprofv3 passes
 # the committed summaries under profiles/ come from — kernel trace + stats per config; FETCH_SIZE and WRITE_SIZE in separate PMC
-# passes; SQ counters in passes of at most 8 (never --pmc together with a trace).  rocprofv3 is given the program itself
-# (python3 bench.py ...), never a wrapper.
-# usage: bash tools/collect_profiles.sh r02   -> everything under gpurun_out/prof_r02/ ; then tools/summarize_profiles.py r02
+# passes per config; SQ counters in passes of at most 8 per config (never --pmc together with a trace).  rocprofv3 is given the
+# program itself (python3 bench.py ...), never a wrapper.
+# usage: bash tools/collect_profiles.sh r03   -> everything under gpurun_out/prof_r03/ ; then tools/summarize_profiles.py r03
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 bench.py > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"; echo bench2 done
-python3 bench.py --config 3 > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"; echo bench3 done
-python3 bench.py --config 5 > "$OUT/bench_c5.json" 2> "$OUT/bench_c5.err"; echo bench5 done
+for c in 2 1 3 5; do
+  python3 bench.py --config $c > "$OUT/bench_c$c.json" 2> "$OUT/bench_c$c.err"; echo bench $c done
+done
 python3 tools/bench_configs.py > "$OUT/configs.log" 2>&1; echo configs done
 for m in "back 256" "front 256" "full 128" "landmark 512" "iris 1024"; do set -- $m; python3 tools/profile_model.py $1 $2 2>/dev/null | grep -v amdgpu > "$OUT/launches_$1.txt"; done; echo launches done
-for c in 2 3 5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --steps 30 --no-cpu-baseline > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
-done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/fetch.log" 2>&1; echo fetch done
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/write.log" 2>&1; echo write done
-i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/sq$i" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/sq$i.log" 2>&1; echo sq pass $i done
+for c in 2 1 3 5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --steps 30 --no-cpu-baseline --single-window > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --single-window > "$OUT/fetch_c$c.log" 2>&1; echo fetch $c done
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --single-window > "$OUT/write_c$c.log" 2>&1; echo write $c done
+  i=0
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --output-format csv -d "$OUT/sq${i}_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --single-window > "$OUT/sq${i}_c$c.log" 2>&1; echo sq pass $i config $c done
+  done
 done
 # keep what gpurun merges back small: counter CSVs and stats only
 find "$OUT" -name "*.db" -delete 2>/dev/null || true
+find "$OUT" -name "*kernel_trace.csv" -delete 2>/dev/null || true
 du -sh "$OUT"

@@ -3,6 +3,7 @@ profiles/.   usage: python tools/summarize_profiles.py r02
 PMC handling follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from separate passes, are
 reported in KiB, and on gfx950 FETCH_SIZE counts exactly half of a wide (16 B/lane) coalesced read stream, so reads = 2 x FETCH_SIZE
 for the block / strip / chain kernels (their loads are 16 B/lane, plain or LDS-DMA); other kernels are listed uncorrected.
+Other kernels (stem, generic, post-processing) are listed uncorrected: their access widths are not calibrated.
 pmc_summary.json is stamped with a hash of the kernel sources: bench.py reports `traffic` only while that hash still matches."""
 import collections, csv, glob, json, os, re, shutil, statistics, sys
 
@@ -37,8 +38,11 @@ def label(name):
     return "%s<%s>" % (m.group(1), ",".join(args))
 
 
+WORKLOADS = {1: "short128_b256", 2: "back256_b256", 3: "landmark192_b512", 5: "pipeline192_b128"}
+WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel")
+
 # ---- kernel stats per config
-for c in (2, 3, 5):
+for c in WORKLOADS:
     ks = one("trace_c%d/**/*_kernel_stats.csv" % c)
     if ks:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats_config%d.csv" % (tag, c)))
@@ -54,52 +58,63 @@ def load(d):
     return by
 
 
-# ---- HBM traffic of config 2's kernels
-f, w = load("fetch"), load("write")
-rows = []
-for (k, _c) in sorted(f, key=lambda kc: -sum(f[kc])):
-    if "mi::" not in k:
-        continue
-    wide = any(t in k for t in ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel"))
-    fk, wk = statistics.mean(f[(k, "FETCH_SIZE")]), statistics.mean(w.get((k, "WRITE_SIZE"), [0]))
-    rows.append({"kernel": k, "label": label(k), "dispatches": len(f[(k, "FETCH_SIZE")]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
-                 "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
+import bench
+entries, rows = [], []
+for c, workload in WORKLOADS.items():
+    # ---- HBM traffic of this config's kernels
+    f, w = load("fetch_c%d" % c), load("write_c%d" % c)
+    crow = []
+    for (k, _c) in sorted(f, key=lambda kc: -sum(f[kc])):
+        if "mi::" not in k:
+            continue
+        wide = any(t in k for t in WIDE)
+        fk, wk = statistics.mean(f[(k, "FETCH_SIZE")]), statistics.mean(w.get((k, "WRITE_SIZE"), [0]))
+        crow.append({"config": c, "kernel": k, "label": label(k), "dispatches": len(f[(k, "FETCH_SIZE")]), "FETCH_SIZE_KiB_avg": round(fk, 1), "WRITE_SIZE_KiB_avg": round(wk, 1),
+                     "fetch_correction": 2 if wide else 1, "hbm_bytes_per_launch": round(((2 if wide else 1) * fk + wk) * 1024)})
+    rows += crow
+    ksc = os.path.join(out, "%s_kernel_stats_config%d.csv" % (tag, c))
+    avg = {}
+    if os.path.exists(ksc):
+        tot = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(ksc)):
+            t = tot[label(r["Name"])]
+            t[0] += float(r["TotalDurationNs"]); t[1] += int(r["Calls"])
+        avg = {k: v[0] / max(v[1], 1) for k, v in tot.items()}
+    by_label = collections.defaultdict(list)
+    for r in crow:
+        by_label[r["label"]].append(r)
+    entries += [{"round": tag, "workload": workload, "kernel": lab, "source_hash": bench.kernel_source_hash(), "rocprof_avg_ns": avg.get(lab),
+                 "hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / sum(r["dispatches"] for r in rs)),
+                 "note": "reads = %d x FETCH_SIZE (gfx950: FETCH_SIZE counts half of a 16 B/lane stream) + WRITE_SIZE, KiB -> bytes; separate --pmc passes" % rs[0]["fetch_correction"]}
+                for lab, rs in by_label.items()]
+    # ---- SQ counters of this config (where a wave's cycles go)
+    sq = {}
+    for i in range(1, 4):
+        for (k, cn), v in load("sq%d_c%d" % (i, c)).items():
+            sq.setdefault(k, {})[cn] = statistics.mean(v)
+    if sq:
+        with open(os.path.join(out, "%s_sq_counters_config%d.txt" % (tag, c)), "w") as fh:
+            fh.write("# rocprofv3 --pmc passes of tools/collect_profiles.sh on bench.py --config %d (%s): per kernel, averages per dispatch;\n"
+                     "# cyc/wave = 4 x SQ_WAVE_CYCLES / SQ_WAVES; wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked at s_waitcnt / barrier); stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls);\n"
+                     "# valu / salu / lds = SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES; mfma = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CYCLES per SIMD: see DESIGN.md); instruction counts per wave\n" % (c, workload))
+            for k, cc in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+                if "mi::" not in k or not cc.get("SQ_WAVES"):
+                    continue
+                wv, wc = cc["SQ_WAVES"], max(cc.get("SQ_WAVE_CYCLES", 0), 1)
+                g = lambda n: cc.get(n, 0)
+                fh.write("%-34s waves %6d cyc/wave %8.0f wait %.2f stall %.2f (lds %.2f) valu %.2f salu %.2f | VALU %.0f MFMA %.0f SALU %.0f LDS %.0f SMEM %.0f VMEM %.0f | mfma-busy cyc/wave %.0f\n" % (
+                    label(k), wv, 4 * wc / wv, g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_ANY") / wc, g("SQ_WAIT_INST_LDS") / wc, g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_SCA") / wc,
+                    g("SQ_INSTS_VALU") / wv, g("SQ_INSTS_MFMA") / wv, g("SQ_INSTS_SALU") / wv, g("SQ_INSTS_LDS") / wv, g("SQ_INSTS_SMEM") / wv,
+                    (g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")) / wv, g("SQ_VALU_MFMA_BUSY_CYCLES") / wv))
 if rows:
     with open(os.path.join(out, "%s_pmc_by_kernel.csv" % tag), "w", newline="") as fh:
         wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
         wr.writeheader()
         wr.writerows(rows)
-    import bench
-    ks2 = os.path.join(out, "%s_kernel_stats_config2.csv" % tag)
-    avg = {label(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(ks2))} if os.path.exists(ks2) else {}
-    by_label = collections.defaultdict(list)
-    for r in rows:
-        by_label[r["label"]].append(r)
-    entries = [{"round": tag, "workload": "back256_b256", "kernel": lab, "source_hash": bench.kernel_source_hash(), "rocprof_avg_ns": avg.get(lab),
-                "hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / sum(r["dispatches"] for r in rs)),
-                "note": "reads = 2 x FETCH_SIZE (gfx950 16 B/lane stream correction) + WRITE_SIZE, KiB -> bytes; separate --pmc passes"}
-               for lab, rs in by_label.items()]
     json.dump({"entries": entries}, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 
-# ---- SQ counters of config 2 (where a wave's cycles go)
-sq = {}
-for i in range(1, 5):
-    for (k, c), v in load("sq%d" % i).items():
-        sq.setdefault(k, {})[c] = statistics.mean(v)
-with open(os.path.join(out, "%s_sq_counters_bench.txt" % tag), "w") as fh:
-    fh.write("# rocprofv3 --pmc passes of tools/collect_profiles.sh on bench.py (BackCamera 256 frames): per kernel, averages per dispatch;\n"
-             "# cyc/wave = 4 x SQ_WAVE_CYCLES / SQ_WAVES; wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; valu / salu = SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES; instruction counts per wave\n")
-    for k, c in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-        if "mi::" not in k or not c.get("SQ_WAVES"):
-            continue
-        wv, wc = c["SQ_WAVES"], max(c.get("SQ_WAVE_CYCLES", 0), 1)
-        g = lambda n: c.get(n, 0)
-        fh.write("%-34s waves %6d cyc/wave %8.0f wait %.2f (lds %.2f) valu %.2f salu %.2f | VALU %.0f SALU %.0f LDS %.0f SMEM %.0f VMEM %.0f\n" % (
-            label(k), wv, 4 * wc / wv, g("SQ_WAIT_ANY") / wc, g("SQ_WAIT_INST_LDS") / wc, g("SQ_ACTIVE_INST_VALU") / wc, g("SQ_ACTIVE_INST_SCA") / wc,
-            g("SQ_INSTS_VALU") / wv, g("SQ_INSTS_SALU") / wv, g("SQ_INSTS_LDS") / wv, g("SQ_INSTS_SMEM") / wv, (g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")) / wv))
-
 # ---- bench lines, per-launch event lists, secondary configs
-for c in (2, 3, 5):
+for c in WORKLOADS:
     p = os.path.join(base, "bench_c%d.json" % c)
     if os.path.exists(p) and open(p).read().strip():
         with open(os.path.join(out, "bench_%s_config%d_n1.json" % (tag, c)), "w") as fh:
