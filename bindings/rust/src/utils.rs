@@ -32,7 +32,7 @@ impl RgbImage {
     }
 }
 
-/// Baseline / extended-sequential Huffman JPEG, 8 bit, grey or YCbCr (h1v1, h2v1, h2v2).  Anything else (progressive,
+/// Baseline / extended-sequential / progressive Huffman JPEG, 8 bit, grey or YCbCr (h1v1, h2v1, h2v2).  Anything else (
 /// arithmetic coding, other containers) is an error: keep `imdecode` for those ("Pictures libmiface does not
 /// decode": fall back to the reference's own `convert_image_to_mat` and pass the `Mat` to `infer` under `--features opencv`).
 pub fn convert_image_to_mat(im_bytes: &[u8]) -> Result<RgbImage, Error> {

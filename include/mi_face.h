@@ -252,7 +252,7 @@ int mi_iris_roi_from_face_landmarks(const mi_landmark *landmarks468, int image_w
 /* utils::convert_image_to_mat(im_bytes) — utils.rs:8-21 (cv::imdecode(IMREAD_COLOR) + cvtColor(BGR2RGB)) for JPEG streams:
  * entropy decoding on the host, dequantisation / IDCT / chroma upsampling / colour conversion on the GPU (the arithmetic
  * of libjpeg-turbo's default decoder, bit for bit).  Baseline and extended-sequential Huffman JPEG, 8 bit, grey or YCbCr with
- * h1v1 / h2v1 / h2v2 sampling; anything else (progressive, arithmetic, CMYK, other containers) is MI_EINVAL with a message.
+ * h1v1 / h2v1 / h2v2 sampling; progressive (SOF2) streams included; anything else (arithmetic coding, 12-bit, CMYK, other containers) is MI_EINVAL with a message.
  * rgb = [height][width][3] u8, at least cap_bytes >= 3*width*height (ask mi_jpeg_info first); follows `mem`. */
 int mi_jpeg_info(const uint8_t *bytes, size_t nbytes, int *width, int *height);
 int mi_jpeg_decode_rgb(int device, const uint8_t *bytes, size_t nbytes, uint8_t *rgb, size_t cap_bytes, int *width,

@@ -7,8 +7,8 @@
  * (Cargo.lock:1001-1004) -> system OpenCV 4.x -> its bundled libjpeg-turbo (libjpeg 6b API: ISLOW integer IDCT, "fancy"
  * triangle-filter chroma upsampling, 16-bit fixed-point YCbCr -> RGB).  This file restates those published algorithms
  * (ITU-T T.81 for the bit stream; jidctint.c / jdsample.c / jdcolor.c for the sample arithmetic) for baseline / extended
- * sequential 8-bit Huffman JPEGs with 1 or 3 components and h1v1 / h2v1 / h2v2 chroma sampling — what the reference's
- * test_data/ images are (all three: baseline, 4:2:0).
+ * sequential and (round 3) progressive 8-bit Huffman JPEGs with 1 or 3 components and h1v1 / h2v1 / h2v2 chroma sampling — the
+ * reference's test_data/ images are all three baseline, 4:2:0; `imdecode` takes progressive files the same way (jdphuff.c).
  *
  * PINNED against libjpeg-turbo itself as present in this image (Pillow's decoder, libjpeg-turbo with the 6.2 API, the same
  * library family OpenCV bundles): bit-exact on the reference's three test JPEGs (tests/test_jpeg.py).
@@ -169,6 +169,168 @@ int orc_jpeg_info(const uint8_t *data, size_t n, int *width, int *height) {
     return -1;
 }
 
+/* Samples from the quantised coefficients of every component: dequantise + ISLOW IDCT, fancy upsampling, YCbCr -> RGB. */
+static void reconstruct(component *comp, int ncomp, int W, int H, int hmax, int vmax, uint16_t (*qt)[64], uint8_t *rgb) {
+    /* ---- samples: dequantise + ISLOW IDCT */
+    for (int c = 0; c < ncomp; c++)
+        for (int by = 0; by < comp[c].bh; by++)
+            for (int bx = 0; bx < comp[c].bw; bx++)
+                idct_block(comp[c].coef + ((size_t)by * comp[c].bw + bx) * 64, qt[comp[c].tq], comp[c].plane + ((size_t)by * 8 * comp[c].bw + bx) * 8,
+                           comp[c].bw * 8);
+    /* ---- fancy upsampling (jdsample.c) + YCbCr -> RGB (jdcolor.c) */
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            int Y = comp[0].plane[(size_t)y * comp[0].bw * 8 + x];
+            uint8_t *o = rgb + ((size_t)y * W + x) * 3;
+            if (ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; continue; }
+            int cc[2];
+            for (int c = 1; c <= 2; c++) {
+                const uint8_t *pl = comp[c].plane;
+                int st = comp[c].bw * 8, dw = comp[c].dw, dh = comp[c].dh;
+                if (hmax == 1 && vmax == 1) {
+                    cc[c - 1] = pl[(size_t)y * st + x];
+                } else if (vmax == 1) { /* h2v1_fancy_upsample */
+                    int cx = x >> 1, t = pl[(size_t)y * st + cx];
+                    if (dw <= 2) { cc[c - 1] = t; } /* the library falls back to replication for planes this narrow */
+                    else if ((x & 1) == 0) cc[c - 1] = cx == 0 ? t : (3 * t + pl[(size_t)y * st + cx - 1] + 1) >> 2;
+                    else cc[c - 1] = cx == dw - 1 ? t : (3 * t + pl[(size_t)y * st + cx + 1] + 2) >> 2;
+                } else { /* h2v2_fancy_upsample: 3/4 nearer + 1/4 further row, then the same along the row, 4-bit rounding */
+                    int cx = x >> 1, cy = y >> 1;
+                    if (dw <= 2) { cc[c - 1] = pl[(size_t)cy * st + cx]; continue; }
+                    int fy = (y & 1) ? cy + 1 : cy - 1; /* context rows: the edge rows replicate */
+                    if (fy < 0) fy = 0;
+                    if (fy > dh - 1) fy = dh - 1;
+                    int tc = 3 * pl[(size_t)cy * st + cx] + pl[(size_t)fy * st + cx];
+                    if ((x & 1) == 0) {
+                        if (cx == 0) cc[c - 1] = (tc * 4 + 8) >> 4;
+                        else cc[c - 1] = (3 * tc + 3 * pl[(size_t)cy * st + cx - 1] + pl[(size_t)fy * st + cx - 1] + 8) >> 4;
+                    } else {
+                        if (cx == dw - 1) cc[c - 1] = (tc * 4 + 7) >> 4;
+                        else cc[c - 1] = (3 * tc + 3 * pl[(size_t)cy * st + cx + 1] + pl[(size_t)fy * st + cx + 1] + 7) >> 4;
+                    }
+                }
+            }
+            int cb = cc[0] - 128, cr = cc[1] - 128;
+            /* SCALEBITS 16: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554 */
+            int r = Y + (int)((91881L * cr + 32768) >> 16);
+            int g = Y + (int)((-22554L * cb + 32768 - 46802L * cr) >> 16);
+            int b = Y + (int)((116130L * cb + 32768) >> 16);
+            o[0] = (uint8_t)clamp255(r); o[1] = (uint8_t)clamp255(g); o[2] = (uint8_t)clamp255(b);
+        }
+}
+
+/* ---- progressive scans (T.81 Annex G; the control flow of libjpeg's jdphuff.c: decode_mcu_DC_first / _AC_first / _DC_refine /
+ * _AC_refine).  One scan adds a band [Ss, Se] of coefficients, or one more bit (Al) of a band, of one component (AC) or of several
+ * interleaved ones (DC).  eobrun: blocks still covered by an end-of-band run. */
+typedef struct { int nc, ci[3], Ss, Se, Ah, Al; } scan_hdr;
+
+static void restart_marker(bitreader *br) {
+    br->bits = 0;
+    if (br->marker >= 0xD0 && br->marker <= 0xD7) { br->p += 2; br->marker = 0; br->insufficient = 0; }
+    else if (br->marker == 0 && br->p + 1 < br->end && br->p[0] == 0xFF && br->p[1] >= 0xD0 && br->p[1] <= 0xD7) { br->p += 2; br->insufficient = 0; }
+}
+
+static void prog_block(bitreader *br, const scan_hdr *sh, component *cp, const hufftab *dct, const hufftab *act, int16_t *blk, int *eobrun) {
+    const int Al = sh->Al;
+    if (sh->Ss == 0) { /* DC */
+        if (sh->Ah == 0) {
+            int t = decode_symbol(br, dct);
+            cp->pred += extend(get_bits(br, t), t);
+            blk[0] = (int16_t)(cp->pred * (1 << Al));
+        } else if (get_bit(br)) {
+            blk[0] |= (int16_t)(1 << Al);
+        }
+        return;
+    }
+    if (sh->Ah == 0) { /* AC first */
+        if (*eobrun > 0) { (*eobrun)--; return; }
+        for (int k = sh->Ss; k <= sh->Se; k++) {
+            int rs = decode_symbol(br, act), r = rs >> 4, sz = rs & 15;
+            if (sz) {
+                k += r;
+                int v = extend(get_bits(br, sz), sz);
+                if (k <= 63) blk[zigzag[k]] = (int16_t)(v * (1 << Al));
+            } else if (r == 15) {
+                k += 15;
+            } else {
+                *eobrun = 1 << r;
+                if (r) *eobrun += get_bits(br, r);
+                (*eobrun)--;
+                break;
+            }
+        }
+        return;
+    }
+    /* AC refinement */
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    int k = sh->Ss;
+    if (*eobrun == 0) {
+        for (; k <= sh->Se; k++) {
+            int rs = decode_symbol(br, act), r = rs >> 4, sz = rs & 15, val = 0;
+            if (sz) {
+                val = get_bit(br) ? p1 : m1; /* sz must be 1 */
+            } else if (r != 15) {
+                *eobrun = 1 << r;
+                if (r) *eobrun += get_bits(br, r);
+                break; /* the rest of the band is handled as part of the run */
+            }
+            do { /* skip r still-zero coefficients; every already-nonzero one on the way takes a correction bit */
+                int16_t *c = &blk[zigzag[k]];
+                if (*c != 0) {
+                    if (get_bit(br) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+                } else if (--r < 0) {
+                    break;
+                }
+                k++;
+            } while (k <= sh->Se);
+            if (sz && k <= 63) blk[zigzag[k]] = (int16_t)val;
+        }
+    }
+    if (*eobrun > 0) {
+        for (; k <= sh->Se; k++) {
+            int16_t *c = &blk[zigzag[k]];
+            if (*c != 0 && get_bit(br) && (*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+        }
+        (*eobrun)--;
+    }
+}
+
+/* One progressive scan; returns the offset of the first byte behind its entropy-coded data. */
+static size_t prog_scan(const uint8_t *data, size_t n, size_t ecs, const scan_hdr *sh, component *comp, int W, int H, int hmax, int vmax, int restart,
+                        const hufftab *dc, const hufftab *ac) {
+    bitreader br = {data + ecs, data + n, 0, 0, 0, 0, 0};
+    int eobrun = 0, mcus = 0;
+    for (int s = 0; s < sh->nc; s++) comp[sh->ci[s]].pred = 0;
+    if (sh->nc == 1) { /* non-interleaved: the component's own blocks in raster order, not padded to whole MCUs */
+        component *cp = &comp[sh->ci[0]];
+        int wib = (cp->dw + 7) / 8, hib = (cp->dh + 7) / 8;
+        for (int by = 0; by < hib; by++)
+            for (int bx = 0; bx < wib; bx++) {
+                if (restart && mcus > 0 && mcus % restart == 0) { restart_marker(&br); cp->pred = 0; eobrun = 0; }
+                mcus++;
+                if (br.insufficient) continue;
+                prog_block(&br, sh, cp, &dc[cp->td], &ac[cp->ta], cp->coef + ((size_t)by * cp->bw + bx) * 64, &eobrun);
+            }
+    } else { /* interleaved (DC scans only) */
+        int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+        for (int my = 0; my < mcuy; my++)
+            for (int mx = 0; mx < mcux; mx++) {
+                if (restart && mcus > 0 && mcus % restart == 0) { restart_marker(&br); for (int s = 0; s < sh->nc; s++) comp[sh->ci[s]].pred = 0; }
+                mcus++;
+                if (br.insufficient) continue;
+                for (int s = 0; s < sh->nc; s++) {
+                    component *cp = &comp[sh->ci[s]];
+                    for (int by = 0; by < cp->v; by++)
+                        for (int bx = 0; bx < cp->h; bx++)
+                            prog_block(&br, sh, cp, &dc[cp->td], &ac[cp->ta], cp->coef + ((size_t)(my * cp->v + by) * cp->bw + mx * cp->h + bx) * 64, &eobrun);
+                }
+            }
+    }
+    /* the reader stops in front of the marker that ends the scan (or at the end of the data) */
+    size_t pos = (size_t)(br.p - data);
+    return pos;
+}
+
 /* imdecode(IMREAD_COLOR) + BGR2RGB (utils.rs:8-21): rgb = [H][W][3]. Returns 0, or a negative code (-2 = unsupported). */
 int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, int cap_h) {
     if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
@@ -178,7 +340,7 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
     memset(ac, 0, sizeof ac);
     component comp[3];
     memset(comp, 0, sizeof comp);
-    int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, rc = -1;
+    int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, rc = -1, progressive = 0, scans = 0;
     size_t i = 2;
     while (i + 4 <= n) {
         if (data[i] != 0xFF) { i++; continue; }
@@ -211,8 +373,9 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
                 build_huff(h);
                 k += 17 + (size_t)total;
             }
-        } else if (m == 0xC0 || m == 0xC1) { /* SOF0 / SOF1: sequential Huffman */
-            if (seg[0] != 8) { rc = -2; goto done; }
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) { /* SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman */
+            if (seg[0] != 8 || ncomp) { rc = -2; goto done; }
+            progressive = m == 0xC2;
             H = (seg[1] << 8) | seg[2];
             W = (seg[3] << 8) | seg[4];
             ncomp = seg[5];
@@ -226,11 +389,43 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
                 if (comp[c].v > vmax) vmax = comp[c].v;
             }
             if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; } /* a single component is never interleaved */
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            rc = -2; /* progressive / lossless / arithmetic: outside this restatement */
+            if (progressive) { /* the coefficient arrays live across the scans */
+                if (ncomp == 3 && !((comp[0].h == 1 || comp[0].h == 2) && (comp[0].v == 1 || comp[0].v == 2) && comp[1].h == 1 && comp[1].v == 1 &&
+                                    comp[2].h == 1 && comp[2].v == 1 && !(comp[0].h == 1 && comp[0].v == 2))) { rc = -2; goto done; }
+                int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+                for (int c = 0; c < ncomp; c++) {
+                    comp[c].bw = mcux * comp[c].h;
+                    comp[c].bh = mcuy * comp[c].v;
+                    comp[c].dw = (W * comp[c].h + hmax - 1) / hmax;
+                    comp[c].dh = (H * comp[c].v + vmax - 1) / vmax;
+                    comp[c].coef = (int16_t *)calloc((size_t)comp[c].bw * comp[c].bh * 64, sizeof(int16_t));
+                    comp[c].plane = (uint8_t *)malloc((size_t)comp[c].bw * comp[c].bh * 64);
+                    if (!comp[c].coef || !comp[c].plane) goto done;
+                }
+            }
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            rc = -2; /* lossless / arithmetic / hierarchical: outside this restatement */
             goto done;
         } else if (m == 0xDD) {
             restart = (seg[0] << 8) | seg[1];
+        } else if (m == 0xDA && progressive) { /* SOS of a progressive frame: one of several scans */
+            scan_hdr sh;
+            sh.nc = seg[0];
+            if (ncomp == 0 || sh.nc < 1 || sh.nc > ncomp || len < (size_t)(6 + 2 * sh.nc)) goto done;
+            for (int s2 = 0; s2 < sh.nc; s2++) {
+                int cid = seg[1 + 2 * s2], c = 0;
+                while (c < ncomp && comp[c].id != cid) c++;
+                if (c == ncomp) goto done;
+                sh.ci[s2] = c;
+                comp[c].td = seg[2 + 2 * s2] >> 4;
+                comp[c].ta = seg[2 + 2 * s2] & 15;
+                if (comp[c].td > 3 || comp[c].ta > 3) goto done;
+            }
+            sh.Ss = seg[1 + 2 * sh.nc]; sh.Se = seg[2 + 2 * sh.nc]; sh.Ah = seg[3 + 2 * sh.nc] >> 4; sh.Al = seg[3 + 2 * sh.nc] & 15;
+            if (sh.Ss > sh.Se || sh.Se > 63 || (sh.Ss == 0 && sh.Se != 0) || (sh.Ss > 0 && sh.nc != 1) || sh.Al > 13 || sh.Ah > 13) goto done;
+            i = prog_scan(data, n, i + 2 + len, &sh, comp, W, H, hmax, vmax, restart, dc, ac);
+            scans++;
+            continue;
         } else if (m == 0xDA) { /* SOS: one interleaved scan holding every component */
             if (ncomp == 0 || seg[0] != ncomp) { rc = -2; goto done; }
             for (int s = 0; s < ncomp; s++) {
@@ -289,56 +484,15 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
                                 }
                             }
                 }
-            /* ---- samples: dequantise + ISLOW IDCT */
-            for (int c = 0; c < ncomp; c++)
-                for (int by = 0; by < comp[c].bh; by++)
-                    for (int bx = 0; bx < comp[c].bw; bx++)
-                        idct_block(comp[c].coef + ((size_t)by * comp[c].bw + bx) * 64, qt[comp[c].tq], comp[c].plane + ((size_t)by * 8 * comp[c].bw + bx) * 8,
-                                   comp[c].bw * 8);
-            /* ---- fancy upsampling (jdsample.c) + YCbCr -> RGB (jdcolor.c) */
-            for (int y = 0; y < H; y++)
-                for (int x = 0; x < W; x++) {
-                    int Y = comp[0].plane[(size_t)y * comp[0].bw * 8 + x];
-                    uint8_t *o = rgb + ((size_t)y * W + x) * 3;
-                    if (ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; continue; }
-                    int cc[2];
-                    for (int c = 1; c <= 2; c++) {
-                        const uint8_t *pl = comp[c].plane;
-                        int st = comp[c].bw * 8, dw = comp[c].dw, dh = comp[c].dh;
-                        if (hmax == 1 && vmax == 1) {
-                            cc[c - 1] = pl[(size_t)y * st + x];
-                        } else if (vmax == 1) { /* h2v1_fancy_upsample */
-                            int cx = x >> 1, t = pl[(size_t)y * st + cx];
-                            if (dw <= 2) { cc[c - 1] = t; } /* the library falls back to replication for planes this narrow */
-                            else if ((x & 1) == 0) cc[c - 1] = cx == 0 ? t : (3 * t + pl[(size_t)y * st + cx - 1] + 1) >> 2;
-                            else cc[c - 1] = cx == dw - 1 ? t : (3 * t + pl[(size_t)y * st + cx + 1] + 2) >> 2;
-                        } else { /* h2v2_fancy_upsample: 3/4 nearer + 1/4 further row, then the same along the row, 4-bit rounding */
-                            int cx = x >> 1, cy = y >> 1;
-                            if (dw <= 2) { cc[c - 1] = pl[(size_t)cy * st + cx]; continue; }
-                            int fy = (y & 1) ? cy + 1 : cy - 1; /* context rows: the edge rows replicate */
-                            if (fy < 0) fy = 0;
-                            if (fy > dh - 1) fy = dh - 1;
-                            int tc = 3 * pl[(size_t)cy * st + cx] + pl[(size_t)fy * st + cx];
-                            if ((x & 1) == 0) {
-                                if (cx == 0) cc[c - 1] = (tc * 4 + 8) >> 4;
-                                else cc[c - 1] = (3 * tc + 3 * pl[(size_t)cy * st + cx - 1] + pl[(size_t)fy * st + cx - 1] + 8) >> 4;
-                            } else {
-                                if (cx == dw - 1) cc[c - 1] = (tc * 4 + 7) >> 4;
-                                else cc[c - 1] = (3 * tc + 3 * pl[(size_t)cy * st + cx + 1] + pl[(size_t)fy * st + cx + 1] + 7) >> 4;
-                            }
-                        }
-                    }
-                    int cb = cc[0] - 128, cr = cc[1] - 128;
-                    /* SCALEBITS 16: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554 */
-                    int r = Y + (int)((91881L * cr + 32768) >> 16);
-                    int g = Y + (int)((-22554L * cb + 32768 - 46802L * cr) >> 16);
-                    int b = Y + (int)((116130L * cb + 32768) >> 16);
-                    o[0] = (uint8_t)clamp255(r); o[1] = (uint8_t)clamp255(g); o[2] = (uint8_t)clamp255(b);
-                }
+            reconstruct(comp, ncomp, W, H, hmax, vmax, qt, rgb);
             rc = 0;
             goto done;
         }
         i += 2 + len;
+    }
+    if (progressive && scans > 0) { /* EOI (or the end of the data): every scan that was there has been added */
+        reconstruct(comp, ncomp, W, H, hmax, vmax, qt, rgb);
+        rc = 0;
     }
 done:
     for (int c = 0; c < 3; c++) { free(comp[c].coef); free(comp[c].plane); }

@@ -3,6 +3,7 @@
 // per-block and per-pixel arithmetic — runs on the GPU (jpeg_kernels.hip).
 #include "jpeg.hpp"
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 
@@ -106,6 +107,10 @@ inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 :
 
 [[noreturn]] void bad(const char* what) { throw std::runtime_error(std::string("jpeg: ") + what); }
 
+struct ScanHdr {  // progressive scans: which components, which band of coefficients [Ss, Se], which bit (Ah: previous, Al: this)
+    int nc = 0, ci[3] = {0, 0, 0}, Ss = 0, Se = 0, Ah = 0, Al = 0;
+};
+
 struct Parser {
     const uint8_t* d;
     size_t n;
@@ -114,10 +119,11 @@ struct Parser {
     int restart_interval = 0;
     bool have_frame = false;
 
-    // walks the markers up to SOS; returns the offset of the entropy-coded data (0 when stop_at_frame and a frame header was found)
-    size_t headers(bool stop_at_frame) {
+    // walks the markers from `start` up to SOS; returns the offset of the entropy-coded data (0 when stop_at_frame and a frame header
+    // was found, or — behind the first scan of a progressive frame, `sh` given — when EOI / the end of the data comes first)
+    size_t headers(bool stop_at_frame, size_t start = 2, ScanHdr* sh = nullptr) {
         if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) bad("not a JPEG stream (no SOI)");
-        size_t i = 2;
+        size_t i = start;
         while (i + 4 <= n) {
             if (d[i] != 0xFF) { i++; continue; }
             const int m = d[i + 1];
@@ -151,7 +157,9 @@ struct Parser {
                     if (!h.build(counts)) bad("bad Huffman table");
                     k += 17 + static_cast<size_t>(total);
                 }
-            } else if (m == 0xC0 || m == 0xC1) {
+            } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+                if (have_frame) bad("second frame header");
+                f->progressive = m == 0xC2;
                 if (body < 6 || seg[0] != 8) bad("unsupported sample precision (8-bit only)");
                 f->height = (seg[1] << 8) | seg[2];
                 f->width = (seg[3] << 8) | seg[4];
@@ -175,11 +183,36 @@ struct Parser {
                 }
                 have_frame = true;
                 if (stop_at_frame) return 0;
-            } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-                bad("unsupported coding process (baseline / extended sequential Huffman only)");
+            } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+                bad("unsupported coding process (baseline / extended sequential / progressive Huffman only)");
             } else if (m == 0xDD) {
                 if (body < 2) bad("bad DRI");
                 restart_interval = (seg[0] << 8) | seg[1];
+            } else if (m == 0xDA && f->progressive) {
+                if (!have_frame || !sh) bad("scan before frame header");
+                sh->nc = body >= 1 ? seg[0] : 0;
+                if (sh->nc < 1 || sh->nc > f->ncomp || body < 4 + 2 * static_cast<size_t>(sh->nc)) bad("bad scan header");
+                for (int s = 0; s < sh->nc; s++) {
+                    int c = 0;
+                    while (c < f->ncomp && f->comp[c].id != seg[1 + 2 * s]) c++;
+                    if (c == f->ncomp) bad("scan names an unknown component");
+                    for (int q = 0; q < s; q++)
+                        if (sh->ci[q] == c) bad("scan names a component twice");
+                    sh->ci[s] = c;
+                    f->comp[c].td = seg[2 + 2 * s] >> 4;
+                    f->comp[c].ta = seg[2 + 2 * s] & 15;
+                    if (f->comp[c].td > 3 || f->comp[c].ta > 3) bad("scan uses an undefined Huffman table");
+                }
+                const uint8_t* t = seg + 1 + 2 * sh->nc;
+                sh->Ss = t[0]; sh->Se = t[1]; sh->Ah = t[2] >> 4; sh->Al = t[2] & 15;
+                // jdphuff.c start_pass_phuff_decoder: the band and the bit positions a scan may name
+                if (sh->Ss > sh->Se || sh->Se > 63 || (sh->Ss == 0 && sh->Se != 0) || (sh->Ss > 0 && sh->nc != 1) || sh->Al > 13 || sh->Ah > 13)
+                    bad("bad progressive scan parameters");
+                for (int s = 0; s < sh->nc; s++) {
+                    const JpegComponent& cp = f->comp[sh->ci[s]];
+                    if (sh->Ss == 0 ? (sh->Ah == 0 && !dc[cp.td].present) : !ac[cp.ta].present) bad("scan uses an undefined Huffman table");
+                }
+                return i + 2 + len;
             } else if (m == 0xDA) {
                 if (!have_frame) bad("scan before frame header");
                 if (body < 1 || seg[0] != f->ncomp || body < 1 + 2 * static_cast<size_t>(f->ncomp)) bad("unsupported scan layout (one interleaved scan)");
@@ -195,9 +228,116 @@ struct Parser {
             }
             i += 2 + len;
         }
+        if (sh && start > 2) return 0;  // EOI, or the data ends: every scan that was there has been read
         bad(stop_at_frame ? "no frame header" : "no scan");
     }
 };
+
+// ---- progressive scans: the control flow of libjpeg's jdphuff.c (decode_mcu_DC_first / _AC_first / _DC_refine / _AC_refine)
+void prog_block(Bits& br, const ScanHdr& sh, int& pred, const Huff& hd, const Huff& ha, int16_t* blk, int& eobrun) {
+    const int Al = sh.Al;
+    if (sh.Ss == 0) {
+        if (sh.Ah == 0) {
+            const int t = br.symbol(hd) & 15;
+            if (t) pred += extend(br.get(t), t);
+            blk[0] = static_cast<int16_t>(pred * (1 << Al));
+        } else if (br.get(1)) {
+            blk[0] = static_cast<int16_t>(blk[0] | (1 << Al));
+        }
+        return;
+    }
+    if (sh.Ah == 0) {  // first pass over a band of AC coefficients
+        if (eobrun > 0) { eobrun--; return; }
+        for (int k = sh.Ss; k <= sh.Se; k++) {
+            const int rs = br.symbol(ha), r = rs >> 4, sz = rs & 15;
+            if (sz) {
+                k += r;
+                const int v = extend(br.get(sz), sz);
+                if (k <= 63) blk[kZigzag[k]] = static_cast<int16_t>(v * (1 << Al));
+            } else if (r == 15) {
+                k += 15;
+            } else {
+                eobrun = 1 << r;
+                if (r) eobrun += br.get(r);
+                eobrun--;
+                break;
+            }
+        }
+        return;
+    }
+    // refinement of a band: one more bit for the coefficients that are non-zero already, new +-1 << Al ones in between
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto correct = [&](int16_t& c) {
+        if (br.get(1) && (c & p1) == 0) c = static_cast<int16_t>(c + (c >= 0 ? p1 : m1));
+    };
+    int k = sh.Ss;
+    if (eobrun == 0) {
+        for (; k <= sh.Se; k++) {
+            const int rs = br.symbol(ha), sz = rs & 15;
+            int r = rs >> 4, val = 0;
+            if (sz) {
+                val = br.get(1) ? p1 : m1;
+            } else if (r != 15) {
+                eobrun = 1 << r;
+                if (r) eobrun += br.get(r);
+                break;  // the rest of the band belongs to the run
+            }
+            do {
+                int16_t& c = blk[kZigzag[k]];
+                if (c != 0) correct(c);
+                else if (--r < 0) break;
+                k++;
+            } while (k <= sh.Se);
+            if (sz && k <= 63) blk[kZigzag[k]] = static_cast<int16_t>(val);
+        }
+    }
+    if (eobrun > 0) {
+        for (; k <= sh.Se; k++) {
+            int16_t& c = blk[kZigzag[k]];
+            if (c != 0) correct(c);
+        }
+        eobrun--;
+    }
+}
+
+// one progressive scan; returns the offset at which the marker walk continues
+size_t prog_scan(const uint8_t* data, size_t n, size_t ecs, const ScanHdr& sh, Parser& p, JpegFrame& f) {
+    Bits br{data + ecs, data + n};
+    int pred[3] = {0, 0, 0}, eobrun = 0, mcus = 0;
+    auto at_restart = [&] {
+        if (p.restart_interval && mcus > 0 && mcus % p.restart_interval == 0) {
+            br.restart();
+            pred[0] = pred[1] = pred[2] = 0;
+            eobrun = 0;
+        }
+        mcus++;
+    };
+    if (sh.nc == 1) {  // non-interleaved: the component's own blocks in raster order, not padded to whole MCUs
+        const JpegComponent& cp = f.comp[sh.ci[0]];
+        const int wib = (cp.dw + 7) / 8, hib = (cp.dh + 7) / 8;
+        for (int by = 0; by < hib; by++)
+            for (int bx = 0; bx < wib; bx++) {
+                at_restart();
+                if (br.insufficient) continue;
+                prog_block(br, sh, pred[0], p.dc[cp.td], p.ac[cp.ta], f.coef.data() + cp.coef_off + (static_cast<size_t>(by) * cp.bw + bx) * 64, eobrun);
+            }
+    } else {  // interleaved (DC scans)
+        const int mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax), mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
+        for (int my = 0; my < mcuy; my++)
+            for (int mx = 0; mx < mcux; mx++) {
+                at_restart();
+                if (br.insufficient) continue;
+                for (int s = 0; s < sh.nc; s++) {
+                    const JpegComponent& cp = f.comp[sh.ci[s]];
+                    for (int by = 0; by < cp.v; by++)
+                        for (int bx = 0; bx < cp.h; bx++)
+                            prog_block(br, sh, pred[s], p.dc[cp.td], p.ac[cp.ta],
+                                       f.coef.data() + cp.coef_off + (static_cast<size_t>(my * cp.v + by) * cp.bw + mx * cp.h + bx) * 64, eobrun);
+                }
+            }
+    }
+    return static_cast<size_t>(br.p - data);  // the reader stops in front of the marker that ends the scan (or at the end)
+}
 
 }  // namespace
 
@@ -213,7 +353,8 @@ void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
     JpegFrame& f = *out;
     f = JpegFrame();
     Parser p{data, n, &f};
-    const size_t ecs = p.headers(false);
+    ScanHdr sh;
+    const size_t ecs = p.headers(false, 2, &sh);
     const int mcux = (f.width + 8 * f.hmax - 1) / (8 * f.hmax), mcuy = (f.height + 8 * f.vmax - 1) / (8 * f.vmax);
     size_t total = 0;
     for (int c = 0; c < f.ncomp; c++) {
@@ -231,6 +372,15 @@ void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
     if (total * sizeof(int16_t) > (32u << 20) && total / 64 > 4 * (n - ecs) + 64)
         bad("truncated stream (fewer entropy-coded bytes than the frame header needs)");
     f.coef.assign(total, 0);
+    if (f.progressive) {  // every scan adds a band, or a bit, to the coefficients
+        size_t pos = prog_scan(data, n, ecs, sh, p, f);
+        for (int scans = 1; scans < 1024; scans++) {
+            const size_t next = p.headers(false, std::max<size_t>(pos, 3), &sh);
+            if (!next) break;
+            pos = prog_scan(data, n, next, sh, p, f);
+        }
+        return;
+    }
     Bits br{data + ecs, data + n};
     int pred[3] = {0, 0, 0};
     int mcus = 0;

@@ -1,5 +1,5 @@
 // jpeg.hpp — `convert_image_to_mat` (/root/reference/src/face_detection_lite/utils.rs:8-21: cv::imdecode(IMREAD_COLOR) +
-// cvtColor(BGR2RGB)) for baseline / extended-sequential Huffman JPEGs: the serial part (marker parsing, entropy decoding)
+// cvtColor(BGR2RGB)) for baseline / extended-sequential and progressive Huffman JPEGs: the serial part (marker parsing, entropy decoding)
 // on the host, the sample arithmetic (dequantise + ISLOW IDCT, fancy chroma upsampling, YCbCr -> RGB: libjpeg-turbo's
 // algorithms, which is what OpenCV's imdecode runs) on the GPU, leaving RGB u8 in HBM for image_to_tensor / the pipeline.
 #pragma once
@@ -22,6 +22,7 @@ struct JpegComponent {
 
 struct JpegFrame {             // host-side result of the entropy decoder
     int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1;
+    bool progressive = false;  // SOF2: the coefficients are the sum of several scans (T.81 Annex G)
     JpegComponent comp[3];
     uint16_t qt[4][64] = {};   // natural order
     std::vector<int16_t> coef; // per component [bh][bw][64], natural order, quantised
@@ -29,7 +30,7 @@ struct JpegFrame {             // host-side result of the entropy decoder
 
 // Parses the headers only. Throws std::runtime_error("unsupported ...") for streams outside the subset.
 void jpeg_parse_size(const uint8_t* data, size_t n, int* width, int* height);
-// Headers + Huffman decoding of the (single, interleaved) scan.
+// Headers + Huffman decoding: the single interleaved scan of a sequential frame, or every scan of a progressive one.
 void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out);
 
 // Device side. d_coef: the frame's coefficients (int16), d_qt: uint16 [4][64], d_planes: scratch of jpeg_plane_bytes(f),

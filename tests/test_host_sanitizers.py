@@ -20,7 +20,7 @@ def test_parsers_under_asan_ubsan(tmp_path):
                            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fuzz_host.cpp"),
                            os.path.join(CSRC, "jpeg.cpp"), os.path.join(CSRC, "tflite_graph.cpp"), "-o", exe])
     files = [os.path.join(GOLDEN, "man.jpg"), os.path.join(GOLDEN, "jpeg", "c420_rst3.jpg"), os.path.join(GOLDEN, "jpeg", "grey.jpg"),
-             os.path.join(GOLDEN, "jpeg", "c444_rstrow.jpg"), os.path.join(MODELS, "face_detection_full_range_sparse.tflite"),
+             os.path.join(GOLDEN, "jpeg", "c444_rstrow.jpg"), os.path.join(GOLDEN, "jpeg", "prog_c420.jpg"), os.path.join(GOLDEN, "jpeg", "prog_grey.jpg"), os.path.join(MODELS, "face_detection_full_range_sparse.tflite"),
              os.path.join(MODELS, "face_detection_front.tflite"), os.path.join(MODELS, "iris_landmark.tflite")]
     r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -38,11 +38,11 @@ def test_oracle_matches_libjpeg_turbo(oracle, rel):
 def test_headers_and_refusals_without_gpu(mi, oracle):
     assert mi.jpeg_info(_bytes("man.jpg")) == (540, 360)          # the reference's test image (lib.rs:23)
     assert mi.jpeg_info(_bytes("russ_cox_2.jpg")) == (200, 225)
-    for bad in (b"", b"\x89PNG\r\n\x1a\n" + b"\0" * 64, _bytes("man.jpg")[:300], _bytes("jpeg/progressive_unsupported.jpg")):
+    for bad in (b"", b"\x89PNG\r\n\x1a\n" + b"\0" * 64, _bytes("man.jpg")[:300], _bytes("jpeg/arithmetic_unsupported.jpg")):
         with pytest.raises(mi.MiError):
             mi.convert_image_to_mat(bad)                           # refused before any device work
     with pytest.raises(ValueError):
-        oracle.jpeg_decode_rgb(_bytes("jpeg/progressive_unsupported.jpg"))
+        oracle.jpeg_decode_rgb(_bytes("jpeg/arithmetic_unsupported.jpg"))
     if mi.device_count() == 0:
         with pytest.raises(mi.MiError) as e:                       # the sample arithmetic has no CPU fallback
             mi.convert_image_to_mat(_bytes("man.jpg"))
