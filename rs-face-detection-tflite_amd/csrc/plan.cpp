@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <map>
 #include <sstream>
+#include <set>
 #include <functional>
 #include <stdexcept>
 
@@ -887,9 +888,57 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
         }
         (void)conv;
     }
+    // Growth groups: classes tied by the channel PAD on the skip of a stride-1 block (the front / short-range graph widens 32 -> 36 -> 42
+    // and 48 -> 56 -> ... -> 88 that way, a few channels per block).  Widened to ONE width, such a run becomes a run of same-shape
+    // blocks with plain skips — the shape the fast kernels exist for (BackCamera's: 48 channels on 32-pixel-wide frames, 96 on
+    // frames of at most 256 pixels) — and its PADs disappear.  The price is arithmetic on zeros; the gain is kernels and launches
+    // (front: five 16x16 blocks of 48..88 channels -> one frame-resident chain).  Only PADs that read a block's own input count: the
+    // stride-2 blocks' PADs (behind the max-pool) separate the groups.
+    std::vector<int> gparent(NT);
+    for (int t = 0; t < NT; t++) gparent[t] = t;
+    std::function<int(int)> gfind = [&](int t) { return gparent[t] == t ? t : gparent[t] = gfind(gparent[t]); };
+    std::vector<char> from_pool(NT, 0);
+    for (const OpInfo& op : g.ops)
+        if (op.op == BuiltinOp::MaxPool2D) from_pool[op.outputs[0]] = 1;
+    static const bool no_groups = getenv("MI_NO_WIDEN_GROUPS") != nullptr;  // tuning aid
+    struct GroupInfo { int maxC = 0, H = 0, W = 0, classes = 0; bool ok = true; };
+    std::map<int, GroupInfo> groups;  // by group root (a class root)
+    if (!no_groups) {
+        for (const OpInfo& op : g.ops)
+            if (op.op == BuiltinOp::Pad) {
+                const int in = op.inputs.at(0), out = op.outputs.at(0);
+                if (!act(in) || from_pool[in] || bad[find(in)] || bad[find(out)]) continue;
+                gparent[gfind(find(in))] = gfind(find(out));
+            }
+        std::map<int, std::set<int>> members;
+        for (const OpInfo& op : g.ops)
+            if (op.op == BuiltinOp::Pad) {
+                const int in = op.inputs.at(0), out = op.outputs.at(0);
+                if (!act(in) || from_pool[in] || bad[find(in)] || bad[find(out)]) continue;
+                GroupInfo& gi = groups[gfind(find(out))];
+                const auto& sh = g.tensors[out].shape;
+                if (gi.H == 0) { gi.H = sh[1]; gi.W = sh[2]; }
+                gi.ok &= gi.H == sh[1] && gi.W == sh[2];
+                gi.maxC = std::max({gi.maxC, g.tensors[in].shape.back(), sh.back()});
+                members[gfind(find(out))].insert(find(in));
+                members[gfind(find(out))].insert(find(out));
+            }
+        for (auto& kv : groups) kv.second.classes = static_cast<int>(members[kv.first].size());
+    }
+    auto group_width = [&](int t) {  // 0: the tensor's class is in no group that gets one width
+        auto it = groups.find(gfind(find(t)));
+        if (it == groups.end() || !it->second.ok || it->second.classes < 2) return 0;
+        const GroupInfo& gi = it->second;
+        if (gi.H * gi.W <= 256 && ((gi.maxC + 31) & ~31) <= 128) return (gi.maxC + 31) & ~31;  // frame-resident chains: whole 32-channel tiles
+        if (gi.W == 32 && gi.H * gi.W <= 1024 && gi.maxC > 32 && gi.maxC <= 48) return 48;     // mstrip_kernel
+        return 0;
+    };
     auto padded = [&](int t) {  // new channel count of activation tensor t (unchanged when its class is left alone)
         const int C = g.tensors[t].shape.back();
-        return (act(t) && g.tensors[t].shape.size() == 4 && !bad[find(t)] && (C & 3)) ? (C + 3) & ~3 : C;
+        if (!(act(t) && g.tensors[t].shape.size() == 4 && !bad[find(t)])) return C;
+        const int gw = group_width(t);
+        if (gw >= C) return gw;
+        return (C & 3) ? (C + 3) & ~3 : C;
     };
     // a channel PAD that consumes a widened tensor must have room for the extra channels
     for (const OpInfo& op : g.ops)
@@ -951,6 +1000,21 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
     }
     for (int t = 0; t < NT; t++)
         if (act(t)) g.tensors[t].shape.back() = newC[t];
+    // channel PADs that no longer append anything: their output is their input
+    std::vector<OpInfo> kept;
+    std::map<int, int> alias;
+    auto resolve = [&](int t) { for (auto it = alias.find(t); it != alias.end(); it = alias.find(t)) t = it->second; return t; };
+    for (OpInfo& op : g.ops) {
+        for (int& t : op.inputs) t = t >= 0 ? resolve(t) : t;
+        if (op.op == BuiltinOp::Pad && act(op.inputs[0]) && g.tensors[op.inputs[1]].i32.size() == 8 && g.tensors[op.inputs[1]].i32[7] == 0 &&
+            g.tensors[op.inputs[0]].shape == g.tensors[op.outputs[0]].shape) {
+            alias[op.outputs[0]] = op.inputs[0];
+            continue;
+        }
+        kept.push_back(std::move(op));
+    }
+    g.ops = std::move(kept);
+    for (int& t : g.outputs) t = resolve(t);
 }
 
 Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads) {
