@@ -31,8 +31,8 @@ def label(name):
         args = args[:5]
     if m.group(1) == "chain_kernel":
         args = args[:1]   # the label carries the tile count only (not the unit-split flag)
-    if m.group(1) == "bneck_kernel":
-        return "bneck_kernel"
+    if m.group(1) in ("bneck_kernel", "dblock_kernel"):
+        return m.group(1)
     if m.group(1) == "stem_conv_kernel":
         return "stem_conv_kernel"
     return "%s<%s>" % (m.group(1), ",".join(args))
