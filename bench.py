@@ -32,6 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_PEAK_TFLOPS = 157.3  # dense f32 (MFMA = packed VALU FMA), /opt/skills/guides/MI355X_MICROARCH.md
+# what the two pipes sustain on this part, every CU busy, two waves per SIMD (tools/valu_bench.hip, profiles/r03_valu_mfma_issue_rates.txt):
+# reported beside `frac` (which stays achieved / data-sheet peak) as `frac_of_measured_ceiling`
+MEASURED_CEILING_TFLOPS = {"valu v_pk_fma_f32": 116.0, "mfma f32": 145.0}
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -273,8 +276,10 @@ def roofline_of(records, workload_tag):
     if hbm_frac >= flop_frac:
         roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic}
     else:   # FLOP-bound launch: the dense f32 rate; "pipe" says whether the kernel reaches it on MFMA or with packed VALU FMAs
-        roof = {"bound": "f32", "pipe": "valu v_pk_fma_f32" if is_valu_kernel(dom) else "mfma f32", "achieved": round(tflops, 2),
-                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic}
+        pipe = "valu v_pk_fma_f32" if is_valu_kernel(dom) else "mfma f32"
+        roof = {"bound": "f32", "pipe": pipe, "achieved": round(tflops, 2),
+                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic,
+                "measured_ceiling": MEASURED_CEILING_TFLOPS[pipe], "frac_of_measured_ceiling": round(tflops / MEASURED_CEILING_TFLOPS[pipe], 4)}
     roof.update(common)
     roof["net_event_ms"] = round(sum(r["ms"] for r in records), 4)
     roof["kernels"] = {k: {"ms": round(v["ms"], 4), "calls": v["calls"], "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
