@@ -228,6 +228,80 @@ def cpu_baseline_1thread(x_host, model_file="face_detection_back.tflite", kind="
             "sample": "%d single-frame calls (model parse + net + decode + NMS each), C oracle, 1 thread, %.1f s" % (frames, dt)}
 
 
+def cpu_baseline_landmark(x_host, threads):
+    """Config 3 on the host: the oracle's face mesh net over ROIs (OpenMP over ROIs) + face flag + landmark projection."""
+    import numpy as np
+    from oracle import pyoracle as po
+    om = po.Model(os.path.join(ROOT, "models", "face_landmark.tflite"))
+    n = min(len(x_host), max(threads, 64))
+    om.run(x_host[: min(n, threads)], nthreads=threads)
+    t0 = time.time()
+    rois = 0
+    while time.time() - t0 < 10.0:
+        raw, flag = om.run(x_host[:n], nthreads=threads)
+        for f in range(n):
+            if po.lib().orc_face_flag_passes(float(flag[f].reshape(-1)[-1])):
+                po.project_landmarks(raw[f], (192, 192), (192, 192))
+        rois += n
+    dt = time.time() - t0
+    return {"value": round(rois / dt, 1), "unit": "ROIs/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d ROIs of the same batch (net + flag + projection), C oracle, OpenMP over ROIs, %.1f s" % (rois, dt),
+            "threads_note": CPU_THREADS_NOTE}
+
+
+def cpu_baseline_pipeline(frames_u8, threads):
+    """Config 5 on the host: lib.rs:18-40 through the oracle, staged over the batch so every net runs OpenMP-over-frames and the
+    per-frame glue (crop / warp, decode + NMS, ROI maths) runs on a thread pool (ctypes drops the GIL inside the C calls)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as po
+    fd = po.Model(os.path.join(ROOT, "models", "face_detection_full_range.tflite"))
+    fl = po.Model(os.path.join(ROOT, "models", "face_landmark.tflite"))
+    ir = po.Model(os.path.join(ROOT, "models", "iris_landmark.tflite"))
+    anchors = po.ssd_anchors(po.FD_FULL)
+    size = fd.input_dims[1]
+    pool = ThreadPoolExecutor(threads)
+
+    def one_pass(imgs):
+        H, W = imgs.shape[1:3]
+        pre = list(pool.map(lambda im: po.image_to_tensor(im, None, (size, size), True, (-1., 1.), False), imgs))
+        rb, rs = fd.run(np.stack([t for t, _ in pre]), nthreads=threads)
+        dets = list(pool.map(lambda i: po.fd_postprocess(rb[i], rs[i], anchors, float(size), pre[i][1]), range(len(imgs))))
+        faces = [i for i, d in enumerate(dets) if len(d)]
+        if not faces:
+            return 0
+        rois = [po.face_detection_to_roi(dets[i][0], (W, H)) for i in faces]
+        pre2 = list(pool.map(lambda k: po.image_to_tensor(imgs[faces[k]], rois[k], (192, 192), False, (0., 1.), False), range(len(faces))))
+        raw, flag = fl.run(np.stack([t for t, _ in pre2]), nthreads=threads)
+        ok = [k for k in range(len(faces)) if po.lib().orc_face_flag_passes(float(flag[k].reshape(-1)[-1]))]
+        lms = {k: po.project_landmarks(raw[k], (192, 192), (W, H), pre2[k][1], rois[k], False) for k in ok}
+        eyes = []
+        for k in ok:
+            left, right = po.iris_rois_from_face_landmarks(lms[k], (W, H))
+            eyes += [(k, left, False), (k, right, True)]
+        if eyes:
+            pre3 = list(pool.map(lambda e: po.image_to_tensor(imgs[faces[e[0]]], e[1], (64, 64), True, (0., 1.), e[2]), eyes))
+            c, i5 = ir.run(np.stack([t for t, _ in pre3]), nthreads=threads)
+            for j, (k, r, flip) in enumerate(eyes):
+                po.project_landmarks(c[j], (64, 64), (W, H), pre3[j][1], r, flip)
+                po.project_landmarks(i5[j], (64, 64), (W, H), pre3[j][1], r, flip)
+        return len(ok)
+
+    n = min(len(frames_u8), max(threads, 64))
+    one_pass(frames_u8[: min(n, threads)])
+    t0 = time.time()
+    frames = present = 0
+    while time.time() - t0 < 10.0:
+        present = one_pass(frames_u8[:n])
+        frames += n
+    dt = time.time() - t0
+    pool.shutdown()
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "%d frames of the same batch (%d of each %d carry a face through all three nets), C oracle staged over the batch, "
+                      "nets OpenMP over frames, glue on a %d-thread pool, %.1f s" % (frames, present, n, threads, dt),
+            "threads_note": CPU_THREADS_NOTE}
+
+
 # ------------------------------------------------------------------------------------------------- roofline helpers
 def kernel_source_hash():
     """Hash of the kernel + planner sources: stamps profiles/pmc_summary.json so a stale PMC figure is never reported."""
@@ -490,6 +564,10 @@ def run_rank(args):
             mf, kd = MODEL_FILES[args.config][0], ("FD_BACK" if args.config == 2 else "FD_SHORT")
             result["cpu_baseline"] = cpu_baseline(x_host, threads, mf, kd)
             result["cpu_baseline_1thread"] = cpu_baseline_1thread(x_host, mf, kd)
+        elif not args.no_cpu_baseline and world == 1 and args.config == 3:
+            result["cpu_baseline"] = cpu_baseline_landmark(x.cpu().numpy(), max(1, min(usable_cpus(), B)))
+        elif not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline_pipeline(frames.cpu().numpy(), max(1, min(usable_cpus(), B)))
     keep.close()
     if dist:
         dist.barrier()
