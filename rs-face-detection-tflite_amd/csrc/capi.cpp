@@ -143,6 +143,7 @@ struct mi_pipeline {
     std::unique_ptr<mi_iris> iris;
     DeviceBuf frames, geom, pad_det, pad_eye, in_det, dets, counts, roi_face, valid_face, in_lm, lm, present, roi_eye, valid_eye,
         flip_eye, in_eye, eyes, sizes, faces;
+    int sizes_B = 0, sizes_w = 0, sizes_h = 0;  // what `sizes` holds (uploaded once per batch geometry, not per call)
 };
 
 struct mi_iris {
@@ -821,11 +822,13 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         auto* d_geom = static_cast<mi::PreGeom*>(p->geom.get(sizeof(mi::PreGeom) * 2 * B));
         // (w, h) of the source image of every ROI, for Rect::scaled in project_landmarks
         int* d_sizes = static_cast<int*>(p->sizes.get(sizeof(int) * 4 * B));
-        {
+        if (p->sizes_B != B || p->sizes_w != width || p->sizes_h != height) {  // a host round trip only when the batch geometry changes
             std::vector<int> hs(4 * static_cast<size_t>(B));
             for (int i = 0; i < 2 * B; i++) { hs[2 * i] = width; hs[2 * i + 1] = height; }
+            p->sizes_B = 0;
             mi::hip_check(hipMemcpyAsync(d_sizes, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D sizes");
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
+            p->sizes_B = B; p->sizes_w = width; p->sizes_h = height;
         }
         // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
         mi::PreItems it{};

@@ -207,6 +207,15 @@ void Model::rebuild() {
             o += static_cast<size_t>(Cmp);
             for (int c = 0; c < Co; c++) { cb[o + c] = pb.b2 >= 0 ? g.tensors[pb.b2].f32[static_cast<size_t>(c)] : 0.f; cb[o + static_cast<size_t>(32) * MT + c] = slope(pb, c); }
             ma.strip = put(cb);
+            // the wide layers also get the constants of the operand-layout kernel (mdblock_kernels.hip); which of the two runs is decided per launch
+            const int Wd = g.tensors[pa.in[0]].shape[2];
+            if (mdblock_shape_ok(Wd, C, Cm, Co) && pa.res < 0 && pb.res == pa.in[0]) {
+                std::vector<float> mc(static_cast<size_t>(mdblock_consts_floats(Wd, C, Cm, Co)));
+                auto ptr = [&](int t) { return t >= 0 ? g.tensors[t].f32.data() : nullptr; };
+                mdblock_pack_consts(Wd, C, Cm, Co, ptr(pa.w), ptr(pa.b), ptr(pa.w2), ptr(pa.b2), pa.act == ACT_PRELU ? ptr(pa.alpha) : nullptr, pa.act,
+                                    ptr(pb.w), ptr(pb.b), ptr(pb.w2), ptr(pb.b2), pb.act == ACT_PRELU ? ptr(pb.alpha) : nullptr, pb.act, mc.data());
+                mb.strip = put(mc);
+            }
             chain_off_[i].push_back(ma);
             chain_off_[i].push_back(mb);
             res_wblk_[i].clear();
@@ -698,6 +707,13 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     a.hi2 = n.members[1].act == ACT_RELU6 ? 6.f : INFINITY;
                     a.skip1 = n.members[0].res >= 0;                       // two plain BlazeBlocks: each adds its own input
                     a.skip2_from_a = n.members[1].res == n.members[0].out;
+                    a.act1 = n.members[0].act; a.act2 = n.members[1].act;
+                    if (chain_off_[i][1].strip >= 0) a.mconsts = d_weights_ + chain_off_[i][1].strip;
+                    if (mdblock_kernel_supports(a)) {
+                        if (labels) labels->back() = "mdblock_kernel";
+                        rc = launch_mdblock(a, s);
+                        break;
+                    }
                     rc = launch_dblock(a, s);
                     break;
                 }

@@ -302,8 +302,18 @@ struct DblockArgs {
     const float* w1 = nullptr;      // block kernel's A-fragment packing of W1 [Cm][C] (MTA = ceil(Cm / 32) tiles)
     const float* w2 = nullptr;      // ... of W2 [C][Cm] (MT tiles, contraction padded to Cmp = roundup8(Cm))
     float hi1 = 0.f, hi2 = 0.f;
+    const float* mconsts = nullptr; // mdblock_pack_consts() blob when the layer has an mdblock_kernels.hip form (else null)
+    int act1 = ACT_RELU, act2 = ACT_RELU;
 };
 bool dblock_kernel_supports(const DblockArgs& a);
+// mdblock_kernels.hip: the double blocks of the 96- and 48-pixel-wide layers with both pointwise convs as 16x16x4 MFMAs in the
+// operand layout (row-walking waves, taps in registers)
+bool mdblock_shape_ok(int W, int C, int Cm, int Co);
+int mdblock_consts_floats(int W, int C, int Cm, int Co);
+void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1,
+                         const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst);
+bool mdblock_kernel_supports(const DblockArgs& a);
+int launch_mdblock(const DblockArgs& a, void* stream);
 int dblock_const_floats(int C, int Cm, int Co);
 int launch_dblock(const DblockArgs& a, void* stream);
 

@@ -1,0 +1,515 @@
+// mdblock_kernels.hip — full_range's "double BlazeBlock" on the wide layers (96x96x32 and 48x48x48), both pointwise convs on the
+// matrix cores with everything else in the matrix operand layout (the mstrip_kernels.hip scheme, two stages deep):
+//
+//   a = act1( W1 . (DW3x3(x) + b_dw1) + b1 )         depthwise, pointwise C -> Cm
+//   y = act2( W2 . (DW3x3(a) + b_dw2) + b2 + x )     depthwise, pointwise Cm -> Co (Co >= C: the skip is x zero-padded to Co channels)
+//
+// (face_detection_full_range.tflite: DEPTHWISE_CONV_2D, CONV_2D + fused RELU, DEPTHWISE_CONV_2D, CONV_2D, ADD, RELU behind
+// `interpreter.invoke()`, /root/reference/src/face_detection_lite/face_detection.rs:235)
+//
+// dblock_kernels.hip runs these with 32-pixel x 32-channel MFMA tiles out of LDS tensors: with Cm = 8 .. 16 three quarters of every
+// stage-1 tile are padding, each channel chunk of each pixel costs 18 sixteen-byte LDS reads (taps + window), and its eight waves
+// share the pixel groups of a band unevenly (in-kernel stamps, round 3: a wave waits at the stage barriers for a third of a band):
+// 0.16 ms per 96x96 block at 128 frames, 1.9 TB/s, for 0.3 GB of traffic.  Here:
+//   * a workgroup = NWV waves side by side on one band of rows of one frame, each wave owning WT 16-pixel tiles of the row, all walking
+//     down the band in step: per step one row of x arrives (LDS-DMA, every wave its own part), stage 1 finishes row r-1 of `a`,
+//     stage 2 finishes row r-2 of `y`.  Two workgroup barriers per step (x row complete, a row complete), equal work per wave.
+//   * lane (kq = lane / 16, p = lane % 16) owns channel 4 ks + kq of pixel p of a tile for every k-step: the depthwise 3x3 runs in
+//     that layout with its taps in registers and vertical reuse in registers (an input row is read from LDS once: three 4-byte reads
+//     per k-step and tile), and its result IS the B operand of v_mfma_f32_16x16x4_f32.  M = 16: Cm = 8 .. 16 is one tile.
+//   * stage 1's result tile (4 consecutive channels of a pixel per lane) is written to a small LDS row image of `a` (the only
+//     transposition), which stage 2 reads back in the operand layout, neighbours from the adjacent waves included.
+//   * the skip of an output row is read from the x row image while that row is current and waits in the accumulator registers for
+//     the two steps until its products arrive.
+// Exact f32; results match dblock_kernels.hip to reassociation of the sums and the folded depthwise biases.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "kernels.hpp"
+#include "launch.hpp"
+
+namespace mi {
+
+namespace {
+
+typedef float df32x4 __attribute__((ext_vector_type(4)));
+
+struct MdbArgs {
+    const float* in;
+    float* out;
+    const float* consts;   // mdblock_pack_consts()
+    long in_fs, out_fs;
+    int B, H;
+    int bands, band_rows;
+    float hi1, hi2;        // upper clamps of the two activations (6 for ReLU6, +inf otherwise)
+};
+
+// CK1 = C / 4 k-steps of stage 1, CK2 = Cm / 4 of stage 2, MT2 = Co / 16 output tiles, WT pixel tiles per wave, NWV waves per workgroup
+template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_>
+struct MD {
+    static constexpr int CK1 = CK1_, CK2 = CK2_, MT2 = MT2_, WT = WT_, NWV = NWV_;
+    static constexpr int C = 4 * CK1, Cm = 4 * CK2, Co = 16 * MT2, W = 16 * WT * NWV, SW = 16 * WT;
+    static constexpr int MT1 = (Cm + 15) / 16;
+    static constexpr int QP = CK1 + 1, PS = 4 * QP;                             // x row image: float4 slots / floats per pixel
+    static constexpr int QPA = ((CK2 + 1) & 1) ? CK2 + 1 : CK2 + 2, PSA = 4 * QPA;  // a row image (odd slot count: the 16 pixels of a tile on distinct banks)
+    static_assert(QP % 2 == 1, "x pixel stride: odd number of float4 slots");
+    static constexpr int XIMG_F = (W + 2) * PS, AIMG_F = (W + 2) * PSA;
+    static constexpr int DPX = 4, NLD = SW / DPX, ACTIVE = DPX * QP;            // LDS-DMA: pixels per instruction, instructions per row and wave, lanes in use
+    static_assert(ACTIVE > 32 && ACTIVE <= 64 && (NLD == 4 || NLD == 8), "DMA shape");
+    static_assert((NLD - 1) * DPX * C * 4 < 4096, "immediate offsets of the DMA instructions");
+    // constants blob (floats): A1 [CK1][MT1][64] | A2 [CK2][MT2][64] | taps1 [CK1][4][12] | taps2 [CK2][4][12] | bias1 [16 MT1] | slope1 [16 MT1] | bias2 [Co] | slope2 [Co]
+    static constexpr int OFF_A1 = 0, A1_F = CK1 * MT1 * 64, OFF_A2 = A1_F, A2_F = CK2 * MT2 * 64, OFF_T1 = OFF_A2 + A2_F, T1_F = CK1 * 48, OFF_T2 = OFF_T1 + T1_F, T2_F = CK2 * 48;
+    static constexpr int OFF_B1 = OFF_T2 + T2_F, OFF_S1 = OFF_B1 + 16 * MT1, OFF_B2 = OFF_S1 + 16 * MT1, OFF_S2 = OFF_B2 + Co, TOTAL = OFF_S2 + Co;
+    static constexpr int LDS_F = TOTAL + 2 * XIMG_F + 2 * AIMG_F;
+};
+
+template <int N>
+__device__ __forceinline__ void dwait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
+__device__ __forceinline__ void dwave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// workgroup barrier behind an LDS-only wait (__syncthreads() would also drain vmcnt: the next row's DMA and the output stores)
+__device__ __forceinline__ void dwg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <class F, int... KS>
+__device__ __forceinline__ void dfor_each(F&& f, std::integer_sequence<int, KS...>) { (f(std::integral_constant<int, KS>{}), ...); }
+
+// One input row of a stage in the operand layout.  src: LDS byte address of this lane's left neighbour pixel, channel kq, of the row
+// image (pixel stride PSV floats; tile nt is 16 pixels on); its ky = 2 / 1 / 0 taps go to the partial depthwise rows r-1 / r / r+1
+// (aPN on entry / aC / aPN on exit).  With EMIT the finished depthwise row r-1 is the B operand of this row's MFMAs into D
+// (A operands: LDS byte address aop + lane, [ks][mt][64]).
+// The LDS reads are inline asm with their own waits: left to the compiler, the reads of a whole row are merged across k-steps and
+// hoisted (the taps get spilled).  Every wait is lgkmcnt(0): scalar loads share the counter and return out of order.
+template <int CK, int MT, int WT, int PSV, bool EMIT>
+__device__ __forceinline__ void mdb_row(const unsigned src, const unsigned aop, const float (&tap)[CK][9], float (&aPN)[CK][WT], float (&aC)[CK][WT],
+                                        df32x4 (&D)[MT][WT]) {
+    float xs[2][3][WT], av[2][MT];
+    auto load_ks = [&](auto ksc, float (&x)[3][WT], float (&aw)[MT]) {
+        constexpr int ks = decltype(ksc)::value;
+        const unsigned xa = src, aa = aop;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x[dx][nt]) : "v"(xa), "n"((dx * PSV + 4 * ks) * 4 + nt * 16 * PSV * 4));
+        if constexpr (EMIT) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(aw[mt]) : "v"(aa), "n"((ks * MT + mt) * 64 * 4));
+        }
+    };
+    auto kstep = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        if constexpr (ks + 1 < CK) load_ks(std::integral_constant<int, ks + 1>{}, xs[(ks + 1) & 1], av[(ks + 1) & 1]);
+        float (&x)[3][WT] = xs[ks & 1];
+        float (&aw)[MT] = av[ks & 1];
+        const float (&w)[9] = tap[ks];
+        float pch[WT];
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++) {
+            float n = x[0][nt] * w[0], c = aC[ks][nt], pc = aPN[ks][nt];
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) {
+                if (EMIT) pc = __builtin_fmaf(x[dx][nt], w[6 + dx], pc);
+                if (dx) n = __builtin_fmaf(x[dx][nt], w[dx], n);
+                c = __builtin_fmaf(x[dx][nt], w[3 + dx], c);
+            }
+            aC[ks][nt] = c;
+            aPN[ks][nt] = n;
+            asm volatile("" : "+v"(aC[ks][nt]), "+v"(aPN[ks][nt]));  // pinned: LLVM would sink these updates into the next row
+            pch[nt] = pc;
+        }
+        if constexpr (EMIT) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < WT; nt++) D[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt], pch[nt], D[mt][nt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next k-step's operands (a whole k-step of cover)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load_ks(std::integral_constant<int, 0>{}, xs[0], av[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    dfor_each(kstep, std::make_integer_sequence<int, CK>{});
+}
+
+template <class K, bool RELU>
+__global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
+    constexpr int CK1 = K::CK1, CK2 = K::CK2, MT1 = K::MT1, MT2 = K::MT2, WT = K::WT, NWV = K::NWV, C = K::C, Co = K::Co, W = K::W;
+    constexpr int PS = K::PS, PSA = K::PSA, QP = K::QP, QPA = K::QPA, XIMG_F = K::XIMG_F, AIMG_F = K::AIMG_F, NLD = K::NLD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kq = lane >> 4, p = lane & 15;
+    float* wgc = lds;                       // the constants blob
+    float* ximg = lds + K::TOTAL;           // [2][XIMG_F]: row images of x, pixel 0 and W + 1 = zero border
+    float* aimg = ximg + 2 * XIMG_F;        // [2][AIMG_F]: row images of a
+    // workgroup = (band, frame): the frames of one band are neighbours in the grid
+    const int band = blockIdx.x / a.B, b = blockIdx.x - band * a.B;
+    const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
+    const int x0 = wave * K::SW;            // this wave's pixels [x0, x0 + SW)
+    const float* in = a.in + (long)b * a.in_fs;
+
+    // ---- LDS-DMA of this wave's part of one input row: instruction k brings in pixels [x0 + 4 k, x0 + 4 k + 4): lane -> (pixel
+    // lane / QP, quad min(lane % QP, CK1 - 1)), lanes >= 4 QP idle; the immediate offset moves source and destination alike, M0 makes
+    // up the difference between the image's pixel stride and the tensor's
+    const int goff = ((lane / QP) * C + 4 * min(lane % QP, CK1 - 1)) * 4;
+    const unsigned lds_x = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ximg);
+    auto issue_row = [&](int r, int slot) {
+        const char* src = reinterpret_cast<const char*>(in + ((long)min(max(r, 0), a.H - 1) * W + x0) * C);
+        const unsigned dstb = lds_x + (unsigned)((slot * XIMG_F + (1 + x0) * PS) * 4);
+        unsigned long long saved;
+#define MI_MDB_DMA(k) "s_add_u32 m0, m0, %5\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
+        if constexpr (NLD == 8) {
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
+                         "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                         MI_MDB_DMA(1) MI_MDB_DMA(2) MI_MDB_DMA(3) MI_MDB_DMA(4) MI_MDB_DMA(5) MI_MDB_DMA(6) MI_MDB_DMA(7)
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(saved)
+                         : "s"(src), "v"(goff), "s"(dstb), "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
+                         : "memory", "scc");
+        } else {
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
+                         "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                         MI_MDB_DMA(1) MI_MDB_DMA(2) MI_MDB_DMA(3)
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(saved)
+                         : "s"(src), "v"(goff), "s"(dstb), "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
+                         : "memory", "scc");
+        }
+#undef MI_MDB_DMA
+    };
+    // rows outside the image are zero padding: the landed (clamped) row is cleared before anybody reads it
+    auto fix_row = [&](int r, int slot) {
+        if (r >= 0 && r < a.H) return;  // wave-uniform
+        float zz = 0.f;
+        asm volatile("" : "+v"(zz));
+        const float4 z = make_float4(zz, zz, zz, zz);
+        float* part = ximg + slot * XIMG_F + (1 + x0) * PS;
+        constexpr int N4 = K::SW * QP;
+#pragma unroll
+        for (int k = 0; k < (N4 + 63) / 64; k++)
+            if (64 * (k + 1) <= N4 || lane < N4 - 64 * k) *reinterpret_cast<float4*>(part + 4 * (lane + 64 * k)) = z;
+    };
+    // border pixel columns of the four images are never written afterwards: cleared once
+    if (wave == 0) {
+        if (lane < 2 * QP) {
+            const int col = lane / QP, qd = lane - col * QP;
+#pragma unroll
+            for (int s = 0; s < 2; s++) *reinterpret_cast<float4*>(ximg + s * XIMG_F + col * (W + 1) * PS + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (lane < 2 * QPA) {
+            const int col = lane / QPA, qd = lane - col * QPA;
+#pragma unroll
+            for (int s = 0; s < 2; s++) *reinterpret_cast<float4*>(aimg + s * AIMG_F + col * (W + 1) * PSA + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // the first row is on its way while the constants are fetched; the second goes out behind them, and only it may still be in
+    // flight when the row loop starts (vector-memory operations retire in issue order; the loop's counted waits assume that nothing
+    // else is outstanding)
+    issue_row(y0 - 2, 0);
+    for (int i = threadIdx.x; i < K::TOTAL / 4; i += NWV * 64) reinterpret_cast<float4*>(wgc)[i] = reinterpret_cast<const float4*>(a.consts)[i];
+    issue_row(y0 - 1, 1);
+    dwait_vm<NLD>();
+    dwg_barrier();
+    asm volatile("" ::: "memory");
+    // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
+    float tap1[CK1][9], tap2[CK2][9];
+    {
+        const float4* tp = reinterpret_cast<const float4*>(wgc + K::OFF_T1) + kq * 3;
+#pragma unroll
+        for (int ks = 0; ks < CK1; ks++) {
+            const float4 t0 = tp[ks * 12], t1 = tp[ks * 12 + 1], t2 = tp[ks * 12 + 2];
+            tap1[ks][0] = t0.x; tap1[ks][1] = t0.y; tap1[ks][2] = t0.z; tap1[ks][3] = t0.w;
+            tap1[ks][4] = t1.x; tap1[ks][5] = t1.y; tap1[ks][6] = t1.z; tap1[ks][7] = t1.w;
+            tap1[ks][8] = t2.x;
+        }
+        const float4* tq = reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3;
+#pragma unroll
+        for (int ks = 0; ks < CK2; ks++) {
+            const float4 t0 = tq[ks * 12], t1 = tq[ks * 12 + 1], t2 = tq[ks * 12 + 2];
+            tap2[ks][0] = t0.x; tap2[ks][1] = t0.y; tap2[ks][2] = t0.z; tap2[ks][3] = t0.w;
+            tap2[ks][4] = t1.x; tap2[ks][5] = t1.y; tap2[ks][6] = t1.z; tap2[ks][7] = t1.w;
+            tap2[ks][8] = t2.x;
+        }
+#pragma unroll
+        for (int ks = 0; ks < CK1; ks++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap1[ks][t]));
+#pragma unroll
+        for (int ks = 0; ks < CK2; ks++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap2[ks][t]));
+    }
+    // ---- per-lane addresses
+    typedef __attribute__((address_space(3))) float lfloat;
+    const unsigned x_lds = (unsigned)(uintptr_t)(lfloat*)(ximg + (x0 + p) * PS + kq);      // B layout: left neighbour of pixel x0 + p, channel kq
+    const unsigned a_lds = (unsigned)(uintptr_t)(lfloat*)(aimg + (x0 + p) * PSA + kq);
+    const unsigned a1_lds = (unsigned)(uintptr_t)(lfloat*)(wgc + K::OFF_A1 + lane);          // A operands [ks][mt][lane]
+    const unsigned a2_lds = (unsigned)(uintptr_t)(lfloat*)(wgc + K::OFF_A2 + lane);
+    const float* sme = ximg + (1 + x0 + p) * PS + 4 * kq;     // D layout: centre pixel, channels 4 kq .. 4 kq + 3 of a 16-channel tile
+    float* awr = aimg + (1 + x0 + p) * PSA + 4 * kq;
+    const unsigned ooff = (unsigned)((x0 + p) * Co + 4 * kq) * 4u;   // bytes: + (16 nt * Co + 16 mt) * 4 for tile (mt, nt)
+
+    float p1A[CK1][WT], p1B[CK1][WT], p2A[CK2][WT], p2B[CK2][WT];   // partial depthwise rows: roles alternate from step to step
+#pragma unroll
+    for (int ks = 0; ks < CK1; ks++)
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++) p1A[ks][nt] = p1B[ks][nt] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < CK2; ks++)
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++) p2A[ks][nt] = p2B[ks][nt] = 0.f;
+    df32x4 D1[MT1][WT], PA[MT2][WT], PB[MT2][WT];   // PA / PB: accumulators of the output rows of even / odd steps, waiting with bias + skip inside
+    auto init_D1 = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT1; mt++) {
+            const float4 bs = *reinterpret_cast<const float4*>(wgc + K::OFF_B1 + 16 * mt + 4 * kq);
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) D1[mt][nt] = df32x4{bs.x, bs.y, bs.z, bs.w};
+        }
+    };
+    // P <- bias2 + skip for the output row whose centre input row sits in x image `slot`
+    auto init_P = [&](df32x4 (&P)[MT2][WT], int slot) {
+        float4 bs[MT2], x[MT2][WT];
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++) bs[mt] = *reinterpret_cast<const float4*>(wgc + K::OFF_B2 + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) {
+                x[mt][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (16 * mt < C) x[mt][nt] = *reinterpret_cast<const float4*>(sme + slot * XIMG_F + 16 * nt * PS + 16 * mt);  // channels >= C: the zero channel-pad of the skip
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) P[mt][nt] = df32x4{x[mt][nt].x + bs[mt].x, x[mt][nt].y + bs[mt].y, x[mt][nt].z + bs[mt].z, x[mt][nt].w + bs[mt].w};
+    };
+    auto act = [&](df32x4 v, const float4& sl, float hi) {
+        if (RELU) return df32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
+        return df32x4{fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), hi), fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), hi),
+                      fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), hi), fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), hi)};
+    };
+    // a row q (image row; zeros outside the image: the next depthwise conv's padding) -> a image `slot`
+    auto store_a = [&](int q, int slot) {
+        const bool inside = q >= 0 && q < a.H;
+#pragma unroll
+        for (int mt = 0; mt < MT1; mt++) {
+            float4 sl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!RELU) sl = *reinterpret_cast<const float4*>(wgc + K::OFF_S1 + 16 * mt + 4 * kq);
+            if (16 * mt + 4 * kq < K::Cm) {
+#pragma unroll
+                for (int nt = 0; nt < WT; nt++) {
+                    df32x4 v = act(D1[mt][nt], sl, a.hi1);
+                    if (!inside) v = df32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<float4*>(awr + slot * AIMG_F + 16 * nt * PSA + 16 * mt) = make_float4(v.x, v.y, v.z, v.w);
+                }
+            }
+        }
+    };
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) df32x4 gf32x4;
+    auto epilogue = [&](df32x4 (&P)[MT2][WT], int y) {
+        gchar* dst = (gchar*)(a.out + (long)b * a.out_fs + (long)y * W * Co);
+        asm volatile("" : "+s"(dst));
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++) {
+            float4 sl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!RELU) sl = *reinterpret_cast<const float4*>(wgc + K::OFF_S2 + 16 * mt + 4 * kq);
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) *(gf32x4*)(dst + ooff + (unsigned)((16 * nt * Co + 16 * mt) * 4)) = act(P[mt][nt], sl, a.hi2);
+        }
+    };
+
+    // vmcnt bookkeeping: vector-memory operations retire in issue order.  A step's operations: the stores of its output row (NST, from
+    // the fifth step on), then the DMA of the row two steps ahead (NLD, while the band has one).  "Row r has landed" = at most what was
+    // issued behind its DMA is outstanding: the previous step's stores and DMA.
+    constexpr int NST = MT2 * WT;
+    const int TL = (y1 - y0) + 3;   // last step; step t handles x row y0 - 2 + t, a row y0 - 3 + t (from t = 2), y row y0 - 4 + t (from t = 4)
+    auto wait_row = [&](int t) {
+        const bool st = t - 1 >= 4, dm = t == 0 || t + 1 <= TL;  // step 0: the prologue's second row is behind it
+        if (st && dm) dwait_vm<NST + NLD>();
+        else if (dm) dwait_vm<NLD>();
+        else if (st) dwait_vm<NST>();
+        else dwait_vm<0>();
+    };
+    // e1 / e2: stage 1 / stage 2 finish a row in this step
+    auto step = [&](auto e1c, auto e2c, int t, float (&q1PN)[CK1][WT], float (&q1C)[CK1][WT], float (&q2PN)[CK2][WT], float (&q2C)[CK2][WT], df32x4 (&P)[MT2][WT]) {
+        constexpr bool E1 = decltype(e1c)::value, E2 = decltype(e2c)::value;
+        const int r = y0 - 2 + t, slot = t & 1;
+        wait_row(t);
+        fix_row(r, slot);
+        dwg_barrier();   // x row r is complete (every wave's part has landed and is fixed)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (E1) init_D1();
+        mdb_row<CK1, MT1, WT, PS, E1>(x_lds + (unsigned)(slot * XIMG_F * 4), a1_lds, tap1, q1PN, q1C, D1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (E1) {
+            store_a(r - 1, slot);
+            dwg_barrier();   // a row r - 1 is complete
+            __builtin_amdgcn_sched_barrier(0);
+            mdb_row<CK2, MT2, WT, PSA, E2>(a_lds + (unsigned)(slot * AIMG_F * 4), a2_lds, tap2, q2PN, q2C, P);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (E2) epilogue(P, r - 2);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            dwg_barrier();   // priming steps: the neighbours have read this row's halo pixels before this wave's next DMA lands on them
+        }
+        init_P(P, slot);   // output row r starts from bias + its skip, the centre pixels of x row r
+        __builtin_amdgcn_sched_barrier(0);
+        dwave_sync();      // every read of x image `slot` by this wave is issued before the DMA below overwrites this wave's part of it
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // ... and has returned (the other waves read row r's halo pixels before the a-row barrier)
+        if (t + 2 <= TL) issue_row(r + 2, slot);
+    };
+    const std::false_type F{};
+    const std::true_type T{};
+    step(F, F, 0, p1A, p1B, p2A, p2B, PA);
+    step(F, F, 1, p1B, p1A, p2B, p2A, PB);
+    step(T, F, 2, p1A, p1B, p2A, p2B, PA);
+    step(T, F, 3, p1B, p1A, p2B, p2A, PB);
+    for (int t = 4; t <= TL; t += 2) {
+        step(T, T, t, p1A, p1B, p2A, p2B, PA);
+        if (t + 1 > TL) break;
+        step(T, T, t + 1, p1B, p1A, p2B, p2A, PB);
+    }
+}
+
+using MD96 = MD<8, 2, 2, 2, 3>;    // 96 x 96: 32 -> 8 -> 32
+using MD48a = MD<12, 3, 3, 1, 3>;  // 48 x 48: 48 -> 12 -> 48
+using MD48b = MD<12, 4, 4, 1, 3>;  // 48 x 48: 48 -> 16 -> 64
+
+template <class K>
+void mdb_pack(const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2,
+              const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst) {
+    constexpr int C = K::C, Cm = K::Cm, Co = K::Co;
+    std::fill(dst, dst + K::TOTAL, 0.f);
+    // A operand of v_mfma_f32_16x16x4_f32 for (k-step ks, output tile mt): lane l holds W[16 mt + l % 16][4 ks + l / 16]
+    for (int ks = 0; ks < K::CK1; ks++)
+        for (int mt = 0; mt < K::MT1; mt++)
+            for (int l = 0; l < 64; l++) {
+                const int o = 16 * mt + (l & 15);
+                if (o < Cm) dst[K::OFF_A1 + (ks * K::MT1 + mt) * 64 + l] = w_pw1[(size_t)o * C + 4 * ks + (l >> 4)];
+            }
+    for (int ks = 0; ks < K::CK2; ks++)
+        for (int mt = 0; mt < K::MT2; mt++)
+            for (int l = 0; l < 64; l++) dst[K::OFF_A2 + (ks * K::MT2 + mt) * 64 + l] = w_pw2[(size_t)(16 * mt + (l & 15)) * Cm + 4 * ks + (l >> 4)];
+    // taps [ks][kq][12]: the nine taps of channel 4 ks + kq (three float4 loads per k-step)
+    for (int ks = 0; ks < K::CK1; ks++)
+        for (int kq = 0; kq < 4; kq++)
+            for (int t = 0; t < 9; t++) dst[K::OFF_T1 + (ks * 4 + kq) * 12 + t] = w_dw1[t * C + 4 * ks + kq];
+    for (int ks = 0; ks < K::CK2; ks++)
+        for (int kq = 0; kq < 4; kq++)
+            for (int t = 0; t < 9; t++) dst[K::OFF_T2 + (ks * 4 + kq) * 12 + t] = w_dw2[t * Cm + 4 * ks + kq];
+    // PW(dw + b_dw) + b_pw = PW(dw) + (W b_dw + b_pw): the depthwise biases are folded into the pointwise biases
+    for (int c = 0; c < Cm; c++) {
+        double acc = b1 ? b1[c] : 0.0;
+        if (b_dw1)
+            for (int k = 0; k < C; k++) acc += (double)w_pw1[(size_t)c * C + k] * b_dw1[k];
+        dst[K::OFF_B1 + c] = (float)acc;
+        dst[K::OFF_S1 + c] = act1 == ACT_PRELU ? alpha1[c] : (act1 == ACT_NONE ? 1.f : 0.f);
+    }
+    for (int c = 0; c < Co; c++) {
+        double acc = b2 ? b2[c] : 0.0;
+        if (b_dw2)
+            for (int k = 0; k < Cm; k++) acc += (double)w_pw2[(size_t)c * Cm + k] * b_dw2[k];
+        dst[K::OFF_B2 + c] = (float)acc;
+        dst[K::OFF_S2 + c] = act2 == ACT_PRELU ? alpha2[c] : (act2 == ACT_NONE ? 1.f : 0.f);
+    }
+}
+
+template <class K>
+int mdb_launch(const DblockArgs& a, hipStream_t s) {
+    MdbArgs ma;
+    ma.in = a.in; ma.out = a.out; ma.consts = a.mconsts; ma.in_fs = a.in_fs; ma.out_fs = a.out_fs;
+    ma.B = a.B; ma.H = a.H;
+    ma.hi1 = a.hi1; ma.hi2 = a.hi2;
+    // bands: enough workgroups for every CU to hold as many as its LDS takes; a band costs four priming steps
+    static const int forced = getenv("MI_MDB_BAND") ? atoi(getenv("MI_MDB_BAND")) : 0;  // tuning aid
+    const int per_cu = std::max(1, std::min(8 / K::NWV, (int)((160 * 1024) / (K::LDS_F * 4))));
+    long bands = std::max<long>(1, ((long)per_cu * device_cu_count() + a.B / 2) / std::max(1, a.B));
+    int rows = (int)((a.H + bands - 1) / bands);
+    rows = std::max(rows, std::min(a.H, 8));
+    if (forced > 0) rows = std::min(forced, a.H);
+    ma.band_rows = rows;
+    ma.bands = (a.H + rows - 1) / rows;
+    const bool relu = a.act1 == ACT_RELU && a.act2 == ACT_RELU;
+    const dim3 grid((unsigned)((long)a.B * ma.bands));
+    const size_t lds_bytes = (size_t)K::LDS_F * 4;
+    if (relu) {
+        auto kern = mdblock_kernel<K, true>;
+        if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
+        return (int)launch_kernel(kern, grid, dim3(K::NWV * 64), lds_bytes, s, ma);
+    }
+    auto kern = mdblock_kernel<K, false>;
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
+    return (int)launch_kernel(kern, grid, dim3(K::NWV * 64), lds_bytes, s, ma);
+}
+
+// 0: none; 1: 96 wide 32 -> 8 -> 32; 2: 48 wide 48 -> 12 -> 48; 3: 48 wide 48 -> 16 -> 64
+int mdb_shape(int W, int C, int Cm, int Co) {
+    static const bool off = getenv("MI_NO_MDBLOCK") != nullptr;  // tuning aid: the LDS-tensor double-block kernel instead
+    if (off) return 0;
+    if (W == 96 && C == 32 && Cm == 8 && Co == 32) return 1;
+    if (W == 48 && C == 48 && Cm == 12 && Co == 48) return 2;
+    if (W == 48 && C == 48 && Cm == 16 && Co == 64) return 3;
+    return 0;
+}
+
+}  // namespace
+
+bool mdblock_shape_ok(int W, int C, int Cm, int Co) { return mdb_shape(W, C, Cm, Co) != 0; }
+
+int mdblock_consts_floats(int W, int C, int Cm, int Co) {
+    switch (mdb_shape(W, C, Cm, Co)) {
+        case 1: return MD96::TOTAL;
+        case 2: return MD48a::TOTAL;
+        case 3: return MD48b::TOTAL;
+    }
+    return 0;
+}
+
+// w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C] (TFLite OHWI with H = W = 1), bias [Co] or null, alpha [Co] or null — per stage
+void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1,
+                         const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst) {
+    switch (mdb_shape(W, C, Cm, Co)) {
+        case 1: mdb_pack<MD96>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
+        case 2: mdb_pack<MD48a>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
+        case 3: mdb_pack<MD48b>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
+    }
+}
+
+// the double block proper (no skip on the first half, the second half's skip is x), constants packed by mdblock_pack_consts()
+bool mdblock_kernel_supports(const DblockArgs& a) {
+    if (!a.mconsts || a.skip1 || a.skip2_from_a || !mdb_shape(a.W, a.C, a.Cm, a.Co) || a.H < 2 || a.B < 1) return false;
+    // the waves of a band walk it row by row: below about one workgroup per CU the launch is latency-bound and the wider kernel finishes sooner
+    static const int min_b = getenv("MI_MDB_MIN_B") ? atoi(getenv("MI_MDB_MIN_B")) : 32;
+    if (a.B < min_b) return false;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return aligned16(a.in) && aligned16(a.out) && aligned16(a.mconsts) && !(a.in_fs & 3) && !(a.out_fs & 3);
+}
+
+int launch_mdblock(const DblockArgs& a, void* stream) {
+    if (!mdblock_kernel_supports(a)) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    switch (mdb_shape(a.W, a.C, a.Cm, a.Co)) {
+        case 1: return mdb_launch<MD96>(a, s);
+        case 2: return mdb_launch<MD48a>(a, s);
+        case 3: return mdb_launch<MD48b>(a, s);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+}  // namespace mi

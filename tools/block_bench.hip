@@ -12,6 +12,7 @@ using namespace mi;
 int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 128, C = argc > 3 ? atoi(argv[3]) : 24, Co = argc > 4 ? atoi(argv[4]) : 24;
     int S = argc > 5 ? atoi(argv[5]) : 1;
+    const bool skip = argc > 6 ? atoi(argv[6]) != 0 : true;  // 0: no skip connection (the contracting blocks of full_range)
     int W = H, Ho = H / S, Wo = W / S;
     size_t nin = (size_t)B * H * W * C, nout = (size_t)B * Ho * Wo * Co;
     float *din, *dout, *dw, *db, *dpw, *dbp;
@@ -29,10 +30,11 @@ int main(int argc, char** argv) {
     a.w_dw = dw; a.b_dw = db; a.w_pw = dpw;
     a.B = B; a.H = H; a.W = W; a.C = C; a.Ho = Ho; a.Wo = Wo; a.Co = Co; a.sh = a.sw = S; a.pt = a.pl = S == 1 ? 1 : 0;
     a.ep.bias = dbp; a.ep.act = ACT_RELU; a.ep.res = din; a.ep.res_fs = a.in_fs; a.ep.res_C = C; a.ep.res_mode = S == 1 ? RES_DIRECT : RES_MAXPOOL;
+    if (!skip || Co < C) { a.ep.res = nullptr; a.ep.res_mode = RES_NONE; a.ep.res_C = 0; }
     BlockGeom g;
     if (!make_geom(a, &g)) { printf("unsupported\n"); return 1; }
     int PG = g.PG;
-    printf("geom: Cp %d PS %d R %d NR %d band %d bands %d MT %d a_lds %d lds %d B  grid %d  PG %d\n", g.Cp, g.PS, g.R, g.NR, g.band, g.bands, g.MT, g.a_lds, g.lds_bytes, B * g.bands, PG);
+    printf("geom: Cp %d PS %d R %d NR %d band %d bands %d MT %d a_lds %d lds %d B  grid %d  PG %d  nsplit %d wmod %d mt_per %d\n", g.Cp, g.PS, g.R, g.NR, g.band, g.bands, g.MT, g.a_lds, g.lds_bytes, B * g.bands * g.nsplit, PG, g.nsplit, g.wmod, g.mt_per);
     hipStream_t s; CK(hipStreamCreate(&s));
     for (int i = 0; i < 3; i++) if (launch_block(a, s)) { printf("launch failed\n"); return 1; }
     CK(hipStreamSynchronize(s));
@@ -46,7 +48,7 @@ int main(int argc, char** argv) {
     printf("B %d %dx%d C %d->%d s%d : %.3f ms  %.1f GB/s algorithmic  %.2f TFLOP/s\n", B, H, W, C, Co, S, ms, bytes / ms / 1e6, 2.0 * B * Ho * Wo * C * (9.0 + Co) / ms / 1e9);
 #ifdef MI_BLOCK_STAMPS
     {
-        size_t nw = (size_t)B * g.bands * 4;
+        size_t nw = (size_t)B * g.bands * g.nsplit * 4;
         unsigned long long* dst; CK(hipMalloc(&dst, nw * 8 * 8)); CK(hipMemset(dst, 0, nw * 64));
         // relaunch once with stamps through the same dispatch table
         g_stamp_ptr = dst;
