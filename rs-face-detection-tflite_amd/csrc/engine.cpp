@@ -102,6 +102,7 @@ void Model::rebuild() {
     chain_off_.assign(NN, {});
     chain_head_off_.assign(NN, {});
     node_strip_.assign(NN, -1);
+    node_mwalk_.assign(NN, -1);
     res_cblob_.assign(NN, {});
     res_wblk_.assign(NN, {});
     // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
@@ -332,6 +333,13 @@ void Model::rebuild() {
                 mstrip_pack_consts(ws[3], g.tensors[n.w].f32.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, g.tensors[n.w2].f32.data(),
                                    n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
                 node_strip_[i] = put(sc);
+            }
+            const int Wn = g.tensors[n.out].shape.size() == 4 ? g.tensors[n.out].shape[2] : 0;
+            if (n.w >= 0 && n.sh == 1 && n.sw == 1 && n.padding == Padding::Same && mwalk_shape_ok(Wn, ws[3], ws[0])) {
+                std::vector<float> sc(static_cast<size_t>(mwalk_consts_floats(Wn, ws[3], ws[0])));
+                mwalk_pack_consts(Wn, ws[3], ws[0], g.tensors[n.w].f32.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, g.tensors[n.w2].f32.data(),
+                                  n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
+                node_mwalk_[i] = put(sc);
             }
         }
     }
@@ -854,6 +862,12 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 if (a.has_dw && n.ept >= 0) { a.pt = n.ept; a.pl = n.epl; }
                 a.ep = ep;
                 a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
+                a.w_mwalk = node_mwalk_[i] >= 0 ? d_weights_ + node_mwalk_[i] : nullptr;
+                if (strip_ && mwalk_kernel_supports(a)) {
+                    if (labels) { char buf[96]; labels->back() = mwalk_kernel_label(a, buf, sizeof buf); }
+                    rc = launch_mwalk(a, s);
+                    break;
+                }
                 const bool strip = strip_ && strip_kernel_supports(a);
                 const bool mstrip = strip_ && !strip && mstrip_kernel_supports(a);
                 if (labels) { char buf[96]; labels->back() = strip ? strip_kernel_label(a, buf, sizeof buf) : (mstrip ? mstrip_kernel_label(a, buf, sizeof buf) : block_kernel_label(a, buf, sizeof buf)); }

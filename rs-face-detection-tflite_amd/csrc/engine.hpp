@@ -82,6 +82,7 @@ class Model {
 
     float* d_weights_ = nullptr;
     std::vector<long> node_w_, node_b_, node_w2_, node_b2_, node_alpha_;  // float offsets into d_weights_ (-1 none)
+    std::vector<long> node_mwalk_;  // mwalk-kernel constants of a Block node (mwalk_pack_consts), -1 when the shape does not qualify
     std::vector<long> node_strip_;  // strip-kernel constants of a Block node (strip_pack_consts), -1 when the shape does not qualify
     struct MemberOff { long w = -1, b = -1, w2 = -1, b2 = -1, alpha = -1, strip = -1; };
     int profile_inner_ = 1;  // executions of a launch between its two profiling marks (profile() only)

@@ -70,6 +70,7 @@ struct BlockArgs {
     const float* b_dw = nullptr;
     const float* w_pw = nullptr;  // [Cop][Cp] row-major (out channel major), zero padded: Cp = C up to 4, Cop = Co up to 16/32
     const float* w_strip = nullptr;  // strip_pack_consts() blob when the shape qualifies for strip_kernels.hip, else null
+    const float* w_mwalk = nullptr;  // mwalk_pack_consts() blob when the shape qualifies for mwalk_kernels.hip, else null
     float* out = nullptr;
     long in_fs = 0, out_fs = 0;
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0;
@@ -253,6 +254,13 @@ void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float*
 const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
 // mstrip_kernels.hip: stride-1 blocks with C = Co = 48 on 32-pixel-wide frames: depthwise stage in the MFMA operand layout, pointwise
 // conv on v_mfma_f32_16x16x4_f32 with resident weights (constants blob through BlockArgs::w_strip)
+// mwalk_kernels.hip: the same scheme for other widths / channel counts (face mesh 48x48x32); constants in BlockArgs::w_mwalk
+int launch_mwalk(const BlockArgs& a, void* stream);
+bool mwalk_kernel_supports(const BlockArgs& a);
+bool mwalk_shape_ok(int W, int C, int Co);
+int mwalk_consts_floats(int W, int C, int Co);
+void mwalk_pack_consts(int W, int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
+const char* mwalk_kernel_label(const BlockArgs& a, char* buf, size_t cap);
 int launch_mstrip(const BlockArgs& a, void* stream);
 bool mstrip_kernel_supports(const BlockArgs& a);
 bool mstrip_shape_ok(int C, int Co);

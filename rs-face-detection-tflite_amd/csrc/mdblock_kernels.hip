@@ -34,12 +34,11 @@
 
 #include "kernels.hpp"
 #include "launch.hpp"
+#include "mrow.hpp"
 
 namespace mi {
 
 namespace {
-
-typedef float df32x4 __attribute__((ext_vector_type(4)));
 
 struct MdbArgs {
     const float* in;
@@ -52,9 +51,10 @@ struct MdbArgs {
 };
 
 // CK1 = C / 4 k-steps of stage 1, CK2 = Cm / 4 of stage 2, MT2 = Co / 16 output tiles, WT pixel tiles per wave, NWV waves per workgroup
-template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_>
+template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false>
 struct MD {
     static constexpr int CK1 = CK1_, CK2 = CK2_, MT2 = MT2_, WT = WT_, NWV = NWV_;
+    static constexpr bool TAPL2 = TAPL2_;   // stage 2's taps stay in LDS (the registers do not hold 9 x (CK1 + CK2) taps beside the accumulators)
     static constexpr int C = 4 * CK1, Cm = 4 * CK2, Co = 16 * MT2, W = 16 * WT * NWV, SW = 16 * WT;
     static constexpr int MT1 = (Cm + 15) / 16;
     static constexpr int QP = CK1 + 1, PS = 4 * QP;                             // x row image: float4 slots / floats per pixel
@@ -69,79 +69,6 @@ struct MD {
     static constexpr int OFF_B1 = OFF_T2 + T2_F, OFF_S1 = OFF_B1 + 16 * MT1, OFF_B2 = OFF_S1 + 16 * MT1, OFF_S2 = OFF_B2 + Co, TOTAL = OFF_S2 + Co;
     static constexpr int LDS_F = TOTAL + 2 * XIMG_F + 2 * AIMG_F;
 };
-
-template <int N>
-__device__ __forceinline__ void dwait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }
-__device__ __forceinline__ void dwave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// workgroup barrier behind an LDS-only wait (__syncthreads() would also drain vmcnt: the next row's DMA and the output stores)
-__device__ __forceinline__ void dwg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <class F, int... KS>
-__device__ __forceinline__ void dfor_each(F&& f, std::integer_sequence<int, KS...>) { (f(std::integral_constant<int, KS>{}), ...); }
-
-// One input row of a stage in the operand layout.  src: LDS byte address of this lane's left neighbour pixel, channel kq, of the row
-// image (pixel stride PSV floats; tile nt is 16 pixels on); its ky = 2 / 1 / 0 taps go to the partial depthwise rows r-1 / r / r+1
-// (aPN on entry / aC / aPN on exit).  With EMIT the finished depthwise row r-1 is the B operand of this row's MFMAs into D
-// (A operands: LDS byte address aop + lane, [ks][mt][64]).
-// The LDS reads are inline asm with their own waits: left to the compiler, the reads of a whole row are merged across k-steps and
-// hoisted (the taps get spilled).  Every wait is lgkmcnt(0): scalar loads share the counter and return out of order.
-template <int CK, int MT, int WT, int PSV, bool EMIT>
-__device__ __forceinline__ void mdb_row(const unsigned src, const unsigned aop, const float (&tap)[CK][9], float (&aPN)[CK][WT], float (&aC)[CK][WT],
-                                        df32x4 (&D)[MT][WT]) {
-    float xs[2][3][WT], av[2][MT];
-    auto load_ks = [&](auto ksc, float (&x)[3][WT], float (&aw)[MT]) {
-        constexpr int ks = decltype(ksc)::value;
-        const unsigned xa = src, aa = aop;
-#pragma unroll
-        for (int dx = 0; dx < 3; dx++)
-#pragma unroll
-            for (int nt = 0; nt < WT; nt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x[dx][nt]) : "v"(xa), "n"((dx * PSV + 4 * ks) * 4 + nt * 16 * PSV * 4));
-        if constexpr (EMIT) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(aw[mt]) : "v"(aa), "n"((ks * MT + mt) * 64 * 4));
-        }
-    };
-    auto kstep = [&](auto ksc) {
-        constexpr int ks = decltype(ksc)::value;
-        if constexpr (ks + 1 < CK) load_ks(std::integral_constant<int, ks + 1>{}, xs[(ks + 1) & 1], av[(ks + 1) & 1]);
-        float (&x)[3][WT] = xs[ks & 1];
-        float (&aw)[MT] = av[ks & 1];
-        const float (&w)[9] = tap[ks];
-        float pch[WT];
-#pragma unroll
-        for (int nt = 0; nt < WT; nt++) {
-            float n = x[0][nt] * w[0], c = aC[ks][nt], pc = aPN[ks][nt];
-#pragma unroll
-            for (int dx = 0; dx < 3; dx++) {
-                if (EMIT) pc = __builtin_fmaf(x[dx][nt], w[6 + dx], pc);
-                if (dx) n = __builtin_fmaf(x[dx][nt], w[dx], n);
-                c = __builtin_fmaf(x[dx][nt], w[3 + dx], c);
-            }
-            aC[ks][nt] = c;
-            aPN[ks][nt] = n;
-            asm volatile("" : "+v"(aC[ks][nt]), "+v"(aPN[ks][nt]));  // pinned: LLVM would sink these updates into the next row
-            pch[nt] = pc;
-        }
-        if constexpr (EMIT) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int nt = 0; nt < WT; nt++) D[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt], pch[nt], D[mt][nt], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next k-step's operands (a whole k-step of cover)
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    load_ks(std::integral_constant<int, 0>{}, xs[0], av[0]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    dfor_each(kstep, std::make_integer_sequence<int, CK>{});
-}
 
 template <class K, bool RELU>
 __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
@@ -225,7 +152,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     dwg_barrier();
     asm volatile("" ::: "memory");
     // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
-    float tap1[CK1][9], tap2[CK2][9];
+    float tap1[CK1][9], tap2[K::TAPL2 ? 1 : CK2][9];
     {
         const float4* tp = reinterpret_cast<const float4*>(wgc + K::OFF_T1) + kq * 3;
 #pragma unroll
@@ -237,7 +164,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
         }
         const float4* tq = reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3;
 #pragma unroll
-        for (int ks = 0; ks < CK2; ks++) {
+        for (int ks = 0; ks < (K::TAPL2 ? 0 : CK2); ks++) {
             const float4 t0 = tq[ks * 12], t1 = tq[ks * 12 + 1], t2 = tq[ks * 12 + 2];
             tap2[ks][0] = t0.x; tap2[ks][1] = t0.y; tap2[ks][2] = t0.z; tap2[ks][3] = t0.w;
             tap2[ks][4] = t1.x; tap2[ks][5] = t1.y; tap2[ks][6] = t1.z; tap2[ks][7] = t1.w;
@@ -248,7 +175,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
 #pragma unroll
             for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap1[ks][t]));
 #pragma unroll
-        for (int ks = 0; ks < CK2; ks++)
+        for (int ks = 0; ks < (K::TAPL2 ? 0 : CK2); ks++)
 #pragma unroll
             for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap2[ks][t]));
     }
@@ -361,7 +288,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
             store_a(r - 1, slot);
             dwg_barrier();   // a row r - 1 is complete
             __builtin_amdgcn_sched_barrier(0);
-            mdb_row<CK2, MT2, WT, PSA, E2>(a_lds + (unsigned)(slot * AIMG_F * 4), a2_lds, tap2, q2PN, q2C, P);
+            mdb_row<CK2, MT2, WT, PSA, E2, K::TAPL2>(a_lds + (unsigned)(slot * AIMG_F * 4), a2_lds, tap2, q2PN, q2C, P, reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (E2) epilogue(P, r - 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -390,6 +317,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
 using MD96 = MD<8, 2, 2, 2, 3>;    // 96 x 96: 32 -> 8 -> 32
 using MD48a = MD<12, 3, 3, 1, 3>;  // 48 x 48: 48 -> 12 -> 48
 using MD48b = MD<12, 4, 4, 1, 3>;  // 48 x 48: 48 -> 16 -> 64
+using MD48c = MD<12, 6, 3, 1, 3, true>;  // 48 x 48: 48 -> 24 -> 48
 
 template <class K>
 void mdb_pack(const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2,
@@ -458,13 +386,14 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
     return (int)launch_kernel(kern, grid, dim3(K::NWV * 64), lds_bytes, s, ma);
 }
 
-// 0: none; 1: 96 wide 32 -> 8 -> 32; 2: 48 wide 48 -> 12 -> 48; 3: 48 wide 48 -> 16 -> 64
+// 0: none; 1: 96 wide 32 -> 8 -> 32; 2: 48 wide 48 -> 12 -> 48; 3: 48 wide 48 -> 16 -> 64; 4: 48 wide 48 -> 24 -> 48
 int mdb_shape(int W, int C, int Cm, int Co) {
     static const bool off = getenv("MI_NO_MDBLOCK") != nullptr;  // tuning aid: the LDS-tensor double-block kernel instead
     if (off) return 0;
     if (W == 96 && C == 32 && Cm == 8 && Co == 32) return 1;
     if (W == 48 && C == 48 && Cm == 12 && Co == 48) return 2;
     if (W == 48 && C == 48 && Cm == 16 && Co == 64) return 3;
+    if (W == 48 && C == 48 && Cm == 24 && Co == 48) return 4;
     return 0;
 }
 
@@ -477,6 +406,7 @@ int mdblock_consts_floats(int W, int C, int Cm, int Co) {
         case 1: return MD96::TOTAL;
         case 2: return MD48a::TOTAL;
         case 3: return MD48b::TOTAL;
+        case 4: return MD48c::TOTAL;
     }
     return 0;
 }
@@ -488,6 +418,7 @@ void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const
         case 1: mdb_pack<MD96>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 2: mdb_pack<MD48a>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 3: mdb_pack<MD48b>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
+        case 4: mdb_pack<MD48c>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
     }
 }
 
@@ -508,6 +439,7 @@ int launch_mdblock(const DblockArgs& a, void* stream) {
         case 1: return mdb_launch<MD96>(a, s);
         case 2: return mdb_launch<MD48a>(a, s);
         case 3: return mdb_launch<MD48b>(a, s);
+        case 4: return mdb_launch<MD48c>(a, s);
     }
     return (int)hipErrorInvalidValue;
 }
