@@ -25,37 +25,95 @@ namespace mi {
 namespace {
 
 // ---------------------------------------------------------------------------------------------- geometry (host + device)
-// `ws`: the 8x9 system.  The row swaps index it dynamically, so a local array lives in scratch memory on the device (a
-// dependent HBM round trip per access: 83 us per launch for one lane's elimination); the batched kernel passes LDS instead.
-__host__ __device__ inline bool solve_homography(const float src[4][2], const float dst[4][2], double M[9], double (*ws)[9] = nullptr) {
+// `ws`: the 8x9 system, element (i, j) at ws[(i * 9 + j) * wstride].  The row swaps index it dynamically, so a local array lives in
+// scratch memory on the device (a dependent HBM round trip per access: 83 us per launch for one lane's elimination); the batched kernel
+// passes LDS instead, lane-minor (wstride = lanes per workgroup: the 64 lanes of a wave touch 64 consecutive doubles, no bank conflicts —
+// one 8x9 block per lane was a 16-way conflict on every access, 35 us per launch).
+__host__ __device__ inline bool solve_homography(const float src[4][2], const float dst[4][2], double M[9], double* ws = nullptr, int wstride = 1) {
     // 8x8 system of cv::getPerspectiveTransform, Gauss-Jordan with partial pivoting in f64
-    double local[8][9];
-    double (*a)[9] = ws ? ws : local;
+    double local[72];
+    double* base = ws ? ws : local;
+    const int st = ws ? wstride : 1;
+    auto a = [&](int i, int j) -> double& { return base[(i * 9 + j) * st]; };
     for (int i = 0; i < 8; i++)
-        for (int j = 0; j < 9; j++) a[i][j] = 0.0;
+        for (int j = 0; j < 9; j++) a(i, j) = 0.0;
     for (int i = 0; i < 4; i++) {
         const double X = src[i][0], Y = src[i][1], u = dst[i][0], v = dst[i][1];
-        a[i][0] = X; a[i][1] = Y; a[i][2] = 1; a[i][6] = -X * u; a[i][7] = -Y * u; a[i][8] = u;
-        a[i + 4][3] = X; a[i + 4][4] = Y; a[i + 4][5] = 1; a[i + 4][6] = -X * v; a[i + 4][7] = -Y * v; a[i + 4][8] = v;
+        a(i, 0) = X; a(i, 1) = Y; a(i, 2) = 1; a(i, 6) = -X * u; a(i, 7) = -Y * u; a(i, 8) = u;
+        a(i + 4, 3) = X; a(i + 4, 4) = Y; a(i + 4, 5) = 1; a(i + 4, 6) = -X * v; a(i + 4, 7) = -Y * v; a(i + 4, 8) = v;
     }
     for (int c = 0; c < 8; c++) {
         int p = c;
         for (int r = c + 1; r < 8; r++)
-            if (fabs(a[r][c]) > fabs(a[p][c])) p = r;
-        if (fabs(a[p][c]) < 1e-300) return false;
+            if (fabs(a(r, c)) > fabs(a(p, c))) p = r;
+        if (fabs(a(p, c)) < 1e-300) return false;
         if (p != c)
-            for (int k = 0; k < 9; k++) { double t = a[c][k]; a[c][k] = a[p][k]; a[p][k] = t; }
+            for (int k = 0; k < 9; k++) { double t = a(c, k); a(c, k) = a(p, k); a(p, k) = t; }
         for (int r = 0; r < 8; r++) {
             if (r == c) continue;
-            const double f = a[r][c] / a[c][c];
+            const double f = a(r, c) / a(c, c);
             if (f != 0.0)
-                for (int k = c; k < 9; k++) a[r][k] -= f * a[c][k];
+                for (int k = c; k < 9; k++) a(r, k) -= f * a(c, k);
         }
     }
-    for (int i = 0; i < 8; i++) M[i] = a[i][8] / a[i][i];
+    for (int i = 0; i < 8; i++) M[i] = a(i, 8) / a(i, i);
     M[8] = 1.0;
     return true;
 }
+
+#ifdef __HIP_DEVICE_COMPILE__
+// The same elimination with one ROW per lane: the 8 lanes of an aligned group (sub = lane % 8) hold the 8 x 9 system in registers,
+// pivot search / row swap / pivot-row broadcast by shuffles.  Every element sees the operations of solve_homography() in the same
+// order (a[r][k] -= (a[r][c] / a[c][c]) * a[c][k], separate multiply and subtract), so the result is bit-identical; one lane walking
+// the system through LDS was a chain of ~1000 dependent LDS round trips (32 us per launch for a few hundred ROIs).
+__device__ inline bool solve_homography_lanes(const float src[4][2], const float dst[4][2], double M[9], int sub) {
+    double a[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) a[j] = 0.0;
+    {
+        const int i = sub & 3;
+        const float Xf = i == 0 ? src[0][0] : i == 1 ? src[1][0] : i == 2 ? src[2][0] : src[3][0], Yf = i == 0 ? src[0][1] : i == 1 ? src[1][1] : i == 2 ? src[2][1] : src[3][1];
+        const float uf = i == 0 ? dst[0][0] : i == 1 ? dst[1][0] : i == 2 ? dst[2][0] : dst[3][0], vf = i == 0 ? dst[0][1] : i == 1 ? dst[1][1] : i == 2 ? dst[2][1] : dst[3][1];
+        const double X = Xf, Y = Yf, u = uf, v = vf;
+        if (sub < 4) { a[0] = X; a[1] = Y; a[2] = 1; a[6] = -X * u; a[7] = -Y * u; a[8] = u; }
+        else { a[3] = X; a[4] = Y; a[5] = 1; a[6] = -X * v; a[7] = -Y * v; a[8] = v; }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const double mag = fabs(a[c]);
+        int p = c;
+        double best = __shfl(mag, c, 8);
+#pragma unroll
+        for (int r = c + 1; r < 8; r++) {
+            const double m = __shfl(mag, r, 8);
+            if (m > best) { best = m; p = r; }
+        }
+        if (best < 1e-300) ok = false;   // uniform over the group; the elimination goes on (its result is discarded) so that the shuffles stay convergent
+        const int partner = sub == c ? p : (sub == p ? c : sub);
+        double piv[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = __shfl(a[k], partner, 8);
+#pragma unroll
+        for (int k = 0; k < 9; k++) piv[k] = __shfl(a[k], c, 8);
+        if (sub != c) {
+            const double f = a[c] / piv[c];
+            if (f != 0.0) {
+#pragma unroll
+                for (int k = c; k < 9; k++) a[k] -= f * piv[k];
+            }
+        }
+    }
+    double diag = a[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) diag = sub == j ? a[j] : diag;
+    const double mi = a[8] / diag;
+#pragma unroll
+    for (int j = 0; j < 8; j++) M[j] = __shfl(mi, j, 8);
+    M[8] = 1.0;
+    return ok;
+}
+#endif
 
 __host__ __device__ inline bool inverse3(const double m[9], double o[9]) {
     const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
@@ -69,7 +127,8 @@ __host__ __device__ inline bool inverse3(const double m[9], double o[9]) {
 }
 
 // transform.rs:190-257 — everything that depends only on (image size, ROI, output size, keep_aspect_ratio)
-__host__ __device__ inline PreGeom compute_geom(int width, int height, const RectD* roi_in, int out_w, int out_h, bool keep_aspect, double (*ws)[9] = nullptr) {
+// lanes_sub >= 0 (device only): the 8 lanes of an aligned group compute the SAME item together (solve_homography_lanes), lanes_sub = lane % 8
+__host__ __device__ inline PreGeom compute_geom(int width, int height, const RectD* roi_in, int out_w, int out_h, bool keep_aspect, double* ws = nullptr, int wstride = 1, int lanes_sub = -1) {
     PreGeom g;
     for (int i = 0; i < 9; i++) g.Minv[i] = 0.0;
     g.pad_x = g.pad_y = 0.0;
@@ -97,7 +156,14 @@ __host__ __device__ inline PreGeom compute_geom(int width, int height, const Rec
     float src[4][2], dst[4][2] = {{0.f, 0.f}, {(float)g.warp_w, 0.f}, {(float)g.warp_w, (float)g.warp_h}, {0.f, (float)g.warp_h}};
     for (int i = 0; i < 4; i++) { src[i][0] = (float)p[i][0]; src[i][1] = (float)p[i][1]; }
     double M[9];
-    if (!solve_homography(src, dst, M, ws) || !inverse3(M, g.Minv)) return g;
+    bool solved;
+#ifdef __HIP_DEVICE_COMPILE__
+    if (lanes_sub >= 0) solved = solve_homography_lanes(src, dst, M, lanes_sub);
+    else
+#endif
+        solved = solve_homography(src, dst, M, ws, wstride);
+    (void)lanes_sub;
+    if (!solved || !inverse3(M, g.Minv)) return g;
     // OpenCV tile geometry of warpPerspective (BLOCK_SZ = 32): bh0 = min(16, h); bw0 = min(1024 / bh0, w)
     const int bh0 = g.warp_h < 16 ? g.warp_h : 16;
     g.bw0 = (1024 / bh0) < g.warp_w ? (1024 / bh0) : g.warp_w;
@@ -194,18 +260,18 @@ __device__ __forceinline__ Px resize_px(int pw, int ph, int dw, int dh, int dy, 
 }
 
 __global__ __launch_bounds__(64) void pre_geom_kernel(PreItems it, PreGeom* geom, double* padding) {
-    __shared__ double sys[64][8][9];  // one 8x9 system per lane
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= it.N) return;
-    double (*ws)[9] = sys[threadIdx.x];
+    // eight lanes per item (the 8 x 8 system of the homography: one row per lane), eight items per workgroup
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    if (i >= it.N) return;   // whole groups of 8 lanes
     PreGeom g;
     if (it.roi_valid && !it.roi_valid[i]) {
-        g = compute_geom(it.width, it.height, nullptr, it.out_w, it.out_h, it.keep_aspect != 0, ws);
+        g = compute_geom(it.width, it.height, nullptr, it.out_w, it.out_h, it.keep_aspect != 0, nullptr, 1, sub);
         g.valid = 0;
         g.pad_x = g.pad_y = 0.0;
     } else {
-        g = compute_geom(it.width, it.height, it.rois ? &it.rois[i] : nullptr, it.out_w, it.out_h, it.keep_aspect != 0, ws);
+        g = compute_geom(it.width, it.height, it.rois ? &it.rois[i] : nullptr, it.out_w, it.out_h, it.keep_aspect != 0, nullptr, 1, sub);
     }
+    if (sub) return;
     geom[i] = g;
     if (padding) { padding[4 * i] = g.pad_x; padding[4 * i + 1] = g.pad_y; padding[4 * i + 2] = g.pad_x; padding[4 * i + 3] = g.pad_y; }
 }
@@ -309,7 +375,7 @@ size_t align256(size_t v) { return (v + 255) & ~static_cast<size_t>(255); }
 
 void launch_pre_geom(const PreItems& it, PreGeom* d_geom, double* d_padding, hipStream_t s) {
     if (it.N <= 0) return;
-    hipLaunchKernelGGL(pre_geom_kernel, dim3((it.N + 63) / 64), dim3(64), 0, s, it, d_geom, d_padding);
+    hipLaunchKernelGGL(pre_geom_kernel, dim3((it.N + 7) / 8), dim3(64), 0, s, it, d_geom, d_padding);
     hip_check(hipGetLastError(), "pre_geom kernel launch");
 }
 
