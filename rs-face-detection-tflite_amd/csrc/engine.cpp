@@ -440,6 +440,27 @@ void Model::rebuild() {
             head_wait_[i] = prod;
             if (prod >= 0) event_after_[prod] = 1;
         }
+        // tail branches (Plan::branch): chain 0 stays on the trunk stream, every other chain runs on a side stream behind the launch
+        // that produced its newest input (the trunk runs in plan order, so the older inputs are done by then; launches of the same
+        // chain share a stream).  The arena keeps everything the branches touch allocated to the end of the plan.
+        static const bool no_branches = getenv("MI_NO_BRANCHES") != nullptr;  // development aid
+        for (size_t i = 0; i < N && !no_branches && plan_.branch.size() == N; i++) {
+            const Node& n = plan_.nodes[i];
+            if (plan_.branch[i] < 1 || is_view(n)) continue;
+            int prod = -1;
+            std::vector<int> srcs = n.in;
+            if (n.res >= 0) srcs.push_back(n.res);
+            for (int t : srcs)
+                for (size_t j = 0; j < i; j++) {
+                    if (is_view(plan_.nodes[j])) continue;
+                    bool makes = root(plan_.nodes[j].out) == root(t);
+                    for (int x : plan_.nodes[j].extra_out) makes |= root(x) == root(t);
+                    if (makes) prod = std::max(prod, static_cast<int>(j));
+                }
+            head_slot_[i] = (plan_.branch[i] - 1) % std::max(1, std::min(head_streams_opt_, kHeadStreams));
+            head_wait_[i] = prod;
+            if (prod >= 0) event_after_[static_cast<size_t>(prod)] = 1;
+        }
     }
     dirty_ = false;
     chunk_cap_ = 0;

@@ -712,10 +712,57 @@ size_t build_dblock(const Graph& g, const std::vector<Node>& ns, size_t i, Node*
     return 2;
 }
 
+// Which nodes read tensor t (as input or skip).
+std::vector<int> readers_of(const std::vector<Node>& ns, int t) {
+    std::vector<int> r;
+    for (size_t k = 0; k < ns.size(); k++)
+        if (std::find(ns[k].in.begin(), ns[k].in.end(), t) != ns[k].in.end() || ns[k].res == t) r.push_back(static_cast<int>(k));
+    return r;
+}
+
+// dep[b][a]: node b needs node a's result, directly or through other nodes (plan order = a topological order)
+std::vector<std::vector<char>> dependence(const std::vector<Node>& ns) {
+    const size_t N = ns.size();
+    std::map<int, int> producer;
+    for (size_t i = 0; i < N; i++) {
+        producer[ns[i].out] = static_cast<int>(i);
+        for (int t : ns[i].extra_out) producer[t] = static_cast<int>(i);
+    }
+    std::vector<std::vector<char>> dep(N, std::vector<char>(N, 0));
+    for (size_t b = 0; b < N; b++) {
+        std::vector<int> srcs = ns[b].in;
+        if (ns[b].res >= 0) srcs.push_back(ns[b].res);
+        for (int t : srcs) {
+            auto it = producer.find(t);
+            if (it == producer.end() || it->second >= static_cast<int>(b)) continue;
+            const size_t a = static_cast<size_t>(it->second);
+            dep[b][a] = 1;
+            for (size_t k = 0; k < N; k++) dep[b][k] |= dep[a][k];
+        }
+    }
+    return dep;
+}
+
+// A fork: node j's output is read by two nodes neither of which needs the other — the start of independent branches (the two heads of
+// the iris / face mesh networks).  A stage program that ran on past the fork would chain one branch behind the common part and leave
+// the other waiting for the whole launch; ending the launch at the fork lets the engine run the branches side by side.
+bool is_fork(const std::vector<Node>& ns, const std::vector<std::vector<char>>& dep, size_t j) {
+    std::vector<int> rd = readers_of(ns, ns[j].out);
+    for (int t : ns[j].extra_out)   // a launch with several outputs: their readers part just the same
+        for (int k : readers_of(ns, t))
+            if (std::find(rd.begin(), rd.end(), k) == rd.end()) rd.push_back(k);
+    for (size_t x = 0; x < rd.size(); x++)
+        for (size_t y = x + 1; y < rd.size(); y++)
+            if (!dep[static_cast<size_t>(rd[y])][static_cast<size_t>(rd[x])] && !dep[static_cast<size_t>(rd[x])][static_cast<size_t>(rd[y])]) return true;
+    return false;
+}
+
 std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget) {
     std::vector<Node> outv;
     static const bool no_bneck = getenv("MI_NO_BNECK") != nullptr;  // development aid
     static const bool no_dblock = getenv("MI_NO_DBLOCK") != nullptr;  // development aid
+    static const bool no_fork_split = getenv("MI_NO_FORK_SPLIT") != nullptr;  // development aid
+    const std::vector<std::vector<char>> dep = dependence(ns);
     for (size_t i = 0; i < ns.size();) {
         {
             Node db;
@@ -744,6 +791,7 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
             best = std::move(cand);
             best_j = j;
             have = true;
+            if (!no_fork_split && j > i && is_fork(ns, dep, j)) break;  // the launch ends where the branches part (a fork at the very start is the previous launch's business)
         }
         // worth a launch of its own: at least two fused nodes, or a k x k convolution (otherwise the generic direct conv)
         bool take = have && (best.members.size() >= 2 || (best.members[0].kind == Node::Conv && best.members[0].KH > 1));
@@ -1339,6 +1387,34 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
         reorder_branches(plan.nodes);
         plan.nodes = group_resident(g, plan.nodes, res_budget_bytes);
     }
+    // ---- tail branches: behind the LAST fork of the plan the remaining launches fall into chains that do not need each other (the
+    // output heads of the iris / face mesh networks: 16 + 16 stage-program nodes).  branch[i] = chain of node i (0 = stays on the trunk
+    // stream, >= 1 = may run on a side stream), -1 for everything up to the fork.  A node that needs two different chains joins them: no
+    // branches then.
+    plan.branch.assign(plan.nodes.size(), -1);
+    if (fuse_level >= 5) {
+        const std::vector<std::vector<char>> dep = dependence(plan.nodes);
+        auto is_view = [](const Node& n) { return n.kind == Node::Reshape || n.kind == Node::Concat; };
+        int fork_at = -1;
+        for (size_t j = 0; j < plan.nodes.size(); j++)
+            if (!is_view(plan.nodes[j]) && is_fork(plan.nodes, dep, j)) fork_at = static_cast<int>(j);
+        if (fork_at >= 0) {
+            std::vector<int> br(plan.nodes.size(), -1);
+            int next = 0;
+            bool ok = true;
+            for (size_t i = static_cast<size_t>(fork_at) + 1; i < plan.nodes.size() && ok; i++) {
+                int mine = -1;
+                for (size_t a = static_cast<size_t>(fork_at) + 1; a < i; a++)
+                    if (dep[i][a] && br[a] >= 0) {
+                        if (mine >= 0 && mine != br[a]) ok = false;
+                        mine = br[a];
+                    }
+                if (is_view(plan.nodes[i]) && mine < 0) continue;  // a view of a tensor from before the fork
+                br[i] = mine >= 0 ? mine : next++;
+            }
+            if (ok && next >= 2) plan.branch = br;
+        }
+    }
 
     // ---- storage: RESHAPE = view of its input; CONCATENATION inputs live inside the joined buffer.
     const int NT = static_cast<int>(g.tensors.size());
@@ -1387,6 +1463,14 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
         for (int t : plan.nodes[i].extra_out) touch(t, i);
     }
     for (int t : g.outputs) touch(t, NN);
+    // tail branches may run side by side in any interleaving: everything they read or write stays allocated to the end of the plan
+    for (int i = 0; i < NN; i++) {
+        if (plan.branch[static_cast<size_t>(i)] < 0) continue;
+        for (int t : plan.nodes[i].in) touch(t, NN);
+        touch(plan.nodes[i].res, NN);
+        touch(plan.nodes[i].out, NN);
+        for (int t : plan.nodes[i].extra_out) touch(t, NN);
+    }
     plan.root_offset.assign(NT, -1);
     plan.root_elems.assign(NT, 0);
     struct Live { long off, size; int until; };

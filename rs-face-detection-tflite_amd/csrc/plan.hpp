@@ -81,6 +81,7 @@ struct Storage {
 struct Plan {
     Graph graph;
     std::vector<Node> nodes;            // live nodes in execution order
+    std::vector<int> branch;            // per node: -1 = trunk; >= 0 = independent chain behind the plan's last fork (0 stays on the trunk stream)
     std::vector<Storage> storage;       // per tensor
     std::vector<long> root_offset;      // per tensor (valid for roots): float offset inside the arena, per frame-slot
     std::vector<long> root_elems;       // per root: floats per frame
