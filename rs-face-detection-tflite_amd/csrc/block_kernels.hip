@@ -101,8 +101,12 @@ __device__ __forceinline__ float4 res_from_global(const Epilogue& ep, int b, int
 // ALDS: the pointwise weights are staged in LDS (g.a_lds), else streamed from L2.  A template parameter, not a run-time choice:
 // selecting between an LDS and a global pointer at run time turns the load into a FLAT load, whose wait covers vmcnt and lgkmcnt —
 // every weight fragment then also waits for the next step's rows, which are meant to stay in flight across the compute phase.
+// The SLOW variants with one or two accumulator tiles are held to 256 registers (two workgroups per CU): left alone they take ~300
+// (prefetched skip quads + row prefetch + accumulators), one workgroup per CU, and the layers whose tiles are spread over 2-4
+// workgroups per frame (6x6 / 12x12 at 128 frames: 384-512 workgroups) ran in two rounds: 36.6 -> 24.6 us for 6x6x96 -> 384.
+// With three or four tiles the spills cost more than the second workgroup brings (12x12x64 -> 256: 33.9 -> 44.9 us), so those stay.
 template <int MTG, int S, int KS, int PG, bool SLOW, int CPT, bool ALDS>
-__global__ __launch_bounds__(256) void block_kernel(BlockArgs a, BlockGeom gin) {
+__global__ __launch_bounds__(256, (SLOW && MTG <= 2) ? 2 : 1) void block_kernel(BlockArgs a, BlockGeom gin) {
     // CPT > 0: padded channel count known at compile time (hot shapes) so that every tap / chunk offset of the LDS reads
     // folds into the ds_read immediate instead of costing a VALU add per load (49 of ~160 VALU ops per chunk at runtime Cp).
     BlockGeom g = gin;
