@@ -254,6 +254,15 @@ void Model::rebuild() {
                     cb[static_cast<size_t>(12 * Cm + C + c)] = slope(pb, c);
                 }
                 ma.strip = put(cb);
+                // 32-pixel-wide pairs also get the constants of the operand-layout kernel (mdblock_kernels.hip, mbneck_kernel)
+                const int Wd = g.tensors[pa.in[0]].shape[2];
+                if (mbneck_shape_ok(Wd, C, Cm)) {
+                    std::vector<float> mc(static_cast<size_t>(mbneck_consts_floats(Wd, C, Cm)));
+                    auto ptr = [&](int t) { return t >= 0 ? g.tensors[t].f32.data() : nullptr; };
+                    mbneck_pack_consts(Wd, C, Cm, ptr(pa.w2), ptr(pa.b2), pa.act == ACT_PRELU ? ptr(pa.alpha) : nullptr, pa.act, ptr(pb.w), ptr(pb.b), ptr(pb.w2), ptr(pb.b2),
+                                       pb.act == ACT_PRELU ? ptr(pb.alpha) : nullptr, pb.act, mc.data());
+                    mb.strip = put(mc);
+                }
                 chain_off_[i].push_back(ma);
                 chain_off_[i].push_back(mb);
             }
@@ -759,6 +768,14 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         a.blocks[k].consts = d_weights_ + ma.strip;
                         a.blocks[k].hi1 = n.members[static_cast<size_t>(2 * k)].act == ACT_RELU6 ? 6.f : INFINITY;
                         a.blocks[k].hi2 = n.members[static_cast<size_t>(2 * k + 1)].act == ACT_RELU6 ? 6.f : INFINITY;
+                        a.blocks[k].act1 = n.members[static_cast<size_t>(2 * k)].act;
+                        a.blocks[k].act2 = n.members[static_cast<size_t>(2 * k + 1)].act;
+                        if (mb.strip >= 0) a.blocks[k].mconsts = d_weights_ + mb.strip;
+                    }
+                    if (mbneck_kernel_supports(a)) {
+                        if (labels) labels->back() = "mbneck_kernel";
+                        rc = launch_mbneck(a, s);
+                        break;
                     }
                     rc = launch_bneck(a, s);
                     break;

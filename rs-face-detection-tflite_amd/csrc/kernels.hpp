@@ -285,6 +285,8 @@ struct BneckBlock {
     const float* w2 = nullptr;      // block kernel's A-fragment packing of W2 [C][Cm]
     const float* consts = nullptr;  // bneck_const_floats(): [b1 Cm][slope1 Cm][dw taps 9 x Cm][b_dw Cm][b2 C][slope2 C] (slope: PReLU alpha, 0 = ReLU, 1 = none)
     float hi1 = 0.f, hi2 = 0.f;     // upper clamps (6 for ReLU6, +inf otherwise)
+    const float* mconsts = nullptr; // mbneck_pack_consts() blob when the pair has an mdblock_kernels.hip form (else null)
+    int act1 = ACT_RELU, act2 = ACT_RELU;
 };
 constexpr int kMaxBneck = 6;
 struct BneckArgs {
@@ -326,6 +328,13 @@ int dblock_const_floats(int C, int Cm, int Co);
 int launch_dblock(const DblockArgs& a, void* stream);
 
 bool bneck_kernel_supports(const BneckArgs& a);
+// mdblock_kernels.hip, mbneck_kernel: the 32-pixel-wide bottleneck pairs (64 -> 32 -> 64) in the operand layout
+bool mbneck_shape_ok(int W, int C, int Cm);
+int mbneck_consts_floats(int W, int C, int Cm);
+void mbneck_pack_consts(int W, int C, int Cm, const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2,
+                        const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst);
+bool mbneck_kernel_supports(const BneckArgs& a);
+int launch_mbneck(const BneckArgs& a, void* stream);
 int bneck_const_floats(int C, int Cm);
 int launch_bneck(const BneckArgs& a, void* stream);
 int launch_head_gemm(const HeadGemmArgs& a, void* stream);

@@ -51,23 +51,26 @@ struct MdbArgs {
 };
 
 // CK1 = C / 4 k-steps of stage 1, CK2 = Cm / 4 of stage 2, MT2 = Co / 16 output tiles, WT pixel tiles per wave, NWV waves per workgroup
-template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false>
+// DPX: pixels per LDS-DMA instruction; NF: frames per workgroup (NF x NWV waves share the constants); PW1: stage 1 is pointwise only
+// (the bottleneck pair of the iris network: a = act1(W1 . x + b1), mbneck_kernel below)
+template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false, int DPX_ = 4, int NF_ = 1, bool PW1_ = false>
 struct MD {
-    static constexpr int CK1 = CK1_, CK2 = CK2_, MT2 = MT2_, WT = WT_, NWV = NWV_;
+    static constexpr int CK1 = CK1_, CK2 = CK2_, MT2 = MT2_, WT = WT_, NWV = NWV_, NF = NF_;
     static constexpr bool TAPL2 = TAPL2_;   // stage 2's taps stay in LDS (the registers do not hold 9 x (CK1 + CK2) taps beside the accumulators)
+    static constexpr bool PW1 = PW1_;
     static constexpr int C = 4 * CK1, Cm = 4 * CK2, Co = 16 * MT2, W = 16 * WT * NWV, SW = 16 * WT;
     static constexpr int MT1 = (Cm + 15) / 16;
     static constexpr int QP = CK1 + 1, PS = 4 * QP;                             // x row image: float4 slots / floats per pixel
     static constexpr int QPA = ((CK2 + 1) & 1) ? CK2 + 1 : CK2 + 2, PSA = 4 * QPA;  // a row image (odd slot count: the 16 pixels of a tile on distinct banks)
     static_assert(QP % 2 == 1, "x pixel stride: odd number of float4 slots");
     static constexpr int XIMG_F = (W + 2) * PS, AIMG_F = (W + 2) * PSA;
-    static constexpr int DPX = 4, NLD = SW / DPX, ACTIVE = DPX * QP;            // LDS-DMA: pixels per instruction, instructions per row and wave, lanes in use
+    static constexpr int DPX = DPX_, NLD = SW / DPX, ACTIVE = DPX * QP;         // LDS-DMA: pixels per instruction, instructions per row and wave, lanes in use
     static_assert(ACTIVE > 32 && ACTIVE <= 64 && (NLD == 4 || NLD == 8), "DMA shape");
     static_assert((NLD - 1) * DPX * C * 4 < 4096, "immediate offsets of the DMA instructions");
     // constants blob (floats): A1 [CK1][MT1][64] | A2 [CK2][MT2][64] | taps1 [CK1][4][12] | taps2 [CK2][4][12] | bias1 [16 MT1] | slope1 [16 MT1] | bias2 [Co] | slope2 [Co]
-    static constexpr int OFF_A1 = 0, A1_F = CK1 * MT1 * 64, OFF_A2 = A1_F, A2_F = CK2 * MT2 * 64, OFF_T1 = OFF_A2 + A2_F, T1_F = CK1 * 48, OFF_T2 = OFF_T1 + T1_F, T2_F = CK2 * 48;
+    static constexpr int OFF_A1 = 0, A1_F = CK1 * MT1 * 64, OFF_A2 = A1_F, A2_F = CK2 * MT2 * 64, OFF_T1 = OFF_A2 + A2_F, T1_F = PW1 ? 0 : CK1 * 48, OFF_T2 = OFF_T1 + T1_F, T2_F = CK2 * 48;
     static constexpr int OFF_B1 = OFF_T2 + T2_F, OFF_S1 = OFF_B1 + 16 * MT1, OFF_B2 = OFF_S1 + 16 * MT1, OFF_S2 = OFF_B2 + Co, TOTAL = OFF_S2 + Co;
-    static constexpr int LDS_F = TOTAL + 2 * XIMG_F + 2 * AIMG_F;
+    static constexpr int LDS_F = TOTAL + NF * (2 * XIMG_F + 2 * AIMG_F);
 };
 
 template <class K, bool RELU>
@@ -314,6 +317,265 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     }
 }
 
+// ---- the bottleneck pair  a = act1(W1 . x + b1);  y = act2(W2 . (DW3x3(a) + b_dw) + b2 + x)  (iris_landmark.tflite: 64 -> 32 -> 64 on 32 x 32;
+// CONV_2D 1x1 + PRELU, DEPTHWISE_CONV_2D, CONV_2D 1x1, ADD, PRELU behind `interpreter.invoke()`, /root/reference/src/face_detection_lite/
+// iris_landmark.rs:203) in the same scheme: stage 1 has no depthwise part, so row r of `a` is finished in the step that
+// brings row r of x (its B operand is the row image's centre pixels as they are), stage 2 finishes output row r - 1, whose bias + skip
+// waited in the other accumulator set for one step.  A workgroup = NF frames x NWV waves on one band; x is read only by the wave that
+// fetched it, so the step has ONE workgroup barrier (the `a` row is complete).
+template <int CK, int MT, int WT, int PSV>
+__device__ __forceinline__ void mpw_row(const unsigned src, const unsigned aop, df32x4 (&D)[MT][WT]) {
+    float xs[2][WT], av[2][MT];
+    auto load_ks = [&](auto ksc, float (&x)[WT], float (&aw)[MT]) {
+        constexpr int ks = decltype(ksc)::value;
+        const unsigned xa = src, aa = aop;
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(x[nt]) : "v"(xa), "n"(4 * ks * 4 + nt * 16 * PSV * 4));
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(aw[mt]) : "v"(aa), "n"((ks * MT + mt) * 64 * 4));
+    };
+    auto kstep = [&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        if constexpr (ks + 1 < CK) load_ks(std::integral_constant<int, ks + 1>{}, xs[(ks + 1) & 1], av[(ks + 1) & 1]);
+        float (&x)[WT] = xs[ks & 1];
+        float (&aw)[MT] = av[ks & 1];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) D[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt], x[nt], D[mt][nt], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load_ks(std::integral_constant<int, 0>{}, xs[0], av[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    dfor_each(kstep, std::make_integer_sequence<int, CK>{});
+}
+
+template <class K, bool RELU>
+__global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void mbneck_kernel(MdbArgs a) {
+    static_assert(K::PW1 && !K::TAPL2, "pointwise first stage, stage-2 taps in registers");
+    constexpr int CK1 = K::CK1, CK2 = K::CK2, MT1 = K::MT1, MT2 = K::MT2, WT = K::WT, NWV = K::NWV, NF = K::NF, C = K::C, Co = K::Co, W = K::W;
+    constexpr int PS = K::PS, PSA = K::PSA, QP = K::QP, QPA = K::QPA, XIMG_F = K::XIMG_F, AIMG_F = K::AIMG_F, NLD = K::NLD;
+    static_assert(NLD == 8, "eight DMA instructions per row and wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = wave / NWV, strip = wave - fr * NWV;
+    const int kq = lane >> 4, p = lane & 15;
+    float* wgc = lds;
+    float* ximg = lds + K::TOTAL + fr * (2 * XIMG_F + 2 * AIMG_F);   // this frame's [2][XIMG_F] row images of x ...
+    float* aimg = ximg + 2 * XIMG_F;                                  // ... and [2][AIMG_F] of a
+    // workgroup = (band, group of NF frames); the last group of an odd batch repeats the last frame (same values stored twice)
+    const int groups = (a.B + NF - 1) / NF;
+    const int band = blockIdx.x / groups, b = min((blockIdx.x - band * groups) * NF + fr, a.B - 1);
+    const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
+    const int x0 = strip * K::SW;
+    const float* in = a.in + (long)b * a.in_fs;
+
+    const int goff = ((lane / QP) * C + 4 * min(lane % QP, CK1 - 1)) * 4;
+    const unsigned lds_x = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ximg);
+    auto issue_row = [&](int r, int slot) {
+        const char* src = reinterpret_cast<const char*>(in + ((long)min(max(r, 0), a.H - 1) * W + x0) * C);
+        const unsigned dstb = lds_x + (unsigned)((slot * XIMG_F + (1 + x0) * PS) * 4);
+        unsigned long long saved;
+#define MI_MDB_DMA(k) "s_add_u32 m0, m0, %5\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
+                     "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     MI_MDB_DMA(1) MI_MDB_DMA(2) MI_MDB_DMA(3) MI_MDB_DMA(4) MI_MDB_DMA(5) MI_MDB_DMA(6) MI_MDB_DMA(7)
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(saved)
+                     : "s"(src), "v"(goff), "s"(dstb), "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
+                     : "memory", "scc");
+#undef MI_MDB_DMA
+    };
+    auto fix_row = [&](int r, int slot) {
+        if (r >= 0 && r < a.H) return;  // wave-uniform
+        float zz = 0.f;
+        asm volatile("" : "+v"(zz));
+        const float4 z = make_float4(zz, zz, zz, zz);
+        float* part = ximg + slot * XIMG_F + (1 + x0) * PS;
+        constexpr int N4 = K::SW * QP;
+#pragma unroll
+        for (int k = 0; k < (N4 + 63) / 64; k++)
+            if (64 * (k + 1) <= N4 || lane < N4 - 64 * k) *reinterpret_cast<float4*>(part + 4 * (lane + 64 * k)) = z;
+    };
+    // border pixel columns of the a images are never written afterwards: cleared once (x's border columns are never read: stage 1 is pointwise)
+    if (strip == 0 && lane < 2 * QPA) {
+        const int col = lane / QPA, qd = lane - col * QPA;
+#pragma unroll
+        for (int s = 0; s < 2; s++) *reinterpret_cast<float4*>(aimg + s * AIMG_F + col * (W + 1) * PSA + 4 * qd) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    issue_row(y0 - 1, 0);
+    for (int i = threadIdx.x; i < K::TOTAL / 4; i += NF * NWV * 64) reinterpret_cast<float4*>(wgc)[i] = reinterpret_cast<const float4*>(a.consts)[i];
+    issue_row(y0, 1);
+    dwait_vm<NLD>();
+    dwg_barrier();
+    asm volatile("" ::: "memory");
+    float tap2[CK2][9];
+    {
+        const float4* tq = reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3;
+#pragma unroll
+        for (int ks = 0; ks < CK2; ks++) {
+            const float4 t0 = tq[ks * 12], t1 = tq[ks * 12 + 1], t2 = tq[ks * 12 + 2];
+            tap2[ks][0] = t0.x; tap2[ks][1] = t0.y; tap2[ks][2] = t0.z; tap2[ks][3] = t0.w;
+            tap2[ks][4] = t1.x; tap2[ks][5] = t1.y; tap2[ks][6] = t1.z; tap2[ks][7] = t1.w;
+            tap2[ks][8] = t2.x;
+        }
+#pragma unroll
+        for (int ks = 0; ks < CK2; ks++)
+#pragma unroll
+            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap2[ks][t]));
+    }
+    typedef __attribute__((address_space(3))) float lfloat;
+    const unsigned xc_lds = (unsigned)(uintptr_t)(lfloat*)(ximg + (1 + x0 + p) * PS + kq);   // B layout: pixel x0 + p itself, channel kq
+    const unsigned a_lds = (unsigned)(uintptr_t)(lfloat*)(aimg + (x0 + p) * PSA + kq);         // ... its left neighbour in the a image
+    const unsigned a1_lds = (unsigned)(uintptr_t)(lfloat*)(wgc + K::OFF_A1 + lane);
+    const unsigned a2_lds = (unsigned)(uintptr_t)(lfloat*)(wgc + K::OFF_A2 + lane);
+    const float* sme = ximg + (1 + x0 + p) * PS + 4 * kq;
+    float* awr = aimg + (1 + x0 + p) * PSA + 4 * kq;
+    const unsigned ooff = (unsigned)((x0 + p) * Co + 4 * kq) * 4u;
+
+    float p2A[CK2][WT], p2B[CK2][WT];
+#pragma unroll
+    for (int ks = 0; ks < CK2; ks++)
+#pragma unroll
+        for (int nt = 0; nt < WT; nt++) p2A[ks][nt] = p2B[ks][nt] = 0.f;
+    df32x4 D1[MT1][WT], PA[MT2][WT], PB[MT2][WT];
+    auto init_D1 = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < MT1; mt++) {
+            const float4 bs = *reinterpret_cast<const float4*>(wgc + K::OFF_B1 + 16 * mt + 4 * kq);
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) D1[mt][nt] = df32x4{bs.x, bs.y, bs.z, bs.w};
+        }
+    };
+    auto init_P = [&](df32x4 (&P)[MT2][WT], int slot) {
+        float4 bs[MT2], x[MT2][WT];
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++) bs[mt] = *reinterpret_cast<const float4*>(wgc + K::OFF_B2 + 16 * mt + 4 * kq);
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) {
+                x[mt][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (16 * mt < C) x[mt][nt] = *reinterpret_cast<const float4*>(sme + slot * XIMG_F + 16 * nt * PS + 16 * mt);
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) P[mt][nt] = df32x4{x[mt][nt].x + bs[mt].x, x[mt][nt].y + bs[mt].y, x[mt][nt].z + bs[mt].z, x[mt][nt].w + bs[mt].w};
+    };
+    auto act = [&](df32x4 v, const float4& sl, float hi) {
+        if (RELU) return df32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+        return df32x4{fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), hi), fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), hi),
+                      fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), hi), fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), hi)};
+    };
+    auto store_a = [&](int q, int slot) {
+        const bool inside = q >= 0 && q < a.H;
+#pragma unroll
+        for (int mt = 0; mt < MT1; mt++) {
+            float4 sl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!RELU) sl = *reinterpret_cast<const float4*>(wgc + K::OFF_S1 + 16 * mt + 4 * kq);
+            if (16 * mt + 4 * kq < K::Cm) {
+#pragma unroll
+                for (int nt = 0; nt < WT; nt++) {
+                    df32x4 v = act(D1[mt][nt], sl, a.hi1);
+                    if (!inside) v = df32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<float4*>(awr + slot * AIMG_F + 16 * nt * PSA + 16 * mt) = make_float4(v.x, v.y, v.z, v.w);
+                }
+            }
+        }
+    };
+    typedef __attribute__((address_space(1))) char gchar;
+    typedef __attribute__((address_space(1))) df32x4 gf32x4;
+    auto epilogue = [&](df32x4 (&P)[MT2][WT], int y) {
+        gchar* dst = (gchar*)(a.out + (long)b * a.out_fs + (long)y * W * Co);
+        asm volatile("" : "+s"(dst));
+#pragma unroll
+        for (int mt = 0; mt < MT2; mt++) {
+            float4 sl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!RELU) sl = *reinterpret_cast<const float4*>(wgc + K::OFF_S2 + 16 * mt + 4 * kq);
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) *(gf32x4*)(dst + ooff + (unsigned)((16 * nt * Co + 16 * mt) * 4)) = act(P[mt][nt], sl, a.hi2);
+        }
+    };
+    // step t handles x row and a row y0 - 1 + t, y row y0 - 2 + t (from t = 2).  vmcnt: the stores of a step's output row (NST, from the
+    // third step on), then the DMA of the row two steps ahead; "row r has landed" = at most the previous step's stores and DMA are outstanding.
+    constexpr int NST = MT2 * WT;
+    const int TL = (y1 - y0) + 1;
+    auto wait_row = [&](int t) {
+        const bool st = t - 1 >= 2, dm = t == 0 || t + 1 <= TL;
+        if (st && dm) dwait_vm<NST + NLD>();
+        else if (dm) dwait_vm<NLD>();
+        else if (st) dwait_vm<NST>();
+        else dwait_vm<0>();
+    };
+    auto step = [&](auto e2c, int t, float (&q2PN)[CK2][WT], float (&q2C)[CK2][WT], df32x4 (&Pc)[MT2][WT], df32x4 (&Pi)[MT2][WT]) {
+        constexpr bool E2 = decltype(e2c)::value;
+        const int r = y0 - 1 + t, slot = t & 1;
+        wait_row(t);
+        fix_row(r, slot);
+        dwave_sync();
+        init_D1();
+        mpw_row<CK1, MT1, WT, PS>(xc_lds + (unsigned)(slot * XIMG_F * 4), a1_lds, D1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(r, slot);
+        dwg_barrier();   // a row r is complete (the neighbours' pixels included)
+        __builtin_amdgcn_sched_barrier(0);
+        mdb_row<CK2, MT2, WT, PSA, E2>(a_lds + (unsigned)(slot * AIMG_F * 4), a2_lds, tap2, q2PN, q2C, Pc);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (E2) epilogue(Pc, r - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        init_P(Pi, slot);   // output row r starts from bias + its skip, the centre pixels of x row r
+        __builtin_amdgcn_sched_barrier(0);
+        dwave_sync();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (t + 2 <= TL) issue_row(r + 2, slot);
+    };
+    const std::false_type F{};
+    const std::true_type T{};
+    step(F, 0, p2A, p2B, PB, PA);
+    step(F, 1, p2B, p2A, PA, PB);
+    for (int t = 2; t <= TL; t += 2) {
+        step(T, t, p2A, p2B, PB, PA);
+        if (t + 1 > TL) break;
+        step(T, t + 1, p2B, p2A, PA, PB);
+    }
+}
+
+using MB32 = MD<16, 8, 4, 1, 2, false, 2, 2, true>;   // 32 x 32: 64 -> 32 -> 64 (iris), two frames per workgroup
+
+template <class K>
+void mbn_pack(const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2,
+              const float* alpha2, int act2, float* dst) {
+    constexpr int C = K::C, Cm = K::Cm, Co = K::Co;
+    std::fill(dst, dst + K::TOTAL, 0.f);
+    for (int ks = 0; ks < K::CK1; ks++)
+        for (int mt = 0; mt < K::MT1; mt++)
+            for (int l = 0; l < 64; l++) {
+                const int o = 16 * mt + (l & 15);
+                if (o < Cm) dst[K::OFF_A1 + (ks * K::MT1 + mt) * 64 + l] = w_pw1[(size_t)o * C + 4 * ks + (l >> 4)];
+            }
+    for (int ks = 0; ks < K::CK2; ks++)
+        for (int mt = 0; mt < K::MT2; mt++)
+            for (int l = 0; l < 64; l++) dst[K::OFF_A2 + (ks * K::MT2 + mt) * 64 + l] = w_pw2[(size_t)(16 * mt + (l & 15)) * Cm + 4 * ks + (l >> 4)];
+    for (int ks = 0; ks < K::CK2; ks++)
+        for (int kq = 0; kq < 4; kq++)
+            for (int t = 0; t < 9; t++) dst[K::OFF_T2 + (ks * 4 + kq) * 12 + t] = w_dw2[t * Cm + 4 * ks + kq];
+    for (int c = 0; c < Cm; c++) {
+        dst[K::OFF_B1 + c] = b1 ? b1[c] : 0.f;
+        dst[K::OFF_S1 + c] = act1 == ACT_PRELU ? alpha1[c] : (act1 == ACT_NONE ? 1.f : 0.f);
+    }
+    for (int c = 0; c < Co; c++) {
+        double acc = b2 ? b2[c] : 0.0;
+        if (b_dw2)
+            for (int k = 0; k < Cm; k++) acc += (double)w_pw2[(size_t)c * Cm + k] * b_dw2[k];
+        dst[K::OFF_B2 + c] = (float)acc;
+        dst[K::OFF_S2 + c] = act2 == ACT_PRELU ? alpha2[c] : (act2 == ACT_NONE ? 1.f : 0.f);
+    }
+}
+
 using MD96 = MD<8, 2, 2, 2, 3>;    // 96 x 96: 32 -> 8 -> 32
 using MD48a = MD<12, 3, 3, 1, 3>;  // 48 x 48: 48 -> 12 -> 48
 using MD48b = MD<12, 4, 4, 1, 3>;  // 48 x 48: 48 -> 16 -> 64
@@ -442,6 +704,57 @@ int launch_mdblock(const DblockArgs& a, void* stream) {
         case 4: return mdb_launch<MD48c>(a, s);
     }
     return (int)hipErrorInvalidValue;
+}
+
+// ---- bottleneck pairs (mbneck_kernel): 32-pixel-wide frames, 64 -> 32 -> 64 channels, one pair per launch
+bool mbneck_shape_ok(int W, int C, int Cm) {
+    static const bool off = getenv("MI_NO_MBNECK") != nullptr;  // tuning aid: bneck_kernels.hip instead
+    return !off && W == 32 && C == 64 && Cm == 32;
+}
+
+int mbneck_consts_floats(int W, int C, int Cm) { return mbneck_shape_ok(W, C, Cm) ? MB32::TOTAL : 0; }
+
+void mbneck_pack_consts(int W, int C, int Cm, const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2,
+                        const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst) {
+    if (mbneck_shape_ok(W, C, Cm)) mbn_pack<MB32>(w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst);
+}
+
+bool mbneck_kernel_supports(const BneckArgs& a) {
+    if (a.nblocks != 1 || !a.blocks[0].mconsts || !mbneck_shape_ok(a.W, a.C, a.Cm) || a.H < 2) return false;
+    static const int min_b = getenv("MI_MDB_MIN_B") ? atoi(getenv("MI_MDB_MIN_B")) : 32;
+    if (a.B < min_b) return false;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return aligned16(a.in) && aligned16(a.out) && aligned16(a.blocks[0].mconsts) && !(a.in_fs & 3) && !(a.out_fs & 3);
+}
+
+int launch_mbneck(const BneckArgs& a, void* stream) {
+    if (!mbneck_kernel_supports(a)) return (int)hipErrorInvalidValue;
+    using K = MB32;
+    MdbArgs ma;
+    ma.in = a.in; ma.out = a.out; ma.consts = a.blocks[0].mconsts; ma.in_fs = a.in_fs; ma.out_fs = a.out_fs;
+    ma.B = a.B; ma.H = a.H;
+    ma.hi1 = a.blocks[0].hi1; ma.hi2 = a.blocks[0].hi2;
+    static const int forced = getenv("MI_MBN_BAND") ? atoi(getenv("MI_MBN_BAND")) : 0;  // tuning aid
+    const int groups = (a.B + K::NF - 1) / K::NF;
+    const int per_cu = std::max(1, std::min(8 / (K::NF * K::NWV), (int)((160 * 1024) / (K::LDS_F * 4))));
+    long bands = std::max<long>(1, ((long)per_cu * device_cu_count() + groups / 2) / std::max(1, groups));
+    int rows = (int)((a.H + bands - 1) / bands);
+    rows = std::max(rows, std::min(a.H, 8));
+    if (forced > 0) rows = std::min(forced, a.H);
+    ma.band_rows = rows;
+    ma.bands = (a.H + rows - 1) / rows;
+    const bool relu = a.blocks[0].act1 == ACT_RELU && a.blocks[0].act2 == ACT_RELU;
+    const dim3 grid((unsigned)((long)groups * ma.bands));
+    const size_t lds_bytes = (size_t)K::LDS_F * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (relu) {
+        auto kern = mbneck_kernel<K, true>;
+        if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
+        return (int)launch_kernel(kern, grid, dim3(K::NF * K::NWV * 64), lds_bytes, s, ma);
+    }
+    auto kern = mbneck_kernel<K, false>;
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
+    return (int)launch_kernel(kern, grid, dim3(K::NF * K::NWV * 64), lds_bytes, s, ma);
 }
 
 }  // namespace mi
