@@ -152,6 +152,21 @@ void Model::rebuild() {
                 }
                 chain_off_[i].push_back(mo);
             }
+            // a row-pipelined pair of plain BlazeBlocks on a wide layer also gets the constants of the operand-layout kernel
+            // (mdblock_kernels.hip, pair form; which of the two runs is decided per launch)
+            if (n.members.size() == 2 && !n.chain_pre && !n.chain_post && n.head_pairs.empty()) {
+                const Node &pa = n.members[0], &pb = n.members[1];
+                const auto& sx = g.tensors[pa.in[0]].shape;
+                auto plain = [&](const Node& m) { return m.w >= 0 && m.sh == 1 && m.sw == 1 && m.res == m.in[0] && m.res_mode == RES_DIRECT && !m.res_after && m.padding == Padding::Same; };
+                const int C = sx[3], Cm = g.tensors[pa.out].shape[3], Co = g.tensors[pb.out].shape[3];
+                if (sx.size() == 4 && plain(pa) && plain(pb) && pb.in[0] == pa.out && mdblock_shape_ok(sx[2], C, Cm, Co, true)) {
+                    std::vector<float> mc(static_cast<size_t>(mdblock_consts_floats(sx[2], C, Cm, Co, true)));
+                    auto ptr = [&](int t) { return t >= 0 ? g.tensors[t].f32.data() : nullptr; };
+                    mdblock_pack_consts(sx[2], C, Cm, Co, ptr(pa.w), ptr(pa.b), ptr(pa.w2), ptr(pa.b2), pa.act == ACT_PRELU ? ptr(pa.alpha) : nullptr, pa.act,
+                                        ptr(pb.w), ptr(pb.b), ptr(pb.w2), ptr(pb.b2), pb.act == ACT_PRELU ? ptr(pb.alpha) : nullptr, pb.act, mc.data(), true);
+                    node_mwalk_[i] = put(mc);   // (the slot of the Block nodes' mwalk constants: a Chain node has none of its own)
+                }
+            }
             // output heads of the launch: the weights of a pair stacked [Co_a + Co_b][C] in A-fragment order, the biases stacked
             for (const Node::HeadPair& hp : n.head_pairs) {
                 const Node* hn[2] = {&n.head_nodes[static_cast<size_t>(hp.a)], hp.b >= 0 ? &n.head_nodes[static_cast<size_t>(hp.b)] : nullptr};
@@ -856,6 +871,21 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     for (size_t k = 0; k < n.members.size(); k++) fill(a.blocks[k], k);
                     rc = launch_chain(a, s);
                     break;
+                }
+                if (strip_ && node_mwalk_[i] >= 0) {   // a pair of plain BlazeBlocks with an operand-layout form
+                    DblockArgs d;
+                    d.in = ip; d.in_fs = in_fs; d.out = op; d.out_fs = out_fs;
+                    d.B = F; d.H = si[1]; d.W = si[2]; d.C = si[3]; d.Cm = g.tensors[n.members[0].out].shape[3]; d.Co = so[3];
+                    d.hi1 = n.members[0].act == ACT_RELU6 ? 6.f : INFINITY;
+                    d.hi2 = n.members[1].act == ACT_RELU6 ? 6.f : INFINITY;
+                    d.skip1 = 1; d.skip2_from_a = 1;
+                    d.act1 = n.members[0].act; d.act2 = n.members[1].act;
+                    d.mconsts = d_weights_ + node_mwalk_[i];
+                    if (mdblock_kernel_supports(d)) {
+                        if (labels) labels->back() = "mdblock_kernel<pair>";
+                        rc = launch_mdblock(d, s);
+                        break;
+                    }
                 }
                 // row-pipelined group of strip blocks: only the first input and the last output exist in memory
                 std::vector<BlockArgs> blk(n.members.size());

@@ -318,10 +318,11 @@ struct DblockArgs {
 bool dblock_kernel_supports(const DblockArgs& a);
 // mdblock_kernels.hip: the double blocks of the 96- and 48-pixel-wide layers with both pointwise convs as 16x16x4 MFMAs in the
 // operand layout (row-walking waves, taps in registers)
-bool mdblock_shape_ok(int W, int C, int Cm, int Co);
-int mdblock_consts_floats(int W, int C, int Cm, int Co);
+// (pair: two plain BlazeBlocks in a row, each adding its own input, instead of the double block)
+bool mdblock_shape_ok(int W, int C, int Cm, int Co, bool pair = false);
+int mdblock_consts_floats(int W, int C, int Cm, int Co, bool pair = false);
 void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1,
-                         const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst);
+                         const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst, bool pair = false);
 bool mdblock_kernel_supports(const DblockArgs& a);
 int launch_mdblock(const DblockArgs& a, void* stream);
 int dblock_const_floats(int C, int Cm, int Co);

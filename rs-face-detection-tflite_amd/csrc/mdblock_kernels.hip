@@ -53,8 +53,10 @@ struct MdbArgs {
 // CK1 = C / 4 k-steps of stage 1, CK2 = Cm / 4 of stage 2, MT2 = Co / 16 output tiles, WT pixel tiles per wave, NWV waves per workgroup
 // DPX: pixels per LDS-DMA instruction; NF: frames per workgroup (NF x NWV waves share the constants); PW1: stage 1 is pointwise only
 // (the bottleneck pair of the iris network: a = act1(W1 . x + b1), mbneck_kernel below)
-template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false, int DPX_ = 4, int NF_ = 1, bool PW1_ = false>
+// PAIR: two plain BlazeBlocks in a row instead of the double block — a = act1(.. + x), y = act2(.. + a): each stage adds its own input
+template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false, int DPX_ = 4, int NF_ = 1, bool PW1_ = false, bool PAIR_ = false>
 struct MD {
+    static constexpr bool PAIR = PAIR_;
     static constexpr int CK1 = CK1_, CK2 = CK2_, MT2 = MT2_, WT = WT_, NWV = NWV_, NF = NF_;
     static constexpr bool TAPL2 = TAPL2_;   // stage 2's taps stay in LDS (the registers do not hold 9 x (CK1 + CK2) taps beside the accumulators)
     static constexpr bool PW1 = PW1_;
@@ -202,12 +204,17 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
 #pragma unroll
         for (int nt = 0; nt < WT; nt++) p2A[ks][nt] = p2B[ks][nt] = 0.f;
     df32x4 D1[MT1][WT], PA[MT2][WT], PB[MT2][WT];   // PA / PB: accumulators of the output rows of even / odd steps, waiting with bias + skip inside
-    auto init_D1 = [&]() {
+    // D1 <- bias1 (+ with PAIR the first block's skip: the centre pixels of the x row in image `slot`, for the a row of the same index)
+    auto init_D1 = [&](int slot) {
 #pragma unroll
         for (int mt = 0; mt < MT1; mt++) {
             const float4 bs = *reinterpret_cast<const float4*>(wgc + K::OFF_B1 + 16 * mt + 4 * kq);
 #pragma unroll
-            for (int nt = 0; nt < WT; nt++) D1[mt][nt] = df32x4{bs.x, bs.y, bs.z, bs.w};
+            for (int nt = 0; nt < WT; nt++) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (K::PAIR && 16 * mt < C) x = *reinterpret_cast<const float4*>(sme + slot * XIMG_F + 16 * nt * PS + 16 * mt);
+                D1[mt][nt] = df32x4{bs.x + x.x, bs.y + x.y, bs.z + x.z, bs.w + x.w};
+            }
         }
     };
     // P <- bias2 + skip for the output row whose centre input row sits in x image `slot`
@@ -220,7 +227,11 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
 #pragma unroll
             for (int nt = 0; nt < WT; nt++) {
                 x[mt][nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (16 * mt < C) x[mt][nt] = *reinterpret_cast<const float4*>(sme + slot * XIMG_F + 16 * nt * PS + 16 * mt);  // channels >= C: the zero channel-pad of the skip
+                if (K::PAIR) {  // the second block's skip: the a row in image `slot` (same pixels, D layout)
+                    if (16 * mt < K::Cm) x[mt][nt] = *reinterpret_cast<const float4*>(awr + slot * AIMG_F + 16 * nt * PSA + 16 * mt);
+                } else if (16 * mt < C) {
+                    x[mt][nt] = *reinterpret_cast<const float4*>(sme + slot * XIMG_F + 16 * nt * PS + 16 * mt);  // channels >= C: the zero channel-pad of the skip
+                }
             }
 #pragma unroll
         for (int mt = 0; mt < MT2; mt++)
@@ -284,13 +295,25 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
         fix_row(r, slot);
         dwg_barrier();   // x row r is complete (every wave's part has landed and is fixed)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (E1) init_D1();
+        if constexpr (E1 && !K::PAIR) init_D1(slot);
         mdb_row<CK1, MT1, WT, PS, E1>(x_lds + (unsigned)(slot * XIMG_F * 4), a1_lds, tap1, q1PN, q1C, D1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (E1) {
+        if constexpr (K::PAIR) {
+            // the next a row (r) starts from bias + ITS skip, the centre pixels of x row r, and waits in D1 for one step
+            if constexpr (E1) store_a(r - 1, slot);
+            init_D1(slot);
+            if constexpr (E1) {
+                dwg_barrier();   // a row r - 1 is complete
+                __builtin_amdgcn_sched_barrier(0);
+                // output row r - 2 starts from bias + the a row r - 2 (finished in the previous step, the other a image)
+                if constexpr (E2) init_P(P, slot ^ 1);
+            }
+        } else if constexpr (E1) {
             store_a(r - 1, slot);
             dwg_barrier();   // a row r - 1 is complete
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (E1) {
             mdb_row<CK2, MT2, WT, PSA, E2, K::TAPL2>(a_lds + (unsigned)(slot * AIMG_F * 4), a2_lds, tap2, q2PN, q2C, P, reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (E2) epilogue(P, r - 2);
@@ -298,7 +321,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
         } else {
             dwg_barrier();   // priming steps: the neighbours have read this row's halo pixels before this wave's next DMA lands on them
         }
-        init_P(P, slot);   // output row r starts from bias + its skip, the centre pixels of x row r
+        if constexpr (!K::PAIR) init_P(P, slot);   // output row r starts from bias + its skip, the centre pixels of x row r
         __builtin_amdgcn_sched_barrier(0);
         dwave_sync();      // every read of x image `slot` by this wave is issued before the DMA below overwrites this wave's part of it
         __builtin_amdgcn_s_waitcnt(0xC07F);  // ... and has returned (the other waves read row r's halo pixels before the a-row barrier)
@@ -580,6 +603,7 @@ using MD96 = MD<8, 2, 2, 2, 3>;    // 96 x 96: 32 -> 8 -> 32
 using MD48a = MD<12, 3, 3, 1, 3>;  // 48 x 48: 48 -> 12 -> 48
 using MD48b = MD<12, 4, 4, 1, 3>;  // 48 x 48: 48 -> 16 -> 64
 using MD48c = MD<12, 6, 3, 1, 3, true>;  // 48 x 48: 48 -> 24 -> 48
+using MP96 = MD<4, 4, 1, 2, 3, false, 8, 1, false, true>;  // 96 x 96: two BlazeBlocks 16 -> 16 -> 16 (face mesh)
 
 template <class K>
 void mdb_pack(const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2,
@@ -628,7 +652,8 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
     ma.hi1 = a.hi1; ma.hi2 = a.hi2;
     // bands: enough workgroups for every CU to hold as many as its LDS takes; a band costs four priming steps
     static const int forced = getenv("MI_MDB_BAND") ? atoi(getenv("MI_MDB_BAND")) : 0;  // tuning aid
-    const int per_cu = std::max(1, std::min(8 / K::NWV, (int)((160 * 1024) / (K::LDS_F * 4))));
+    // (the pair form on 16 channels needs ~160 registers: three waves per SIMD)
+    const int per_cu = std::max(1, std::min((K::PAIR ? 12 : 8) / K::NWV, (int)((160 * 1024) / (K::LDS_F * 4))));
     long bands = std::max<long>(1, ((long)per_cu * device_cu_count() + a.B / 2) / std::max(1, a.B));
     int rows = (int)((a.H + bands - 1) / bands);
     rows = std::max(rows, std::min(a.H, 8));
@@ -648,10 +673,12 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
     return (int)launch_kernel(kern, grid, dim3(K::NWV * 64), lds_bytes, s, ma);
 }
 
-// 0: none; 1: 96 wide 32 -> 8 -> 32; 2: 48 wide 48 -> 12 -> 48; 3: 48 wide 48 -> 16 -> 64; 4: 48 wide 48 -> 24 -> 48
-int mdb_shape(int W, int C, int Cm, int Co) {
+// 0: none; 1: 96 wide 32 -> 8 -> 32; 2: 48 wide 48 -> 12 -> 48; 3: 48 wide 48 -> 16 -> 64; 4: 48 wide 48 -> 24 -> 48;
+// 5: two plain BlazeBlocks (pair), 96 wide 16 -> 16 -> 16
+int mdb_shape(int W, int C, int Cm, int Co, bool pair = false) {
     static const bool off = getenv("MI_NO_MDBLOCK") != nullptr;  // tuning aid: the LDS-tensor double-block kernel instead
     if (off) return 0;
+    if (pair) return (W == 96 && C == 16 && Cm == 16 && Co == 16) ? 5 : 0;
     if (W == 96 && C == 32 && Cm == 8 && Co == 32) return 1;
     if (W == 48 && C == 48 && Cm == 12 && Co == 48) return 2;
     if (W == 48 && C == 48 && Cm == 16 && Co == 64) return 3;
@@ -661,10 +688,11 @@ int mdb_shape(int W, int C, int Cm, int Co) {
 
 }  // namespace
 
-bool mdblock_shape_ok(int W, int C, int Cm, int Co) { return mdb_shape(W, C, Cm, Co) != 0; }
+bool mdblock_shape_ok(int W, int C, int Cm, int Co, bool pair) { return mdb_shape(W, C, Cm, Co, pair) != 0; }
 
-int mdblock_consts_floats(int W, int C, int Cm, int Co) {
-    switch (mdb_shape(W, C, Cm, Co)) {
+int mdblock_consts_floats(int W, int C, int Cm, int Co, bool pair) {
+    switch (mdb_shape(W, C, Cm, Co, pair)) {
+        case 5: return MP96::TOTAL;
         case 1: return MD96::TOTAL;
         case 2: return MD48a::TOTAL;
         case 3: return MD48b::TOTAL;
@@ -675,8 +703,9 @@ int mdblock_consts_floats(int W, int C, int Cm, int Co) {
 
 // w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C] (TFLite OHWI with H = W = 1), bias [Co] or null, alpha [Co] or null — per stage
 void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1,
-                         const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst) {
-    switch (mdb_shape(W, C, Cm, Co)) {
+                         const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst, bool pair) {
+    switch (mdb_shape(W, C, Cm, Co, pair)) {
+        case 5: mdb_pack<MP96>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 1: mdb_pack<MD96>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 2: mdb_pack<MD48a>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 3: mdb_pack<MD48b>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
@@ -684,9 +713,11 @@ void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const
     }
 }
 
-// the double block proper (no skip on the first half, the second half's skip is x), constants packed by mdblock_pack_consts()
+// the double block proper (no skip on the first half, the second half's skip is x) or a pair of plain BlazeBlocks (both skips), constants
+// packed by mdblock_pack_consts()
 bool mdblock_kernel_supports(const DblockArgs& a) {
-    if (!a.mconsts || a.skip1 || a.skip2_from_a || !mdb_shape(a.W, a.C, a.Cm, a.Co) || a.H < 2 || a.B < 1) return false;
+    if (a.skip1 != a.skip2_from_a) return false;
+    if (!a.mconsts || !mdb_shape(a.W, a.C, a.Cm, a.Co, a.skip1 != 0) || a.H < 2 || a.B < 1) return false;
     // the waves of a band walk it row by row: below about one workgroup per CU the launch is latency-bound and the wider kernel finishes sooner
     static const int min_b = getenv("MI_MDB_MIN_B") ? atoi(getenv("MI_MDB_MIN_B")) : 32;
     if (a.B < min_b) return false;
@@ -697,7 +728,8 @@ bool mdblock_kernel_supports(const DblockArgs& a) {
 int launch_mdblock(const DblockArgs& a, void* stream) {
     if (!mdblock_kernel_supports(a)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    switch (mdb_shape(a.W, a.C, a.Cm, a.Co)) {
+    switch (mdb_shape(a.W, a.C, a.Cm, a.Co, a.skip1 != 0)) {
+        case 5: return mdb_launch<MP96>(a, s);
         case 1: return mdb_launch<MD96>(a, s);
         case 2: return mdb_launch<MD48a>(a, s);
         case 3: return mdb_launch<MD48b>(a, s);

@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 128, H = argc > 2 ? atoi(argv[2]) : 96, W = argc > 3 ? atoi(argv[3]) : 96;
     int C = argc > 4 ? atoi(argv[4]) : 32, Cm = argc > 5 ? atoi(argv[5]) : 8, Co = argc > 6 ? atoi(argv[6]) : 32;
     int act = argc > 7 ? atoi(argv[7]) : ACT_RELU;
+    const bool pair = argc > 8 ? atoi(argv[8]) != 0 : false;  // two plain BlazeBlocks (each adds its own input) instead of the double block
     const size_t nin = (size_t)B * H * W * C, nout = (size_t)B * H * W * Co;
     float *din, *dout, *dref;
     CK(hipMalloc(&din, nin * 4)); CK(hipMalloc(&dout, nout * 4)); CK(hipMalloc(&dref, nout * 4));
@@ -64,14 +65,15 @@ int main(int argc, char** argv) {
     for (int c = 0; c < Cm; c++) cb[o + c] = bdw2[c];
     o += Cmp;
     for (int c = 0; c < Co; c++) { cb[o + c] = b2[c]; cb[o + 32 * MT + c] = slope(al2, c); }
-    std::vector<float> mc((size_t)std::max(1, mdblock_consts_floats(W, C, Cm, Co)), 0.f);
-    mdblock_pack_consts(W, C, Cm, Co, wdw1.data(), bdw1.data(), pw1.data(), b1.data(), al1.data(), act, wdw2.data(), bdw2.data(), pw2.data(), b2.data(), al2.data(), act, mc.data());
+    std::vector<float> mc((size_t)std::max(1, mdblock_consts_floats(W, C, Cm, Co, pair)), 0.f);
+    mdblock_pack_consts(W, C, Cm, Co, wdw1.data(), bdw1.data(), pw1.data(), b1.data(), al1.data(), act, wdw2.data(), bdw2.data(), pw2.data(), b2.data(), al2.data(), act, mc.data(), pair);
     DblockArgs a;
     a.in = din; a.out = dref; a.in_fs = (long)H * W * C; a.out_fs = (long)H * W * Co;
     a.B = B; a.H = H; a.W = W; a.C = C; a.Cm = Cm; a.Co = Co;
     a.consts = up(cb); a.w1 = up(pack_pw(pw1, Cm, C)); a.w2 = up(pack_pw(pw2, Co, Cm));
     a.hi1 = a.hi2 = act == ACT_RELU6 ? 6.f : INFINITY;
     a.mconsts = up(mc); a.act1 = a.act2 = act;
+    if (pair) a.skip1 = a.skip2_from_a = 1;
     DblockArgs a2 = a; a2.out = dout;
     hipStream_t s; CK(hipStreamCreate(&s));
     if (!dblock_kernel_supports(a)) { printf("dblock: unsupported\n"); return 1; }
