@@ -762,7 +762,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     a.skip2_from_a = n.members[1].res == n.members[0].out;
                     a.act1 = n.members[0].act; a.act2 = n.members[1].act;
                     if (chain_off_[i][1].strip >= 0) a.mconsts = d_weights_ + chain_off_[i][1].strip;
-                    if (mdblock_kernel_supports(a)) {
+                    if (strip_ && mdblock_kernel_supports(a)) {
                         if (labels) labels->back() = "mdblock_kernel";
                         rc = launch_mdblock(a, s);
                         break;
@@ -787,7 +787,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         a.blocks[k].act2 = n.members[static_cast<size_t>(2 * k + 1)].act;
                         if (mb.strip >= 0) a.blocks[k].mconsts = d_weights_ + mb.strip;
                     }
-                    if (mbneck_kernel_supports(a)) {
+                    if (strip_ && mbneck_kernel_supports(a)) {
                         if (labels) labels->back() = "mbneck_kernel";
                         rc = launch_mbneck(a, s);
                         break;

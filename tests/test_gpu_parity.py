@@ -198,6 +198,36 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     m.close()
 
 
+@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel"]), ("landmark", ["mwalk_kernel", "mdblock_kernel<pair>"]), ("iris", ["mbneck_kernel"])])
+def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, kernels):
+    """The row-walking MFMA kernels of round 3 (mdblock / mwalk / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand layout)
+    take the wide double blocks of full_range, the 48x48x32 blocks and the 96x96x16 block pair of the face mesh and the 32x32 bottleneck
+    pairs of the iris network from 32 frames per launch on.  An odd batch of 33 frames (mbneck: the last workgroup repeats the last frame)
+    against the oracle frame by frame, against the LDS-tensor kernels ("strip" = 0), and frame 7 alone (batch 1: the older kernels)
+    against frame 7 inside the batch."""
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path(name))
+    x = seeded_input(name, 33, 4242, m.input_dims[1:3])
+    x[5] = 0.0                                   # an all-zero frame: biases only
+    x[9, :, : x.shape[2] // 2] = x.min()         # half-saturated frame
+    outs = [o.copy() for o in m.run(x)]
+    labels = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+    for k in kernels:
+        assert any(l.startswith(k) for l in labels), (k, labels)
+    om = oracle.Model(model_path(name))
+    refs = om.run(x, nthreads=8)
+    for o, r in zip(outs, refs):
+        _raw_close(o, r)
+    for o, r in zip(m.run(x[7:8]), outs):
+        _raw_close(o[0], r[7])
+    m.set_option("strip", 0)
+    labels0 = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+    assert not any(l.startswith(("mdblock", "mwalk", "mbneck")) for l in labels0), labels0
+    for o, r in zip(m.run(x), outs):
+        _raw_close(o, r)
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))
