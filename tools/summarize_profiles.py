@@ -22,9 +22,19 @@ def one(pattern):
 
 def label(name):
     # rocprofv3 symbol -> the label mi_model_profile / bench.py use: template arguments as integers, SLOW / CPT dropped for block kernels
-    m = re.search(r"(\w+)<([^>]*)>", name.replace("(anonymous namespace)::", ""))
+    name = name.replace("(anonymous namespace)::", "")
+    # the operand-layout kernels carry a geometry struct as template argument: mdblock_kernel<mi::MD<8, 2, 2, 2, 3, false, 4, 1, false, false>, true>
+    m0 = re.search(r"(mdblock_kernel|mbneck_kernel|mwalk_kernel)<(?:mi::)?M[DW]<([^>]*)>", name)
+    if m0:
+        a = [x.strip() for x in m0.group(2).split(",")]
+        if m0.group(1) == "mwalk_kernel":
+            return "mwalk_kernel<%s>" % ",".join(a[:3])
+        if m0.group(1) == "mdblock_kernel" and len(a) >= 10 and a[9] == "true":
+            return "mdblock_kernel<pair>"
+        return m0.group(1)
+    m = re.search(r"(\w+)<([^>]*)>", name)
     if not m:
-        m2 = re.search(r"(\w+)\(", name.replace("(anonymous namespace)::", ""))
+        m2 = re.search(r"(\w+)\(", name)
         return m2.group(1) if m2 else name
     args = [{"true": "1", "false": "0"}.get(a.strip(), a.strip()) for a in m.group(2).split(",")]
     if m.group(1) == "block_kernel":
@@ -39,7 +49,7 @@ def label(name):
 
 
 WORKLOADS = {1: "short128_b256", 2: "back256_b256", 3: "landmark192_b512", 5: "pipeline192_b128"}
-WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel")
+WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel")
 
 # ---- kernel stats per config
 for c in WORKLOADS:
