@@ -17,7 +17,7 @@ os.makedirs(out, exist_ok=True)
 
 def one(pattern):
     hits = glob.glob(os.path.join(base, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None   # gpurun merges into gpurun_out/: files of an earlier collection may still be there
 
 
 def label(name):
