@@ -199,6 +199,20 @@ void Model::rebuild() {
             }
             continue;
         }
+        if (n.kind == Node::Resident && n.xc) {
+            // expand / contract runs (xc_kernels.hip): per member the depthwise taps and biases as stored, the pointwise matrix in the block kernel's packing
+            for (const Node& m : n.members) {
+                MemberOff mo;
+                if (m.w >= 0) mo.w = put(g.tensors[m.w].f32);
+                if (m.b >= 0) mo.b = put(g.tensors[m.b].f32);
+                mo.w2 = pack_pw(m.w2);
+                if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
+                chain_off_[i].push_back(mo);
+            }
+            res_wblk_[i].clear();
+            res_cblob_[i].clear();
+            continue;
+        }
         if (n.kind == Node::Resident && n.dblock) {
             // double block (dblock_kernels.hip): both pointwise matrices in the block kernel's packing, one blob of small constants
             const Node &pa = n.members[0], &pb = n.members[1];
@@ -554,7 +568,7 @@ std::string Model::node_label(const Node& n) const {
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
             return std::string(strip_pipe_rows_per_step(sin[1], pipe_rows_) == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<") + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
-        case Node::Resident: return n.dblock ? "dblock_kernel" : (n.bneck ? "bneck_kernel" : "resident_kernel");
+        case Node::Resident: return n.xc ? "xc_kernel" : (n.dblock ? "dblock_kernel" : (n.bneck ? "bneck_kernel" : "resident_kernel"));
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -749,6 +763,28 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 break;
             }
             case Node::Resident: {
+                if (n.xc) {
+                    XcArgs a;
+                    a.in = ip; a.in_fs = in_fs; a.out = op; a.out_fs = out_fs;
+                    a.B = F; a.H = si[1]; a.W = si[2]; a.nstages = static_cast<int>(n.members.size());
+                    for (size_t k = 0; k < n.members.size(); k++) {
+                        const Node& m = n.members[k];
+                        const MemberOff& mo = chain_off_[i][k];
+                        XcStage& st = a.st[k];
+                        st.w_dw = mo.w >= 0 ? d_weights_ + mo.w : nullptr;
+                        st.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
+                        st.w_pw = d_weights_ + mo.w2;
+                        st.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
+                        st.C = g.tensors[m.in[0]].shape[3]; st.Co = g.tensors[m.out].shape[3]; st.act = m.act;
+                        st.skip = m.res < 0 ? 0 : (m.res == m.in[0] ? 1 : (k >= 2 && m.res == n.members[k - 2].out ? 3 : 2));
+                        if (st.skip == 2) {
+                            st.res = tensor_ptr(m.res, in, chunk_start, &st.res_fs);
+                            st.res_C = g.tensors[m.res].shape[3]; st.res_W = g.tensors[m.res].shape[2];
+                        }
+                    }
+                    rc = launch_xc(a, s);
+                    break;
+                }
                 if (n.dblock) {
                     DblockArgs a;
                     a.in = ip; a.in_fs = in_fs; a.out = op; a.out_fs = out_fs;

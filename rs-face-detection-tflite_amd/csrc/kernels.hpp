@@ -298,6 +298,31 @@ struct BneckArgs {
                                     // > 1: row bands of ceil(H / bands) rows (<= 256 pixels each), one block per launch
     BneckBlock blocks[kMaxBneck];
 };
+// ---- runs of expand / contract BlazeBlocks on tiny frames as one frame-resident launch (xc_kernels.hip):
+//   even stages: wide = act(W . (DW3x3(narrow) + b_dw) + b + skip);  odd stages: narrow = act(W . (DW3x3(wide) + b_dw) + b)
+struct XcStage {
+    const float* w_dw = nullptr;    // [3][3][C]; null: the stage is pointwise only
+    const float* b_dw = nullptr;    // [C] or null
+    const float* w_pw = nullptr;    // block kernel's A-fragment packing of W [Co][C]
+    const float* bias = nullptr;    // [Co] or null
+    int C = 0, Co = 0;
+    int act = ACT_RELU;             // ACT_NONE / ACT_RELU / ACT_RELU6
+    int skip = 0;                   // 0: none; 1: the stage's own input (channels >= C: zero); 2: 2x2 max-pool of `res` ([2H][2W][res_C], channels >= res_C: zero);
+                                    // 3: the output of the expand stage two stages back (same shape; updated in place)
+    const float* res = nullptr;
+    long res_fs = 0;
+    int res_C = 0, res_W = 0;
+};
+constexpr int kMaxXc = 8;
+struct XcArgs {
+    const float* in = nullptr;      // [B][H][W][st[0].C]
+    float* out = nullptr;           // [B][H][W][st[nstages - 1].Co]
+    long in_fs = 0, out_fs = 0;
+    int B = 0, H = 0, W = 0, nstages = 0;
+    XcStage st[kMaxXc];
+};
+bool xc_kernel_supports(const XcArgs& a);
+int launch_xc(const XcArgs& a, void* stream);
 // ---- full_range's double BlazeBlock as one launch (dblock_kernels.hip):
 //   a = act1(W1 . (DW3x3(x) + b_dw1) + b1) (C -> Cm);  y = act2(W2 . (DW3x3(a) + b_dw2) + b2 + pad(x)) (Cm -> Co >= C)
 struct DblockArgs {

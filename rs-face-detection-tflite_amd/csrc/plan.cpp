@@ -712,6 +712,95 @@ size_t build_dblock(const Graph& g, const std::vector<Node>& ns, size_t i, Node*
     return 2;
 }
 
+// Level 5: runs of stride-1 BlazeBlocks on tiny frames (<= 64 pixels) whose channel count alternates narrow -> wide -> narrow ...
+// (full_range's 6x6x96 -> 384 -> 96 pairs) as one frame-resident launch of xc_kernels.hip.  Returns the number of plan nodes consumed (0: no match).
+size_t build_xc(const Graph& g, const std::vector<Node>& ns, size_t i, Node* out) {
+    static const bool off = getenv("MI_NO_XC") != nullptr;  // development aid
+    if (off || i + 1 >= ns.size()) return 0;
+    auto plain = [](const Node& n) {
+        return n.kind == Node::Block && n.w >= 0 && n.KH == 3 && n.KW == 3 && n.sh == 1 && n.sw == 1 && n.padding == Padding::Same && n.ept < 0 && n.epl < 0 &&
+               n.in.size() == 1 && !n.res_after && n.act != ACT_PRELU;
+    };
+    // (a contract stage may be pointwise only: the last block of full_range's 6x6 run)
+    auto pointwise = [](const Node& n) { return n.kind == Node::Block && n.w < 0 && n.sh == 1 && n.sw == 1 && n.in.size() == 1 && !n.res_after && n.act != ACT_PRELU; };
+    if (!plain(ns[i])) return 0;
+    const auto& s0 = g.tensors[ns[i].in[0]].shape;
+    if (s0.size() != 4 || s0[1] * s0[2] > 64) return 0;
+    // skip of an expand stage: 0 none, 1 its own input, 2 the max-pooled previous resolution, 3 the wide tensor of the pair before (full_range's
+    // double block: wide -> narrow -> wide with the skip around both), -1 something else
+    auto skip_of = [&](size_t n) {
+        const Node& m = ns[i + n];
+        if (m.res < 0) return 0;
+        const auto &sr = g.tensors[m.res].shape, &so = g.tensors[m.out].shape;
+        if (sr.size() != 4 || sr[3] % 4 || sr[3] > so[3]) return -1;
+        if (m.res == m.in[0]) return m.res_mode == RES_DIRECT ? 1 : -1;
+        if (n >= 2 && m.res == ns[i + n - 2].out) return (m.res_mode == RES_DIRECT && sr == so) ? 3 : -1;
+        return (m.res_mode == RES_MAXPOOL && sr[1] == 2 * s0[1] && sr[2] == 2 * s0[2]) ? 2 : -1;
+    };
+    size_t n = 0;
+    while (n < static_cast<size_t>(kMaxXc) && i + n < ns.size()) {
+        const Node& m = ns[i + n];
+        if (!plain(m) && !((n & 1) && pointwise(m))) break;
+        if (n > 0 && m.in[0] != ns[i + n - 1].out) break;
+        const auto &si = g.tensors[m.in[0]].shape, &so = g.tensors[m.out].shape;
+        if (si.size() != 4 || so.size() != 4 || so[1] != s0[1] || so[2] != s0[2] || si[1] != s0[1] || si[2] != s0[2]) break;
+        if (n & 1) {   // contract: back to the narrow width, no skip
+            if (m.res >= 0 || so[3] != s0[3]) break;
+        } else {       // expand: from the narrow width
+            if (si[3] != s0[3] || so[3] <= si[3]) break;
+            if (n >= 2 && so[3] != g.tensors[ns[i].out].shape[3]) break;
+            if (skip_of(n) < 0) break;
+        }
+        n++;
+    }
+    // whole pairs whose intermediate tensors nobody outside the run reads (and that are no graph outputs)
+    auto internal_ok = [&](size_t len) {
+        for (size_t k = 0; k + 1 < len; k++) {
+            const int t = ns[i + k].out;
+            if (std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end()) return false;
+            for (size_t q = 0; q < ns.size(); q++) {
+                if (q >= i && q < i + len) continue;
+                if (std::find(ns[q].in.begin(), ns[q].in.end(), t) != ns[q].in.end() || ns[q].res == t) return false;
+            }
+        }
+        return true;
+    };
+    n &= ~static_cast<size_t>(1);
+    while (n >= 2 && !internal_ok(n)) n -= 2;
+    if (n < 2) return 0;
+    XcArgs xa;
+    xa.in = reinterpret_cast<const float*>(0x1000); xa.out = reinterpret_cast<float*>(0x2000);
+    xa.in_fs = xa.out_fs = static_cast<long>(g.tensors[ns[i].in[0]].elems());
+    xa.B = 1; xa.H = s0[1]; xa.W = s0[2]; xa.nstages = static_cast<int>(n);
+    std::vector<int> extra_in;
+    for (size_t k = 0; k < n; k++) {
+        const Node& m = ns[i + k];
+        XcStage& st = xa.st[k];
+        st.w_dw = st.w_pw = st.b_dw = st.bias = reinterpret_cast<const float*>(0x3000);
+        if (m.w < 0) st.w_dw = st.b_dw = nullptr;
+        st.C = g.tensors[m.in[0]].shape[3]; st.Co = g.tensors[m.out].shape[3]; st.act = m.act;
+        st.skip = (k & 1) ? 0 : skip_of(k);
+        if (st.skip == 2) {
+            st.res = reinterpret_cast<const float*>(0x4000); st.res_fs = static_cast<long>(g.tensors[m.res].elems());
+            st.res_C = g.tensors[m.res].shape[3]; st.res_W = g.tensors[m.res].shape[2];
+            if (std::find(extra_in.begin(), extra_in.end(), m.res) == extra_in.end()) extra_in.push_back(m.res);
+        }
+    }
+    if (!xc_kernel_supports(xa)) return 0;
+    Node r;
+    r.kind = Node::Resident;
+    r.xc = true;
+    r.in = {ns[i].in[0]};
+    for (int t : extra_in) r.in.push_back(t);
+    r.out = ns[i + n - 1].out;
+    for (size_t k = i; k < i + n; k++) {
+        r.members.push_back(ns[k]);
+        r.src_ops.insert(r.src_ops.end(), ns[k].src_ops.begin(), ns[k].src_ops.end());
+    }
+    *out = std::move(r);
+    return n;
+}
+
 // Which nodes read tensor t (as input or skip).
 std::vector<int> readers_of(const std::vector<Node>& ns, int t) {
     std::vector<int> r;
@@ -764,6 +853,15 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
     static const bool no_fork_split = getenv("MI_NO_FORK_SPLIT") != nullptr;  // development aid
     const std::vector<std::vector<char>> dep = dependence(ns);
     for (size_t i = 0; i < ns.size();) {
+        {
+            Node xn;
+            const size_t used = build_xc(g, ns, i, &xn);
+            if (used) {
+                outv.push_back(std::move(xn));
+                i += used;
+                continue;
+            }
+        }
         {
             Node db;
             const size_t used = no_dblock ? 0 : build_dblock(g, ns, i, &db);
@@ -1574,6 +1672,9 @@ std::string Plan::describe() const {
         if (n.kind == Node::Resident && n.dblock) {
             os << (n.members[0].res >= 0 ? " two BlazeBlocks (" : " double block (") << graph.tensors[n.members[0].in[0]].shape[3] << " -> " << graph.tensors[n.members[0].out].shape[3] << " -> " << graph.tensors[n.members[1].out].shape[3]
                << " channels), walking row bands, narrow tensor in LDS";
+        } else if (n.kind == Node::Resident && n.xc) {
+            os << " x" << n.members.size() / 2 << " expand / contract pairs (" << graph.tensors[n.members[0].in[0]].shape[3] << " <-> " << graph.tensors[n.members[0].out].shape[3]
+               << " channels), frame resident, depthwise stages on the fly";
         } else if (n.kind == Node::Resident && n.bneck) {
             os << " x" << n.members.size() / 2 << " bottleneck blocks, wide tensor in registers, " << (n.res_bands > 1 ? std::to_string(n.res_bands) + " row bands" : std::string("frame resident"));
         } else if (n.kind == Node::Resident) {

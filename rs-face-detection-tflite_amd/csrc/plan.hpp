@@ -36,6 +36,7 @@ struct Node {
     int res_const_off = 0, res_const_floats = 0, res_lds_bytes = 0;
     int res_bands = 1;           // Resident: workgroups per frame (row bands; 1 = the whole frame is resident)
     bool dblock = false;         // Resident without stages: members are the two blocks of a full_range double block (dblock_kernels.hip)
+    bool xc = false;             // Resident without stages: members alternate expand / contract blocks on a tiny frame (xc_kernels.hip)
     bool bneck = false;          // Resident without stages: members are (pointwise C -> Cm, depthwise block Cm -> C + skip) pairs run by
                                  // bneck_kernels.hip with the C-channel tensor in registers
     // frame-resident Chain: output heads run by its launch.  head_nodes = the absorbed 1x1 convolutions; a pair = up to two of them
