@@ -885,6 +885,10 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
         bool have = false;
         for (size_t j = i; j < ns.size(); j++) {
             Node cand;
+            {   // a stage program does not run on into an expand / contract run: that one has its own launch (xc_kernels.hip)
+                Node xn;
+                if (j > i && build_xc(g, ns, j, &xn)) break;
+            }
             if (!build_resident(g, ns, i, j, budget, &cand)) break;  // a longer run only needs more
             best = std::move(cand);
             best_j = j;

@@ -333,6 +333,22 @@ def full_like(seed, size, c=32, cm=12):
     return g.finish()
 
 
+def full_tail(seed, h, w, cn=32, cw=128, cp=64, pairs=2, pointwise_last=True):
+    """full_range's coarsest resolution: a narrow tensor from a stride-2 block, an expand block whose skip is the max-pooled, channel-padded
+    previous resolution, `pairs` double blocks (wide -> narrow -> wide, skip around both), a contract block (pointwise only, as in the
+    reference graph, or with its depthwise stage) — the run xc_kernels.hip takes as one launch when the frame has <= 64 pixels."""
+    g = GraphBuilder(seed, [1, h, w, 3])
+    p = g.relu(g.conv(g.input, cp, 3, 2))                      # previous resolution: (h/2) x (w/2) x cp
+    x = g.relu(g.conv(g.dw(p, 3, 2), cn))                      # narrow, (h/4) x (w/4) x cn
+    y = g.conv(g.dw(x), cw)
+    x = g.relu(g.add(y, g.pad_channels(g.maxpool(p), cw - cp)))
+    for _ in range(pairs):
+        x = g.double_block(x, cn)
+    x = g.relu(g.conv(x if pointwise_last else g.dw(x), cn))
+    g.outputs = [g.conv(x, 7)]
+    return g.finish()
+
+
 def mesh_like(seed, size, c0=16):
     """face-mesh style: stem 3x3 s2 + PReLU -> 2 blocks(c0) -> s2 to 2c0 -> 2 blocks -> s2 to 4c0 -> 2 blocks -> s2 to 8c0 -> 3 blocks -> s2 -> 2 blocks;
     two branches of small-spatial work ending in whole-frame convolutions (the GEMM heads)."""
@@ -372,6 +388,10 @@ CASES = {
     "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
     "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames
     "full_widen_70x44": (lambda: full_widen(33, 70, 44), 70, 44),                           # 35 x 22 frames: ragged bands, widening double block
+    # (wide tensors too large for the stage programs' depthwise scratch: these runs go to xc_kernel)
+    "full_tail_6x6": (lambda: full_tail(34, 24, 24, 96, 384, 256, 2), 24, 24),                  # 6 x 6: expand (max-pool skip) + 2 double blocks + pointwise contract, full_range's widths
+    "full_tail_8x8_dw_last": (lambda: full_tail(35, 32, 32, 64, 224, 40, 3, False), 32, 32),   # 8 x 8 = two full pixel groups, 64 <-> 224 channels (7 tiles), depthwise contract at the end
+    "full_tail_5x7": (lambda: full_tail(36, 20, 28, 48, 328, 24, 1), 20, 28),                  # 35 pixels (partial second group), 328 wide channels = 10.25 tiles, 6 k-chunks per stage-1 wave
     "full_64": (lambda: full_like(31, 64), 64, 64),                                        # double blocks, odd middle widths
     "full_80_c48": (lambda: full_like(32, 80, 48, 20), 80, 80),
 }
