@@ -157,33 +157,9 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     dwg_barrier();
     asm volatile("" ::: "memory");
     // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
-    float tap1[CK1][9], tap2[K::TAPL2 ? 1 : CK2][9];
-    {
-        const float4* tp = reinterpret_cast<const float4*>(wgc + K::OFF_T1) + kq * 3;
-#pragma unroll
-        for (int ks = 0; ks < CK1; ks++) {
-            const float4 t0 = tp[ks * 12], t1 = tp[ks * 12 + 1], t2 = tp[ks * 12 + 2];
-            tap1[ks][0] = t0.x; tap1[ks][1] = t0.y; tap1[ks][2] = t0.z; tap1[ks][3] = t0.w;
-            tap1[ks][4] = t1.x; tap1[ks][5] = t1.y; tap1[ks][6] = t1.z; tap1[ks][7] = t1.w;
-            tap1[ks][8] = t2.x;
-        }
-        const float4* tq = reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3;
-#pragma unroll
-        for (int ks = 0; ks < (K::TAPL2 ? 0 : CK2); ks++) {
-            const float4 t0 = tq[ks * 12], t1 = tq[ks * 12 + 1], t2 = tq[ks * 12 + 2];
-            tap2[ks][0] = t0.x; tap2[ks][1] = t0.y; tap2[ks][2] = t0.z; tap2[ks][3] = t0.w;
-            tap2[ks][4] = t1.x; tap2[ks][5] = t1.y; tap2[ks][6] = t1.z; tap2[ks][7] = t1.w;
-            tap2[ks][8] = t2.x;
-        }
-#pragma unroll
-        for (int ks = 0; ks < CK1; ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap1[ks][t]));
-#pragma unroll
-        for (int ks = 0; ks < (K::TAPL2 ? 0 : CK2); ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap2[ks][t]));
-    }
+    dv2f tap1[CK1][5], tap2[K::TAPL2 ? 1 : CK2][5];
+    dload_taps<CK1>(reinterpret_cast<const float4*>(wgc + K::OFF_T1) + kq * 3, tap1);
+    if constexpr (!K::TAPL2) dload_taps<CK2>(reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3, tap2);
     // ---- per-lane addresses
     typedef __attribute__((address_space(3))) float lfloat;
     const unsigned x_lds = (unsigned)(uintptr_t)(lfloat*)(ximg + (x0 + p) * PS + kq);      // B layout: left neighbour of pixel x0 + p, channel kq
@@ -194,15 +170,11 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     float* awr = aimg + (1 + x0 + p) * PSA + 4 * kq;
     const unsigned ooff = (unsigned)((x0 + p) * Co + 4 * kq) * 4u;   // bytes: + (16 nt * Co + 16 mt) * 4 for tile (mt, nt)
 
-    float p1A[CK1][WT], p1B[CK1][WT], p2A[CK2][WT], p2B[CK2][WT];   // partial depthwise rows: roles alternate from step to step
+    RowAcc<WT> p1A[CK1], p1B[CK1], p2A[CK2], p2B[CK2];   // partial depthwise rows: roles alternate from step to step
 #pragma unroll
-    for (int ks = 0; ks < CK1; ks++)
+    for (int ks = 0; ks < CK1; ks++) { p1A[ks].clear(); p1B[ks].clear(); }
 #pragma unroll
-        for (int nt = 0; nt < WT; nt++) p1A[ks][nt] = p1B[ks][nt] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < CK2; ks++)
-#pragma unroll
-        for (int nt = 0; nt < WT; nt++) p2A[ks][nt] = p2B[ks][nt] = 0.f;
+    for (int ks = 0; ks < CK2; ks++) { p2A[ks].clear(); p2B[ks].clear(); }
     df32x4 D1[MT1][WT], PA[MT2][WT], PB[MT2][WT];   // PA / PB: accumulators of the output rows of even / odd steps, waiting with bias + skip inside
     // D1 <- bias1 (+ with PAIR the first block's skip: the centre pixels of the x row in image `slot`, for the a row of the same index)
     auto init_D1 = [&](int slot) {
@@ -288,7 +260,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
         else dwait_vm<0>();
     };
     // e1 / e2: stage 1 / stage 2 finish a row in this step
-    auto step = [&](auto e1c, auto e2c, int t, float (&q1PN)[CK1][WT], float (&q1C)[CK1][WT], float (&q2PN)[CK2][WT], float (&q2C)[CK2][WT], df32x4 (&P)[MT2][WT]) {
+    auto step = [&](auto e1c, auto e2c, int t, RowAcc<WT> (&q1PN)[CK1], RowAcc<WT> (&q1C)[CK1], RowAcc<WT> (&q2PN)[CK2], RowAcc<WT> (&q2C)[CK2], df32x4 (&P)[MT2][WT]) {
         constexpr bool E1 = decltype(e1c)::value, E2 = decltype(e2c)::value;
         const int r = y0 - 2 + t, slot = t & 1;
         wait_row(t);
@@ -435,21 +407,8 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void mbneck_kernel(MdbArgs 
     dwait_vm<NLD>();
     dwg_barrier();
     asm volatile("" ::: "memory");
-    float tap2[CK2][9];
-    {
-        const float4* tq = reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3;
-#pragma unroll
-        for (int ks = 0; ks < CK2; ks++) {
-            const float4 t0 = tq[ks * 12], t1 = tq[ks * 12 + 1], t2 = tq[ks * 12 + 2];
-            tap2[ks][0] = t0.x; tap2[ks][1] = t0.y; tap2[ks][2] = t0.z; tap2[ks][3] = t0.w;
-            tap2[ks][4] = t1.x; tap2[ks][5] = t1.y; tap2[ks][6] = t1.z; tap2[ks][7] = t1.w;
-            tap2[ks][8] = t2.x;
-        }
-#pragma unroll
-        for (int ks = 0; ks < CK2; ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap2[ks][t]));
-    }
+    dv2f tap2[CK2][5];
+    dload_taps<CK2>(reinterpret_cast<const float4*>(wgc + K::OFF_T2) + kq * 3, tap2);
     typedef __attribute__((address_space(3))) float lfloat;
     const unsigned xc_lds = (unsigned)(uintptr_t)(lfloat*)(ximg + (1 + x0 + p) * PS + kq);   // B layout: pixel x0 + p itself, channel kq
     const unsigned a_lds = (unsigned)(uintptr_t)(lfloat*)(aimg + (x0 + p) * PSA + kq);         // ... its left neighbour in the a image
@@ -459,11 +418,9 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void mbneck_kernel(MdbArgs 
     float* awr = aimg + (1 + x0 + p) * PSA + 4 * kq;
     const unsigned ooff = (unsigned)((x0 + p) * Co + 4 * kq) * 4u;
 
-    float p2A[CK2][WT], p2B[CK2][WT];
+    RowAcc<WT> p2A[CK2], p2B[CK2];
 #pragma unroll
-    for (int ks = 0; ks < CK2; ks++)
-#pragma unroll
-        for (int nt = 0; nt < WT; nt++) p2A[ks][nt] = p2B[ks][nt] = 0.f;
+    for (int ks = 0; ks < CK2; ks++) { p2A[ks].clear(); p2B[ks].clear(); }
     df32x4 D1[MT1][WT], PA[MT2][WT], PB[MT2][WT];
     auto init_D1 = [&]() {
 #pragma unroll
@@ -534,7 +491,7 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void mbneck_kernel(MdbArgs 
         else if (st) dwait_vm<NST>();
         else dwait_vm<0>();
     };
-    auto step = [&](auto e2c, int t, float (&q2PN)[CK2][WT], float (&q2C)[CK2][WT], df32x4 (&Pc)[MT2][WT], df32x4 (&Pi)[MT2][WT]) {
+    auto step = [&](auto e2c, int t, RowAcc<WT> (&q2PN)[CK2], RowAcc<WT> (&q2C)[CK2], df32x4 (&Pc)[MT2][WT], df32x4 (&Pi)[MT2][WT]) {
         constexpr bool E2 = decltype(e2c)::value;
         const int r = y0 - 1 + t, slot = t & 1;
         wait_row(t);

@@ -127,21 +127,8 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
     dwg_barrier();   // the only workgroup-level synchronisation of the kernel
     asm volatile("" ::: "memory");
     // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
-    float tap[CK][9];
-    {
-        const float4* tp = reinterpret_cast<const float4*>(wgc + K::OFF_TAP) + kq * 3;
-#pragma unroll
-        for (int ks = 0; ks < CK; ks++) {
-            const float4 t0 = tp[ks * 12], t1 = tp[ks * 12 + 1], t2 = tp[ks * 12 + 2];
-            tap[ks][0] = t0.x; tap[ks][1] = t0.y; tap[ks][2] = t0.z; tap[ks][3] = t0.w;
-            tap[ks][4] = t1.x; tap[ks][5] = t1.y; tap[ks][6] = t1.z; tap[ks][7] = t1.w;
-            tap[ks][8] = t2.x;
-        }
-#pragma unroll
-        for (int ks = 0; ks < CK; ks++)
-#pragma unroll
-            for (int t = 0; t < 9; t++) asm volatile("" : "+v"(tap[ks][t]));
-    }
+    dv2f tap[CK][5];
+    dload_taps<CK>(reinterpret_cast<const float4*>(wgc + K::OFF_TAP) + kq * 3, tap);
     if (!active) return;
     // ---- per-lane addresses
     typedef __attribute__((address_space(3))) float lfloat;
@@ -150,11 +137,9 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
     const float* sme = img + (1 + p) * PS + 4 * kq;                                    // D layout: centre pixel p, channels 4 kq .. of a 16-channel tile
     const unsigned ooff = (unsigned)(p * Co + 4 * kq) * 4u;                             // bytes: + (16 nt * Co + 16 mt) * 4 for tile (mt, nt)
 
-    float accA[CK][WT], accB[CK][WT];   // partial depthwise rows: roles alternate from row to row
+    RowAcc<WT> accA[CK], accB[CK];   // partial depthwise rows: roles alternate from row to row
 #pragma unroll
-    for (int ks = 0; ks < CK; ks++)
-#pragma unroll
-        for (int nt = 0; nt < WT; nt++) accA[ks][nt] = accB[ks][nt] = 0.f;
+    for (int ks = 0; ks < CK; ks++) { accA[ks].clear(); accB[ks].clear(); }
     df32x4 D[MT][WT];
     // D <- bias + skip for the output row whose centre input row sits in image bi
     auto init_D = [&](int bi) {
@@ -214,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
         else if (st) dwait_vm<NST>();
         else dwait_vm<0>();
     };
-    auto step = [&](auto emit, int r, float (&aPN)[CK][WT], float (&aC)[CK][WT]) {
+    auto step = [&](auto emit, int r, RowAcc<WT> (&aPN)[CK], RowAcc<WT> (&aC)[CK]) {
         const int t = r - (y0 - 1), bi = t & 1;
         wait_row(t);
         fix_row(r, bi);
