@@ -100,6 +100,18 @@ __device__ __forceinline__ void mdb_row(const unsigned src, const unsigned aop, 
             for (int mt = 0; mt < MT; mt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(aw[mt]) : "v"(aa), "n"((ks * MT + mt) * 64 * 4));
         }
     };
+    // The loaded registers pass through an (empty) asm statement behind the wait: their consumers then depend on something that is ordered
+    // behind the s_waitcnt, whatever a later compiler would like to hoist (to the compiler the ds_read asm "returned" its value at once).
+    auto landed = [&](float (&x)[3][WT], float (&aw)[MT]) {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+            for (int nt = 0; nt < WT; nt++) asm volatile("" : "+v"(x[dx][nt]));
+        if constexpr (EMIT) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) asm volatile("" : "+v"(aw[mt]));
+        }
+    };
     auto kstep = [&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
         if constexpr (ks + 1 < CK) load_ks(std::integral_constant<int, ks + 1>{}, xs[(ks + 1) & 1], av[(ks + 1) & 1]);
@@ -155,10 +167,12 @@ __device__ __forceinline__ void mdb_row(const unsigned src, const unsigned aop, 
                 for (int nt = 0; nt < WT; nt++) D[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt], pch[nt], D[mt][nt], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next k-step's operands (a whole k-step of cover)
+        if constexpr (ks + 1 < CK) landed(xs[(ks + 1) & 1], av[(ks + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
     };
     load_ks(std::integral_constant<int, 0>{}, xs[0], av[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    landed(xs[0], av[0]);
     __builtin_amdgcn_sched_barrier(0);
     dfor_each(kstep, std::make_integer_sequence<int, CK>{});
 }
