@@ -266,6 +266,16 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
                 for (int mt = 0; mt < MT; mt++) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(aw[mt]) : "v"(aa), "n"((ks * MT + mt) * 64 * 4));
             }
         };
+        // the loaded registers pass through an (empty) asm statement behind the wait: their consumers then depend on something that is
+        // ordered behind the s_waitcnt (to the compiler the ds_read asm "returned" its value at once)
+        auto landed = [&](float (&x)[3][2], float (&aw)[MT]) {
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) asm volatile("" : "+v"(x[dx][0]), "+v"(x[dx][1]));
+            if constexpr (EMIT) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) asm volatile("" : "+v"(aw[mt]));
+            }
+        };
         auto kstep = [&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             if constexpr (ks + 1 < CK) load_ks(std::integral_constant<int, ks + 1>{}, xs[(ks + 1) & 1], av[(ks + 1) & 1]);
@@ -299,10 +309,12 @@ __global__ __launch_bounds__(256, 2) void mstrip_kernel(MstripArgs a) {
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the next k-step's operands (a whole k-step of cover)
+            if constexpr (ks + 1 < CK) landed(xs[(ks + 1) & 1], av[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
         };
         load_ks(std::integral_constant<int, 0>{}, xs[0], av[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        landed(xs[0], av[0]);
         __builtin_amdgcn_sched_barrier(0);
         mfor_each(kstep, std::make_integer_sequence<int, CK>{});
     };
