@@ -3,8 +3,9 @@
 //   out = act( PW1x1( DW3x3(in) + b_dw ) + b_pw + in )
 //
 // (DEPTHWISE_CONV_2D -> CONV_2D 1x1 -> ADD -> PRELU/RELU behind `interpreter.invoke()`, /root/reference/src/face_detection_lite/
-// face_landmark.rs:265; graph: SURVEY.md Appendix A.3, the face mesh's 48x48x32 blocks) with one WAVE walking down a band of rows of
-// one frame: W = 16 WT pixels = WT tiles of v_mfma_f32_16x16x4_f32, C = 4 CK channels in, 16 MT out.  Lane (kq = lane / 16,
+// face_landmark.rs:265; graph: SURVEY.md Appendix A.3, the face mesh's 48x48x32 and 24x24x64 blocks) with one WAVE walking down a band of
+// rows of one frame: W <= 16 WT pixels = WT tiles of v_mfma_f32_16x16x4_f32 (the last one may be partly outside the frame), C = 4 CK
+// channels in, 16 MT out.  Lane (kq = lane / 16,
 // p = lane % 16) owns channel 4 ks + kq of pixel p of every tile: the depthwise 3x3 runs in the MFMA B-operand layout with its taps
 // in registers (mrow.hpp), the pointwise weights are A operands read from LDS, the input rows arrive by LDS-DMA in wave-private
 // row images, bias + skip + activation on the result tiles, one 16-byte store per lane and tile.  No workgroup synchronisation
@@ -46,18 +47,24 @@ constexpr int mw_pick_dpx(int qp, int w) {  // pixels per LDS-DMA instruction: 8
     return 0;
 }
 
-template <int CK_, int MT_, int WT_>
+// W_: frame width (default 16 WT; less: the last tile is partly outside the frame — its lanes compute on whatever lies behind the row in
+// the image and store nothing).  TAPL_: the depthwise taps stay in LDS and are read per k-step (channel counts whose 10 x CK tap
+// registers do not fit beside the accumulators).
+template <int CK_, int MT_, int WT_, int W_ = 16 * WT_, bool TAPL_ = false>
 struct MW {
-    static constexpr int CK = CK_, MT = MT_, WT = WT_, C = 4 * CK, Co = 16 * MT, W = 16 * WT;
+    static constexpr int CK = CK_, MT = MT_, WT = WT_, C = 4 * CK, Co = 16 * MT, W = W_;
+    static constexpr bool TAPL = TAPL_;
+    static_assert(W <= 16 * WT && W > 16 * (WT - 1), "WT tiles cover the row");
     static constexpr int QP = CK + 1, PS = 4 * QP;      // float4 slots / floats per pixel of the row image (odd slot count: a tile's pixels on distinct banks)
     static_assert(QP % 2 == 1, "odd number of float4 slots per pixel");
     static constexpr int IMG_F = (W + 2) * PS;
+    static constexpr int SLACK_F = (16 * WT - W) * PS;  // the lanes of a partly used last tile read on behind the row: into the next image, or this slack behind the last one
     static constexpr int DPX = mw_pick_dpx(QP, W), NLD = 8, ACTIVE = DPX * QP;
     static_assert(DPX > 0 && ACTIVE > 32 && ACTIVE < 64, "DMA shape: eight instructions per row (two source bases, four immediate offsets each)");
     static_assert(3 * DPX * C * 4 < 4096, "immediate offsets of the DMA instructions");
     // constants blob (floats): A operands [CK][MT][64] | taps [CK][4][12] | bias [Co] | slopes [Co]
     static constexpr int OFF_A = 0, A_F = CK * MT * 64, OFF_TAP = A_F, TAP_F = CK * 48, OFF_BIAS = OFF_TAP + TAP_F, OFF_SLOPE = OFF_BIAS + Co, TOTAL = OFF_SLOPE + Co;
-    static constexpr int NBUF = 2, LDS_F = TOTAL + 4 * NBUF * IMG_F;
+    static constexpr int NBUF = 2, LDS_F = TOTAL + 4 * NBUF * IMG_F + SLACK_F;
 };
 
 template <class K, bool RELU>
@@ -127,8 +134,8 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
     dwg_barrier();   // the only workgroup-level synchronisation of the kernel
     asm volatile("" ::: "memory");
     // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
-    dv2f tap[CK][5];
-    dload_taps<CK>(reinterpret_cast<const float4*>(wgc + K::OFF_TAP) + kq * 3, tap);
+    dv2f tap[K::TAPL ? 1 : CK][5];
+    if constexpr (!K::TAPL) dload_taps<CK>(reinterpret_cast<const float4*>(wgc + K::OFF_TAP) + kq * 3, tap);
     if (!active) return;
     // ---- per-lane addresses
     typedef __attribute__((address_space(3))) float lfloat;
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
                     v = df32x4{fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi), fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi),
                                fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi), fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi)};
                 }
-                *(gf32x4*)(dst + ooff + (unsigned)((16 * nt * Co + 16 * mt) * 4)) = v;
+                if (16 * (nt + 1) <= W || 16 * nt + p < W) *(gf32x4*)(dst + ooff + (unsigned)((16 * nt * Co + 16 * mt) * 4)) = v;   // (a partly used last tile)
             }
         }
     };
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
         wait_row(t);
         fix_row(r, bi);
         dwave_sync();
-        mdb_row<CK, MT, WT, PS, decltype(emit)::value>(x_lds + (unsigned)(bi * IMG_F * 4), a_lds, tap, aPN, aC, D);
+        mdb_row<CK, MT, WT, PS, decltype(emit)::value, K::TAPL>(x_lds + (unsigned)(bi * IMG_F * 4), a_lds, tap, aPN, aC, D, reinterpret_cast<const float4*>(wgc + K::OFF_TAP) + kq * 3);
         __builtin_amdgcn_sched_barrier(0);  // (fences: the old and the new accumulator tiles are never live together)
         if constexpr (decltype(emit)::value) epilogue(r - 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
 }
 
 using MW48 = MW<8, 2, 3>;   // 48 pixels wide, 32 -> 32 channels (face mesh)
+using MW24 = MW<16, 4, 2, 24, true>;   // 24 pixels wide (1.5 tiles), 64 -> 64 channels (face mesh), taps in LDS
 
 template <class K>
 void mw_pack(const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
@@ -278,16 +286,21 @@ int mw_launch(const BlockArgs& a, hipStream_t s) {
 }  // namespace
 
 // Shapes the kernel takes: stride-1 depthwise 3x3 (SAME) + pointwise, skip = the block's own input (or none)
-bool mwalk_shape_ok(int W, int C, int Co) {
+static int mw_shape(int W, int C, int Co) {
     static const bool off = getenv("MI_NO_MWALK") != nullptr;  // tuning aid: the strip / block kernels instead
-    return !off && W == 48 && C == 32 && Co == 32;
+    if (off) return 0;
+    if (W == 48 && C == 32 && Co == 32) return 1;
+    if (W == 24 && C == 64 && Co == 64) return 2;
+    return 0;
 }
+bool mwalk_shape_ok(int W, int C, int Co) { return mw_shape(W, C, Co) != 0; }
 
-int mwalk_consts_floats(int W, int C, int Co) { return mwalk_shape_ok(W, C, Co) ? MW48::TOTAL : 0; }
+int mwalk_consts_floats(int W, int C, int Co) { return mw_shape(W, C, Co) == 1 ? MW48::TOTAL : (mw_shape(W, C, Co) == 2 ? MW24::TOTAL : 0); }
 
 // w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C] (TFLite OHWI with H = W = 1), bias [Co] or null, alpha [Co] or null.
 void mwalk_pack_consts(int W, int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
-    if (mwalk_shape_ok(W, C, Co)) mw_pack<MW48>(w_dw, b_dw, w_pw, bias, alpha, act, dst);
+    if (mw_shape(W, C, Co) == 1) mw_pack<MW48>(w_dw, b_dw, w_pw, bias, alpha, act, dst);
+    if (mw_shape(W, C, Co) == 2) mw_pack<MW24>(w_dw, b_dw, w_pw, bias, alpha, act, dst);
 }
 
 bool mwalk_kernel_supports(const BlockArgs& a) {
@@ -298,20 +311,21 @@ bool mwalk_kernel_supports(const BlockArgs& a) {
         if (a.ep.res_mode != RES_DIRECT || a.ep.res != a.in || a.ep.res_fs != a.in_fs || a.ep.res_C != a.C) return false;
     }
     // a wave walks its band row by row: below about one wave per SIMD over the chip the launch is latency-bound
-    static const int min_b = getenv("MI_MWALK_MIN_B") ? atoi(getenv("MI_MWALK_MIN_B")) : 32;
-    if (a.B < min_b) return false;
+    // (the 24-pixel rows fill 1.5 of their 2 tiles: 0.0211 against the block kernel's 0.0201 ms at 64 frames, 0.0233 / 0.0322 at 128)
+    static const int min_b = getenv("MI_MWALK_MIN_B") ? atoi(getenv("MI_MWALK_MIN_B")) : 0;
+    if (a.B < (min_b > 0 ? min_b : (mw_shape(a.W, a.C, a.Co) == 2 ? 96 : 32))) return false;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     return aligned16(a.in) && aligned16(a.out) && aligned16(a.w_mwalk) && !(a.in_fs & 3) && !(a.out_fs & 3);
 }
 
 const char* mwalk_kernel_label(const BlockArgs& a, char* buf, size_t cap) {
-    snprintf(buf, cap, "mwalk_kernel<%d,%d,%d>", a.C / 4, a.Co / 16, a.W / 16);
+    snprintf(buf, cap, "mwalk_kernel<%d,%d,%d>", a.C / 4, a.Co / 16, (a.W + 15) / 16);
     return buf;
 }
 
 int launch_mwalk(const BlockArgs& a, void* stream) {
     if (!mwalk_kernel_supports(a)) return (int)hipErrorInvalidValue;
-    return mw_launch<MW48>(a, (hipStream_t)stream);
+    return mw_shape(a.W, a.C, a.Co) == 2 ? mw_launch<MW24>(a, (hipStream_t)stream) : mw_launch<MW48>(a, (hipStream_t)stream);
 }
 
 }  // namespace mi

@@ -198,16 +198,17 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel"]), ("landmark", ["mwalk_kernel", "mdblock_kernel<pair>"]), ("iris", ["mbneck_kernel"])])
+@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<pair>"]), ("iris", ["mbneck_kernel"])])
 def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, kernels):
     """The row-walking MFMA kernels of round 3 (mdblock / mwalk / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand layout)
     take the wide double blocks of full_range, the 48x48x32 blocks and the 96x96x16 block pair of the face mesh and the 32x32 bottleneck
-    pairs of the iris network from 32 frames per launch on.  An odd batch of 33 frames (mbneck: the last workgroup repeats the last frame)
+    pairs of the iris network from 32 frames per launch on.  An odd batch of 33 frames (97 for the mesh; mbneck: the last workgroup repeats the last frame)
     against the oracle frame by frame, against the LDS-tensor kernels ("strip" = 0), and frame 7 alone (batch 1: the older kernels)
     against frame 7 inside the batch."""
     torch = pytest.importorskip("torch")
     m = gpu.Model(model_path(name))
-    x = seeded_input(name, 33, 4242, m.input_dims[1:3])
+    nb = 97 if name == "landmark" else 33   # (the 24-pixel-wide mwalk form starts at 96 ROIs)
+    x = seeded_input(name, nb, 4242, m.input_dims[1:3])
     x[5] = 0.0                                   # an all-zero frame: biases only
     x[9, :, : x.shape[2] // 2] = x.min()         # half-saturated frame
     outs = [o.copy() for o in m.run(x)]

@@ -17,7 +17,7 @@ static float rnd(unsigned& s) { s = s * 1664525u + 1013904223u; return (float)(s
 int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 256, H = argc > 2 ? atoi(argv[2]) : 48;
     int act = argc > 3 ? atoi(argv[3]) : ACT_RELU, has_res = argc > 4 ? atoi(argv[4]) : 1, nb = argc > 5 ? atoi(argv[5]) : 7;
-    const int C = 32, Co = 32, W = 48;
+    const int W = argc > 6 ? atoi(argv[6]) : 48, C = argc > 7 ? atoi(argv[7]) : 32, Co = C;
     const bool ms = true;
     auto supports = [&](const BlockArgs& x) { return mwalk_kernel_supports(x); };
     auto launch = [&](const BlockArgs& x, hipStream_t st) { return launch_mwalk(x, st); };
