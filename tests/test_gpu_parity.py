@@ -229,6 +229,25 @@ def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, ker
     m.close()
 
 
+@pytest.mark.parametrize("name", ["back", "front", "full", "landmark", "iris"])
+def test_batch_size_sweep_across_kernel_thresholds(gpu, oracle, name):
+    """Which kernel runs a layer depends on the batch (the row-walking kernels start at 32 or 96 frames per launch, small grids spread
+    their tiles, two-frame workgroups repeat the last frame of an odd batch): batches just below, at and above every threshold — and odd
+    ones — must agree with the LDS-tensor kernels ("strip" = 0) on the same frames, which in turn agree with the oracle on a sample."""
+    m = gpu.Model(model_path(name))
+    x = seeded_input(name, 130, 777, m.input_dims[1:3])
+    m.set_option("strip", 0)
+    ref = [o.copy() for o in m.run(x)]
+    om = oracle.Model(model_path(name))
+    for o, r in zip(ref, om.run(x[[0, 31, 64, 129]], nthreads=4)):
+        _raw_close(o[[0, 31, 64, 129]], r)
+    m.set_option("strip", 1)
+    for nb in (1, 2, 5, 31, 32, 33, 63, 95, 96, 97, 128, 129, 130):
+        for o, r in zip(m.run(x[:nb]), ref):
+            _raw_close(o, r[:nb])
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))
