@@ -379,6 +379,16 @@ void Model::rebuild() {
                                   n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
                 node_mwalk_[i] = put(sc);
             }
+            // stride-2 blocks with an operand-layout form (ms2_kernels.hip; the same slot: a node is one or the other)
+            const auto& sin = g.tensors[n.in[0]].shape;
+            const bool pool_skip = n.res >= 0 && n.res == n.in[0] && n.res_mode == RES_MAXPOOL && !n.res_after;
+            if (n.w >= 0 && n.sh == 2 && n.sw == 2 && n.padding == Padding::Same && n.ept < 0 && sin.size() == 4 && (n.res < 0 || pool_skip) &&
+                ms2_shape_ok(sin[2], ws[3], ws[0], pool_skip)) {
+                std::vector<float> sc(static_cast<size_t>(ms2_consts_floats(sin[2], ws[3], ws[0], pool_skip)));
+                ms2_pack_consts(sin[2], ws[3], ws[0], pool_skip, g.tensors[n.w].f32.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, g.tensors[n.w2].f32.data(),
+                                n.b2 >= 0 ? g.tensors[n.b2].f32.data() : nullptr, n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
+                node_mwalk_[i] = put(sc);
+            }
         }
     }
     host.resize(host.size() + 4096, 0.f);  // slack: the stage programs' A-fragment prefetch walks up to 8 KiB past a tile's last chunk
@@ -967,6 +977,11 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.ep = ep;
                 a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
                 a.w_mwalk = node_mwalk_[i] >= 0 ? d_weights_ + node_mwalk_[i] : nullptr;
+                if (strip_ && ms2_kernel_supports(a)) {
+                    if (labels) { char buf[96]; labels->back() = ms2_kernel_label(a, buf, sizeof buf); }
+                    rc = launch_ms2(a, s);
+                    break;
+                }
                 if (strip_ && mwalk_kernel_supports(a)) {
                     if (labels) { char buf[96]; labels->back() = mwalk_kernel_label(a, buf, sizeof buf); }
                     rc = launch_mwalk(a, s);

@@ -261,6 +261,13 @@ bool mwalk_shape_ok(int W, int C, int Co);
 int mwalk_consts_floats(int W, int C, int Co);
 void mwalk_pack_consts(int W, int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
 const char* mwalk_kernel_label(const BlockArgs& a, char* buf, size_t cap);
+// ms2_kernels.hip: stride-2 blocks in the same scheme (two input rows per step, max-pool skip from the row images); constants in BlockArgs::w_mwalk
+int launch_ms2(const BlockArgs& a, void* stream);
+bool ms2_kernel_supports(const BlockArgs& a);
+bool ms2_shape_ok(int W, int C, int Co, bool skip);   // W: input width
+int ms2_consts_floats(int W, int C, int Co, bool skip);
+void ms2_pack_consts(int W, int C, int Co, bool skip, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
+const char* ms2_kernel_label(const BlockArgs& a, char* buf, size_t cap);
 int launch_mstrip(const BlockArgs& a, void* stream);
 bool mstrip_kernel_supports(const BlockArgs& a);
 bool mstrip_shape_ok(int C, int Co);

@@ -198,11 +198,11 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<pair>"]), ("iris", ["mbneck_kernel"])])
+@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<pair>", "ms2_kernel<8,4,2>"]), ("iris", ["mbneck_kernel"])])
 def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, kernels):
-    """The row-walking MFMA kernels of round 3 (mdblock / mwalk / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand layout)
-    take the wide double blocks of full_range, the 48x48x32 blocks and the 96x96x16 block pair of the face mesh and the 32x32 bottleneck
-    pairs of the iris network from 32 frames per launch on.  An odd batch of 33 frames (97 for the mesh; mbneck: the last workgroup repeats the last frame)
+    """The row-walking MFMA kernels of round 3 (mdblock / mwalk / ms2 / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand
+    layout) take the wide double blocks and stride-2 blocks of full_range, the 48x48x32 / 24x24x64 blocks, the 96x96x16 block pair and the
+    48 -> 24 stride-2 block of the face mesh and the 32x32 bottleneck pairs of the iris network from 32 (96) frames per launch on.  An odd batch of 33 frames (97 for the mesh; mbneck: the last workgroup repeats the last frame)
     against the oracle frame by frame, against the LDS-tensor kernels ("strip" = 0), and frame 7 alone (batch 1: the older kernels)
     against frame 7 inside the batch."""
     torch = pytest.importorskip("torch")
@@ -223,7 +223,7 @@ def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, ker
         _raw_close(o[0], r[7])
     m.set_option("strip", 0)
     labels0 = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
-    assert not any(l.startswith(("mdblock", "mwalk", "mbneck")) for l in labels0), labels0
+    assert not any(l.startswith(("mdblock", "mwalk", "mbneck", "ms2")) for l in labels0), labels0
     for o, r in zip(m.run(x), outs):
         _raw_close(o, r)
     m.close()

@@ -24,6 +24,10 @@ def label(name):
     # rocprofv3 symbol -> the label mi_model_profile / bench.py use: template arguments as integers, SLOW / CPT dropped for block kernels
     name = name.replace("(anonymous namespace)::", "")
     # the operand-layout kernels carry a geometry struct as template argument: mdblock_kernel<mi::MD<8, 2, 2, 2, 3, false, 4, 1, false, false>, true>
+    m1 = re.search(r"ms2_kernel<(?:mi::)?MS2<([^>]*)>", name)
+    if m1:   # MS2<CK, MT, CO, NWV, WO, ...> -> the engine's label <C / 4, output tiles, pixel tiles>
+        a = [x.strip() for x in m1.group(1).split(",")]
+        return "ms2_kernel<%s,%s,%s>" % (a[0], a[1], a[3])
     m0 = re.search(r"(mdblock_kernel|mbneck_kernel|mwalk_kernel)<(?:mi::)?M[DW]<([^>]*)>", name)
     if m0:
         a = [x.strip() for x in m0.group(2).split(",")]
@@ -49,7 +53,7 @@ def label(name):
 
 
 WORKLOADS = {1: "short128_b256", 2: "back256_b256", 3: "landmark192_b512", 5: "pipeline192_b128"}
-WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel")
+WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel", "ms2_kernel", "xc_kernel")
 
 # ---- kernel stats per config
 for c in WORKLOADS:
