@@ -812,6 +812,7 @@ std::vector<int> readers_of(const std::vector<Node>& ns, int t) {
 // dep[b][a]: node b needs node a's result, directly or through other nodes (plan order = a topological order)
 std::vector<std::vector<char>> dependence(const std::vector<Node>& ns) {
     const size_t N = ns.size();
+    if (N > 2048) return {};   // (an N x N table: graphs of that size — none of the reference's has 200 operators — do without the fork analysis)
     std::map<int, int> producer;
     for (size_t i = 0; i < N; i++) {
         producer[ns[i].out] = static_cast<int>(i);
@@ -836,6 +837,7 @@ std::vector<std::vector<char>> dependence(const std::vector<Node>& ns) {
 // the iris / face mesh networks).  A stage program that ran on past the fork would chain one branch behind the common part and leave
 // the other waiting for the whole launch; ending the launch at the fork lets the engine run the branches side by side.
 bool is_fork(const std::vector<Node>& ns, const std::vector<std::vector<char>>& dep, size_t j) {
+    if (dep.size() != ns.size()) return false;
     std::vector<int> rd = readers_of(ns, ns[j].out);
     for (int t : ns[j].extra_out)   // a launch with several outputs: their readers part just the same
         for (int k : readers_of(ns, t))
@@ -1498,6 +1500,7 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
         const std::vector<std::vector<char>> dep = dependence(plan.nodes);
         auto is_view = [](const Node& n) { return n.kind == Node::Reshape || n.kind == Node::Concat; };
         int fork_at = -1;
+        if (dep.size() == plan.nodes.size())
         for (size_t j = 0; j < plan.nodes.size(); j++)
             if (!is_view(plan.nodes[j]) && is_fork(plan.nodes, dep, j)) fork_at = static_cast<int>(j);
         if (fork_at >= 0) {
