@@ -130,9 +130,19 @@ if rows:
 # ---- bench lines, per-launch event lists, secondary configs
 for c in WORKLOADS:
     p = os.path.join(base, "bench_c%d.json" % c)
+    dst = os.path.join(out, "bench_%s_config%d_n1.json" % (tag, c))
     if os.path.exists(p) and open(p).read().strip():
-        with open(os.path.join(out, "bench_%s_config%d_n1.json" % (tag, c)), "w") as fh:
-            fh.write(open(p).read().strip().splitlines()[-1] + "\n")
+        line = open(p).read().strip().splitlines()[-1]
+        # the collection's own bench line ran BEFORE this summary existed (traffic null): it does not replace a committed line that carries
+        # traffic (bench.py run again behind the summary: profiles/bench_<tag>_config<c>_n1.json is refreshed by hand from that run)
+        keep = False
+        try:
+            keep = os.path.exists(dst) and json.loads(open(dst).read().strip().splitlines()[-1])["roofline"].get("traffic") and not json.loads(line)["roofline"].get("traffic")
+        except Exception:
+            keep = False
+        if not keep:
+            with open(dst, "w") as fh:
+                fh.write(line + "\n")
 for fpath in glob.glob(os.path.join(base, "launches_*.txt")):
     shutil.copy(fpath, os.path.join(out, "%s_%s" % (tag, os.path.basename(fpath))))
 if os.path.exists(os.path.join(base, "configs.log")):
