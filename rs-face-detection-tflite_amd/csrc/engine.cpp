@@ -203,10 +203,18 @@ void Model::rebuild() {
             // expand / contract runs (xc_kernels.hip): per member the depthwise taps and biases as stored, the pointwise matrix in the block kernel's packing
             for (const Node& m : n.members) {
                 MemberOff mo;
-                if (m.w >= 0) mo.w = put(g.tensors[m.w].f32);
-                if (m.b >= 0) mo.b = put(g.tensors[m.b].f32);
                 mo.w2 = pack_pw(m.w2);
-                if (m.b2 >= 0) mo.b2 = put(g.tensors[m.b2].f32);
+                // the stage's small constants as the kernel copies them to LDS: taps [9][Cp], depthwise bias [Cp], pointwise bias [Cop]
+                const int C = g.tensors[m.in[0]].shape[3], Co = g.tensors[m.out].shape[3], Cp = (C + 7) & ~7;
+                std::vector<float> cb(static_cast<size_t>(xc_const_floats(C, Co)), 0.f);
+                if (m.w >= 0)
+                    for (int t = 0; t < 9; t++)
+                        for (int c = 0; c < C; c++) cb[static_cast<size_t>(t) * Cp + c] = g.tensors[m.w].f32[static_cast<size_t>(t) * C + c];
+                if (m.b >= 0)
+                    for (int c = 0; c < C; c++) cb[static_cast<size_t>(9) * Cp + c] = g.tensors[m.b].f32[static_cast<size_t>(c)];
+                if (m.b2 >= 0)
+                    for (int c = 0; c < Co; c++) cb[static_cast<size_t>(10) * Cp + c] = g.tensors[m.b2].f32[static_cast<size_t>(c)];
+                mo.strip = put(cb);
                 chain_off_[i].push_back(mo);
             }
             res_wblk_[i].clear();
@@ -781,10 +789,9 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         const Node& m = n.members[k];
                         const MemberOff& mo = chain_off_[i][k];
                         XcStage& st = a.st[k];
-                        st.w_dw = mo.w >= 0 ? d_weights_ + mo.w : nullptr;
-                        st.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
+                        st.cblob = d_weights_ + mo.strip;
+                        st.has_dw = m.w >= 0;
                         st.w_pw = d_weights_ + mo.w2;
-                        st.bias = mo.b2 >= 0 ? d_weights_ + mo.b2 : nullptr;
                         st.C = g.tensors[m.in[0]].shape[3]; st.Co = g.tensors[m.out].shape[3]; st.act = m.act;
                         st.skip = m.res < 0 ? 0 : (m.res == m.in[0] ? 1 : (k >= 2 && m.res == n.members[k - 2].out ? 3 : 2));
                         if (st.skip == 2) {

@@ -308,10 +308,10 @@ struct BneckArgs {
 // ---- runs of expand / contract BlazeBlocks on tiny frames as one frame-resident launch (xc_kernels.hip):
 //   even stages: wide = act(W . (DW3x3(narrow) + b_dw) + b + skip);  odd stages: narrow = act(W . (DW3x3(wide) + b_dw) + b)
 struct XcStage {
-    const float* w_dw = nullptr;    // [3][3][C]; null: the stage is pointwise only
-    const float* b_dw = nullptr;    // [C] or null
+    const float* cblob = nullptr;   // xc_const_floats(C, Co) floats, 16-byte aligned: depthwise taps [9][Cp] (zeros: none), depthwise bias [Cp], pointwise bias [Cop]
+                                    // (Cp = C rounded up to 8, Cop = Co rounded up to 32): copied to LDS as they are
+    int has_dw = 1;                 // 0: the stage is pointwise only
     const float* w_pw = nullptr;    // block kernel's A-fragment packing of W [Co][C]
-    const float* bias = nullptr;    // [Co] or null
     int C = 0, Co = 0;
     int act = ACT_RELU;             // ACT_NONE / ACT_RELU / ACT_RELU6
     int skip = 0;                   // 0: none; 1: the stage's own input (channels >= C: zero); 2: 2x2 max-pool of `res` ([2H][2W][res_C], channels >= res_C: zero);
@@ -329,6 +329,7 @@ struct XcArgs {
     XcStage st[kMaxXc];
 };
 bool xc_kernel_supports(const XcArgs& a);
+int xc_const_floats(int C, int Co);
 int launch_xc(const XcArgs& a, void* stream);
 // ---- full_range's double BlazeBlock as one launch (dblock_kernels.hip):
 //   a = act1(W1 . (DW3x3(x) + b_dw1) + b1) (C -> Cm);  y = act2(W2 . (DW3x3(a) + b_dw2) + b2 + pad(x)) (Cm -> Co >= C)

@@ -81,7 +81,6 @@ __device__ __forceinline__ void mwave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ v2f mpkfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 template <class F, int... KS>
 __device__ __forceinline__ void mfor_each(F&& f, std::integer_sequence<int, KS...>) { (f(std::integral_constant<int, KS>{}), ...); }

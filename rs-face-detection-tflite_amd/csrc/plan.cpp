@@ -776,8 +776,8 @@ size_t build_xc(const Graph& g, const std::vector<Node>& ns, size_t i, Node* out
     for (size_t k = 0; k < n; k++) {
         const Node& m = ns[i + k];
         XcStage& st = xa.st[k];
-        st.w_dw = st.w_pw = st.b_dw = st.bias = reinterpret_cast<const float*>(0x3000);
-        if (m.w < 0) st.w_dw = st.b_dw = nullptr;
+        st.w_pw = st.cblob = reinterpret_cast<const float*>(0x3000);
+        st.has_dw = m.w >= 0;
         st.C = g.tensors[m.in[0]].shape[3]; st.Co = g.tensors[m.out].shape[3]; st.act = m.act;
         st.skip = (k & 1) ? 0 : skip_of(k);
         if (st.skip == 2) {

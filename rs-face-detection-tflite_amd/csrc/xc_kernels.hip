@@ -91,7 +91,7 @@ __device__ __forceinline__ void xc_unit(const XcStage& st, const XcArgs& a, int 
     auto chunk = [&](int j, const float4 (&av)[MTG]) {
         const int c0 = 4 * j;
         float4 bf;
-        if (st.w_dw) {   // wave-uniform
+        if (st.has_dw) {   // wave-uniform
             bf = xld4(bdw + h * Ch + c0);
 #pragma unroll
             for (int ky = 0; ky < 3; ky++)
@@ -227,13 +227,11 @@ __global__ __launch_bounds__(512) void xc_kernel(XcArgs a, XcGeom g) {
         float* dst = expand ? wide : nar;
         const int PSs = expand ? g.PSn : g.PSw, PSd = expand ? g.PSw : g.PSn;
         const int Cp = (st.C + 7) & ~7, MT = (st.Co + 31) >> 5, Cop = MT * 32;
-        // ---- this stage's small constants: depthwise taps [9][Cp], depthwise bias [Cp], pointwise bias [Cop]
-        for (int i = tid; i < 9 * Cp && st.w_dw; i += 512) {
-            const int t = i / Cp, c = i - t * Cp;
-            cst[i] = c < st.C ? st.w_dw[t * st.C + c] : 0.f;
+        // ---- this stage's small constants (depthwise taps [9][Cp], depthwise bias [Cp], pointwise bias [Cop]: one packed blob, copied as it is)
+        {
+            const int n4 = (10 * Cp + Cop) >> 2;
+            for (int i = tid; i < n4; i += 512) reinterpret_cast<float4*>(cst)[i] = xld4(st.cblob + 4 * (long)i);
         }
-        for (int i = tid; i < Cp; i += 512) cst[9 * Cp + i] = (i < st.C && st.b_dw) ? st.b_dw[i] : 0.f;
-        for (int i = tid; i < Cop; i += 512) cst[10 * Cp + i] = (i < st.Co && st.bias) ? st.bias[i] : 0.f;
         XC_STAMP(2 + 4 * s)
         __syncthreads();
         XC_STAMP(3 + 4 * s)
@@ -289,7 +287,7 @@ bool make_xc_geom(const XcArgs& a, XcGeom* out) {
         side = st.C;
         cmax = std::max(cmax, 10 * ((st.C + 7) & ~7) + MT * 32);
         auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        if (!aligned16(st.w_pw) || (st.skip == 2 && (!aligned16(st.res) || (st.res_fs & 3)))) return false;
+        if (!aligned16(st.w_pw) || !st.cblob || !aligned16(st.cblob) || (st.skip == 2 && (!aligned16(st.res) || (st.res_fs & 3)))) return false;
     }
     if (a.st[a.nstages - 1].Co != Cn) return false;   // the run ends on the narrow side
     XcGeom g{};
@@ -309,6 +307,8 @@ bool make_xc_geom(const XcArgs& a, XcGeom* out) {
 }
 
 }  // namespace
+
+int xc_const_floats(int C, int Co) { return 10 * ((C + 7) & ~7) + (Co + 31) / 32 * 32; }
 
 bool xc_kernel_supports(const XcArgs& a) {
     XcGeom g;
