@@ -40,6 +40,7 @@ namespace {
 
 typedef float sf32x16 __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef float __attribute__((address_space(4))) cfloat;
 
@@ -66,7 +67,10 @@ struct SK {
     // constants blob (floats): per input-channel pair a stage record of ST_F floats = depthwise taps [9][2] at 0, pointwise
     // columns W[0..C)[2st] at 32 and W[0..C)[2st+1] at 32 + C; then the pointwise bias (+ W b_dw) and the negative slopes
     static constexpr int ST_F = 32 + 2 * C + (16 - (2 * C) % 16) % 16;
-    static constexpr int OFF_DW = 0, OFF_BIAS = K2 * ST_F, OFF_SLOPE = OFF_BIAS + 32, TOTAL = OFF_SLOPE + 32;
+    // ... then (strip_pipe2m_kernel) the pointwise filter as A operands of v_mfma_f32_4x4x1_16b_f32: NA registers of 64 lanes; the 4 x 1
+    // block (input channel k, output channels 4t .. 4t+3) is block n % 16 (lanes 4 (n % 16) + i) of register n / 16, n = k CQ + t
+    static constexpr int NA = (C * CQ + 15) / 16;
+    static constexpr int OFF_DW = 0, OFF_BIAS = K2 * ST_F, OFF_SLOPE = OFF_BIAS + 32, OFF_A = OFF_SLOPE + 32, TOTAL = OFF_A + 64 * NA;
 };
 
 __device__ __forceinline__ float4 sld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -336,6 +340,14 @@ __device__ __forceinline__ void strip_row2(const float* me0, const float* me1, c
     }
 }
 
+// max(x, 0) as ONE v_max_f32: fmaxf() first canonicalises an operand it cannot prove to be quiet (the accumulators pass through empty
+// asm statements), two instructions per value
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // activation of a finished output row (lane = pixel, channel quads)
 template <int CQ, bool RELU>
 __device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloat* slopes, float hi, float4 (&o)[CQ]) {
@@ -343,7 +355,7 @@ __device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloa
     for (int q = 0; q < CQ; q++) {
         o[q] = make_float4(oacc[2 * q].x, oacc[2 * q].y, oacc[2 * q + 1].x, oacc[2 * q + 1].y);
         if (RELU) {
-            o[q].x = fmaxf(o[q].x, 0.f); o[q].y = fmaxf(o[q].y, 0.f); o[q].z = fmaxf(o[q].z, 0.f); o[q].w = fmaxf(o[q].w, 0.f);
+            o[q].x = relu1(o[q].x); o[q].y = relu1(o[q].y); o[q].z = relu1(o[q].z); o[q].w = relu1(o[q].w);
         } else {
             // act(v) = min(max(v,0) + slope*min(v,0), hi): ReLU (slope 0), PReLU (alpha), none (1), ReLU6 (hi = 6)
             const cfloat* sq = slopes + 4 * q;
@@ -355,6 +367,169 @@ __device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloa
     }
 }
 
+// D = A[block `blk` of `a`, broadcast to all 16 blocks] x B + C (the builtin wants the block as a literal; `blk` is a constant once
+// the caller's loops are unrolled, and the switch folds away)
+__device__ __forceinline__ v4f mfma4_bcast(float a, float b, v4f c, int blk) {
+    switch (blk) {
+#define MI_M4(N) case N: return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, N, 0);
+        MI_M4(0) MI_M4(1) MI_M4(2) MI_M4(3) MI_M4(4) MI_M4(5) MI_M4(6) MI_M4(7) MI_M4(8) MI_M4(9) MI_M4(10) MI_M4(11) MI_M4(12) MI_M4(13) MI_M4(14)
+#undef MI_M4
+        default: return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, 15, 0);
+    }
+}
+
+// strip_row2 with the pointwise conv on the matrix cores, in the layout the depthwise stage already has (lane = pixel).
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent (4 x 1)(1 x 4) outer products: block b = lanes 4b .. 4b+3, D[i][lane] = A[block, i] *
+// B[lane] + C[i][lane].  With B = the finished depthwise value of input channel k (one register, lane = pixel) and A = four
+// output-channel weights W[4t .. 4t+3][k], broadcast from ONE block of a weight register to all sixteen (cbsz = 4, abid =
+// block), D = four output channels of every pixel, lane = pixel, register = channel: the accumulator layout of the packed-FMA
+// form, no transposition, no padding (24 = 6 x 4), the same k-sequential f32 fma chain per output (bit-identical).  The
+// whole pointwise filter is NA = 9 registers per wave (24 x 24), loaded once per launch: no weight stream; what is left in
+// the scalar stream are the 18 depthwise taps of a channel pair, fetched a full stage ahead (one wait per stage).
+//   me0 / me1: this lane's left neighbour in the images of input rows c0, c0 + 1; ps: pixel stride of those images (floats).
+//   cb: pointwise bias (+ W b_dw), wd[0]: the taps of stage 0 — both asked for by the caller before the step's barrier.
+//   onext: bias + skip of the first row this call finishes (= centre pixels of the previous call's second row, put there by that
+//   call: they are the C operand of this call's first MFMAs, whose D is oacc0 — no copy, no separate add); the call leaves the next one's.
+template <int CQ>
+__device__ __forceinline__ void strip_row2m(const float* me0, const float* me1, int ps, const cfloat* cst, bool has_res, v2f (&aA)[CQ][2], v2f (&aB)[CQ][2],
+                                            float4 (&onext)[CQ], v4f (&oacc0)[CQ], v4f (&oacc1)[CQ], const float (&wa)[SK<CQ>::NA],
+                                            const float (&cb)[4 * CQ], float (&wd)[2][18]) {
+    using K = SK<CQ>;
+    float4 xbuf[2][2][3];
+    const float* r0[3] = {me0, me0 + ps, me0 + 2 * ps};
+    const float* r1[3] = {me1, me1 + ps, me1 + 2 * ps};
+#ifdef MI_ABL_M_NOSMEM  // timing ablations (development harness only; the ablated kernels compute wrong values)
+    float abl_w = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, aA[0][0].x)));
+    auto load_taps = [&](int st) {
+        asm volatile("" : "+s"(abl_w));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[st & 1][i] = abl_w;
+    };
+#else
+    auto load_taps = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[st & 1][i] = p[K::OFF_DW + st * K::ST_F + i];
+    };
+#endif
+    auto load_x = [&](int q, float4 (&x)[2][3]) {
+#ifdef MI_ABL_M_NOLDS
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            x[0][kx] = onext[(q + kx) % CQ];
+            x[1][kx] = onext[(q + kx + 1) % CQ];
+            asm volatile("" : "+v"(x[0][kx].x), "+v"(x[0][kx].y), "+v"(x[0][kx].z), "+v"(x[0][kx].w), "+v"(x[1][kx].x), "+v"(x[1][kx].y), "+v"(x[1][kx].z), "+v"(x[1][kx].w));
+        }
+#else
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            x[0][kx] = sld4(r0[kx] + 4 * q);
+            x[1][kx] = sld4(r1[kx] + 4 * q);
+        }
+#endif
+    };
+    auto bias4 = [&](int q) { return v4f{cb[4 * q], cb[4 * q + 1], cb[4 * q + 2], cb[4 * q + 3]}; };
+    // second finished row: bias + skip (centre pixels of row c0); quad 0's window is asked for behind them and lands while these are added
+    if (has_res) {  // wave-uniform branch
+        float4 xm[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; q++) xm[q] = sld4(r0[1] + 4 * q);
+        load_x(0, xbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CQ; q++) {
+            oacc1[q] = v4f{xm[q].x, xm[q].y, xm[q].z, xm[q].w} + bias4(q);
+            asm volatile("" : "+v"(oacc1[q]));
+        }
+    } else {
+        load_x(0, xbuf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CQ; q++) {
+            oacc1[q] = bias4(q);
+            asm volatile("" : "+v"(oacc1[q]));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 2 * CQ; st++) {
+        const int q = st >> 1, h = st & 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's taps (asked for a stage ago) and pixels
+        if (st + 1 < 2 * CQ) {
+            load_taps(st + 1);
+            if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&x)[2][3] = xbuf[q & 1];
+        v2f t0[3], t1[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            t0[kx] = h == 0 ? v2f{x[0][kx].x, x[0][kx].y} : v2f{x[0][kx].z, x[0][kx].w};
+            t1[kx] = h == 0 ? v2f{x[1][kx].x, x[1][kx].y} : v2f{x[1][kx].z, x[1][kx].w};
+        }
+        const float (&w)[18] = wd[st & 1];
+        auto wv = [&](int tap) { return v2f{w[2 * tap], w[2 * tap + 1]}; };
+        v2f p0 = aA[q][h], p1 = aB[q][h], nA = t0[0] * wv(0), nB = t1[0] * wv(0);
+#ifdef MI_ABL_M_NODW
+        if (false)
+#endif
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            p0 = pkfma(t0[kx], wv(6 + kx), p0);
+            p1 = pkfma(t0[kx], wv(3 + kx), p1);
+            if (kx) nA = pkfma(t0[kx], wv(kx), nA);
+        }
+#ifdef MI_ABL_M_NODW
+        if (false)
+#endif
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            p1 = pkfma(t1[kx], wv(6 + kx), p1);
+            nA = pkfma(t1[kx], wv(3 + kx), nA);
+            if (kx) nB = pkfma(t1[kx], wv(kx), nB);
+        }
+        aA[q][h] = nA;
+        aB[q][h] = nB;
+        asm volatile("" : "+v"(aA[q][h]), "+v"(aB[q][h]));
+        // the depthwise stage ends here and the MFMAs run as one block: left to itself the scheduler interleaves the last packed FMAs
+        // with the first MFMAs, and every switch between the two costs issue cycles (measured on the harness: 0.384 -> 0.353 ms)
+        asm volatile("" : "+v"(p0), "+v"(p1));
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef MI_ABL_M_NOMFMA
+        asm volatile("" : "+v"(p0), "+v"(p1));
+        if (false)
+#endif
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float b0 = e ? p0.y : p0.x, b1 = e ? p1.y : p1.x;
+#pragma unroll
+            for (int t = 0; t < CQ; t++) {
+                const int n = (2 * st + e) * CQ + t;
+                const v4f c0 = (st == 0 && e == 0) ? v4f{onext[t].x, onext[t].y, onext[t].z, onext[t].w} : oacc0[t];
+                oacc0[t] = mfma4_bcast(wa[n >> 4], b0, c0, n & 15);
+                oacc1[t] = mfma4_bcast(wa[n >> 4], b1, oacc1[t], n & 15);
+            }
+        }
+        if (h == 0 && has_res) {  // the next call's first row starts from bias + centre pixels of row c0 + 1
+            const v4f nx = v4f{x[1][1].x, x[1][1].y, x[1][1].z, x[1][1].w} + bias4(q);
+            onext[q] = make_float4(nx.x, nx.y, nx.z, nx.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int CQ, bool RELU>
+__device__ __forceinline__ void strip_act(const v4f (&oacc)[CQ], const cfloat* slopes, float hi, float4 (&o)[CQ]) {
+    v2f t[2 * CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; q++) {
+        t[2 * q] = v2f{oacc[q].x, oacc[q].y};
+        t[2 * q + 1] = v2f{oacc[q].z, oacc[q].w};
+    }
+    strip_act<CQ, RELU>(t, slopes, hi, o);
+}
+
 // Stride-2 tail of a row pipeline (the BlazeBlock that halves the resolution: DW3x3 s2 (TF SAME on an even size = taps at
 // rows 2oy..2oy+2, columns 2ox..2ox+2) -> PW1x1 C -> NH*C -> + [2x2 max-pool of the input, zero channel-pad] -> act).
 // lane = OUTPUT pixel; `me2` = this lane's first tap column in the full-width row image the last stride-1 block wrote.
@@ -363,7 +538,7 @@ __device__ __forceinline__ void strip_act(const v2f (&oacc)[2 * CQ], const cfloa
 // it (max over the kx = 0, 1 taps of rows 2k, 2k+1).  MODE 0: odd row, 1: even row that only starts, 2: even row that
 // finishes and starts.  Constants record per channel pair: depthwise taps [9][2] at 0, pointwise columns of the two
 // channels at 32 and 32 + NH*C (this wave reads entries [hf*C, hf*C + C) of them).
-template <int CQ, int NH, int MODE>
+template <int CQ, int NH, int MODE, int PS = 4 * CQ>
 __device__ __forceinline__ void strip_row_s2(const float* me2, const cfloat* cst, int hf, bool has_skip, v2f (&acc)[CQ][2], float4 (&mx)[CQ],
                                              v2f (&oacc)[2 * CQ]) {
     constexpr int C = 4 * CQ, Co = NH * C;
@@ -389,7 +564,7 @@ __device__ __forceinline__ void strip_row_s2(const float* me2, const cfloat* cst
     };
     auto load_x = [&](int q, float4 (&x)[3]) {
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me2 + kx * C + 4 * q);
+        for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me2 + kx * PS + 4 * q);
     };
     if constexpr (MODE == 2) {  // accumulators start from bias (+ the finished max-pool of rows 2k-2, 2k-1 for channels < C)
         const cfloat* bp = cst + OFF_BIAS2 + hf * C;
@@ -637,9 +812,13 @@ struct PipeArgs {
     long in_fs, out_fs;
     int B, H, W;
     int strips, bands, band_rows, units;
-    int rows_per_step;              // 1: strip_pipe_kernel, 2: strip_pipe2_kernel (even band starts / lengths)
+    int rows_per_step;              // 1: strip_pipe_kernel, 2: strip_pipe2_kernel (even band starts / lengths), 3: strip_pipe2m_kernel
     int has_res[kMaxPipe];
     float hi[kMaxPipe];
+    int prio;                       // strip_pipe2m_kernel: which waves run at issue priority 1 (1: both ends of the pipeline, 0: none, 2: block 0, 3: last stage)
+#ifdef MI_PIPE_STAMPS  // development harness only: s_memtime accumulators per wave (8 per wave: compute, barrier 1, hand-over / store, barrier 2, steps)
+    unsigned long long* stamps;
+#endif
 };
 
 // NH2 > 0: the chain ends in a stride-2 block (see strip_row_s2) run by NH2 extra waves (one per C output channels); KB
@@ -959,6 +1138,12 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
 
+#ifdef MI_PIPE_STAMPS
+    unsigned long long ps_acc[4] = {0, 0, 0, 0}, ps_prev = __builtin_amdgcn_s_memtime();
+#define MI_PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); ps_acc[k] += t_ - ps_prev; ps_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_PSTAMP(k)
+#endif
     auto wg_barrier = [&]() {
         // raw s_barrier with an LDS-only wait, so that the stores of the last block and the DMA of block 0 stay in flight across it
         asm volatile("" ::: "memory");
@@ -1082,7 +1267,9 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         if constexpr (NH2 > 0) {
             if (tail) tail_step(t, tacc, tmx);
         }
+        MI_PSTAMP(0)
         wg_barrier();  // every reader of the previous pair is done
+        MI_PSTAMP(1)
         if (hand_over) {
             hand_row(c0 - 1, 0, o0);
             hand_row(c0, 1, o1);
@@ -1090,7 +1277,9 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
             store_row(c0 - 1, o0);
             store_row(c0, o1);
         }
+        MI_PSTAMP(2)
         wg_barrier();
+        MI_PSTAMP(3)
     };
     const int T = NH2 ? 2 * S + a.band_rows / 2 + 1 : 2 * S - 1 + a.band_rows / 2;
     for (int t = 0; t < T; t += 2) {
@@ -1098,14 +1287,324 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         if (t + 1 >= T) break;
         step(t + 1, xb, xa, aA, xa);
     }
+#ifdef MI_PIPE_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* d = a.stamps + ((size_t)blockIdx.x * 8 + w) * 8;
+        for (int k = 0; k < 4; k++) d[k] = ps_acc[k];
+        d[4] = T;
+    }
+#endif
+#undef MI_PSTAMP
+}
+
+// strip_pipe2_kernel with the pointwise convs of the stride-1 blocks on the matrix cores (strip_row2m): the filters live in registers, the
+// only scalar stream left is the depthwise taps (a stage ahead; the bias and the first stage's taps are asked for BEFORE the barrier that
+// ends the previous step), and the hand-over rings have a pixel stride of C + 4 floats, which makes their 16-byte reads and writes
+// free of bank conflicts (lane stride 24 floats: lanes l and l + 8 meet in the same banks; 28: the 16 lanes of a pass cover all 64).
+// Bit-identical to strip_pipe2_kernel (tools/strip_bench.hip compares them).
+template <int CQ, int KB, bool RELU, int NH2>
+__global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void strip_pipe2m_kernel(PipeArgs a) {
+    using K = SK<CQ>;
+    constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
+    constexpr int S = NH2 ? KB - 1 : KB;         // stride-1 blocks
+    constexpr int NT = 128 * S + 64 * NH2;       // threads
+    constexpr int PXS = C + 4;                   // pixel stride of a hand-over row image (floats)
+    constexpr int IMG = 132 * PXS;               // floats of one full-width row image (<= 130 pixels used)
+    constexpr int RING_F = (KB - 1) * 2 * IMG;   // KB-1 hand-over rings of one pair of row images
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool tail = NH2 && w >= 2 * S;
+    const int p = tail ? 0 : (w & 1), role = tail ? S : (w >> 1);
+    const int hf = tail ? w - 2 * S : 0;
+    // Static issue priority for the two ends of the pipeline: block 0's waves (they also wait for and issue the DMA) and the
+    // waves of the last stage (the last block stores to memory; a stride-2 tail wave serves both strips alone).  A step ends
+    // when its slowest wave reaches the barrier, and these are the slowest: measured on the harness (tools/strip_bench.hip)
+    // -1.5 % (4 blocks at 128^2), -3 % (64^2), -6 % / -7 % (with a stride-2 tail); any other choice of waves is neutral or slower.
+    {
+        const bool first = role == 0, last = tail || (NH2 == 0 && role == S - 1);
+        if ((a.prio == 1 && (first || last)) || (a.prio == 2 && first) || (a.prio == 3 && last)) __builtin_amdgcn_s_setprio(1);
+    }
+    // wave-private scratch: block 0 waves own two pairs of DMA row buffers each, the waves that store one transposition buffer
+    float* scratch = lds + RING_F + (role == 0 ? p * 4 * BUF_F : 8 * BUF_F + (tail ? hf : p) * BUF_F);
+    const int unit = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + p;
+    const bool active = unit < a.units;
+    const int band = unit % a.bands, b = min(unit / a.bands, a.B - 1);
+    const int x0 = a.strips == 2 ? 64 * p : 0;
+    const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
+    const float* in = a.in + (long)b * a.in_fs;
+    float* out = a.out + (long)b * a.out_fs;
+    const cfloat* cst = (const cfloat*)a.consts[role];
+    const bool has_res = a.has_res[role] != 0;
+    const float hi = a.hi[role];
+    // the last stride-1 block produces rows [y0, hi_last): two more rows when a stride-2 tail follows (its third tap row,
+    // and one to keep the count even)
+    const int hi_last = NH2 ? y1 + 2 : y1;
+    const int lo_j = y0 - (S - 1 - role), hi_j = hi_last + (S - 1 - role);  // this (stride-1) block produces rows [lo_j, hi_j)
+    const int P = (hi_j - lo_j + 2) >> 1;                                   // row pairs it consumes: (lo_j - 1 + 2m, lo_j + 2m)
+    const int img_p = a.strips == 2 ? 64 * PXS * p : 66 * PXS * p;
+
+    for (int i = threadIdx.x; i < RING_F / 4; i += NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int goff[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int f = min(lane + 64 * k, K::NF - 1), px = f / CQ, qd = f - px * CQ;
+        goff[k] = (min(max(x0 - 1 + px, 0), a.W - 1) * C + 4 * qd) * 4;
+    }
+    const int npx = min(64, a.W - x0);
+    const bool full = npx == 64;
+    const int zl = x0 == 0 ? 0 : -1;
+    const int zr = x0 + 64 >= a.W ? npx + 1 : -1;
+    const long gout = (long)x0 * C + 4 * lane;
+    const unsigned lds_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)scratch);
+    auto issue_row = [&](int r, int bi) {
+        const char* src = reinterpret_cast<const char*>(in + (long)min(max(r, 0), a.H - 1) * a.W * C);
+        const unsigned dstb = lds_scratch + (unsigned)(bi * BUF_F * 4);
+        constexpr int TAIL = K::NF - 64 * (NL - 1);
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            if (k < NL - 1 || TAIL == 64) {
+                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+            } else {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+            }
+        }
+    };
+    const int zfix = lane < CQ ? (zl >= 0 ? zl * C + 4 * lane : -1) : (lane < 2 * CQ ? (zr >= 0 ? zr * C + 4 * (lane - CQ) : -1) : -1);
+    auto fix_row = [&](int r, int bi) {
+        float* buf = scratch + bi * BUF_F;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 0 || r >= a.H) {
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
+        } else if (zfix >= 0) {
+            sst4(buf + zfix, z);
+        }
+    };
+
+    v2f aA[CQ][2], aB[CQ][2];
+    v4f oacc0[CQ], oacc1[CQ];
+    v2f toacc[2 * CQ];   // stride-2 tail wave: accumulators (its partial depthwise row / running max-pool live in aA / onext)
+    float4 onext[CQ];    // stride-1 waves: bias + skip of the next step's first finished row
+    float wa[K::NA];     // pointwise filter, A operands (SK::OFF_A)
+    float cb[C], wd[2][18];
+#pragma unroll
+    for (int q = 0; q < CQ; q++) {
+        aA[q][0] = aA[q][1] = aB[q][0] = aB[q][1] = v2f{0.f, 0.f};
+        onext[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // bias and first-stage taps of the coming step: scalar loads issued before a barrier, complete when it opens
+    auto prefetch_consts = [&]() {  // (a stride-2 tail wave reads the same offsets of its own, larger blob and ignores them)
+        const cfloat* pc = cst;
+        asm volatile("" : "+s"(pc));
+#pragma unroll
+        for (int i = 0; i < C; i++) cb[i] = pc[K::OFF_BIAS + i];
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[0][i] = pc[K::OFF_DW + i];
+    };
+    auto pin_consts = [&]() {  // behind the barrier's lgkmcnt(0): keeps the loads above in front of it
+#pragma unroll
+        for (int i = 0; i < C; i++) asm volatile("" : "+s"(cb[i]));
+#pragma unroll
+        for (int i = 0; i < 18; i++) asm volatile("" : "+s"(wd[0][i]));
+    };
+    if (!tail) {
+#pragma unroll
+        for (int i = 0; i < K::NA; i++) wa[i] = a.consts[role][K::OFF_A + 64 * i + lane];
+    }
+    prefetch_consts();
+    if (role == 0 && active) {
+        issue_row(lo_j - 1, 0);
+        issue_row(lo_j, 1);
+        if (P > 1) {
+            issue_row(lo_j + 1, 2);
+            issue_row(lo_j + 2, 3);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    pin_consts();
+    __builtin_amdgcn_s_barrier();
+    if (!tail && !has_res) {  // no skip: the first finished row of every step starts from the bias alone
+#pragma unroll
+        for (int q = 0; q < CQ; q++) onext[q] = make_float4(cb[4 * q], cb[4 * q + 1], cb[4 * q + 2], cb[4 * q + 3]);
+    }
+
+#ifdef MI_PIPE_STAMPS
+    unsigned long long ps_acc[4] = {0, 0, 0, 0}, ps_prev = __builtin_amdgcn_s_memtime();
+#define MI_PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); ps_acc[k] += t_ - ps_prev; ps_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_PSTAMP(k)
+#endif
+    auto wg_barrier = [&]() {
+        // raw s_barrier with an LDS-only wait, so that the stores of the last block and the DMA of block 0 stay in flight across it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#ifndef MI_ABL_NOBAR
+        __builtin_amdgcn_s_barrier();
+#endif
+        asm volatile("" ::: "memory");
+    };
+    auto store_row = [&](int e, const float4 (&o)[CQ]) {  // transposed through LDS: 1 KiB of consecutive bytes per store instruction
+        float* obuf = scratch;
+#pragma unroll
+        for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+        wave_sync();
+        float* dst = out + (long)e * a.W * C + gout;
+        if (full) {
+#pragma unroll
+            for (int k = 0; k < CQ; k++) sst4(dst + 256 * k, sld4(obuf + 4 * lane + 256 * k));
+        } else {
+#pragma unroll
+            for (int k = 0; k < CQ; k++) {
+                const float4 v = sld4(obuf + 4 * lane + 256 * k);
+                if (lane + 64 * k < npx * CQ) sst4(dst + 256 * k, v);
+            }
+        }
+        wave_sync();
+    };
+    auto hand_row = [&](int e, int which, const float4 (&o)[CQ]) {  // rows outside the image are the next block's zero padding
+        float* dstl = lds + (role * 2 + which) * IMG + img_p + (1 + lane) * PXS;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < 0 || e >= a.H) {  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, z);
+        } else if (full) {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, o[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, lane >= npx ? z : o[q]);
+        }
+    };
+    // ---- stride-2 tail: consumes the pair (even row, odd row) the last stride-1 block handed over in the previous step
+    auto tail_step = [&](int t, v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
+        if constexpr (NH2 > 0) {
+            const int mt = t - 2 * S;
+            if (mt < 0 || 2 * mt > a.band_rows) return;
+            const int k = 2 * mt;  // band-relative index of the even row
+            constexpr int Co = NH2 * C;
+            constexpr int ST2 = (32 + 2 * Co + 15) / 16 * 16, OFF_SLOPE2 = (C / 2) * ST2 + 64;
+            const cfloat* cst2 = (const cfloat*)a.consts[S];
+            const float* img = lds + ((S - 1) * 2) * IMG;
+            const int tu = a.strips == 2 ? 0 : lane >> 5, tox = a.strips == 2 ? lane : lane & 31;
+            const float* me2 = img + tu * 66 * PXS + (2 * tox + 1) * PXS;
+            const bool skip = hf == 0 && a.has_res[S] != 0;
+            if (mt == 0) {
+                strip_row_s2<CQ, NH2, 1, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc);
+            } else {
+                strip_row_s2<CQ, NH2, 2, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc);
+                float4 o[CQ];
+                strip_act<CQ, RELU>(toacc, cst2 + OFF_SLOPE2 + hf * C, a.hi[S], o);
+                float* obuf = scratch;
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+                wave_sync();
+                const int Wo = a.W >> 1;
+#pragma unroll
+                for (int j = 0; j < CQ; j++) {
+                    const int f = lane + 64 * j, px = f / CQ, qd = f - px * CQ;
+                    const int u = a.strips == 2 ? 0 : px >> 5, ox = a.strips == 2 ? px : px & 31;
+                    const int un = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + u;
+                    const int ub = un % a.bands, bb = min(un / a.bands, a.B - 1);
+                    const int uy0 = ub * a.band_rows, uy1 = min(uy0 + a.band_rows, a.H);
+                    const float4 v = sld4(obuf + 4 * f);
+                    if (un < a.units && uy0 + k <= uy1 && ox < Wo) {
+                        const int oy = (uy0 + k - 2) >> 1;
+                        sst4(a.out + (long)bb * a.out_fs + ((long)oy * Wo + ox) * Co + hf * C + 4 * qd, v);
+                    }
+                }
+                wave_sync();
+            }
+            if (k + 1 < a.band_rows) strip_row_s2<CQ, NH2, 0, PXS>(me2 + IMG, cst2, hf, skip, tacc, tmx, toacc);
+        }
+    };
+    auto step = [&](int t) {
+        v2f (&tacc)[CQ][2] = aA;
+        float4 (&tmx)[CQ] = onext;
+        const int m = t - 2 * role;  // pair index of this block in this step
+        const int c0 = lo_j - 1 + 2 * m;
+        bool hand_over = false, store_out = false;
+        float4 o0[CQ], o1[CQ];
+        if (!tail && active && m >= 0 && m < P) {
+            const float *me0, *me1;
+            int ps;
+            if (role == 0) {
+                if (m + 1 < P) wait_vm<2 * NL>();
+                else wait_vm<0>();
+                fix_row(c0, (m & 1) * 2);
+                fix_row(c0 + 1, (m & 1) * 2 + 1);
+                wave_sync();
+                me0 = scratch + ((m & 1) * 2) * BUF_F + lane * C;
+                me1 = me0 + BUF_F;
+                ps = C;
+            } else {
+                me0 = lds + ((role - 1) * 2) * IMG + img_p + lane * PXS;
+                me1 = me0 + IMG;
+                ps = PXS;
+            }
+            strip_row2m<CQ>(me0, me1, ps, cst, has_res, aA, aB, onext, oacc0, oacc1, wa, cb, wd);
+            wave_sync();
+            if (m >= 1) {  // rows c0 - 1 and c0 are finished
+                strip_act<CQ, RELU>(oacc0, cst + K::OFF_SLOPE, hi, o0);
+                strip_act<CQ, RELU>(oacc1, cst + K::OFF_SLOPE, hi, o1);
+                if (NH2 || role < S - 1) hand_over = true;
+#ifdef MI_ABL_STORE_EARLY
+                else { store_row(c0 - 1, o0); store_row(c0, o1); }
+#else
+                else store_out = true;  // the last block's rows go to memory in the hand-over phase, while the others write their rings
+#endif
+            }
+            if (role == 0 && m + 2 < P) {
+                wave_sync();
+                issue_row(c0 + 4, (m & 1) * 2);
+                issue_row(c0 + 5, (m & 1) * 2 + 1);
+            }
+        }
+        if constexpr (NH2 > 0) {
+            if (tail) tail_step(t, tacc, tmx);
+        }
+        MI_PSTAMP(0)
+        wg_barrier();  // every reader of the previous pair is done
+        MI_PSTAMP(1)
+        if (hand_over) {
+            hand_row(c0 - 1, 0, o0);
+            hand_row(c0, 1, o1);
+        } else if (store_out) {
+            store_row(c0 - 1, o0);
+            store_row(c0, o1);
+        }
+        MI_PSTAMP(2)
+        prefetch_consts();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        pin_consts();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        MI_PSTAMP(3)
+    };
+    const int T = NH2 ? 2 * S + a.band_rows / 2 + 1 : 2 * S - 1 + a.band_rows / 2;
+    for (int t = 0; t < T; t++) step(t);
+#ifdef MI_PIPE_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* d = a.stamps + ((size_t)blockIdx.x * 8 + w) * 8;
+        for (int k = 0; k < 4; k++) d[k] = ps_acc[k];
+        d[4] = T;
+    }
+#endif
+#undef MI_PSTAMP
 }
 
 template <int CQ, int KB, bool RELU, int NH2>
 int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
     using K = SK<CQ>;
-    const bool two = pa.rows_per_step == 2;
-    auto kern = two ? strip_pipe2_kernel<CQ, KB, RELU, NH2> : strip_pipe_kernel<CQ, KB, RELU, NH2>;
-    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * K::C + (two ? 10 : 6) * K::BUF_F) * 4;
+    const bool two = pa.rows_per_step >= 2;
+    const bool mf = pa.rows_per_step == 3;
+    auto kern = mf ? strip_pipe2m_kernel<CQ, KB, RELU, NH2> : (two ? strip_pipe2_kernel<CQ, KB, RELU, NH2> : strip_pipe_kernel<CQ, KB, RELU, NH2>);
+    const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * (mf ? K::C + 4 : K::C) + (two ? 10 : 6) * K::BUF_F) * 4;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     const int wgs = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
     return (int)launch_kernel(kern, dim3((unsigned)wgs), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds_bytes, s, pa);
@@ -1166,7 +1665,7 @@ bool strip_kernel_supports(const BlockArgs& a) {
 bool strip_shape_ok(int C, int Co) { return C == Co && (C == 16 || C == 24 || C == 32); }
 
 static int strip_stage_floats(int C) { return 32 + 2 * C + (16 - (2 * C) % 16) % 16; }
-int strip_consts_floats(int C) { return C / 2 * strip_stage_floats(C) + 64; }
+int strip_consts_floats(int C) { return C / 2 * strip_stage_floats(C) + 64 + 64 * ((C * (C / 4) + 15) / 16); }
 
 // w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C] (TFLite OHWI with H = W = 1), bias [Co] or null, alpha [Co] or null.
 void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
@@ -1189,6 +1688,15 @@ void strip_pack_consts(int C, const float* w_dw, const float* b_dw, const float*
         pb[c] = (float)acc;
         ps[c] = act == ACT_PRELU ? alpha[c] : (act == ACT_NONE ? 1.f : 0.f);
     }
+    // A operands of v_mfma_f32_4x4x1_16b_f32 (SK::OFF_A): register n / 16, lanes 4 (n % 16) + i = W[4t + i][k], n = k CQ + t
+    float* pa = ps + 32;
+    const int CQ = C / 4;
+    for (int k = 0; k < C; k++)
+        for (int t = 0; t < CQ; t++)
+            for (int i = 0; i < 4; i++) {
+                const int n = k * CQ + t;
+                pa[(n >> 4) * 64 + 4 * (n & 15) + i] = w_pw[(size_t)(4 * t + i) * C + k];
+            }
 }
 
 const char* strip_kernel_label(const BlockArgs& a, char* buf, size_t cap) {
@@ -1270,13 +1778,15 @@ void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, c
 // rows a pipeline step handles: two (strip_pipe2_kernel) whenever the height is even
 int strip_pipe_rows_per_step(int H, int hint) {
     static const int rows_forced = getenv("MI_PIPE_ROWS") ? atoi(getenv("MI_PIPE_ROWS")) : 0;  // tuning aid
-    return (rows_forced == 1 || hint == 1 || (H & 1)) ? 1 : 2;
+    static const bool no_mfma = getenv("MI_PIPE_NO_MFMA") != nullptr;                           // tuning aid: packed-FMA pointwise convs
+    if (rows_forced == 1 || hint == 1 || (H & 1)) return 1;
+    return (no_mfma || rows_forced == 2 || hint == 2) ? 2 : 3;
 }
 
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap) {
     const int nh2 = blocks[n - 1].sh == 2 ? blocks[n - 1].Co / blocks[n - 1].C : 0;
-    snprintf(buf, cap, "strip_pipe%s_kernel<%d,%d,%d,%d>", strip_pipe_rows_per_step(blocks[0].H, blocks[0].pipe_rows) == 2 ? "2" : "", blocks[0].C / 4, n,
-             blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
+    const int rps = strip_pipe_rows_per_step(blocks[0].H, blocks[0].pipe_rows);
+    snprintf(buf, cap, "strip_pipe%s_kernel<%d,%d,%d,%d>", rps == 3 ? "2m" : (rps == 2 ? "2" : ""), blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
     return buf;
 }
 
@@ -1302,19 +1812,32 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     rows = std::max(rows, std::min(a.H, 8 * n));
     if (forced > 0) rows = std::min(forced, a.H);
     pa.rows_per_step = strip_pipe_rows_per_step(a.H, a.pipe_rows);
-    if (nh2 || pa.rows_per_step == 2) rows = std::min(a.H, (rows + 1) & ~1);  // bands that start on even rows
+    if (nh2 || pa.rows_per_step >= 2) rows = std::min(a.H, (rows + 1) & ~1);  // bands that start on even rows
     pa.band_rows = rows;
     pa.bands = (a.H + rows - 1) / rows;
     pa.units = a.B * pa.bands;
+    static const int prio_forced = getenv("MI_PIPE_PRIO") ? atoi(getenv("MI_PIPE_PRIO")) : -1;  // tuning aid
+    pa.prio = prio_forced >= 0 ? prio_forced : 1;
+#ifdef MI_PIPE_STAMPS
+    pa.stamps = g_strip_stamps;
+#endif
     hipStream_t s = (hipStream_t)stream;
     const bool relu = a.ep.act == ACT_RELU;
 #define MI_PIPE_CASE(Q, KBV) \
     if (a.C == 4 * Q && n == KBV && nh2 == 0) return relu ? launch_pipe_inst<Q, KBV, true, 0>(pa, s) : launch_pipe_inst<Q, KBV, false, 0>(pa, s);
+#ifdef MI_DEV_ONE  // development builds (tools/isa_report.py, quick harness turns): only the four-stage 24-channel pipelines
+    MI_PIPE_CASE(6, 4)
+#else
     MI_PIPE_CASE(4, 2) MI_PIPE_CASE(4, 3) MI_PIPE_CASE(4, 4) MI_PIPE_CASE(6, 2) MI_PIPE_CASE(6, 3) MI_PIPE_CASE(6, 4)
+#endif
 #undef MI_PIPE_CASE
 #define MI_TAIL_CASE(KBV, NH) \
     if (a.C == 24 && n == KBV && nh2 == NH && relu) return launch_pipe_inst<6, KBV, true, NH>(pa, s);
+#ifdef MI_DEV_ONE
+    MI_TAIL_CASE(4, 1) MI_TAIL_CASE(4, 2)
+#else
     MI_TAIL_CASE(2, 1) MI_TAIL_CASE(3, 1) MI_TAIL_CASE(4, 1) MI_TAIL_CASE(2, 2) MI_TAIL_CASE(3, 2) MI_TAIL_CASE(4, 2)
+#endif
 #undef MI_TAIL_CASE
     return (int)hipErrorInvalidValue;
 }

@@ -139,7 +139,8 @@ def test_stage_programs_vs_oracle(gpu, oracle, name, budget_kib):
 def test_strip_and_pipeline_kernels_agree(gpu, name):
     """The kernels that can run a BlazeBlock are interchangeable.  However a run of blocks is cut into row-pipelined
     chains (fuse 4, "pipe" = 2 / 3 / 4 blocks per launch) the bits are the same: the chains execute the same operations
-    in the same order, one or two rows per pipeline step.  One strip-kernel launch per block (fuse 3) and the LDS-ring block kernel ("strip" = 0) agree with
+    in the same order, one or two rows per pipeline step, the 1x1 convs as packed FMAs or on v_mfma_f32_4x4x1_16b_f32 (an f32
+    MFMA accumulates like an fmaf chain).  One strip-kernel launch per block (fuse 3) and the LDS-ring block kernel ("strip" = 0) agree with
     them up to the order of the 3x3 sum / the depthwise bias folded into the pointwise bias (the stride-2 block that ends
     a chain is computed that way, the stand-alone block kernel adds the bias first): raw-output tolerance of the oracle
     comparison."""
@@ -155,9 +156,17 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
         m.set_option("pipe", pipe)
         for o, r in zip(m.run(x), chained):
             np.testing.assert_array_equal(o, r)
-    m.set_option("pipe_rows", 1)  # one row per pipeline step (the kernel used for odd heights)
-    for o, r in zip(m.run(x), chained):
-        np.testing.assert_array_equal(o, r)
+    import torch
+    if name != "front":  # default: two rows per step, pointwise convs on v_mfma_f32_4x4x1_16b_f32 (strip_pipe2m_kernel)
+        labels = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+        assert any(k.startswith("strip_pipe2m_kernel") for k in labels), labels
+    for rows, sym in ((1, "strip_pipe_kernel"), (2, "strip_pipe2_kernel")):  # one row per step (odd heights); two rows, packed-FMA pointwise convs
+        m.set_option("pipe_rows", rows)
+        for o, r in zip(m.run(x), chained):
+            np.testing.assert_array_equal(o, r)
+        if name != "front":
+            labels = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+            assert any(k.startswith(sym + "<") for k in labels) and not any(k.startswith("strip_pipe2m_kernel") for k in labels), labels
     m.set_option("pipe_rows", 0)
     m.set_option("fork", 0)  # output heads on the trunk's stream instead of side streams
     for o, r in zip(m.run(x), chained):

@@ -4,6 +4,7 @@
 #include "../rs-face-detection-tflite_amd/csrc/strip_kernels.hip"
 
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -138,6 +139,28 @@ int main(int argc, char** argv) {
         printf("pipe x%d%s check: max |diff| %.3g, %zu of %zu outside %.0e", nb, tail ? " (stride-2 tail)" : "", md, nbad, nlast, tol);
         if (nbad) { size_t px = fi / Cl; printf("  first at frame %zu y %zu x %zu c %zu: ref %g got %g", px / ((size_t)Hl * Wl), px / Wl % Hl, px % Wl, fi % Cl, r0[fi], r1[fi]); }
         printf("\n");
+        {   // packed-FMA form of the same pipeline (pipe_rows hint 2) against the default (MFMA pointwise convs): bit for bit
+            std::vector<BlockArgs> pv = pb;
+            for (auto& b : pv) b.pipe_rows = 2;
+            float* dpv; CK(hipMalloc(&dpv, nlast * 4)); CK(hipMemset(dpv, 0xff, nlast * 4));
+            pv[nb - 1].out = dpv;
+            if (launch_strip_pipe(pv.data(), nb, s)) { printf("pipe (packed FMA) launch failed\n"); return 1; }
+            CK(hipStreamSynchronize(s));
+            std::vector<float> r2(nlast);
+            CK(hipMemcpy(r2.data(), dpv, nlast * 4, hipMemcpyDeviceToHost));
+            size_t ndiff = 0;
+            for (size_t i = 0; i < nlast; i++) ndiff += memcmp(&r2[i], &r1[i], 4) != 0;
+            char l0[96], l1[96];
+            printf("%s vs %s: %zu of %zu values differ in any bit\n", strip_pipe_label(pb.data(), nb, l0, sizeof l0), strip_pipe_label(pv.data(), nb, l1, sizeof l1), ndiff, nlast);
+            if (ndiff) nbad += ndiff;
+            const int it = 20;
+            for (int i = 0; i < 3; i++) launch_strip_pipe(pv.data(), nb, s);
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < it; i++) launch_strip_pipe(pv.data(), nb, s);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+            printf("pipe (packed FMA) x%d B %d %dx%d C %d : %.4f ms (%.4f per block)\n", nb, B, H, W, C, ms, ms / nb);
+        }
         for (int which = 0; which < 2; which++) {
             const int it = 20;
             auto run = [&] { if (which) launch_strip_pipe(pb.data(), nb, s); else for (int k = 0; k < nb; k++) { if (tail && k == nb - 1) launch_block(blk[k], s); else launch_strip(blk[k], s); } };
@@ -148,6 +171,29 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
             printf("%s x%d B %d %dx%d C %d : %.4f ms (%.4f per block)\n", which ? "pipe " : "separate", nb, B, H, W, C, ms, ms / nb);
         }
+#ifdef MI_PIPE_STAMPS
+        for (int mf = 0; mf < 2; mf++) {   // where a wave's time goes, per role: s_memtime ticks per step
+            std::vector<BlockArgs> pv = pb;
+            for (auto& b : pv) b.pipe_rows = mf ? 0 : 2;
+            const size_t nw = (size_t)B * 64 * 8;  // upper bound on workgroups x 8 waves
+            unsigned long long* dstp; CK(hipMalloc(&dstp, nw * 64)); CK(hipMemset(dstp, 0, nw * 64));
+            g_strip_stamps = dstp;
+            launch_strip_pipe(pv.data(), nb, s); CK(hipStreamSynchronize(s));
+            g_strip_stamps = nullptr;
+            std::vector<unsigned long long> h(nw * 8);
+            CK(hipMemcpy(h.data(), dstp, nw * 64, hipMemcpyDeviceToHost));
+            char lb[96];
+            printf("stamps %s: ticks per step per wave [compute | barrier 1 | hand-over / store | barrier 2]\n", strip_pipe_label(pv.data(), nb, lb, sizeof lb));
+            for (int w = 0; w < 8; w++) {
+                double acc[4] = {0, 0, 0, 0}, steps = 0; size_t cnt = 0;
+                for (size_t g = 0; g < nw / 8; g++) { const unsigned long long* d = &h[(g * 8 + w) * 8]; if (!d[4]) continue; cnt++; steps += d[4]; for (int k = 0; k < 4; k++) acc[k] += d[k]; }
+                if (!cnt) continue;
+                printf("  wave %d (block %d): %7.0f | %7.0f | %7.0f | %7.0f   total %7.0f per step, %d steps, %zu waves\n", w, w / 2, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps,
+                       (acc[0] + acc[1] + acc[2] + acc[3]) / steps, (int)(steps / cnt), cnt);
+            }
+            CK(hipFree(dstp));
+        }
+#endif
         return nbad ? 2 : 0;
     }
 #ifdef MI_STRIP_STAMPS
