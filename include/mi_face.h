@@ -157,6 +157,26 @@ int mi_fd_postprocess(mi_fd *h, const float *raw_boxes, const float *raw_scores,
 int mi_fd_infer_image(mi_fd *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
                       mi_detection *out, int cap, int *count);
 
+/* Batched FaceDetection::infer(&Mat, Option<Rect>) — face_detection.rs:205-267 over `batch` equally sized 8UC3 RGB frames
+ * (utils.rs:8-21; rows of `stride` bytes, frames `stride*height` bytes apart): image_to_tensor(frame, roi, (w,h),
+ * keep_aspect_ratio = true, (-1,1)) with the u8 -> f32 loop of transform.rs:292-301 on the device, the network, decode +
+ * sigmoid + weighted NMS, letterbox removal — one call, no f32 frames cross the bus (a 256x256 frame is 196 KB instead
+ * of 786 KB).  rois NULL (whole frames) or [batch]; frames / rois / out / counts follow `mem`; out / counts as for
+ * mi_fd_infer_tensor. */
+int mi_fd_infer_images(mi_fd *h, const uint8_t *frames, int batch, int width, int height, int stride, const mi_rect *rois,
+                       mi_detection *out, int cap_per_frame, int *counts, int mem, void *stream);
+/* The same for a host feed, split in two so that the copy of one batch overlaps the kernels of the other: submit queues
+ * H2D copy (on the slot's own stream), pre-processing, network, post-processing and the copy of the results into pinned
+ * memory and returns; collect waits for that slot and hands the results out.  Two slots (0 / 1); a slot must be collected
+ * before it is submitted again; `frames` must stay valid until then and should be pinned (mi_host_alloc) — a pageable
+ * buffer is copied synchronously by the runtime.  Whole frames (roi = None). */
+int mi_fd_submit_images(mi_fd *h, int slot, const uint8_t *frames, int batch, int width, int height, int stride,
+                        int cap_per_frame);
+int mi_fd_collect(mi_fd *h, int slot, mi_detection *out, int *counts);
+/* Page-locked host memory for frames handed to mi_fd_submit_images (hipHostMalloc / hipHostFree). */
+int mi_host_alloc(size_t bytes, void **out);
+void mi_host_free(void *p);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * L1 — FaceLandmark (face_landmark.rs:200-306)
  * ---------------------------------------------------------------------------------------------------------------- */

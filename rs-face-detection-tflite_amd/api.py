@@ -32,7 +32,8 @@ EXPORTS = [
     "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
     "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
-    "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image",
+    "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
+    "mi_fd_collect", "mi_host_alloc", "mi_host_free",
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
     "mi_iris_infer_image",
@@ -157,6 +158,12 @@ def lib():
     L.mi_fd_anchors.argtypes = [vp, fp, C.c_int]
     L.mi_fd_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]
     L.mi_fd_postprocess.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]
+    L.mi_fd_infer_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]
+    L.mi_fd_submit_images.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mi_fd_collect.argtypes = [vp, C.c_int, vp, vp]
+    L.mi_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.mi_host_free.argtypes = [vp]
+    L.mi_host_free.restype = None
     L.mi_fd_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(CDetection), C.c_int, ip]
     L.mi_fl_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.mi_fl_create_from_bytes.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
@@ -340,6 +347,29 @@ def _image_args(image):
     return image, w, h, image.strides[0]
 
 
+class PinnedBuffer:
+    """Page-locked host memory (mi_host_alloc) viewed as a numpy array; freed with the object."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.L = lib()
+        self.ptr = C.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _check(self.L.mi_host_alloc(n, C.byref(self.ptr)))
+        self.array = np.frombuffer((C.c_char * n).from_address(self.ptr.value), dtype=dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None) and self.ptr.value:
+            self.array = None
+            self.L.mi_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class FaceDetection:
     """BlazeFace detector — mirrors face_detection.rs:146-267."""
 
@@ -411,6 +441,52 @@ class FaceDetection:
                 padding = np.ascontiguousarray(padding, np.float64).reshape(B, 4)
             pp = C.c_void_p(padding.ctypes.data) if padding is not None else None
         _check(self.L.mi_fd_infer_tensor(self.h, p, B, pp, _ptr(out)[0], cap, _ptr(counts)[0], mem, C.c_void_p(stream or 0)))
+        return out, counts
+
+    def infer_images(self, frames, rois=None, cap=64, out=None, counts=None, stream=None):
+        """Batched FaceDetection::infer on u8 RGB frames [B,H,W,3] (numpy, or a torch CUDA uint8 tensor): device-side
+        image_to_tensor + network + post-processing in one call.  rois: None or a sequence of B Rect (host frames only).
+        Returns (detections [B,cap,17] f32, counts [B] i32) in the memory space of `frames`."""
+        p, mem = _ptr(frames)
+        B, H, W = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        if mem == MI_MEM_DEVICE:
+            import torch
+            if frames.dtype != torch.uint8 or not frames.is_contiguous() or frames.shape[3] != 3:
+                raise ValueError("frames must be a contiguous uint8 [B,H,W,3] tensor")
+            if rois is not None:
+                raise ValueError("rois are host-side only here")
+            stride = 3 * W
+            out = torch.zeros((B, cap, 17), dtype=torch.float32, device=frames.device) if out is None else out
+            counts = torch.zeros((B,), dtype=torch.int32, device=frames.device) if counts is None else counts
+            rp = None
+            _device_ready(frames, self.device, None, dtype="uint8")
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            if frames.ndim != 4 or frames.shape[3] != 3:
+                raise ValueError("frames must be uint8 [B,H,W,3]")
+            p, stride = C.c_void_p(frames.ctypes.data), frames.strides[1]
+            out = np.zeros((B, cap, 17), np.float32) if out is None else out
+            counts = np.zeros((B,), np.int32) if counts is None else counts
+            rarr = (Rect * B)(*rois) if rois is not None else None
+            rp = C.cast(rarr, C.c_void_p) if rarr is not None else None
+        _check(self.L.mi_fd_infer_images(self.h, p, B, W, H, stride, rp, _ptr(out)[0], cap, _ptr(counts)[0], mem, C.c_void_p(stream or 0)))
+        return out, counts
+
+    def submit_images(self, slot, frames, cap=64):
+        """Queues one batch of host frames (numpy uint8 [B,H,W,3]; pinned — `pinned_frames()` — for the copy to overlap the other
+        slot's kernels) and returns at once; `collect(slot)` hands the results out."""
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3 or not frames.flags["C_CONTIGUOUS"]:
+            raise ValueError("frames must be a C-contiguous uint8 [B,H,W,3] array")
+        B, H, W = frames.shape[:3]
+        _check(self.L.mi_fd_submit_images(self.h, slot, C.c_void_p(frames.ctypes.data), B, W, H, frames.strides[1], cap))
+        self._slot_shape = getattr(self, "_slot_shape", {})
+        self._slot_shape[slot] = (B, cap, frames)   # keeps the frames alive until collect()
+
+    def collect(self, slot):
+        B, cap, _ = self._slot_shape.pop(slot)
+        out = np.zeros((B, cap, 17), np.float32)
+        counts = np.zeros((B,), np.int32)
+        _check(self.L.mi_fd_collect(self.h, slot, C.c_void_p(out.ctypes.data), C.c_void_p(counts.ctypes.data)))
         return out, counts
 
     def postprocess(self, raw_boxes, raw_scores, padding=None, cap=64):

@@ -120,14 +120,36 @@ struct Use {
 };
 }  // namespace
 
+// One of the two slots of the host-fed batch form (mi_fd_submit_images / mi_fd_collect): its own copy stream, device frames
+// and results, pinned host results.  The network itself runs on the handle's stream (one arena per handle), so the copies
+// of one slot overlap the kernels of the other.
+struct FdSlot {
+    hipStream_t copy = nullptr;
+    hipEvent_t copied = nullptr, done = nullptr;
+    DeviceBuf d_frames, d_pad;
+    void* h_out = nullptr;      // pinned + mapped: [batch][cap] detections, then [batch] counts (written by the post-processing kernel)
+    size_t h_cap = 0;
+    int batch = 0, cap = 0;
+    bool pending = false;
+    ~FdSlot() {
+        if (copy) hipStreamDestroy(copy);
+        if (copied) hipEventDestroy(copied);
+        if (done) hipEventDestroy(done);
+        if (h_out) hipHostFree(h_out);
+    }
+};
+
 struct mi_fd {
     mi_model model;
     int kind = 0, in_w = 0, in_h = 0, n_anchors = 0;
     std::vector<float> anchors;
     float* d_anchors = nullptr;
-    DeviceBuf d_in, d_pad, d_out, d_counts, d_img;
+    float* d_lut = nullptr;  // u8 -> f32 in (-1, 1), 256 entries (frames of the network's own size feed the first convolution as bytes)
+    DeviceBuf d_in, d_pad, d_out, d_counts, d_img, d_geom, d_roi;
+    FdSlot slot[2];
     ~mi_fd() {
         if (d_anchors) hipFree(d_anchors);
+        if (d_lut) hipFree(d_lut);
     }
 };
 
@@ -464,6 +486,159 @@ int mi_fd_infer_image(mi_fd* h, const uint8_t* rgb, int width, int height, int s
         m.run_device(d_t, 1, s);
         fd_post(h, m.output_device(0), m.output_device(1), 1, pad, out, cap, count, MI_MEM_HOST, s);
     });
+}
+
+// image_to_tensor(frame, roi, (w,h), keep_aspect_ratio = true, (-1,1)) for a batch of frames already in device memory, then the
+// network and the post-processing into device buffers (face_detection.rs:219-265).  d_rois: device [batch] or null.
+static void fd_images_device(mi_fd* h, const uint8_t* d_frames, int batch, int width, int height, int stride, const mi::RectD* d_rois,
+                             double* d_pad, mi_detection* d_out, int cap, int* d_counts, hipStream_t s) {
+    mi::Model& m = *h->model.m;
+    static const bool no_u8_stem = getenv("MI_NO_U8_STEM") != nullptr;  // tuning aid: always through the f32 tensor
+    if (!d_rois && width == h->in_w && height == h->in_h && !no_u8_stem && m.takes_u8_input()) {
+        // Frames of exactly the network's input size: image_to_tensor is the u8 -> f32 loop alone (transform.rs:292-301, no warp, no
+        // letterbox, padding 0), and that loop is a 256-entry table inside the first convolution's tile load: no f32 copy of the frames
+        if (!h->d_lut) {
+            float lut[256];
+            const double k = 1.0 - (-1.0);
+            for (int v = 0; v < 256; v++) lut[v] = static_cast<float>(static_cast<double>(v) * k / 255.0 + (-1.0));
+            mi::hip_check(hipMalloc(reinterpret_cast<void**>(&h->d_lut), sizeof lut), "hipMalloc lut");
+            mi::hip_check(hipMemcpy(h->d_lut, lut, sizeof lut, hipMemcpyHostToDevice), "H2D lut");
+        }
+        m.run_device_u8(d_frames, static_cast<long>(stride) * height, stride, h->d_lut, batch, s);
+        fd_post(h, m.output_device(0), m.output_device(1), batch, nullptr, d_out, cap, d_counts, MI_MEM_DEVICE, s);
+        return;
+    }
+    mi::PreItems it{};
+    it.frames = d_frames; it.frame_bytes = static_cast<long>(stride) * height; it.width = width; it.height = height; it.stride = stride;
+    it.rois = d_rois; it.items_per_frame = 1; it.N = batch; it.out_w = h->in_w; it.out_h = h->in_h; it.keep_aspect = 1;
+    it.range_min = -1.0; it.range_max = 1.0;
+    auto* d_geom = static_cast<mi::PreGeom*>(h->d_geom.get(sizeof(mi::PreGeom) * batch));
+    float* d_in = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float) * batch));
+    mi::launch_pre_geom(it, d_geom, d_pad, s);
+    mi::launch_pre_tensor(it, d_geom, d_in, s);
+    m.run_device(d_in, batch, s);
+    fd_post(h, m.output_device(0), m.output_device(1), batch, d_pad, d_out, cap, d_counts, MI_MEM_DEVICE, s);
+}
+
+static size_t frames_bytes(int batch, int width, int height, int stride) {
+    // the last frame's last row owns 3 * width bytes, not a whole stride
+    return static_cast<size_t>(stride) * height * (batch - 1) + static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width;
+}
+
+int mi_fd_infer_images(mi_fd* h, const uint8_t* frames, int batch, int width, int height, int stride, const mi_rect* rois, mi_detection* out,
+                       int cap_per_frame, int* counts, int mem, void* stream) {
+    return guarded([&] {
+        require(h && frames && out && counts, "null argument");
+        require(batch > 0 && cap_per_frame > 0 && width > 0 && height > 0 && stride >= 3 * width, "bad frame geometry");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
+        const uint8_t* d_frames = frames;
+        const mi::RectD* d_rois = nullptr;
+        static_assert(sizeof(mi::RectD) == sizeof(mi_rect), "mi_rect and RectD must have one layout");
+        if (mem == MI_MEM_HOST) {
+            d_frames = static_cast<const uint8_t*>(h->d_img.get(static_cast<size_t>(stride) * height * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, frames_bytes(batch, width, height, stride), hipMemcpyHostToDevice, s), "H2D frames");
+            if (rois) {
+                d_rois = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect) * batch));
+                mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_rois), rois, sizeof(mi_rect) * batch, hipMemcpyHostToDevice, s), "H2D rois");
+            }
+        } else {
+            d_rois = reinterpret_cast<const mi::RectD*>(rois);
+        }
+        double* d_pad = static_cast<double*>(h->d_pad.get(sizeof(double) * 4 * batch));
+        if (mem == MI_MEM_DEVICE) {
+            fd_images_device(h, d_frames, batch, width, height, stride, d_rois, d_pad, out, cap_per_frame, counts, s);
+            if (!stream) mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+            return;
+        }
+        const size_t nout = sizeof(mi_detection) * static_cast<size_t>(cap_per_frame) * batch;
+        auto* d_out = static_cast<mi_detection*>(h->d_out.get(nout));
+        int* d_counts = static_cast<int*>(h->d_counts.get(sizeof(int) * batch));
+        mi::hip_check(hipMemsetAsync(d_out, 0, nout, s), "hipMemsetAsync");  // unused slots of the caller's buffer read as zeros
+        fd_images_device(h, d_frames, batch, width, height, stride, d_rois, d_pad, d_out, cap_per_frame, d_counts, s);
+        mi::hip_check(hipMemcpyAsync(out, d_out, nout, hipMemcpyDeviceToHost, s), "D2H detections");
+        mi::hip_check(hipMemcpyAsync(counts, d_counts, sizeof(int) * batch, hipMemcpyDeviceToHost, s), "D2H counts");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        for (int b = 0; b < batch; b++)
+            if (counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
+    });
+}
+
+int mi_fd_submit_images(mi_fd* h, int slot, const uint8_t* frames, int batch, int width, int height, int stride, int cap_per_frame) {
+    return guarded([&] {
+        require(h && frames, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        require(batch > 0 && cap_per_frame > 0 && width > 0 && height > 0 && stride >= 3 * width, "bad frame geometry");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = m.stream();
+        Use use(h->model, s);
+        FdSlot& sl = h->slot[slot];
+        if (sl.pending) throw ApiError(MI_EINVAL, "slot still holds an uncollected batch (call mi_fd_collect first)");
+        if (!sl.copy) mi::hip_check(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking), "hipStreamCreate");
+        if (!sl.copied) mi::hip_check(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate");
+        if (!sl.done) mi::hip_check(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate");
+        const size_t nout = sizeof(mi_detection) * static_cast<size_t>(cap_per_frame) * batch, ncnt = sizeof(int) * batch;
+        if (nout + ncnt > sl.h_cap) {
+            if (sl.h_out) hipHostFree(sl.h_out);
+            sl.h_out = nullptr; sl.h_cap = 0;
+            mi::hip_check(hipHostMalloc(&sl.h_out, nout + ncnt, hipHostMallocMapped), "hipHostMalloc");
+            sl.h_cap = nout + ncnt;
+        }
+        // frames: host -> device on the slot's copy stream (asynchronous when `frames` is pinned memory: mi_host_alloc);
+        // everything else on the handle's stream, behind the copy
+        // frames: host -> device on the slot's copy stream (asynchronous when `frames` is pinned memory: mi_host_alloc);
+        // everything else on the handle's stream, behind the copy.  The post-processing kernel writes detections and counts
+        // straight into the slot's pinned host block (mapped into the device's address space): a hipMemcpyAsync of the results
+        // blocked the host for whole batches on this runtime (measured: every third call, 7 ms).
+        auto* d_frames = static_cast<uint8_t*>(sl.d_frames.get(static_cast<size_t>(stride) * height * batch));
+        mi::hip_check(hipMemcpyAsync(d_frames, frames, frames_bytes(batch, width, height, stride), hipMemcpyHostToDevice, sl.copy), "H2D frames");
+        mi::hip_check(hipEventRecord(sl.copied, sl.copy), "hipEventRecord");
+        mi::hip_check(hipStreamWaitEvent(s, sl.copied, 0), "hipStreamWaitEvent");
+        std::memset(sl.h_out, 0, nout + ncnt);  // slots beyond a frame's count read as zeros (the slot was collected: nothing in flight writes here)
+        void* mapped = nullptr;
+        mi::hip_check(hipHostGetDevicePointer(&mapped, sl.h_out, 0), "hipHostGetDevicePointer");
+        double* d_pad = static_cast<double*>(sl.d_pad.get(sizeof(double) * 4 * batch));
+        fd_images_device(h, d_frames, batch, width, height, stride, nullptr, d_pad, static_cast<mi_detection*>(mapped), cap_per_frame,
+                         reinterpret_cast<int*>(static_cast<char*>(mapped) + nout), s);
+        mi::hip_check(hipEventRecord(sl.done, s), "hipEventRecord");
+        sl.batch = batch; sl.cap = cap_per_frame; sl.pending = true;
+    });
+}
+
+int mi_fd_collect(mi_fd* h, int slot, mi_detection* out, int* counts) {
+    return guarded([&] {
+        require(h && out && counts, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        FdSlot& sl = h->slot[slot];
+        {
+            std::lock_guard<std::mutex> g(h->model.mu);
+            if (!sl.pending) throw ApiError(MI_EINVAL, "nothing was submitted to this slot");
+        }
+        mi::hip_check(hipSetDevice(h->model.m->device()), "hipSetDevice");
+        mi::hip_check(hipEventSynchronize(sl.done), "hipEventSynchronize");
+        std::lock_guard<std::mutex> g(h->model.mu);
+        const size_t nout = sizeof(mi_detection) * static_cast<size_t>(sl.cap) * sl.batch;
+        std::memcpy(out, sl.h_out, nout);
+        std::memcpy(counts, static_cast<char*>(sl.h_out) + nout, sizeof(int) * sl.batch);
+        sl.pending = false;
+        for (int b = 0; b < sl.batch; b++)
+            if (counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
+    });
+}
+
+int mi_host_alloc(size_t bytes, void** out) {
+    return guarded([&] {
+        require(out && bytes > 0, "null argument");
+        *out = nullptr;
+        mi::hip_check(hipHostMalloc(out, bytes, hipHostMallocDefault), "hipHostMalloc");
+    });
+}
+void mi_host_free(void* p) {
+    if (p) hipHostFree(p);
 }
 
 // ------------------------------------------------------------------------------------------------ FaceLandmark

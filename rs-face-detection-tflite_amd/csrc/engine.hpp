@@ -41,6 +41,11 @@ class Model {
     void run(const float* in, int batch, float* const* outs, int mem, hipStream_t stream);
     float* output_device(int i) const { return d_out_.at(i); }
     hipStream_t stream() const { return stream_; }
+    // u8 frames as the graph input (8UC3 rows of row_bytes bytes, frames frame_bytes apart, exactly the input size of the graph):
+    // possible when the graph input is read by one node only and that node is the specialised stem convolution, which then
+    // normalises a byte through `lut` (device, 256 floats) while it fills its tile.  run_device with bytes instead of floats.
+    bool takes_u8_input();
+    void run_device_u8(const uint8_t* frames, long frame_bytes, int row_bytes, const float* lut, int batch, hipStream_t stream);
 
     // Per-launch timing with HIP events on the stream the kernels are launched on (eager launches, whole batch in one
     // chunk layout as configured). Returns one record per launch: kernel label, avg milliseconds, algorithmic bytes
@@ -104,10 +109,24 @@ class Model {
 
     hipStream_t stream_ = nullptr;
     struct GraphKey {
-        const float* in;
+        const void* in;
         int batch;
-        bool operator<(const GraphKey& o) const { return in != o.in ? in < o.in : batch < o.batch; }
+        long u8_frame_bytes;  // 0: f32 input
+        int u8_row_bytes;
+        bool operator<(const GraphKey& o) const {
+            if (in != o.in) return in < o.in;
+            if (batch != o.batch) return batch < o.batch;
+            if (u8_frame_bytes != o.u8_frame_bytes) return u8_frame_bytes < o.u8_frame_bytes;
+            return u8_row_bytes < o.u8_row_bytes;
+        }
     };
+    struct U8Input {  // set by run_device_u8 for the duration of the enqueue
+        const uint8_t* frames = nullptr;
+        const float* lut = nullptr;
+        long frame_bytes = 0;
+        int row_bytes = 0;
+    } u8_;
+    void run_graph_or_eager(const float* in, int batch, hipStream_t s, const GraphKey& key);
     std::map<GraphKey, hipGraphExec_t> graphs_;
 };
 

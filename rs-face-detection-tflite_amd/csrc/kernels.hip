@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void pw_few_kernel(ConvArgs a) {
 // One thread = one output pixel x all CO channels: the K*K*3 filter taps are wave-uniform, so the weights travel
 // through the scalar cache into SGPR operands of v_fmac and every VALU lane does useful work; the input patch comes
 // from an LDS tile (zero padded, TF SAME), staged with coalesced row-segment loads.  Output 16 B stores.
-template <int K, int CO>
+// U8: the input is 8UC3 frames (rows of u8_row_bytes bytes); a byte is normalised through a 256-entry table while the tile is filled.
+template <int K, int CO, bool U8 = false>
 __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     // PP output pixels per thread (rows ly and ly + 8): every scalar-loaded weight pair then feeds PP packed FMAs, which
     // halves the scalar-cache round trips per FMA (they, not the VALU, set the pace at one pixel per thread)
@@ -182,10 +183,22 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     const int e_col = min(tid, ROWF - 1);
     const int ix = ix0 + e_col / 3;
     const bool x_ok = tid < ROWF && ix >= 0 && ix < a.W;
-    const float* colp = in + (long)min(max(ix, 0), a.W - 1) * 3 + (e_col - (e_col / 3) * 3);
     float stage[IH];
+    if constexpr (U8) {
+        __shared__ float lut[256];
+        lut[tid] = a.u8_lut[tid];
+        const uint8_t* colb = a.in_u8 + (long)b * a.u8_frame_bytes + (long)min(max(ix, 0), a.W - 1) * 3 + (e_col - (e_col / 3) * 3);
+        unsigned char raw[IH];
 #pragma unroll
-    for (int r = 0; r < IH; r++) stage[r] = colp[(long)min(max(iy0 + r, 0), a.H - 1) * a.W * 3];   // iy0 + r is wave-uniform
+        for (int r = 0; r < IH; r++) raw[r] = colb[(long)min(max(iy0 + r, 0), a.H - 1) * a.u8_row_bytes];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IH; r++) stage[r] = lut[raw[r]];
+    } else {
+        const float* colp = in + (long)min(max(ix, 0), a.W - 1) * 3 + (e_col - (e_col / 3) * 3);
+#pragma unroll
+        for (int r = 0; r < IH; r++) stage[r] = colp[(long)min(max(iy0 + r, 0), a.H - 1) * a.W * 3];   // iy0 + r is wave-uniform
+    }
     if (tid < ROWF) {
 #pragma unroll
         for (int r = 0; r < IH; r++) {
@@ -274,7 +287,8 @@ template <int K, int CO>
 static int launch_stem(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 16;  // rows of a tile (two output pixels per thread)
     unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + TH - 1) / TH));
-    return (int)launch_kernel(stem_conv_kernel<K, CO>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
+    if (a.in_u8) return (int)launch_kernel(stem_conv_kernel<K, CO, true>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
+    return (int)launch_kernel(stem_conv_kernel<K, CO, false>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
 }
 
 // true when (and how) the specialised stem kernel takes this convolution
@@ -288,6 +302,7 @@ static bool pw_few_applicable(const ConvArgs& a) {
     return a.KH == 1 && a.KW == 1 && a.sh == 1 && a.sw == 1 && a.Cop == 4 && a.C % 4 == 0 && a.H == a.Ho && a.W == a.Wo && (a.in_fs & 3) == 0 &&
            (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
 }
+bool conv_takes_u8(const ConvArgs& a) { return stem_applicable(a); }
 const char* conv_kernel_label(const ConvArgs& a) { return stem_applicable(a) ? "stem_conv_kernel" : (pw_few_applicable(a) ? "pw_few_kernel" : "conv_generic_kernel"); }
 
 int launch_conv(const ConvArgs& a, void* stream) {

@@ -30,6 +30,12 @@ struct Epilogue {
 
 struct ConvArgs {
     const float* in = nullptr;
+    // u8 input (the stem of a detector fed with 8UC3 frames, transform.rs:292-301 folded into the tile load): in_u8 != null replaces `in`;
+    // a value v becomes u8_lut[v] = (f32)((f64)v * (max - min) / 255 + min), the 256 results computed on the host with that expression
+    const uint8_t* in_u8 = nullptr;
+    const float* u8_lut = nullptr;
+    long u8_frame_bytes = 0;
+    int u8_row_bytes = 0;
     const float* w = nullptr;   // [KH][KW][C][Cop]   (Cop = Co rounded up to 4, zero padded)
     float* out = nullptr;
     long in_fs = 0, out_fs = 0;
@@ -241,6 +247,7 @@ constexpr int kResConstMax = 5120;               // most constants a stage may h
 // ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).
 int launch_conv(const ConvArgs& a, void* stream);
 const char* conv_kernel_label(const ConvArgs& a);
+bool conv_takes_u8(const ConvArgs& a);  // the specialised stem kernel: the only convolution with a u8 input form
 int launch_dw(const DwArgs& a, void* stream);
 int launch_block(const BlockArgs& a, void* stream);
 bool block_kernel_supports(const BlockArgs& a);

@@ -101,23 +101,23 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
         const char* src = reinterpret_cast<const char*>(in + ((long)min(max(r, 0), a.H - 1) * W + x0) * C);
         const unsigned dstb = lds_x + (unsigned)((slot * XIMG_F + (1 + x0) * PS) * 4);
         unsigned long long saved;
-#define MI_MDB_DMA(k) "s_add_u32 m0, m0, %5\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
+#define MI_MDB_DMA(k) "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
         if constexpr (NLD == 8) {
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
-                         "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
                          MI_MDB_DMA(1) MI_MDB_DMA(2) MI_MDB_DMA(3) MI_MDB_DMA(4) MI_MDB_DMA(5) MI_MDB_DMA(6) MI_MDB_DMA(7)
                          "s_mov_b64 exec, %0"
                          : "=&s"(saved)
                          : "s"(src), "v"(goff), "s"(dstb), "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
-                         : "memory", "scc");
+                         : "memory", "scc", "m0");
         } else {
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
-                         "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
                          MI_MDB_DMA(1) MI_MDB_DMA(2) MI_MDB_DMA(3)
                          "s_mov_b64 exec, %0"
                          : "=&s"(saved)
                          : "s"(src), "v"(goff), "s"(dstb), "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
-                         : "memory", "scc");
+                         : "memory", "scc", "m0");
         }
 #undef MI_MDB_DMA
     };
@@ -374,14 +374,14 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void mbneck_kernel(MdbArgs 
         const char* src = reinterpret_cast<const char*>(in + ((long)min(max(r, 0), a.H - 1) * W + x0) * C);
         const unsigned dstb = lds_x + (unsigned)((slot * XIMG_F + (1 + x0) * PS) * 4);
         unsigned long long saved;
-#define MI_MDB_DMA(k) "s_add_u32 m0, m0, %5\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
+#define MI_MDB_DMA(k) "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
-                     "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                     "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
                      MI_MDB_DMA(1) MI_MDB_DMA(2) MI_MDB_DMA(3) MI_MDB_DMA(4) MI_MDB_DMA(5) MI_MDB_DMA(6) MI_MDB_DMA(7)
                      "s_mov_b64 exec, %0"
                      : "=&s"(saved)
                      : "s"(src), "v"(goff), "s"(dstb), "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
-                     : "memory", "scc");
+                     : "memory", "scc", "m0");
 #undef MI_MDB_DMA
     };
     auto fix_row = [&](int r, int slot) {

@@ -159,14 +159,14 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void ms2_kernel(Ms2Args a) 
         unsigned dstb = lds_img + (unsigned)((slot * IMG_F + 2 * xo0 * PS) * 4);
         for (int gi = 0; gi < ngrp; gi++) {   // wave-uniform
             unsigned long long saved;
-#define MI_MS2_DMA(k) "s_add_u32 m0, m0, %5\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
+#define MI_MS2_DMA(k) "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1 offset:" #k "*%6\n\t"
             asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %4\n\t"
-                         "s_mov_b32 m0, %3\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %1\n\t"
                          MI_MS2_DMA(1) MI_MS2_DMA(2) MI_MS2_DMA(3)
                          "s_mov_b64 exec, %0"
                          : "=&s"(saved)
                          : "s"(src), "v"(goff), "s"(dstb), "n"(K::ACTIVE == 64 ? 0xffffffffu : ((1u << (K::ACTIVE - 32)) - 1)), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
-                         : "memory", "scc");
+                         : "memory", "scc", "m0");
 #undef MI_MS2_DMA
             src += 4 * K::DPX * C * 4;
             dstb += 4 * K::DPX * PS * 4;

@@ -93,17 +93,17 @@ __global__ __launch_bounds__(256, 2) void mwalk_kernel(MwalkArgs a) {
         const char* src1 = src + (NLD / 2) * K::DPX * C * 4;
         const unsigned dstb = lds_img + (unsigned)((bi * IMG_F + PS) * 4);
         unsigned long long saved;
-#define MI_MW_DMA(base, k) "s_add_u32 m0, m0, %7\n\tglobal_load_lds_dwordx4 %3, " base " offset:" #k "*%8\n\t"
+#define MI_MW_DMA(base, k) "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, " base " offset:" #k "*%8\n\t"
         asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, -1\n\ts_mov_b32 exec_hi, %6\n\t"
-                     "s_mov_b32 m0, %4\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
                      MI_MW_DMA("%1", 1) MI_MW_DMA("%1", 2) MI_MW_DMA("%1", 3)
-                     "s_add_u32 m0, m0, %5\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
+                     "s_add_u32 m0, m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %2\n\t"
                      MI_MW_DMA("%2", 1) MI_MW_DMA("%2", 2) MI_MW_DMA("%2", 3)
                      "s_mov_b64 exec, %0"
                      : "=&s"(saved)
                      : "s"(src), "s"(src1), "v"(goff), "s"(dstb), "n"((NLD / 2) * K::DPX * PS * 4 - (NLD / 2 - 1) * K::DPX * (PS - C) * 4),
                        "n"((1u << (K::ACTIVE - 32)) - 1), "n"(K::DPX * (PS - C) * 4), "n"(K::DPX * C * 4)
-                     : "memory", "scc");
+                     : "memory", "scc", "m0");
 #undef MI_MW_DMA
     };
     // rows outside the image are zero padding: the landed (clamped) row is cleared before it is read

@@ -691,11 +691,11 @@ __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             if (k < NL - 1 || TAIL == 64) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory", "m0");
             } else {
                 unsigned long long saved;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
-                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory", "m0");
             }
         }
     };
@@ -877,11 +877,11 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             if (k < NL - 1 || TAIL == 64) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory", "m0");
             } else {
                 unsigned long long saved;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
-                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory", "m0");
             }
         }
     };
@@ -1099,11 +1099,11 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             if (k < NL - 1 || TAIL == 64) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory", "m0");
             } else {
                 unsigned long long saved;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
-                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory", "m0");
             }
         }
     };
@@ -1365,11 +1365,11 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
 #pragma unroll
         for (int k = 0; k < NL; k++) {
             if (k < NL - 1 || TAIL == 64) {
-                asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory", "m0");
             } else {
                 unsigned long long saved;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
-                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory");
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory", "m0");
             }
         }
     };

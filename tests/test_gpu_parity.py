@@ -420,6 +420,105 @@ def test_detector_on_man_jpg_vs_oracle(gpu, oracle, man_image, kind, name):
     fd.close()
 
 
+def test_fd_infer_images_batch_vs_oracle_and_tensor_path(gpu, oracle, gold, man_image):
+    """Batched u8 detector entry (mi_fd_infer_images; FaceDetection::infer over a batch of Mats, face_detection.rs:205-267 with the
+    u8 -> f32 loop of transform.rs:292-301 on the device).  (a) 256 model-size frames (8 distinct u8 frames x 32, shuffled): copies
+    bit-equal, the result equal to the tensor entry fed with the ORACLE's image_to_tensor of the same frames (device pre-processing is
+    bit-exact, so the two paths must agree bit for bit), the 8 originals against the oracle's whole call.  (b) frames of another size
+    (man.jpg, letterboxed) with one ROI per frame — the 26-ROI style set of test_image_to_tensor_vs_oracle — against the oracle
+    detection by detection.  (c) device frames (torch uint8) equal host frames."""
+    torch = pytest.importorskip("torch")
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    rs = np.random.RandomState(31)
+    face = gold["man_back_u8"].astype(np.uint8)
+    base = np.stack([face, face[:, ::-1].copy(), np.roll(face, (28, -21), axis=(0, 1)), (face * 0.8).astype(np.uint8)] +
+                    [rs.randint(0, 256, face.shape).astype(np.uint8) for _ in range(4)])
+    order = rs.permutation(256) % 8
+    frames = np.ascontiguousarray(base[order])
+    out, counts = fd.infer_images(frames, cap=16)
+    first = {int(k): int(np.where(order == k)[0][0]) for k in range(8)}
+    for i in range(256):
+        j = first[int(order[i])]
+        assert counts[i] == counts[j]
+        np.testing.assert_array_equal(out[i, : counts[i]], out[j, : counts[j]])
+    tens = np.stack([oracle.image_to_tensor(b, None, (256, 256), True, (-1., 1.), False)[0] for b in base])
+    out_t, counts_t = fd.infer_tensor(np.ascontiguousarray(tens[order]), cap=16)
+    np.testing.assert_array_equal(counts, counts_t)
+    np.testing.assert_array_equal(out, out_t)
+    om = oracle.Model(model_path("back"))
+    rb, rsc = om.run(tens, nthreads=8)
+    anchors = oracle.ssd_anchors(oracle.FD_BACK)
+    found = 0
+    for k in range(8):
+        want = oracle.fd_postprocess(rb[k], rsc[k], anchors, 256.0)
+        j = first[k]
+        assert counts[j] == len(want)
+        if len(want):
+            np.testing.assert_allclose(out[j, : len(want)], want, atol=2e-5)
+            found += 1
+    assert found >= 3
+    # (c) the same frames already in device memory
+    out_d, counts_d = fd.infer_images(torch.from_numpy(frames).cuda(), cap=16)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out_d.cpu().numpy(), out)
+    np.testing.assert_array_equal(counts_d.cpu().numpy(), counts)
+    # (b) another frame size, one ROI per frame
+    rois = [None, np.array([0.5, 0.5, 0.9, 0.9, 0.0, 1]), np.array([300.0, 150.0, 333.0, 217.0, -0.7, 0]), np.array([0.5, 0.4, 0.6, 0.7, 0.3, 1]),
+            np.array([0.05, 0.1, 0.5, 0.45, 2.4, 1])]
+    for k in range(8):
+        rois.append(np.array([rs.uniform(0.3, 0.7), rs.uniform(0.3, 0.7), rs.uniform(0.3, 0.9), rs.uniform(0.3, 0.9), rs.uniform(-3.1, 3.1), 1]))
+    H, W = man_image.shape[:2]
+    full = np.array([0.5, 0.5, 1.0, 1.0, 0.0, 1])
+    batch = np.ascontiguousarray(np.stack([man_image] * len(rois)))
+    grects = [gpu.Rect(*[float(v) for v in (r if r is not None else full)[:5]], int((r if r is not None else full)[5])) for r in rois]
+    out_r, counts_r = fd.infer_images(batch, rois=grects, cap=16)
+    for k, r in enumerate(rois):
+        o = oracle.Rect(*[float(v) for v in r[:5]], int(r[5])) if r is not None else oracle.Rect(0.5, 0.5, 1.0, 1.0, 0.0, 1)
+        t, pad = oracle.image_to_tensor(man_image, o, (256, 256), True, (-1., 1.), False)
+        rbk, rsk = om.run(t[None])
+        want = oracle.fd_postprocess(rbk[0], rsk[0], anchors, 256.0, pad)
+        assert counts_r[k] == len(want), (k, counts_r[k], len(want))
+        if len(want):
+            np.testing.assert_allclose(out_r[k, : len(want)], want, atol=2e-5)
+    assert counts_r[0] >= 1
+    fd.close()
+
+
+def test_fd_submit_collect_two_slots(gpu, gold):
+    """Host feed in two slots (mi_fd_submit_images / mi_fd_collect): four batches of pinned u8 frames alternate between the slots, the
+    copy of one overlapping the kernels of the other; every batch equals the synchronous entry's result.  A slot cannot be submitted
+    twice without a collect, nor collected when empty."""
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    rs = np.random.RandomState(5)
+    face = gold["man_back_u8"].astype(np.uint8)
+    pins = [gpu.PinnedBuffer((48, 256, 256, 3)) for _ in range(2)]
+    batches = []
+    for b in range(4):
+        fr = np.stack([np.roll(face, (int(rs.randint(-30, 30)), int(rs.randint(-30, 30))), axis=(0, 1)) if i % 3 else rs.randint(0, 256, face.shape).astype(np.uint8)
+                       for i in range(48)])
+        batches.append(fr)
+    want = [fd.infer_images(fr, cap=8) for fr in batches]
+    got = [None] * 4
+    pins[0].array[...] = batches[0]
+    fd.submit_images(0, pins[0].array, cap=8)
+    with pytest.raises(gpu.MiError):
+        fd.submit_images(0, pins[0].array, cap=8)
+    for b in range(1, 4):
+        pins[b & 1].array[...] = batches[b]            # fill the other slot's frames while the previous batch runs
+        fd.submit_images(b & 1, pins[b & 1].array, cap=8)
+        got[b - 1] = fd.collect((b - 1) & 1)
+    got[3] = fd.collect(1)
+    with pytest.raises(KeyError):
+        fd.collect(1)
+    for (o, c), (wo, wc) in zip(got, want):
+        np.testing.assert_array_equal(c, wc)
+        np.testing.assert_array_equal(o, wo)
+    assert sum(int((c > 0).sum()) for _, c in got) >= 64
+    for p in pins:
+        p.close()
+    fd.close()
+
+
 def test_landmark_tensor_path_vs_oracle(gpu, oracle, gold):
     fl = gpu.FaceLandmark()
     om = oracle.Model(model_path("landmark"))

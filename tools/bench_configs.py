@@ -73,3 +73,40 @@ for name, arr in (("pageable", xh), ("pinned", xp)):
     for _ in range(5): fd.infer_tensor(arr, cap=16)
     dt = (time.perf_counter() - t) / 5
     print(json.dumps({"config": "BackCamera 256 frames from %s HOST memory (H2D 201 MB + net + NMS + D2H per call)" % name, "ms_per_batch": round(dt * 1e3, 3), "frames_per_s": round(256 / dt)}))
+
+# the same from u8 frames (what the reference's callers hold: Mat 8UC3, utils.rs:8-21) — mi_fd_infer_images: 50 MB instead of 201 MB per
+# batch over the bus, image_to_tensor on the device; then the two-slot host feed (mi_fd_submit_images / mi_fd_collect): the copy of
+# batch n+1 on its own stream while the kernels of batch n run
+u8 = np.random.RandomState(2).randint(0, 256, (256, 256, 256, 3)).astype(np.uint8)
+u8[1::2] = gold["man_back_u8"].astype(np.uint8)
+pins = [mi.PinnedBuffer(u8.shape) for _ in range(2)]
+for p in pins: p.array[...] = u8
+ud = torch.from_numpy(u8).cuda()
+dt = timeit(lambda: fd.infer_images(ud, cap=16))
+print(json.dumps({"config": "BackCamera 256 u8 frames resident in HBM (image_to_tensor + net + NMS, mi_fd_infer_images)", "ms_per_batch": round(dt * 1e3, 3), "frames_per_s": round(256 / dt)}))
+for name, arr in (("pageable", u8), ("pinned", pins[0].array)):
+    for _ in range(2): fd.infer_images(arr, cap=16)
+    t = time.perf_counter()
+    for _ in range(10): fd.infer_images(arr, cap=16)
+    dt = (time.perf_counter() - t) / 10
+    print(json.dumps({"config": "BackCamera 256 u8 frames from %s HOST memory, one call at a time (H2D 50 MB + image_to_tensor + net + NMS + D2H)" % name,
+                      "ms_per_batch": round(dt * 1e3, 3), "frames_per_s": round(256 / dt), "h2d_GBps_if_copy_only": round(u8.nbytes / dt / 1e9, 1)}))
+nb = 40
+fd.submit_images(0, pins[0].array, cap=16)
+t = time.perf_counter()
+for b in range(1, nb + 1):
+    fd.submit_images(b & 1, pins[b & 1].array, cap=16)
+    out, counts = fd.collect((b - 1) & 1)
+dt = (time.perf_counter() - t) / nb
+fd.collect(nb & 1)
+# the copy alone, for the H2D rate of this box
+hs = torch.cuda.Stream()
+dst = torch.empty_like(ud)
+src = torch.from_numpy(pins[0].array)
+with torch.cuda.stream(hs):
+    for _ in range(3): dst.copy_(src, non_blocking=True)
+    hs.synchronize(); t = time.perf_counter()
+    for _ in range(10): dst.copy_(src, non_blocking=True)
+    hs.synchronize(); dc = (time.perf_counter() - t) / 10
+print(json.dumps({"config": "BackCamera 256 u8 frames from pinned HOST memory, two slots (copy of batch n+1 overlaps the kernels of batch n)", "ms_per_batch": round(dt * 1e3, 3),
+                  "frames_per_s": round(256 / dt), "faces_in_last_batch": int((counts > 0).sum()), "h2d_copy_alone_ms": round(dc * 1e3, 3), "h2d_GBps": round(u8.nbytes / dc / 1e9, 1)}))
