@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 F32_PEAK_TFLOPS = 157.3  # dense f32 (MFMA = packed VALU FMA), /opt/skills/guides/MI355X_MICROARCH.md
 # what the two pipes sustain on this part, every CU busy, two waves per SIMD (tools/valu_bench.hip, profiles/r03_valu_mfma_issue_rates.txt):
 # reported beside `frac` (which stays achieved / data-sheet peak) as `frac_of_measured_ceiling`
-MEASURED_CEILING_TFLOPS = {"valu v_pk_fma_f32": 116.0, "mfma f32": 145.0}
+# (round 4: the row pipelines' mix — 18 v_pk_fma_f32 + 24 v_mfma_f32_4x4x1_16b_f32 per stage — sustains 141 TFLOP/s, profiles/r04_valu_mfma_issue_rates.txt)
+MEASURED_CEILING_TFLOPS = {"valu v_pk_fma_f32": 116.0, "mfma f32": 145.0, "mfma f32 4x4x1 (1x1 convs) + valu v_pk_fma_f32 (depthwise)": 141.0}
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -317,7 +318,13 @@ def kernel_source_hash():
 def is_valu_kernel(label):
     """The strip / stem kernels do their contractions with packed VALU FMAs (v_pk_fma_f32), the others on MFMA; both have the
     same dense f32 peak on gfx950."""
-    return label.startswith(("strip_", "stem_conv"))
+    return label.startswith(("strip_", "stem_conv")) and not label.startswith("strip_pipe2m")
+
+
+def pipe_of(label):
+    if label.startswith("strip_pipe2m"):
+        return "mfma f32 4x4x1 (1x1 convs) + valu v_pk_fma_f32 (depthwise)"
+    return "valu v_pk_fma_f32" if is_valu_kernel(label) else "mfma f32"
 
 
 def roofline_of(records, workload_tag):
@@ -350,11 +357,21 @@ def roofline_of(records, workload_tag):
     if hbm_frac >= flop_frac:
         roof = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4), "traffic": traffic}
     else:   # FLOP-bound launch: the dense f32 rate; "pipe" says whether the kernel reaches it on MFMA or with packed VALU FMAs
-        pipe = "valu v_pk_fma_f32" if is_valu_kernel(dom) else "mfma f32"
+        pipe = pipe_of(dom)
         roof = {"bound": "f32", "pipe": pipe, "achieved": round(tflops, 2),
                 "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic,
                 "measured_ceiling": MEASURED_CEILING_TFLOPS[pipe], "frac_of_measured_ceiling": round(tflops / MEASURED_CEILING_TFLOPS[pipe], 4)}
     roof.update(common)
+    # one record per (kernel, shape): a symbol that runs on two shapes (the 128^2 and 64^2 pipelines) is not averaged here
+    shapes = {}
+    for r in records:
+        k = shapes.setdefault((r["kernel"], r.get("shape", "")), {"ms": 0.0, "bytes": 0.0, "macs": 0.0, "calls": 0})
+        k["ms"] += r["ms"]; k["bytes"] += r["bytes"]; k["macs"] += r["macs"]; k["calls"] += 1
+    roof["by_shape"] = [{"kernel": k[0], "shape": k[1], "calls": v["calls"], "avg_launch_ms": round(v["ms"] / v["calls"], 5),
+                         "TFLOPs": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 2), "f32_frac": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9 / F32_PEAK_TFLOPS, 4),
+                         "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1), "hbm_frac": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 4)}
+                        for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])]
+    roof["step_algorithmic"] = {"flops": round(2 * sum(r["macs"] for r in records)), "bytes": round(sum(r["bytes"] for r in records))}
     roof["net_event_ms"] = round(sum(r["ms"] for r in records), 4)
     roof["kernels"] = {k: {"ms": round(v["ms"], 4), "calls": v["calls"], "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
                            "TFLOPs": round(2 * v["macs"] / max(v["ms"], 1e-9) / 1e9, 2)} for k, v in by.items()}
@@ -390,13 +407,22 @@ def rehearse(args, rank, world):
         time.sleep(0.001 * (rank + 1))
     dist.barrier()
     elapsed = mdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    local_rank = int(os.environ.get("LOCAL_RANK", "-1"))
     shards = [None] * world
-    dist.all_gather_object(shards, (lo, hi, plans))
+    dist.all_gather_object(shards, (lo, hi, plans, rank, local_rank))
+    gathered = None
+    if args.gather:  # optional result collection of SURVEY.md 8e: every rank's per-frame counts on every rank (all_gather of fixed-size records)
+        mine = torch.arange(lo, hi, dtype=torch.int32)  # stand-in for the shard's detection counts: its global frame numbers
+        parts = mdist.gather_counts(mine, dist, dev)
+        gathered = bool(torch.equal(torch.cat(parts), torch.arange(0, world * B, dtype=torch.int32)))
     if rank == 0:
         print(json.dumps({"metric": "rehearsal (gloo, CPU, no kernels)", "value": None, "unit": "faces/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "rehearsal": True, "config": {"workload": "config %d" % args.config, "global_batch": world * B,
-                                                        "shards": [s[:2] for s in shards], "plans_identical": all(s[2] == plans for s in shards)}}), flush=True)
+                                                        "shards": [s[:2] for s in shards], "plans_identical": all(s[2] == plans for s in shards),
+                                                        # the device a rank binds on a GPU node is cuda:LOCAL_RANK (run_rank): one distinct device per rank
+                                                        "rank_to_device": ["rank %d -> cuda:%d" % (s[3], s[4]) for s in shards],
+                                                        "gathered_counts_in_rank_order": gathered}}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -537,6 +563,10 @@ def run_rank(args):
         windows = [mdist.max_over_ranks(w, dist, device) for w in windows[:1]] + \
                   [float(v) for v in mdist.max_over_ranks_vec(windows[1:], dist, device)]
 
+    gathered = None
+    if args.gather and args.config in (1, 2):  # optional result collection, outside the timed window
+        parts = mdist.gather_counts(counts, dist, device)
+        gathered = [int((p > 0).sum().item()) for p in parts]
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events between launches on the launch stream (eager replays of the same plans on
         # resident inputs of the same shapes), grouped by kernel symbol like rocprofv3 --stats does.
@@ -556,9 +586,25 @@ def run_rank(args):
             "config": {"workload": workload, "global_batch": world * B, "frames_with_faces": n_found,
                        "parallelism": "frames sharded %d/GPU, one process per GPU, no data-path collective" % B,
                        "weight_broadcast_ms": round(bcast_ms, 3), "weight_broadcast_bytes": sum(len(b) for b in blobs),
+                       "frames_with_faces_per_rank": gathered,
                        "plan": " | ".join(m.describe().splitlines()[0] for m, _ in models)},
             "roofline": roofline_of(recs, tag),
         }
+        # the whole step against the same roofs (algorithmic FLOPs / bytes of all launches over ms_per_step)
+        sa = result["roofline"].pop("step_algorithmic")
+        ms_step = elapsed / args.steps * 1e3
+        result["roofline"]["whole_step"] = {"algorithmic_flops": sa["flops"], "algorithmic_bytes": sa["bytes"],
+                                            "f32_frac": round(sa["flops"] / (ms_step * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
+                                            "hbm_frac": round(sa["bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if world == 1 and not args.no_latency:
+            # the reference's own operating point: ONE image per call through the three `infer`s (face_detection.rs:205-267,
+            # face_landmark.rs:232-306, iris_landmark.rs:158-248), host Mat in, results out — outside the timed window
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                import latency_probe
+                result["single_image_latency_us"] = latency_probe.measure(n=args.latency_calls)
+            except Exception as e:  # noqa: BLE001
+                result["single_image_latency_us"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1 and args.config in (1, 2):  # CPU baseline: rank 0 at N = 1 only
             threads = max(1, min(usable_cpus(), B))
             mf, kd = MODEL_FILES[args.config][0], ("FD_BACK" if args.config == 2 else "FD_SHORT")
@@ -587,6 +633,9 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (one child process)")
     ap.add_argument("--single-window", action="store_true", help="time the K steps once only (no repeated windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-image per-call latency block (N = 1)")
+    ap.add_argument("--latency-calls", type=int, default=200)
+    ap.add_argument("--gather", action="store_true", help="N > 1: collect every rank's per-frame detection counts on rank 0 (dist.gather_counts), outside the timed window")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing over gloo (no kernels)")
     ap.add_argument("--fuse", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)

@@ -44,6 +44,7 @@ Model::~Model() {
     if (d_weights_) hipFree(d_weights_);
     if (d_programs_) hipFree(d_programs_);
     if (d_arena_) hipFree(d_arena_);
+    if (d_small_) hipFree(d_small_);
     if (d_in_stage_) hipFree(d_in_stage_);
     for (float* p : d_out_)
         if (p) hipFree(p);
@@ -67,6 +68,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "fuse") { fuse_level_ = std::min(5, std::max(0, value)); dirty_ = true; }
     else if (key == "res_budget") { res_budget_ = std::min(156, std::max(16, value)) * 1024; dirty_ = true; }  // LDS (KiB) a stage program may use
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
+    else if (key == "small_chain") { small_chain_ = std::max(0, std::min(value, 64)); if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; } invalidate_graphs(); }  // frames up to which a row-pipelined chain runs one launch per block (0: never)
     else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel)
     else if (key == "strip") { strip_ = value != 0; }
     else if (key == "fork") { fork_ = value != 0; }
@@ -79,6 +81,7 @@ void Model::set_option(const std::string& key, int value) {
 }
 
 void Model::rebuild() {
+    if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; }  // sized for the plan it was allocated under
     hip_check(hipSetDevice(device_), "hipSetDevice");
     invalidate_graphs();
     plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_, pipe_max_, res_budget_);
@@ -534,6 +537,18 @@ void Model::ensure_capacity(int batch) {
         hip_check(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(arena_floats_, 64) * sizeof(float)), "hipMalloc arena");
         chunk_cap_ = chunk;
     }
+    if (!d_small_ && small_chain_ > 0) {  // ping-pong scratch of the small-batch form of the row-pipelined chains (fixed size: replay graphs hold the pointer)
+        size_t fmax = 0;
+        for (const Node& n : plan_.nodes)
+            if (n.kind == Node::Chain) {
+                const auto& sh = plan_.graph.tensors[n.in[0]].shape;
+                if (sh.size() == 4 && sh[1] * sh[2] > 256) fmax = std::max(fmax, static_cast<size_t>(sh[1]) * sh[2] * sh[3]);
+            }
+        if (fmax) {
+            small_floats_ = 2 * static_cast<size_t>(small_chain_) * fmax;
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d_small_), small_floats_ * sizeof(float)), "hipMalloc small-batch scratch");
+        }
+    }
     if (batch > batch_cap_) {
         invalidate_graphs();
         for (float* p : d_out_)
@@ -969,6 +984,31 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         b.sh = b.sw = 2; b.pt = b.pl = 0;
                         b.Ho = so[1]; b.Wo = so[2]; b.Co = so[3];
                         if (m.res >= 0) { b.ep.res_mode = RES_MAXPOOL; b.ep.res_H = b.H; b.ep.res_W = b.W; }
+                    }
+                }
+                // Small batches: a row pipeline is a chain of 2S + rows/2 dependent steps of ~5 us whatever the batch (88 us per launch for ONE
+                // BackCamera frame, four such launches of its 0.6 ms), while one strip-kernel launch per block is hundreds of independent
+                // waves (~5 us).  Below `small_chain_` frames the members run one launch each, ping-ponging through a per-handle scratch.
+                if (small_chain_ > 0 && F <= small_chain_ && lanes_ == 1 && d_small_) {
+                    const int nb = static_cast<int>(blk.size());
+                    const long fsz = static_cast<long>(si[1]) * si[2] * si[3];
+                    float* T[2] = {d_small_, d_small_ + static_cast<size_t>(small_chain_) * fsz};
+                    std::vector<BlockArgs> sb = blk;
+                    const float* cur = ip;
+                    long cur_fs = in_fs;
+                    bool ok = static_cast<size_t>(2 * small_chain_) * fsz <= small_floats_;
+                    for (int k = 0; k < nb && ok; k++) {
+                        BlockArgs& b = sb[static_cast<size_t>(k)];
+                        b.in = cur; b.in_fs = cur_fs;
+                        if (b.ep.res_mode != RES_NONE) { b.ep.res = cur; b.ep.res_fs = cur_fs; }
+                        if (k == nb - 1) { b.out = op; b.out_fs = out_fs; } else { b.out = T[k & 1]; b.out_fs = fsz; }
+                        if (b.sh == 1) ok = strip_kernel_supports(b);
+                        cur = b.out; cur_fs = b.out_fs;
+                    }
+                    if (ok) {
+                        if (labels) { char buf[96]; snprintf(buf, sizeof buf, "%s x%d%s (small batch)", strip_kernel_label(sb[0], buf + 48, 48), sb[static_cast<size_t>(nb - 1)].sh == 2 ? nb - 1 : nb, sb[static_cast<size_t>(nb - 1)].sh == 2 ? " + block_kernel" : ""); labels->back() = buf; }
+                        for (int k = 0; k < nb && rc == 0; k++) rc = sb[static_cast<size_t>(k)].sh == 1 ? launch_strip(sb[static_cast<size_t>(k)], s) : launch_block(sb[static_cast<size_t>(k)], s);
+                        break;
                     }
                 }
                 if (!strip_pipe_supports(blk.data(), static_cast<int>(blk.size()))) throw std::runtime_error("chain node without a kernel");

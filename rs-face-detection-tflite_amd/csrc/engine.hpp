@@ -108,6 +108,9 @@ class Model {
     int last_chunk_frames_ = 0;
 
     hipStream_t stream_ = nullptr;
+    int small_chain_ = 16;          // option "small_chain" (measured on BackCamera: block by block wins up to ~24 frames, tools/small_batch_probe.py)
+    float* d_small_ = nullptr;      // [2][small_chain_][largest chain frame] ping-pong scratch
+    size_t small_floats_ = 0;
     struct GraphKey {
         const void* in;
         int batch;

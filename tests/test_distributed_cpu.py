@@ -110,6 +110,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def test_world8_rehearsal_with_result_gather():
+    """The launcher at the size of a whole node (8 ranks, BASELINE configs[3] and configs[4]): every rank receives the frozen graph(s)
+    by broadcast and lowers them to the same plan, shards are contiguous / disjoint / complete, rank r would bind cuda:LOCAL_RANK = r
+    (one distinct device per rank), the optional result collection of SURVEY.md 8e (`--gather`: dist.gather_counts, an all_gather
+    of fixed-size records) returns the shards in rank order, and rank 0 prints one JSON line.  gloo on CPU — no run on more than one
+    GPU exists."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    for cfg, B in ((2, 256), (5, 128)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rehearse", "--gather", "--steps", "2", "--config", str(cfg)],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        out = json.loads(lines[0])
+        c = out["config"]
+        assert out["n_gpus"] == 8 and out["rehearsal"] is True and c["global_batch"] == 8 * B
+        assert c["shards"] == [[k * B, (k + 1) * B] for k in range(8)]
+        assert c["plans_identical"] is True
+        assert c["rank_to_device"] == ["rank %d -> cuda:%d" % (k, k) for k in range(8)]
+        assert c["gathered_counts_in_rank_order"] is True
+        assert out["ms_per_step"] >= 8.0                            # max over ranks: rank 7 sleeps 8 ms per step
+
+
 def test_launcher_parent_stays_clear_of_torch_and_hip():
     """The process that starts the ranks must not have initialised the GPU: it may not even import torch (whose device count can
     fall through to hipGetDeviceCount).  Importing bench.py and running its launcher (one rehearsal rank through --spawn) leaves

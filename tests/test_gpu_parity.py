@@ -147,6 +147,7 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
     m = gpu.Model(model_path(name))
     x = seeded_input(name, 6, 99, m.input_dims[1:3])
     m.set_option("fuse", 4)
+    m.set_option("small_chain", 0)   # 6 frames would otherwise take the small-batch form (one launch per block, next test)
     chained = [o.copy() for o in m.run(x)]
     if name != "front":  # the front model has no run of equal-shape narrow blocks
         assert "row-pipelined" in m.describe()
@@ -178,6 +179,33 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
     m.set_option("strip", 0)
     for o, r in zip(m.run(x), chained):
         _raw_close(o, r)
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["back", "landmark"])
+def test_small_batch_chains_run_block_by_block(gpu, oracle, name):
+    """A row pipeline is a chain of dependent steps whose length does not shrink with the batch (88 us per launch for ONE BackCamera
+    frame): up to `small_chain` frames (default 8) the members of such a chain run as one strip-kernel launch each through a
+    ping-pong scratch — FaceDetection::infer(&Mat) is a batch of one (face_detection.rs:205-267).  Batches 1, 3 and 8 against the
+    oracle, against the pipelined form (tolerance: the stride-2 block that ends a chain folds its depthwise bias differently in the
+    stand-alone block kernel), batch 9 back on the pipelines, and the launch labels of both."""
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path(name))
+    om = oracle.Model(model_path(name))
+    for nb in (1, 3, 8, 9):
+        x = seeded_input(name, nb, 400 + nb, m.input_dims[1:3])
+        m.set_option("small_chain", 8)
+        outs = [o.copy() for o in m.run(x)]
+        labels = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+        small = any("(small batch)" in k for k in labels)
+        piped = any(k.startswith("strip_pipe") for k in labels)
+        if name == "back":
+            assert small == (nb <= 8) and piped == (nb > 8), labels
+        for o, r in zip(outs, om.run(x, nthreads=4)):
+            _raw_close(o, r)
+        m.set_option("small_chain", 0)
+        for o, r in zip(m.run(x), outs):
+            _raw_close(o, r)
     m.close()
 
 

@@ -1,0 +1,51 @@
+"""Per-call latency of the reference's own operating point: one image per call through the three `infer`s
+(face_detection.rs:205-267, face_landmark.rs:232-306, iris_landmark.rs:158-248) and JPEG bytes -> detections (lib.rs:24-40).
+Prints p50 / p99 / mean in microseconds.  bench.py reports the same figures under `single_image_latency_us`."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import rs_face_detection_tflite_amd as mi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pct(ts):
+    a = np.sort(np.asarray(ts)) * 1e6
+    return {"p50": round(float(a[len(a) // 2]), 1), "p99": round(float(a[min(len(a) - 1, int(len(a) * 0.99))]), 1), "mean": round(float(a.mean()), 1), "calls": len(a)}
+
+
+def timed(fn, n=300, warm=20):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(n):
+        t = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t)
+    return pct(ts)
+
+
+def measure(n=300):
+    from PIL import Image
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+    jpg = open(os.path.join(ROOT, "tests", "golden", "man.jpg"), "rb").read()
+    img = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "man.jpg")).convert("RGB"))
+    out = {}
+    for kind in ("BackCamera", "Short", "Full"):
+        fd = mi.FaceDetection(getattr(mi.FaceDetectionModel, kind))
+        out["FaceDetection::infer %s (man.jpg 540x360, Mat in host memory)" % kind] = timed(lambda: fd.infer(img, None), n)
+        if kind == "BackCamera":
+            out["convert_image_to_mat + FaceDetection::infer BackCamera (JPEG bytes -> detections)"] = timed(lambda: fd.infer(mi.convert_image_to_mat(jpg), None), n)
+        fd.close()
+    fl = mi.FaceLandmark()
+    roi = mi.Rect(*[float(v) for v in gold["man_face_roi"][:5]], int(gold["man_face_roi"][5]))
+    out["FaceLandmark::infer (man.jpg, face ROI)"] = timed(lambda: fl.infer(img, roi), n)
+    ir = mi.IrisLandmark()
+    eye = mi.Rect(*[float(v) for v in gold["man_eye_left_roi"][:5]], int(gold["man_eye_left_roi"][5]))
+    out["IrisLandmark::infer (man.jpg, left-eye ROI)"] = timed(lambda: ir.infer(img, eye, False), n)
+    return out
+
+
+if __name__ == "__main__":
+    for k, v in measure().items():
+        print(json.dumps({"call": k, **v}))
