@@ -341,6 +341,8 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
     component comp[3];
     memset(comp, 0, sizeof comp);
     int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, rc = -1, progressive = 0, scans = 0;
+    int coef_bits[3][64];
+    memset(coef_bits, 0xff, sizeof coef_bits); /* -1: never sent */
     size_t i = 2;
     while (i + 4 <= n) {
         if (data[i] != 0xFF) { i++; continue; }
@@ -423,6 +425,8 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
             }
             sh.Ss = seg[1 + 2 * sh.nc]; sh.Se = seg[2 + 2 * sh.nc]; sh.Ah = seg[3 + 2 * sh.nc] >> 4; sh.Al = seg[3 + 2 * sh.nc] & 15;
             if (sh.Ss > sh.Se || sh.Se > 63 || (sh.Ss == 0 && sh.Se != 0) || (sh.Ss > 0 && sh.nc != 1) || sh.Al > 13 || sh.Ah > 13) goto done;
+            for (int s2 = 0; s2 < sh.nc; s2++) /* jdphuff.c start_pass_phuff_decoder: the Al of the last scan that carried coefficient k */
+                for (int k = sh.Ss; k <= sh.Se; k++) coef_bits[sh.ci[s2]][k] = sh.Al;
             i = prog_scan(data, n, i + 2 + len, &sh, comp, W, H, hmax, vmax, restart, dc, ac);
             scans++;
             continue;
@@ -491,6 +495,15 @@ int orc_jpeg_decode_rgb(const uint8_t *data, size_t n, uint8_t *rgb, int cap_w, 
         i += 2 + len;
     }
     if (progressive && scans > 0) { /* EOI (or the end of the data): every scan that was there has been added */
+        /* jdcoefct.c smoothing_ok(): with every component's DC known and one of the first AC coefficients (1..9 in libjpeg-turbo >= 2.1)
+         * missing or not refined to its last bit, libjpeg decodes through decompress_smooth_data (inter-block smoothing).  That pass is
+         * outside this restatement: such an INCOMPLETE progressive stream is refused (-3), never decoded differently. */
+        int dc_known = 1, low_ac_open = 0;
+        for (int c = 0; c < ncomp; c++) {
+            if (coef_bits[c][0] < 0) dc_known = 0;
+            for (int k = 1; k <= 9; k++) if (coef_bits[c][k] != 0) low_ac_open = 1;
+        }
+        if (dc_known && low_ac_open) { rc = -3; goto done; }
         reconstruct(comp, ncomp, W, H, hmax, vmax, qt, rgb);
         rc = 0;
     }

@@ -369,16 +369,38 @@ void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
     // the `insufficient` flag below).  What is refused is the allocation bomb: a few header bytes that promise a huge frame.
     // Every block costs at least two bits of entropy-coded data (one DC and one AC symbol); a header asking for more than 32 MiB
     // of coefficients that the remaining bytes cannot possibly hold is refused before the buffer is allocated.
-    if (total * sizeof(int16_t) > (32u << 20) && total / 64 > 4 * (n - ecs) + 64)
+    // (a progressive frame can spend a single bit per block — a DC-only first scan — and almost nothing on end-of-band runs)
+    if (total * sizeof(int16_t) > (32u << 20) && total / 64 > (f.progressive ? 8 : 4) * (n - ecs) + 64)
         bad("truncated stream (fewer entropy-coded bytes than the frame header needs)");
     f.coef.assign(total, 0);
     if (f.progressive) {  // every scan adds a band, or a bit, to the coefficients
+        // jdphuff.c start_pass_phuff_decoder: coef_bits[component][k] = the Al of the last scan that carried coefficient k (-1: never sent)
+        int coef_bits[3][64];
+        for (auto& cb : coef_bits)
+            for (int& v : cb) v = -1;
+        auto note_scan = [&](const ScanHdr& h) {
+            for (int s = 0; s < h.nc; s++)
+                for (int k = h.Ss; k <= h.Se; k++) coef_bits[h.ci[s]][k] = h.Al;
+        };
+        note_scan(sh);
         size_t pos = prog_scan(data, n, ecs, sh, p, f);
         for (int scans = 1; scans < 1024; scans++) {
             const size_t next = p.headers(false, std::max<size_t>(pos, 3), &sh);
             if (!next) break;
+            note_scan(sh);
             pos = prog_scan(data, n, next, sh, p, f);
         }
+        // An INCOMPLETE progressive stream (scans missing: the first AC coefficients never sent or not refined to their last bit) is
+        // not decoded the plain way by libjpeg: with every component's DC known, jdcoefct.c smoothing_ok() turns on inter-block
+        // smoothing (decompress_smooth_data estimates the missing low AC terms from the neighbours' DC values).  That pass is not
+        // restated here, so such a stream is refused and the caller falls back to imdecode — silently
+        // different pixels would be worse.  (AC coefficients 1..9: libjpeg-turbo >= 2.1; older versions look at 1..5.)
+        bool dc_known = true, low_ac_open = false;
+        for (int c = 0; c < f.ncomp; c++) {
+            dc_known &= coef_bits[c][0] >= 0;
+            for (int k = 1; k <= 9; k++) low_ac_open |= coef_bits[c][k] != 0;
+        }
+        if (dc_known && low_ac_open) bad("incomplete progressive stream (libjpeg would apply inter-block smoothing, which is not implemented)");
         return;
     }
     Bits br{data + ecs, data + n};

@@ -47,7 +47,9 @@ struct RowAcc {
 
 // acc += x * w.lo / w.hi on both lanes (S = 0: the low half of the tap pair, 1: the high half).  Inline asm: written as vector code
 // (splat folded into op_sel by LLVM) the register allocator scalarises half of the operations again and spills.  The instructions are
-// then invisible to the hazard recogniser: see MI_PK_NOPS in mdb_row.
+// then invisible to the hazard recogniser (a v_mfma reads a register v_pk_fma_f32 wrote 0 or 1 instructions earlier STALE,
+// tools/pk_mfma_hazard.hip): mrow_stage computes a pair's finished row first and puts a scheduling fence in front of the MFMAs, so
+// that six packed operations lie between; tests/test_isa_checks.py keeps these kernels free of spills, which would break the count.
 template <int S>
 __device__ __forceinline__ void dpk_fma(dv2f& acc, const dv2f x, const dv2f w) {
     if constexpr (S == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(w));

@@ -1025,6 +1025,7 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
                 break;
             case BuiltinOp::Add:
                 if (!act(op.inputs.at(1))) mark(op.inputs[0]);  // constant addend: not handled
+                if (!act(op.inputs.at(0))) { mark(op.inputs[1]); mark(op.outputs.at(0)); }  // ... on either side
                 break;
             case BuiltinOp::Pad: {
                 const auto& pd = g.tensors[op.inputs.at(1)].i32;
@@ -1092,12 +1093,17 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
         if (gw >= C) return gw;
         return (C & 3) ? (C + 3) & ~3 : C;
     };
-    // a channel PAD that consumes a widened tensor must have room for the extra channels
-    for (const OpInfo& op : g.ops)
-        if (op.op == BuiltinOp::Pad) {
-            const int in = op.inputs.at(0), out = op.outputs.at(0);
-            if (padded(out) - padded(in) < 0) { mark(in); mark(out); }
-        }
+    // a channel PAD that consumes a widened tensor must have room for the extra channels.  Marking a class changes what its
+    // neighbours (and its growth group) are padded to, so the check runs to a fixpoint (a single pass could leave an
+    // earlier PAD with a negative amount on crafted graphs)
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (const OpInfo& op : g.ops)
+            if (op.op == BuiltinOp::Pad) {
+                const int in = op.inputs.at(0), out = op.outputs.at(0);
+                if (padded(out) - padded(in) < 0 && !(bad[find(in)] && bad[find(out)])) { mark(in); mark(out); changed = true; }
+            }
+    }
     std::vector<int> newC(NT);
     bool any = false;
     for (int t = 0; t < NT; t++) {
@@ -1105,6 +1111,23 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
         any |= act(t) && newC[t] != g.tensors[t].shape.back();
     }
     if (!any) return;
+    // last line of defence before anything is rewritten: the new widths must be consistent operator by operator, or the graph stays
+    // exactly as it was stored
+    for (const OpInfo& op : g.ops) {
+        const int in = op.inputs.at(0), out = op.outputs.at(0);
+        switch (op.op) {
+            case BuiltinOp::Pad:
+                if (act(in) && newC[out] - newC[in] < 0) return;
+                break;
+            case BuiltinOp::DepthwiseConv2D: case BuiltinOp::Relu: case BuiltinOp::Prelu: case BuiltinOp::MaxPool2D:
+                if (act(in) && newC[in] != newC[out]) return;
+                break;
+            case BuiltinOp::Add:
+                if ((act(in) && newC[in] != newC[out]) || (act(op.inputs.at(1)) && newC[op.inputs[1]] != newC[out])) return;
+                break;
+            default: break;
+        }
+    }
     auto clone_const = [&](int t) {  // constants may be shared between operators: every change goes to a private copy
         g.tensors.push_back(g.tensors[t]);
         logical_elems->push_back((*logical_elems)[t]);

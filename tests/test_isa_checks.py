@@ -1,0 +1,48 @@
+"""Build-time checks on the gfx950 ISA of the kernels that live at the register limit (mrow.hpp's LDS reads and their
+waits are separate asm statements, correct only while the compiler neither spills nor copies the values in between).  Cross-compiles
+the sources to assembly (no GPU needed) and reads the kernel descriptors: no scratch, no spilled VGPRs."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_report  # noqa: E402
+
+# file -> (extra flags as in build.sh, kernels that must not use scratch: substring filter, "" = every kernel of the file)
+CASES = {
+    "mstrip_kernels.hip": (["-fno-slp-vectorize"], [""]),
+    "mwalk_kernels.hip": (["-fno-slp-vectorize"], [""]),
+    "ms2_kernels.hip": (["-fno-slp-vectorize"], [""]),
+    "mdblock_kernels.hip": (["-fno-slp-vectorize"], [""]),
+    # the row pipelines of BASELINE config 2 (four stages, 24 channels, plain and with either stride-2 tail)
+    "strip_kernels.hip": (["-DMI_DEV_ONE"], ["strip_pipe2m_kernel<6, 4, true, 0>", "strip_pipe2m_kernel<6, 4, true, 1>", "strip_pipe2m_kernel<6, 4, true, 2>"]),
+}
+
+
+def _compile(item):
+    name, (flags, _) = item
+    out = os.path.join("/tmp", "isa_check_%d_%s.s" % (os.getpid(), name))
+    isa_report.compile_asm(os.path.join(isa_report.CSRC, name), out, flags)
+    ks = isa_report.kernels(out)
+    os.unlink(out)
+    return name, ks
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_register_limit_kernels_do_not_spill():
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        results = dict(ex.map(_compile, CASES.items()))
+    for name, (_, filters) in CASES.items():
+        ks = results[name]
+        assert ks, name
+        for f in filters:
+            sel = [k for k in ks if f in k["pretty"]]
+            assert sel, (name, f)
+            for k in sel:
+                assert k["scratch"] == 0 and k["vspill"] == 0, (name, k["pretty"], k["vgpr"], k["vspill"], k["scratch"])
+                assert k["vgpr"] + k["agpr"] <= 256, (name, k["pretty"])      # two waves per SIMD

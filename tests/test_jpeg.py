@@ -87,6 +87,81 @@ def test_malformed_huffman_tables_and_sizes_are_refused(mi, oracle):
     assert "too large" in str(e.value)
 
 
+PROGRESSIVE = [k for k in FILES if "prog_" in k]
+
+
+def _scan_cuts(data):
+    """Variants of a progressive file with whole scans missing (cut in front of the k-th SOS, EOI appended) and one cut inside the last
+    scan's entropy-coded data."""
+    sos = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    cuts = [("scans<%d" % k, data[: sos[k]] + b"\xff\xd9") for k in range(1, len(sos))]
+    last = sos[-1] + 2 + int.from_bytes(data[sos[-1] + 2: sos[-1] + 4], "big")
+    cuts.append(("last scan cut", data[: last + (len(data) - last) // 2]))
+    return cuts
+
+
+@pytest.mark.parametrize("rel", PROGRESSIVE)
+def test_incomplete_progressive_streams_vs_libjpeg_turbo(oracle, rel):
+    """ADVICE r3: libjpeg (hence cv::imdecode, utils.rs:10) decodes an INCOMPLETE progressive stream through inter-block smoothing
+    (jdcoefct.c smoothing_ok / decompress_smooth_data) whenever every DC is known and one of the first AC coefficients is missing or
+    not refined to its last bit.  That pass is not restated: such streams are REFUSED; everything the decoders accept must still be
+    libjpeg-turbo's picture bit for bit (Pillow, truncated files allowed) — streams whose last scan is cut short included."""
+    pil = pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
+    accepted = refused = 0
+    for what, cut in _scan_cuts(_bytes(rel)):
+        ImageFile.LOAD_TRUNCATED_IMAGES = True
+        try:
+            ref = np.asarray(pil.open(io.BytesIO(cut)).convert("RGB"))
+        finally:
+            ImageFile.LOAD_TRUNCATED_IMAGES = False
+        try:
+            got = oracle.jpeg_decode_rgb(cut)
+        except ValueError as e:
+            assert "(-3)" in str(e), (rel, what, e)      # the incomplete-stream refusal, nothing else
+            refused += 1
+            continue
+        np.testing.assert_array_equal(got, ref, err_msg="%s, %s" % (rel, what))
+        accepted += 1
+    assert accepted >= 1 and refused >= 1, (rel, accepted, refused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rel", PROGRESSIVE)
+def test_gpu_incomplete_progressive_streams(mi, oracle, rel):
+    """The product refuses exactly the streams the checker refuses (MI_EINVAL, "incomplete progressive stream": the caller falls back
+    to imdecode) and agrees with it byte for byte on the others."""
+    for what, cut in _scan_cuts(_bytes(rel)):
+        try:
+            want = oracle.jpeg_decode_rgb(cut)
+        except ValueError:
+            with pytest.raises(mi.MiError) as e:
+                mi.convert_image_to_mat(cut)
+            assert "incomplete progressive" in str(e.value) and e.value.code == -1, (rel, what)
+            continue
+        np.testing.assert_array_equal(mi.convert_image_to_mat(cut), want, err_msg="%s, %s" % (rel, what))
+
+
+def test_progressive_allocation_guard_counts_one_bit_per_block(mi):
+    """a progressive frame may spend a single bit per block (a DC-only first scan), so the allocation-bomb guard must not
+    refuse a large flat progressive picture that libjpeg decodes: 32.5 MiB of coefficients backed by 1 bit per block pass the header
+    check (they fail later, or not at all, for other reasons), the same header backed by 100 bytes does not."""
+    W = H = 4128                                         # 516 x 516 blocks x 64 x 2 B = 32.5 MiB of coefficients
+    sof = _segment(0xC2, bytes([8]) + H.to_bytes(2, "big") + W.to_bytes(2, "big") + bytes([1, 1, 0x11, 0]))
+    dht = _segment(0xC4, bytes([0x00]) + bytes([1] + [0] * 15) + bytes([0]))       # one 1-bit code: DC difference 0
+    sos = _segment(0xDA, bytes([1, 1, 0x00, 0, 0, 0x00]))
+    blocks = (W // 8) * (H // 8)
+    flat = b"\xff\xd8" + _segment(0xDB, bytes([0]) + bytes([16] * 64)) + sof + dht + sos + bytes(blocks // 8 + 1) + b"\xff\xd9"
+    short = flat[: flat.index(b"\xff\xda") + 10 + 100] + b"\xff\xd9"
+    for data, needle in ((short, "truncated stream"),):
+        with pytest.raises(mi.MiError) as e:
+            mi.convert_image_to_mat(data)
+        assert needle in str(e.value)
+    with pytest.raises(mi.MiError) as e:                 # passes the guard; stops at the next check (no device here / DC-only stream)
+        mi.convert_image_to_mat(flat)
+    assert "truncated stream" not in str(e.value)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rel", FILES)
 def test_gpu_decode_is_bit_exact(mi, oracle, rel):

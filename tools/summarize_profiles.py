@@ -11,7 +11,9 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 base = os.path.join(root, "gpurun_out", "prof_" + tag)
-out = os.path.join(root, "profiles")
+# second argument: where the summaries go (tools/collect_profiles.sh summarises ON the GPU box into gpurun_out/prof_<tag>/summary, so
+# that the bench lines it takes afterwards read the PMC summary of the same collection; copy that directory into profiles/ afterwards)
+out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 
@@ -53,13 +55,33 @@ def label(name):
 
 
 WORKLOADS = {1: "short128_b256", 2: "back256_b256", 3: "landmark192_b512", 5: "pipeline192_b128"}
-WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel", "ms2_kernel", "xc_kernel")
+WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "strip_pipe2m_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel", "ms2_kernel", "xc_kernel")
 
 # ---- kernel stats per config
 for c in WORKLOADS:
     ks = one("trace_c%d/**/*_kernel_stats.csv" % c)
     if ks:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats_config%d.csv" % (tag, c)))
+
+
+# ---- the kernel-trace rows the per-symbol averages of --stats come from, per (kernel, grid size): a symbol that runs on two shapes (the
+# 128^2 and 64^2 row pipelines) is two lines here
+for c in WORKLOADS:
+    kt = one("trace_c%d/**/*_kernel_trace.csv" % c)
+    if not kt:
+        continue
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        if "mi::" not in r["Kernel_Name"]:
+            continue
+        grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+        wg = "x".join(str(r.get(k, "")) for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z"))
+        per[(label(r["Kernel_Name"]), grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(out, "%s_kernel_trace_by_shape_config%d.csv" % (tag, c)), "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(["kernel", "grid_threads", "workgroup", "dispatches", "avg_ns", "median_ns", "min_ns", "max_ns"])
+        for (lab, grid, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            wr.writerow([lab, grid, wg, len(v), round(statistics.mean(v)), round(statistics.median(v)), min(v), max(v)])
 
 
 def load(d):
@@ -133,16 +155,8 @@ for c in WORKLOADS:
     dst = os.path.join(out, "bench_%s_config%d_n1.json" % (tag, c))
     if os.path.exists(p) and open(p).read().strip():
         line = open(p).read().strip().splitlines()[-1]
-        # the collection's own bench line ran BEFORE this summary existed (traffic null): it does not replace a committed line that carries
-        # traffic (bench.py run again behind the summary: profiles/bench_<tag>_config<c>_n1.json is refreshed by hand from that run)
-        keep = False
-        try:
-            keep = os.path.exists(dst) and json.loads(open(dst).read().strip().splitlines()[-1])["roofline"].get("traffic") and not json.loads(line)["roofline"].get("traffic")
-        except Exception:
-            keep = False
-        if not keep:
-            with open(dst, "w") as fh:
-                fh.write(line + "\n")
+        with open(dst, "w") as fh:
+            fh.write(line + "\n")
 for fpath in glob.glob(os.path.join(base, "launches_*.txt")):
     shutil.copy(fpath, os.path.join(out, "%s_%s" % (tag, os.path.basename(fpath))))
 if os.path.exists(os.path.join(base, "configs.log")):
