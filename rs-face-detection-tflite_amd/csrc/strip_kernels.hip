@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         float4 (&tmx)[CQ] = onext;
         const int m = t - 2 * role;  // pair index of this block in this step
         const int c0 = lo_j - 1 + 2 * m;
-        bool hand_over = false, store_out = false;
+        bool hand_over = false;
         float4 o0[CQ], o1[CQ];
         if (!tail && active && m >= 0 && m < P) {
             const float *me0, *me1;
@@ -1552,11 +1552,10 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
                 strip_act<CQ, RELU>(oacc0, cst + K::OFF_SLOPE, hi, o0);
                 strip_act<CQ, RELU>(oacc1, cst + K::OFF_SLOPE, hi, o1);
                 if (NH2 || role < S - 1) hand_over = true;
-#ifdef MI_ABL_STORE_EARLY
+                // the last block's rows go to memory at once: its waves run at issue priority and reach the barrier thousands of cycles
+                // before their SIMD partners, and its transposition buffer is private — stored here, their 24 KB of LDS writes are out of
+                // the hand-over phase, which is bound by the LDS write rate (harness: 0.354 -> 0.345 ms)
                 else { store_row(c0 - 1, o0); store_row(c0, o1); }
-#else
-                else store_out = true;  // the last block's rows go to memory in the hand-over phase, while the others write their rings
-#endif
             }
             if (role == 0 && m + 2 < P) {
                 wave_sync();
@@ -1573,9 +1572,6 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         if (hand_over) {
             hand_row(c0 - 1, 0, o0);
             hand_row(c0, 1, o1);
-        } else if (store_out) {
-            store_row(c0 - 1, o0);
-            store_row(c0, o1);
         }
         MI_PSTAMP(2)
         prefetch_consts();
