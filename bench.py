@@ -351,6 +351,14 @@ def roofline_of(records, workload_tag):
                         note = "profiles/pmc_summary.json was measured on other kernel sources: not reported"
         except Exception:  # noqa: BLE001
             pass
+    rocprof_ns = None
+    if os.path.exists(tpath):
+        try:
+            for pm in json.load(open(tpath)).get("entries", []):
+                if pm.get("workload") == workload_tag and pm.get("kernel") == dom and pm.get("source_hash") == kernel_source_hash():
+                    rocprof_ns = pm.get("rocprof_avg_ns")
+        except Exception:  # noqa: BLE001
+            pass
     common = {"kernel": dom, "launches_per_step": d["calls"], "avg_launch_ms": round(d["ms"] / d["calls"], 5),
               "algorithmic_bytes_per_launch": round(d["bytes"] / d["calls"]), "algorithmic_flops_per_launch": round(2 * d["macs"] / d["calls"]),
               "hbm_GBps": round(gbps, 1), "hbm_frac": round(hbm_frac, 4), "f32_TFLOPs": round(tflops, 2), "f32_frac": round(flop_frac, 4),
@@ -363,6 +371,12 @@ def roofline_of(records, workload_tag):
                 "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_frac, 4), "traffic": traffic,
                 "measured_ceiling": MEASURED_CEILING_TFLOPS[pipe], "frac_of_measured_ceiling": round(tflops / MEASURED_CEILING_TFLOPS[pipe], 4)}
     roof.update(common)
+    if rocprof_ns:  # the same symbol's average duration in `rocprofv3 --kernel-trace --stats` of this workload (profiles/<round>_kernel_stats_config*.csv)
+        work = 2 * d["macs"] / d["calls"] if roof["bound"] == "f32" else d["bytes"] / d["calls"]
+        peak = F32_PEAK_TFLOPS * 1e12 if roof["bound"] == "f32" else HBM_PEAK_GBS * 1e9
+        roof["rocprof"] = {"avg_launch_ms": round(rocprof_ns / 1e6, 5), "frac": round(work / (rocprof_ns * 1e-9) / peak, 4),
+                           "note": "rocprofv3 kernel durations run 3-5 % above the event figures: their sum over a step exceeds the step's wall clock "
+                                   "(intervals of consecutive kernels overlap) and tracing itself slows the step by ~3 % (DESIGN.md section 5)"}
     # one record per (kernel, shape): a symbol that runs on two shapes (the 128^2 and 64^2 pipelines) is not averaged here
     shapes = {}
     for r in records:
@@ -573,7 +587,7 @@ def run_rank(args):
         # resident inputs of the same shapes), grouped by kernel symbol like rocprofv3 --stats does.
         recs = []
         for m, xin in models:
-            recs += m.profile(xin, reps=5)
+            recs += m.profile(xin, reps=5) if not (args.no_event_profile and world == 1) else []
         value = world * B * args.steps / elapsed
         result = {
             "metric": metric, "value": round(value, 1), "unit": unit,
@@ -589,8 +603,12 @@ def run_rank(args):
                        "weight_broadcast_ms": round(bcast_ms, 3), "weight_broadcast_bytes": sum(len(b) for b in blobs),
                        "frames_with_faces_per_rank": gathered,
                        "plan": " | ".join(m.describe().splitlines()[0] for m, _ in models)},
-            "roofline": roofline_of(recs, tag),
+            "roofline": roofline_of(recs, tag) if recs else None,
         }
+        if not recs:  # --no-event-profile (rocprofv3 kernel-trace runs: the dispatch sequence stays one step after the other)
+            print(json.dumps(result), flush=True)
+            keep.close()
+            return
         # the whole step against the same roofs (algorithmic FLOPs / bytes of all launches over ms_per_step)
         sa = result["roofline"].pop("step_algorithmic")
         ms_step = elapsed / args.steps * 1e3
@@ -634,6 +652,7 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="go through the rank launcher even for --gpus 1 (one child process)")
     ap.add_argument("--single-window", action="store_true", help="time the K steps once only (no repeated windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-event-profile", action="store_true", help="N = 1: skip the per-launch HIP-event pass (no roofline object); for rocprofv3 kernel-trace runs")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-image per-call latency block (N = 1)")
     ap.add_argument("--latency-calls", type=int, default=200)
     ap.add_argument("--gather", action="store_true", help="N > 1: collect every rank's per-frame detection counts on rank 0 (dist.gather_counts), outside the timed window")

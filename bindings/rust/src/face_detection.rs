@@ -95,6 +95,29 @@ impl FaceDetection {
     }
 }
 
+impl FaceDetection {
+    /// `infer` over a batch of equally sized frames in ONE call (`mi_fd_infer_images`): u8 RGB frames cross the bus (a quarter of
+    /// the f32 tensors), image_to_tensor runs on the device.  `frames` = `batch` frames of `height` rows of `stride` bytes.
+    pub fn infer_batch(&self, frames: &[u8], batch: usize, width: i32, height: i32, stride: i32, cap_per_frame: usize) -> Result<Vec<Vec<Detection>>, Error> {
+        let need = (stride as usize) * (height as usize) * batch.saturating_sub(1) + (stride as usize) * (height as usize - 1) + 3 * width as usize;
+        if batch == 0 || batch > i32::MAX as usize || cap_per_frame == 0 || width <= 0 || height <= 0 || stride < 3 * width || frames.len() < need {
+            return Err(Error::msg("frames must hold batch frames of height rows of stride bytes"));
+        }
+        let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; batch * cap_per_frame];
+        let mut counts = vec![0i32; batch];
+        check(unsafe {
+            ffi::mi_fd_infer_images(self.handle, frames.as_ptr(), batch as i32, width, height, stride, std::ptr::null(), out.as_mut_ptr(),
+                                    cap_per_frame as i32, counts.as_mut_ptr(), ffi::MI_MEM_HOST, std::ptr::null_mut())
+        })?;
+        Ok((0..batch)
+            .map(|b| {
+                let n = (counts[b].max(0) as usize).min(cap_per_frame);
+                out[b * cap_per_frame..b * cap_per_frame + n].iter().map(Detection::from_mi).collect()
+            })
+            .collect())
+    }
+}
+
 impl Drop for FaceDetection {
     fn drop(&mut self) {
         unsafe { ffi::mi_fd_free(self.handle) }

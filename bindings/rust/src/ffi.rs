@@ -57,6 +57,14 @@ extern "C" {
                              out: *mut mi_detection, cap: c_int, count: *mut c_int) -> c_int;
     pub fn mi_fd_infer_tensor(h: *mut mi_fd, input: *const c_float, batch: c_int, padding: *const c_double, out: *mut mi_detection,
                               cap_per_frame: c_int, counts: *mut c_int, mem: c_int, stream: *mut c_void) -> c_int;
+    pub fn mi_fd_infer_images(h: *mut mi_fd, frames: *const u8, batch: c_int, width: c_int, height: c_int, stride: c_int,
+                              rois: *const mi_rect, out: *mut mi_detection, cap_per_frame: c_int, counts: *mut c_int, mem: c_int,
+                              stream: *mut c_void) -> c_int;
+    pub fn mi_fd_submit_images(h: *mut mi_fd, slot: c_int, frames: *const u8, batch: c_int, width: c_int, height: c_int, stride: c_int,
+                               cap_per_frame: c_int) -> c_int;
+    pub fn mi_fd_collect(h: *mut mi_fd, slot: c_int, out: *mut mi_detection, counts: *mut c_int) -> c_int;
+    pub fn mi_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn mi_host_free(p: *mut c_void);
 
     // FaceLandmark — face_landmark.rs:200-306
     pub fn mi_fl_create(model_path: *const c_char, device: c_int, out: *mut *mut mi_fl) -> c_int;

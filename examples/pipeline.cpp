@@ -4,6 +4,7 @@
 //        pipeline <picture.jpg> 0 0 [model_dir]                     (encoded bytes -> convert_image_to_mat, utils.rs:8-21, as the
 //                                                                    reference's test does with include_bytes!(man.jpg))
 // Prints one line per result so that tests can parse it.
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iterator>
@@ -57,6 +58,16 @@ int main(int argc, char** argv) {
         const auto refined = update_face_landmarks_with_iris_results(lmks, left, right);
         std::printf("refined %zu lm33 %.9g %.9g lm263 %.9g %.9g contour0 %.9g %.9g %.9g %.9g\n", refined.size(), refined[33].x, refined[33].y,
                     refined[263].x, refined[263].y, left.contour[0].x, left.contour[0].y, right.contour[0].x, right.contour[0].y);
+        // the batched u8 entry (mi_fd_infer_images): the same picture three times in one call gives the single-image result three times
+        {
+            std::vector<std::uint8_t> three;
+            for (int k = 0; k < 3; k++)
+                for (int y = 0; y < h; y++) three.insert(three.end(), image.rgb + static_cast<std::size_t>(y) * image.stride, image.rgb + static_cast<std::size_t>(y) * image.stride + 3 * w);
+            const auto batch = face_detection.infer_batch(three.data(), 3, w, h, 3 * w);
+            bool same = batch.size() == 3;
+            for (const auto& f : batch) same = same && f.size() == faces.size() && std::fabs(f[0].bbox().xmin - bb.xmin) < 2e-5 && std::fabs(f[0].score - faces[0].score) < 2e-5;
+            std::printf("batch3 %s\n", same ? "same" : "DIFFERENT");
+        }
         const auto eye_box = bbox_from_landmarks(left.contour);
         std::printf("left_eye_box %.9g %.9g %.9g %.9g\n", eye_box[0], eye_box[1], eye_box[2], eye_box[3]);
     } catch (const mi_face::Error& e) {

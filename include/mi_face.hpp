@@ -11,6 +11,7 @@
 #pragma once
 
 #include <array>
+#include <algorithm>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -110,6 +111,27 @@ class FaceDetection {
             dets[i].score = out[i].score;
         }
         return dets;
+    }
+    // infer() over a batch of equally sized frames in one call (mi_fd_infer_images): `frames` = batch x height rows of `stride`
+    // bytes, host memory; rois empty (whole frames) or one per frame.  Up to cap_per_frame detections per frame are returned.
+    std::vector<std::vector<Detection>> infer_batch(const std::uint8_t* frames, int batch, int width, int height, int stride,
+                                                    const std::vector<Rect>& rois = {}, int cap_per_frame = 64) const {
+        std::vector<mi_detection> out(static_cast<std::size_t>(batch) * cap_per_frame);
+        std::vector<int> counts(static_cast<std::size_t>(batch));
+        std::vector<mi_rect> r;
+        for (const Rect& x : rois) r.push_back(x.c());
+        detail::check(mi_fd_infer_images(h_, frames, batch, width, height, stride, r.empty() ? nullptr : r.data(), out.data(), cap_per_frame,
+                                         counts.data(), MI_MEM_HOST, nullptr));
+        std::vector<std::vector<Detection>> res(static_cast<std::size_t>(batch));
+        for (int b = 0; b < batch; b++)
+            for (int i = 0; i < std::min(counts[static_cast<std::size_t>(b)], cap_per_frame); i++) {
+                Detection d;
+                const mi_detection& m = out[static_cast<std::size_t>(b) * cap_per_frame + i];
+                for (int k = 0; k < 16; k++) d.data[k] = m.data[k];
+                d.score = m.score;
+                res[static_cast<std::size_t>(b)].push_back(d);
+            }
+        return res;
     }
     mi_fd* handle() const { return h_; }
 

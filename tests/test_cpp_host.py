@@ -49,6 +49,7 @@ def test_cpp_pipeline_on_man_jpg(tmp_path, man_image):
     # update_face_landmarks_with_iris_results: mesh points 33 / 263 are replaced by the first contour landmark of each eye
     r = out["refined"]
     assert r[0] == "468" and r[2:4] == r[8:10] and r[5:7] == r[10:12]
+    assert out["batch3"] == ["same"]        # FaceDetection::infer_batch (mi_fd_infer_images) == infer, frame by frame
     # the same flow from the encoded bytes (convert_image_to_mat on the GPU path), like the reference's test (lib.rs:23-24)
     r2 = subprocess.run([exe, os.path.join(GOLDEN, "man.jpg"), "0", "0", MODELS], capture_output=True, text=True)
     assert r2.returncode == 0, r2.stderr

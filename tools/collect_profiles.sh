@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 python3 tools/bench_configs.py > "$OUT/configs.log" 2>&1; echo configs done
 for m in "back 256" "front 256" "full 128" "landmark 512" "iris 1024"; do set -- $m; python3 tools/profile_model.py $1 $2 2>/dev/null | grep -v amdgpu > "$OUT/launches_$1.txt"; done; echo launches done
 for c in 2 1 3 5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --steps 30 --no-cpu-baseline --no-latency --single-window > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --steps 30 --no-cpu-baseline --no-latency --no-event-profile --single-window > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --single-window > "$OUT/fetch_c$c.log" 2>&1; echo fetch $c done
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --single-window > "$OUT/write_c$c.log" 2>&1; echo write $c done
   i=0
@@ -30,5 +30,5 @@ done
 python3 tools/summarize_profiles.py "$TAG" "$OUT/summary" > "$OUT/summarize.log" 2>&1   # again: picks the bench lines up
 # keep what gpurun merges back small: counter CSVs, stats and the summaries only
 find "$OUT" -name "*.db" -delete 2>/dev/null || true
-find "$OUT" -name "*kernel_trace.csv" -delete 2>/dev/null || true
+find "$OUT" -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null || true
 du -sh "$OUT"

@@ -70,18 +70,32 @@ for c in WORKLOADS:
     kt = one("trace_c%d/**/*_kernel_trace.csv" % c)
     if not kt:
         continue
+    # the shapes a symbol runs on, in launch order within one step: the per-launch event list of the same model (tools/profile_model.py);
+    # the k-th dispatch of a symbol is its (k mod launches-per-step)-th launch of the step (two shapes can share a grid size: the 128^2
+    # and 64^2 row pipelines are both 256 workgroups)
+    order = collections.defaultdict(list)
+    lf = os.path.join(base, "launches_%s.txt" % {1: "front", 2: "back", 3: "landmark"}.get(c, "none"))
+    if os.path.exists(lf):
+        for line in open(lf):
+            parts = line.split()
+            if len(parts) >= 4 and parts[1] == "ms":
+                order[parts[2]].append(parts[3])
+    rows_kt = sorted((r for r in csv.DictReader(open(kt)) if "mi::" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))
+    seen = collections.Counter()
     per = collections.defaultdict(list)
-    for r in csv.DictReader(open(kt)):
-        if "mi::" not in r["Kernel_Name"]:
-            continue
+    for r in rows_kt:
+        lab = label(r["Kernel_Name"])
+        shapes = order.get(lab, [])
+        shape = shapes[seen[lab] % len(shapes)] if shapes else ""
+        seen[lab] += 1
         grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
         wg = "x".join(str(r.get(k, "")) for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z"))
-        per[(label(r["Kernel_Name"]), grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        per[(lab, shape, grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(os.path.join(out, "%s_kernel_trace_by_shape_config%d.csv" % (tag, c)), "w", newline="") as fh:
         wr = csv.writer(fh)
-        wr.writerow(["kernel", "grid_threads", "workgroup", "dispatches", "avg_ns", "median_ns", "min_ns", "max_ns"])
-        for (lab, grid, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            wr.writerow([lab, grid, wg, len(v), round(statistics.mean(v)), round(statistics.median(v)), min(v), max(v)])
+        wr.writerow(["kernel", "shape", "grid_threads", "workgroup", "dispatches", "avg_ns", "median_ns", "min_ns", "max_ns"])
+        for (lab, shape, grid, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            wr.writerow([lab, shape, grid, wg, len(v), round(statistics.mean(v)), round(statistics.median(v)), min(v), max(v)])
 
 
 def load(d):
