@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     }
 
 #ifdef MI_PIPE_STAMPS
-    unsigned long long ps_acc[4] = {0, 0, 0, 0}, ps_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long ps_acc[7] = {0, 0, 0, 0, 0, 0, 0}, ps_prev = __builtin_amdgcn_s_memtime();
 #define MI_PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); ps_acc[k] += t_ - ps_prev; ps_prev = t_; __builtin_amdgcn_sched_barrier(0); }
 #else
 #define MI_PSTAMP(k)
@@ -1546,8 +1546,10 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
                 me1 = me0 + IMG;
                 ps = PXS;
             }
+            MI_PSTAMP(4)
             strip_row2m<CQ>(me0, me1, ps, cst, has_res, aA, aB, onext, oacc0, oacc1, wa, cb, wd);
             wave_sync();
+            MI_PSTAMP(5)
             if (m >= 1) {  // rows c0 - 1 and c0 are finished
                 strip_act<CQ, RELU>(oacc0, cst + K::OFF_SLOPE, hi, o0);
                 strip_act<CQ, RELU>(oacc1, cst + K::OFF_SLOPE, hi, o1);
@@ -1566,7 +1568,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
         if constexpr (NH2 > 0) {
             if (tail) tail_step(t, tacc, tmx);
         }
-        MI_PSTAMP(0)
+        MI_PSTAMP(6)
         wg_barrier();  // every reader of the previous pair is done
         MI_PSTAMP(1)
         if (hand_over) {
@@ -1587,8 +1589,9 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
 #ifdef MI_PIPE_STAMPS
     if (a.stamps && lane == 0) {
         unsigned long long* d = a.stamps + ((size_t)blockIdx.x * 8 + w) * 8;
-        for (int k = 0; k < 4; k++) d[k] = ps_acc[k];
-        d[4] = T;
+        d[0] = ps_acc[4] + ps_acc[5] + ps_acc[6];   // compute = before the row function + the row function + behind it
+        for (int k = 1; k < 4; k++) d[k] = ps_acc[k];
+        d[4] = T; d[5] = ps_acc[4]; d[6] = ps_acc[5]; d[7] = ps_acc[6];
     }
 #endif
 #undef MI_PSTAMP

@@ -188,8 +188,12 @@ int main(int argc, char** argv) {
                 double acc[4] = {0, 0, 0, 0}, steps = 0; size_t cnt = 0;
                 for (size_t g = 0; g < nw / 8; g++) { const unsigned long long* d = &h[(g * 8 + w) * 8]; if (!d[4]) continue; cnt++; steps += d[4]; for (int k = 0; k < 4; k++) acc[k] += d[k]; }
                 if (!cnt) continue;
-                printf("  wave %d (block %d): %7.0f | %7.0f | %7.0f | %7.0f   total %7.0f per step, %d steps, %zu waves\n", w, w / 2, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps,
+                double sub[3] = {0, 0, 0};
+                for (size_t g = 0; g < nw / 8; g++) { const unsigned long long* d = &h[(g * 8 + w) * 8]; if (!d[4]) continue; for (int k = 0; k < 3; k++) sub[k] += d[5 + k]; }
+                printf("  wave %d (block %d): %7.0f | %7.0f | %7.0f | %7.0f   total %7.0f per step, %d steps, %zu waves", w, w / 2, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps,
                        (acc[0] + acc[1] + acc[2] + acc[3]) / steps, (int)(steps / cnt), cnt);
+                if (sub[1] > 0) printf("   compute = %5.0f before + %6.0f row function + %5.0f behind", sub[0] / steps, sub[1] / steps, sub[2] / steps);
+                printf("\n");
             }
             CK(hipFree(dstp));
         }
