@@ -512,6 +512,29 @@ def test_fd_infer_images_batch_vs_oracle_and_tensor_path(gpu, oracle, gold, man_
     fd.close()
 
 
+@pytest.mark.parametrize("kind,name,size", [("Short", "short", 128), ("Full", "full", 192), ("FullSparse", "full_sparse", 192)])
+def test_fd_infer_images_u8_stem_other_detectors(gpu, oracle, gold, kind, name, size):
+    """The u8 form of the first convolution (bytes normalised through a 256-entry table while the tile is filled) for the other
+    detectors' stems (5x5 -> 24 at 128^2, 3x3 -> 32 at 192^2): frames of the network's own size through mi_fd_infer_images equal, bit
+    for bit, the tensor entry fed with the oracle's image_to_tensor of the same frames; 37 frames (a partial last tile of workgroups)."""
+    fd = gpu.FaceDetection(getattr(gpu.FaceDetectionModel, kind))
+    rs = np.random.RandomState(size)
+    base = gold["man_back_u8"].astype(np.uint8)
+    if size == 128:
+        base = base.reshape(128, 2, 128, 2, 3).mean(axis=(1, 3)).astype(np.uint8)
+    else:
+        base = np.ascontiguousarray(base[32:224, 32:224])
+    frames = np.stack([np.roll(base, (int(rs.randint(-9, 10)), int(rs.randint(-9, 10))), axis=(0, 1)) if i % 3 else rs.randint(0, 256, base.shape).astype(np.uint8)
+                       for i in range(37)])
+    out, counts = fd.infer_images(frames, cap=16)
+    tens = np.stack([oracle.image_to_tensor(f, None, (size, size), True, (-1., 1.), False)[0] for f in frames])
+    out_t, counts_t = fd.infer_tensor(tens, cap=16)
+    np.testing.assert_array_equal(counts, counts_t)
+    np.testing.assert_array_equal(out, out_t)
+    assert int((counts > 0).sum()) >= 12
+    fd.close()
+
+
 def test_fd_submit_collect_two_slots(gpu, gold):
     """Host feed in two slots (mi_fd_submit_images / mi_fd_collect): four batches of pinned u8 frames alternate between the slots, the
     copy of one overlapping the kernels of the other; every batch equals the synchronous entry's result.  A slot cannot be submitted
