@@ -615,6 +615,29 @@ def run_rank(args):
         result["roofline"]["whole_step"] = {"algorithmic_flops": sa["flops"], "algorithmic_bytes": sa["bytes"],
                                             "f32_frac": round(sa["flops"] / (ms_step * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
                                             "hbm_frac": round(sa["bytes"] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if world == 1 and args.config == 2 and not args.no_host_feed:
+            # the same workload fed from HOST memory as u8 frames (what the reference's callers hold), outside the timed window and never
+            # `value`: two-slot feed, the copy of batch n + 1 on its own stream while batch n runs (mi_fd_submit_images / mi_fd_collect)
+            try:
+                u8 = np.clip((x_host + 1.0) * 127.5, 0, 255).astype(np.uint8)
+                pins = [mi.PinnedBuffer(u8.shape) for _ in range(2)]
+                for pb in pins:
+                    pb.array[...] = u8
+                nbatches = 40
+                fd.submit_images(0, pins[0].array, cap=cap)
+                t0 = time.perf_counter()
+                for bi in range(1, nbatches + 1):
+                    fd.submit_images(bi & 1, pins[bi & 1].array, cap=cap)
+                    _, hc = fd.collect((bi - 1) & 1)
+                dt = (time.perf_counter() - t0) / nbatches
+                fd.collect(nbatches & 1)
+                result["host_feed"] = {"frames_per_s": round(B / dt, 1), "ms_per_batch": round(dt * 1e3, 4), "input": "u8 RGB frames in pinned host memory, %d B per frame" % (u8.nbytes // B),
+                                       "h2d_bytes_per_batch": int(u8.nbytes), "frames_with_faces": int((hc > 0).sum()),
+                                       "note": "mi_fd_submit_images / mi_fd_collect, two slots; includes H2D copy, device image_to_tensor (u8 stem), net, post-processing, results to host"}
+                for pb in pins:
+                    pb.close()
+            except Exception as e:  # noqa: BLE001
+                result["host_feed"] = {"error": str(e)}
         if world == 1 and not args.no_latency:
             # the reference's own operating point: ONE image per call through the three `infer`s (face_detection.rs:205-267,
             # face_landmark.rs:232-306, iris_landmark.rs:158-248), host Mat in, results out — outside the timed window
@@ -653,6 +676,7 @@ def main():
     ap.add_argument("--single-window", action="store_true", help="time the K steps once only (no repeated windows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-event-profile", action="store_true", help="N = 1: skip the per-launch HIP-event pass (no roofline object); for rocprofv3 kernel-trace runs")
+    ap.add_argument("--no-host-feed", action="store_true", help="skip the host-fed u8 variant of config 2 (N = 1, extra key, outside the timed window)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-image per-call latency block (N = 1)")
     ap.add_argument("--latency-calls", type=int, default=200)
     ap.add_argument("--gather", action="store_true", help="N > 1: collect every rank's per-frame detection counts on rank 0 (dist.gather_counts), outside the timed window")
