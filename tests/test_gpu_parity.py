@@ -924,6 +924,9 @@ def test_one_handle_from_several_threads(gpu, gold, man_image):
     want_img = [key(fd.infer(im, None)) for im in imgs]
     want_t = [fd.infer_tensor(b, cap=8) for b in batches]
     want_lm = [fl.infer_tensor(c) for c in crops]
+    u8 = gold["man_back_u8"].astype(np.uint8)
+    frames8 = [np.stack([np.roll(u8, (2 * k + j, -3 * j), axis=(0, 1)) for j in range(5)]) for k in range(4)]   # batched u8 entry (u8 stem)
+    want_u8 = [fd.infer_images(f, cap=8) for f in frames8]
     # device tensors on four different torch streams through the asynchronous entry point
     dev = [torch.from_numpy(b).cuda() for b in batches]
     streams = [torch.cuda.Stream() for _ in range(4)]
@@ -939,6 +942,8 @@ def test_one_handle_from_several_threads(gpu, gold, man_image):
                 assert np.array_equal(out, want_t[k][0]) and np.array_equal(counts, want_t[k][1])
                 lm, present, flag = fl.infer_tensor(crops[k])
                 assert np.array_equal(lm, want_lm[k][0]) and np.array_equal(present, want_lm[k][1])
+                o8, c8 = fd.infer_images(frames8[k], cap=8)
+                assert np.array_equal(o8, want_u8[k][0]) and np.array_equal(c8, want_u8[k][1])
                 o = torch.zeros((3, 8, 17), dtype=torch.float32, device="cuda")
                 c = torch.zeros((3,), dtype=torch.int32, device="cuda")
                 torch.cuda.synchronize()
