@@ -641,6 +641,92 @@ __device__ __forceinline__ void strip_row_s2(const float* me2, const cfloat* cst
     }
 }
 
+// strip_row_s2 with the pointwise conv of MODE 2 on v_mfma_f32_4x4x1_16b_f32 (see strip_row2m): lane = OUTPUT pixel, wa = this wave's C x C
+// slice of the filter as A operands (strip_pack_consts_s2: OFF_A2 + hf NA 64), one wait per stage (only the 18 taps are streamed).
+template <int CQ, int NH, int MODE, int PS>
+__device__ __forceinline__ void strip_row_s2m(const float* me2, const cfloat* cst, int hf, bool has_skip, v2f (&acc)[CQ][2], float4 (&mx)[CQ],
+                                              v4f (&oacc)[CQ], const float (&wa)[SK<CQ>::NA]) {
+    constexpr int C = 4 * CQ, Co = NH * C;
+    constexpr int ST2 = (32 + 2 * Co + 15) / 16 * 16, OFF_BIAS2 = (C / 2) * ST2;
+    float wd[2][18];
+    float4 xbuf[2][3];
+    auto load_taps = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[st & 1][i] = p[st * ST2 + i];
+    };
+    auto load_x = [&](int q, float4 (&x)[3]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) x[kx] = sld4(me2 + kx * PS + 4 * q);
+    };
+    if constexpr (MODE == 2) {  // accumulators start from bias (+ the finished max-pool of rows 2k-2, 2k-1 for channels < C)
+        const cfloat* bp = cst + OFF_BIAS2 + hf * C;
+        asm volatile("" : "+s"(bp));
+        if (has_skip) {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) oacc[q] = v4f{mx[q].x, mx[q].y, mx[q].z, mx[q].w} + v4f{bp[4 * q], bp[4 * q + 1], bp[4 * q + 2], bp[4 * q + 3]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < CQ; q++) oacc[q] = v4f{bp[4 * q], bp[4 * q + 1], bp[4 * q + 2], bp[4 * q + 3]};
+        }
+#pragma unroll
+        for (int q = 0; q < CQ; q++) asm volatile("" : "+v"(oacc[q]));
+    }
+    load_taps(0);
+    load_x(0, xbuf[0]);
+#pragma unroll
+    for (int st = 0; st < 2 * CQ; st++) {
+        const int q = st >> 1, h = st & 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (st + 1 < 2 * CQ) {
+            load_taps(st + 1);
+            if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&x)[3] = xbuf[q & 1];
+        if (h == 0) {  // running 2x2 max-pool of this quad (columns 2ox, 2ox+1 = taps 0, 1)
+            float4 m = make_float4(fmaxf(x[0].x, x[1].x), fmaxf(x[0].y, x[1].y), fmaxf(x[0].z, x[1].z), fmaxf(x[0].w, x[1].w));
+            if (MODE == 0) m = make_float4(fmaxf(m.x, mx[q].x), fmaxf(m.y, mx[q].y), fmaxf(m.z, mx[q].z), fmaxf(m.w, mx[q].w));
+            mx[q] = m;
+        }
+        v2f t[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
+        const float (&w)[18] = wd[st & 1];
+        auto wv = [&](int tap) { return v2f{w[2 * tap], w[2 * tap + 1]}; };
+        v2f pch = acc[q][h], n;
+        if (MODE == 0) {
+            n = pch;
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) n = pkfma(t[kx], wv(3 + kx), n);
+        } else {
+            n = t[0] * wv(0);
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                if (MODE == 2) pch = pkfma(t[kx], wv(6 + kx), pch);
+                if (kx) n = pkfma(t[kx], wv(kx), n);
+            }
+        }
+        acc[q][h] = n;
+        asm volatile("" : "+v"(acc[q][h]));
+        if constexpr (MODE == 2) {
+            asm volatile("" : "+v"(pch));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const float bv = e ? pch.y : pch.x;
+#pragma unroll
+                for (int tq = 0; tq < CQ; tq++) {
+                    const int nn = (2 * st + e) * CQ + tq;
+                    oacc[tq] = mfma4_bcast(wa[nn >> 4], bv, oacc[tq], nn & 15);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int CQ, bool RELU>
 __global__ __launch_bounds__(256, CQ <= 6 ? 3 : 2) void strip_kernel(StripArgs a) {
     using K = SK<CQ>;
@@ -1388,7 +1474,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
 
     v2f aA[CQ][2], aB[CQ][2];
     v4f oacc0[CQ], oacc1[CQ];
-    v2f toacc[2 * CQ];   // stride-2 tail wave: accumulators (its partial depthwise row / running max-pool live in aA / onext)
+    v4f toacc[CQ];       // stride-2 tail wave: accumulators (its partial depthwise row / running max-pool live in aA / onext)
     float4 onext[CQ];    // stride-1 waves: bias + skip of the next step's first finished row
     float wa[K::NA];     // pointwise filter, A operands (SK::OFF_A)
     float cb[C], wd[2][18];
@@ -1415,6 +1501,10 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     if (!tail) {
 #pragma unroll
         for (int i = 0; i < K::NA; i++) wa[i] = a.consts[role][K::OFF_A + 64 * i + lane];
+    } else if constexpr (NH2 > 0) {  // this tail wave's C x C slice of the stride-2 block's filter (strip_pack_consts_s2)
+        constexpr int ST2h = (32 + 2 * NH2 * C + 15) / 16 * 16, OFF_A2 = (C / 2) * ST2h + 128;
+#pragma unroll
+        for (int i = 0; i < K::NA; i++) wa[i] = a.consts[S][OFF_A2 + (hf * K::NA + i) * 64 + lane];
     }
     prefetch_consts();
     if (role == 0 && active) {
@@ -1494,9 +1584,9 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
             const float* me2 = img + tu * 66 * PXS + (2 * tox + 1) * PXS;
             const bool skip = hf == 0 && a.has_res[S] != 0;
             if (mt == 0) {
-                strip_row_s2<CQ, NH2, 1, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc);
+                strip_row_s2m<CQ, NH2, 1, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc, wa);
             } else {
-                strip_row_s2<CQ, NH2, 2, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc);
+                strip_row_s2m<CQ, NH2, 2, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc, wa);
                 float4 o[CQ];
                 strip_act<CQ, RELU>(toacc, cst2 + OFF_SLOPE2 + hf * C, a.hi[S], o);
                 float* obuf = scratch;
@@ -1519,7 +1609,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
                 }
                 wave_sync();
             }
-            if (k + 1 < a.band_rows) strip_row_s2<CQ, NH2, 0, PXS>(me2 + IMG, cst2, hf, skip, tacc, tmx, toacc);
+            if (k + 1 < a.band_rows) strip_row_s2m<CQ, NH2, 0, PXS>(me2 + IMG, cst2, hf, skip, tacc, tmx, toacc, wa);
         }
     };
     auto step = [&](int t) {
@@ -1750,7 +1840,7 @@ bool strip_pipe_supports(const BlockArgs* blocks, int n) {
 bool strip_pipe_shape_ok(int C, int W) { return getenv("MI_NO_PIPE") == nullptr && (C == 16 || C == 24) && W <= 128; }
 bool strip_tail_shape_ok(int C, int Co, int H, int W) { return C == 24 && (Co == C || Co == 2 * C) && !(H & 1) && !(W & 1) && W <= 128; }
 
-int strip_consts_s2_floats(int C, int Co) { return C / 2 * ((32 + 2 * Co + 15) / 16 * 16) + 128; }
+int strip_consts_s2_floats(int C, int Co) { return C / 2 * ((32 + 2 * Co + 15) / 16 * 16) + 128 + (Co / C) * ((C * (C / 4) + 15) / 16) * 64; }
 
 // constants of a stride-2 tail block: w_dw [3][3][C], b_dw [C] or null, w_pw [Co][C], bias [Co] or null, alpha [Co] or null
 void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
@@ -1772,6 +1862,17 @@ void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, c
         pb[c] = (float)acc;
         ps[c] = act == ACT_PRELU ? alpha[c] : (act == ACT_NONE ? 1.f : 0.f);
     }
+    // A operands of v_mfma_f32_4x4x1_16b_f32 for the tail waves of strip_pipe2m_kernel, one C x C slice per C output channels (hf):
+    // register n / 16, lanes 4 (n % 16) + i = W[hf C + 4t + i][k], n = k CQ + t
+    const int CQ = C / 4, NA = (C * CQ + 15) / 16;
+    float* pa = pb + 128;
+    for (int hf = 0; hf < Co / C; hf++)
+        for (int k = 0; k < C; k++)
+            for (int t = 0; t < CQ; t++)
+                for (int i = 0; i < 4; i++) {
+                    const int n = k * CQ + t;
+                    pa[(size_t)(hf * NA + (n >> 4)) * 64 + 4 * (n & 15) + i] = w_pw[(size_t)(hf * C + 4 * t + i) * C + k];
+                }
 }
 
 // rows a pipeline step handles: two (strip_pipe2_kernel) whenever the height is even
