@@ -79,6 +79,24 @@ def test_no_cpu_fallback(mi):
     assert e.value.code == -4
 
 
+def test_batched_u8_entry_points_refuse_bad_arguments_without_gpu(mi):
+    """mi_fd_infer_images / mi_fd_submit_images / mi_fd_collect / mi_host_alloc: null handles and pointers are MI_EINVAL with a message,
+    never a crash — checked before any device work, so it runs without a GPU."""
+    import ctypes as C
+    L = mi.lib()
+    buf = (C.c_uint8 * 64)()
+    out = (C.c_float * 17)()
+    cnt = C.c_int()
+    assert L.mi_fd_infer_images(None, buf, 1, 2, 2, 6, None, out, 1, C.byref(cnt), 0, None) == -1
+    assert b"null" in L.mi_last_error()
+    assert L.mi_fd_submit_images(None, 0, buf, 1, 2, 2, 6, 1) == -1
+    assert L.mi_fd_collect(None, 0, out, C.byref(cnt)) == -1
+    p = C.c_void_p()
+    assert L.mi_host_alloc(0, C.byref(p)) == -1 and not p.value
+    assert L.mi_host_alloc(16, None) == -1
+    L.mi_host_free(None)            # a no-op
+
+
 def test_header_is_plain_c99(tmp_path):
     """The drop-in boundary is a C ABI: include/mi_face.h must compile as C99 (no C++-isms), alone and from a C translation unit
     that takes the address of every declared function with its declared type."""
