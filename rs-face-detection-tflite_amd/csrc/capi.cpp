@@ -132,6 +132,7 @@ struct FdSlot {
     int batch = 0, cap = 0;
     bool pending = false;
     ~FdSlot() {
+        if (pending && done) hipEventSynchronize(done);  // a batch was submitted and never collected: its kernels still write into h_out
         if (copy) hipStreamDestroy(copy);
         if (copied) hipEventDestroy(copied);
         if (done) hipEventDestroy(done);

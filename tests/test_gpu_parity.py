@@ -565,9 +565,12 @@ def test_fd_submit_collect_two_slots(gpu, gold):
         np.testing.assert_array_equal(c, wc)
         np.testing.assert_array_equal(o, wo)
     assert sum(int((c > 0).sum()) for _, c in got) >= 64
+    # a handle freed with a batch still in flight waits for it (its kernels write into the slot's pinned results)
+    pins[0].array[...] = batches[0]
+    fd.submit_images(0, pins[0].array, cap=8)
+    fd.close()
     for p in pins:
         p.close()
-    fd.close()
 
 
 def test_landmark_tensor_path_vs_oracle(gpu, oracle, gold):
