@@ -69,7 +69,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "res_budget") { res_budget_ = std::min(156, std::max(16, value)) * 1024; dirty_ = true; }  // LDS (KiB) a stage program may use
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
     else if (key == "small_chain") { small_chain_ = std::max(0, std::min(value, 64)); if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; } invalidate_graphs(); }  // frames up to which a row-pipelined chain runs one launch per block (0: never)
-    else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel)
+    else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2 || value == 4) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel), 4: one row, MFMA pointwise convs (strip_pipe1m_kernel)
     else if (key == "strip") { strip_ = value != 0; }
     else if (key == "fork") { fork_ = value != 0; }
     else if (key == "heads") { head_streams_opt_ = std::min(kHeadStreams, std::max(1, value)); dirty_ = true; }  // side streams the output heads are spread over                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
@@ -600,7 +600,7 @@ std::string Model::node_label(const Node& n) const {
             const auto& sin = g.tensors[n.in[0]].shape;
             const int nh2 = n.members.back().sh == 2 ? so.back() / sin.back() : 0;
             const int rps = strip_pipe_rows_per_step(sin[1], pipe_rows_);
-            return std::string(rps == 3 ? "strip_pipe2m_kernel<" : (rps == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<")) + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
+            return std::string(rps == 4 ? "strip_pipe1m_kernel<" : (rps == 3 ? "strip_pipe2m_kernel<" : (rps == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<"))) + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
         case Node::Resident: return n.xc ? "xc_kernel" : (n.dblock ? "dblock_kernel" : (n.bneck ? "bneck_kernel" : "resident_kernel"));
         case Node::Add: return "add_kernel";

@@ -519,6 +519,73 @@ __device__ __forceinline__ void strip_row2m(const float* me0, const float* me1, 
     }
 }
 
+// strip_row (one input row per call) with the pointwise conv on v_mfma_f32_4x4x1_16b_f32: see strip_row2m.  Input row r: its ky = 2 / 1 / 0
+// taps go to the partial output rows r-1 / r / r+1 (aPN on entry / aC / aPN on exit); the finished row r-1 is the B operand of the MFMAs, whose
+// first C operand is `onext` = bias + skip of row r-1 (left by the previous call); the call leaves bias + centre pixels of row r there.
+template <int CQ>
+__device__ __forceinline__ void strip_row1m(const float* me, int ps, const cfloat* cst, bool has_res, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2],
+                                            float4 (&onext)[CQ], v4f (&oacc)[CQ], const float (&wa)[SK<CQ>::NA], const float (&cb)[4 * CQ],
+                                            float (&wd)[2][18]) {
+    using K = SK<CQ>;
+    float4 xbuf[2][3];
+    const float* r[3] = {me, me + ps, me + 2 * ps};
+    auto load_taps = [&](int st) {
+        const cfloat* p = cst;
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[st & 1][i] = p[K::OFF_DW + st * K::ST_F + i];
+    };
+    auto load_x = [&](int q, float4 (&x)[3]) {
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) x[kx] = sld4(r[kx] + 4 * q);
+    };
+    auto bias4 = [&](int q) { return v4f{cb[4 * q], cb[4 * q + 1], cb[4 * q + 2], cb[4 * q + 3]}; };
+    load_x(0, xbuf[0]);
+#pragma unroll
+    for (int st = 0; st < 2 * CQ; st++) {
+        const int q = st >> 1, h = st & 1;
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this stage's taps (asked for a stage ago) and pixels
+        if (st + 1 < 2 * CQ) {
+            load_taps(st + 1);
+            if (h == 1) load_x(q + 1, xbuf[(q + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 (&x)[3] = xbuf[q & 1];
+        v2f t[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) t[kx] = h == 0 ? v2f{x[kx].x, x[kx].y} : v2f{x[kx].z, x[kx].w};
+        const float (&w)[18] = wd[st & 1];
+        auto wv = [&](int tap) { return v2f{w[2 * tap], w[2 * tap + 1]}; };
+        v2f n = t[0] * wv(0), c = aC[q][h], pch = aPN[q][h];
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            pch = pkfma(t[kx], wv(6 + kx), pch);
+            if (kx) n = pkfma(t[kx], wv(kx), n);
+            c = pkfma(t[kx], wv(3 + kx), c);
+        }
+        aC[q][h] = c;
+        aPN[q][h] = n;
+        asm volatile("" : "+v"(aC[q][h]), "+v"(aPN[q][h]));
+        asm volatile("" : "+v"(pch));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float bv = e ? pch.y : pch.x;
+#pragma unroll
+            for (int tq = 0; tq < CQ; tq++) {
+                const int nn = (2 * st + e) * CQ + tq;
+                const v4f c0 = (st == 0 && e == 0) ? v4f{onext[tq].x, onext[tq].y, onext[tq].z, onext[tq].w} : oacc[tq];
+                oacc[tq] = mfma4_bcast(wa[nn >> 4], bv, c0, nn & 15);
+            }
+        }
+        if (h == 0 && has_res) {  // the next call's finished row starts from bias + centre pixels of row r
+            const v4f nx = v4f{x[1].x, x[1].y, x[1].z, x[1].w} + bias4(q);
+            onext[q] = make_float4(nx.x, nx.y, nx.z, nx.w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int CQ, bool RELU>
 __device__ __forceinline__ void strip_act(const v4f (&oacc)[CQ], const cfloat* slopes, float hi, float4 (&o)[CQ]) {
     v2f t[2 * CQ];
@@ -1123,6 +1190,267 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
     }
 }
 
+// strip_pipe_kernel (ONE row per step: double-buffered single-row rings, one barrier per step, the hand-over writes of the waves that
+// finish early overlap the others' compute) with the pointwise convs on the matrix cores (strip_row1m) — the resident filters took away
+// what made two rows per step pay (a scalar weight stream per row).  Bit-identical to the other pipeline kernels.
+template <int CQ, int KB, bool RELU, int NH2>
+__global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void strip_pipe1m_kernel(PipeArgs a) {
+    using K = SK<CQ>;
+    constexpr int C = K::C, NL = K::NL, BUF_F = K::BUF_F;
+    constexpr int S = NH2 ? KB - 1 : KB;         // stride-1 blocks
+    constexpr int NT = 128 * S + 64 * NH2;       // threads
+    constexpr int SLOTS = 2;
+    constexpr int PXS = C + 4;                   // pixel stride of a hand-over row image (floats): conflict-free 16-byte reads and writes
+    constexpr int IMG = 132 * PXS;               // floats of one full-width row image (<= 130 pixels used)
+    constexpr int RING_F = (KB - 1) * SLOTS * IMG;   // KB-1 hand-over rings of two row images
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool tail = NH2 && w >= 2 * S;         // wave of the stride-2 block
+    const int p = tail ? 0 : (w & 1), role = tail ? S : (w >> 1);
+    const int hf = tail ? w - 2 * S : 0;         // which C output channels a tail wave computes
+    // wave-private scratch: block 0 waves own two DMA row buffers each, the waves that store one transposition buffer each
+    float* scratch = lds + RING_F + (role == 0 ? p * 2 * BUF_F : 4 * BUF_F + (tail ? hf : p) * BUF_F);
+    const int unit = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + p;
+    const bool active = unit < a.units;
+    const int band = unit % a.bands, b = min(unit / a.bands, a.B - 1);
+    const int x0 = a.strips == 2 ? 64 * p : 0;
+    const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
+    const float* in = a.in + (long)b * a.in_fs;
+    float* out = a.out + (long)b * a.out_fs;
+    const cfloat* cst = (const cfloat*)a.consts[role];
+    const bool has_res = a.has_res[role] != 0;
+    const float hi = a.hi[role];
+    // the last stride-1 block produces rows [y0, hi_last): one more row when a stride-2 tail follows (its third tap row)
+    const int hi_last = NH2 ? y1 + 1 : y1;
+    const int lo_j = y0 - (S - 1 - role), hi_j = hi_last + (S - 1 - role);  // this (stride-1) block produces rows [lo_j, hi_j)
+    const int img_p = a.strips == 2 ? 64 * PXS * p : 66 * PXS * p;       // this wave's window / sub-image inside a row image
+    {
+        const bool first = role == 0, last = tail || (NH2 == 0 && role == S - 1);
+        if ((a.prio == 1 && (first || last)) || (a.prio == 2 && first) || (a.prio == 3 && last)) __builtin_amdgcn_s_setprio(1);
+    }
+
+    // clear the hand-over rings once: their border pixel columns (left of x = 0, right of x = W-1) are never written
+    for (int i = threadIdx.x; i < RING_F / 4; i += NT) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int goff[NL];  // block 0: byte offset of the lane's float4 from the row start, per DMA instruction (see strip_kernel)
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        const int f = min(lane + 64 * k, K::NF - 1), px = f / CQ, qd = f - px * CQ;
+        goff[k] = (min(max(x0 - 1 + px, 0), a.W - 1) * C + 4 * qd) * 4;
+    }
+    const int npx = min(64, a.W - x0);
+    const bool full = npx == 64;
+    const int zl = x0 == 0 ? 0 : -1;
+    const int zr = x0 + 64 >= a.W ? npx + 1 : -1;
+    const long gout = (long)x0 * C + 4 * lane;
+    const unsigned lds_scratch = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)scratch);
+    auto issue_row = [&](int r, int bi) {
+        const char* src = reinterpret_cast<const char*>(in + (long)min(max(r, 0), a.H - 1) * a.W * C);
+        const unsigned dstb = lds_scratch + (unsigned)(bi * BUF_F * 4);
+        constexpr int TAIL = K::NF - 64 * (NL - 1);
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            if (k < NL - 1 || TAIL == 64) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dstb + 1024u * k), "v"(goff[k]), "s"(src) : "memory", "m0");
+            } else {
+                unsigned long long saved;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved) : "s"(dstb + 1024u * k), "v"(goff[k]), "s"(src), "n"((1ull << (TAIL & 63)) - 1) : "memory", "m0");
+            }
+        }
+    };
+    const int zfix = lane < CQ ? (zl >= 0 ? zl * C + 4 * lane : -1) : (lane < 2 * CQ ? (zr >= 0 ? zr * C + 4 * (lane - CQ) : -1) : -1);
+    auto fix_row = [&](int r, int bi) {
+        float* buf = scratch + bi * BUF_F;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < 0 || r >= a.H) {
+#pragma unroll
+            for (int k = 0; k < NL; k++)
+                if (64 * (k + 1) <= K::NF || lane < K::NF - 64 * k) sst4(buf + 4 * (lane + 64 * k), z);
+        } else if (zfix >= 0) {
+            sst4(buf + zfix, z);
+        }
+    };
+
+    v2f acc0[CQ][2], acc1[CQ][2];
+    v4f oacc[CQ], toacc[CQ];
+    float4 onext[CQ];    // bias + skip of the row the next call finishes (stride-2 tail wave: its running max-pool)
+    float wa[K::NA];     // pointwise filter, A operands
+    float cb[C], wd[2][18];
+#pragma unroll
+    for (int q = 0; q < CQ; q++) {
+        acc0[q][0] = acc0[q][1] = acc1[q][0] = acc1[q][1] = v2f{0.f, 0.f};
+        onext[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto prefetch_consts = [&]() {  // bias + first-stage taps of the coming step, asked for before the barrier
+        const cfloat* pc = cst;
+        asm volatile("" : "+s"(pc));
+#pragma unroll
+        for (int i = 0; i < C; i++) cb[i] = pc[K::OFF_BIAS + i];
+#pragma unroll
+        for (int i = 0; i < 18; i++) wd[0][i] = pc[K::OFF_DW + i];
+    };
+    auto pin_consts = [&]() {
+#pragma unroll
+        for (int i = 0; i < C; i++) asm volatile("" : "+s"(cb[i]));
+#pragma unroll
+        for (int i = 0; i < 18; i++) asm volatile("" : "+s"(wd[0][i]));
+    };
+    if (!tail) {
+#pragma unroll
+        for (int i = 0; i < K::NA; i++) wa[i] = a.consts[role][K::OFF_A + 64 * i + lane];
+    } else if constexpr (NH2 > 0) {
+        constexpr int ST2h = (32 + 2 * NH2 * C + 15) / 16 * 16, OFF_A2 = (C / 2) * ST2h + 128;
+#pragma unroll
+        for (int i = 0; i < K::NA; i++) wa[i] = a.consts[S][OFF_A2 + (hf * K::NA + i) * 64 + lane];
+    }
+    prefetch_consts();
+    const int c_first = y0 - S - 2 * role;  // row this block would consume at step 0 (it starts at step 3 * role)
+    if (role == 0 && active) {
+        issue_row(c_first, 0);
+        issue_row(c_first + 1, 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    pin_consts();
+    __builtin_amdgcn_s_barrier();
+    if (!tail && !has_res) {
+#pragma unroll
+        for (int q = 0; q < CQ; q++) onext[q] = make_float4(cb[4 * q], cb[4 * q + 1], cb[4 * q + 2], cb[4 * q + 3]);
+    }
+
+    auto wg_barrier = [&]() {
+        // raw s_barrier with an LDS-only wait (and the scalar loads of the next step's constants), so that the stores of block KB-1 and the
+        // DMA of block 0 stay in flight across it
+        prefetch_consts();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        pin_consts();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // ---- stride-2 tail: one wave serves both strips (W > 64: lane = output column) or both units (W <= 64: 32 lanes each).
+    // Its state (partial depthwise row, running max-pool) lives in the registers the stride-1 waves use for acc0 / xa.
+    auto tail_step = [&](int t, v2f (&tacc)[CQ][2], float4 (&tmx)[CQ]) {
+        if constexpr (NH2 > 0) {
+            const int k = t - 3 * S;  // band-relative index of the row the last stride-1 block handed over in step t-1
+            if (k < 0 || k > a.band_rows) return;
+            constexpr int Co = NH2 * C;
+            constexpr int ST2 = (32 + 2 * Co + 15) / 16 * 16, OFF_SLOPE2 = (C / 2) * ST2 + 64;
+            const cfloat* cst2 = (const cfloat*)a.consts[S];
+            const float* img = lds + ((S - 1) * SLOTS + ((t - 1) & 1)) * IMG;
+            const int tu = a.strips == 2 ? 0 : lane >> 5, tox = a.strips == 2 ? lane : lane & 31;
+            const float* me2 = img + tu * 66 * PXS + (2 * tox + 1) * PXS;
+            const bool skip = hf == 0 && a.has_res[S] != 0;
+            if (k & 1) {
+                strip_row_s2m<CQ, NH2, 0, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc, wa);
+            } else if (k < 2) {
+                strip_row_s2m<CQ, NH2, 1, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc, wa);
+            } else {
+                strip_row_s2m<CQ, NH2, 2, PXS>(me2, cst2, hf, skip, tacc, tmx, toacc, wa);
+                float4 o[CQ];
+                strip_act<CQ, RELU>(toacc, cst2 + OFF_SLOPE2 + hf * C, a.hi[S], o);
+                float* obuf = scratch;
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+                wave_sync();
+                // coalesced read-back: float4 f = lane + 64 j of the [64 pixels][C] image -> pixel f / CQ (unit, column)
+                const int Wo = a.W >> 1;
+#pragma unroll
+                for (int j = 0; j < CQ; j++) {
+                    const int f = lane + 64 * j, px = f / CQ, qd = f - px * CQ;
+                    const int u = a.strips == 2 ? 0 : px >> 5, ox = a.strips == 2 ? px : px & 31;
+                    const int un = a.strips == 2 ? (int)blockIdx.x : 2 * (int)blockIdx.x + u;
+                    const int ub = un % a.bands, bb = min(un / a.bands, a.B - 1);
+                    const int uy0 = ub * a.band_rows, uy1 = min(uy0 + a.band_rows, a.H);
+                    const float4 v = sld4(obuf + 4 * f);
+                    if (un < a.units && uy0 + k <= uy1 && ox < Wo) {
+                        const int oy = (uy0 + k - 2) >> 1;
+                        sst4(a.out + (long)bb * a.out_fs + ((long)oy * Wo + ox) * Co + hf * C + 4 * qd, v);
+                    }
+                }
+                wave_sync();
+            }
+        }
+    };
+    auto step = [&](int t, v2f (&aPN)[CQ][2], v2f (&aC)[CQ][2]) {
+        v2f (&tacc)[CQ][2] = acc0;
+        float4 (&tmx)[CQ] = onext;
+        const int c = c_first + t;  // row consumed in this step; the row it completes is c - 1
+        const int e = c - 1;
+        bool hand_over = false;     // this wave has a finished row for the next block
+        float4 o[CQ];
+        if (!tail && active && c >= lo_j - 1 && c <= hi_j) {
+            const float* me;
+            int ps;
+            if (role == 0) {
+                if (c + 1 <= hi_j) wait_vm<NL>();
+                else wait_vm<0>();
+                fix_row(c, t & 1);
+                wave_sync();
+                me = scratch + (t & 1) * BUF_F + lane * C;
+                ps = C;
+            } else {
+                me = lds + ((role - 1) * SLOTS + ((t - 1) & 1)) * IMG + img_p + lane * PXS;
+                ps = PXS;
+            }
+            strip_row1m<CQ>(me, ps, cst, has_res, aPN, aC, onext, oacc, wa, cb, wd);
+            wave_sync();
+            if (e >= lo_j && e < hi_j) {
+                strip_act<CQ, RELU>(oacc, cst + K::OFF_SLOPE, hi, o);
+                if (NH2 || role < S - 1) {
+                    hand_over = true;
+                } else {
+                    float* obuf = scratch;
+#pragma unroll
+                    for (int q = 0; q < CQ; q++) sst4(obuf + lane * C + 4 * q, o[q]);
+                    wave_sync();
+                    float* dst = out + (long)e * a.W * C + gout;
+                    if (full) {
+#pragma unroll
+                        for (int k = 0; k < CQ; k++) sst4(dst + 256 * k, sld4(obuf + 4 * lane + 256 * k));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < CQ; k++) {
+                            const float4 v = sld4(obuf + 4 * lane + 256 * k);
+                            if (lane + 64 * k < npx * CQ) sst4(dst + 256 * k, v);
+                        }
+                    }
+                }
+            }
+            if (role == 0 && c + 2 <= hi_j) {
+                wave_sync();
+                issue_row(c + 2, t & 1);
+            }
+        }
+        if constexpr (NH2 > 0) {
+            if (tail) tail_step(t, tacc, tmx);
+        }
+        if (hand_over) {
+            // hand the row to the next block; rows outside the image are that block's zero padding
+            float* dstl = lds + (role * SLOTS + (t & 1)) * IMG + img_p + (1 + lane) * PXS;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < 0 || e >= a.H) {  // wave-uniform
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, z);
+            } else if (full) {
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, o[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < CQ; q++) sst4(dstl + 4 * q, lane >= npx ? z : o[q]);
+            }
+        }
+        wg_barrier();
+    };
+    const int T = NH2 ? a.band_rows + 3 * S + 1 : a.band_rows + 3 * S - 1;
+    for (int t = 0; t < T; t += 2) {
+        step(t, acc0, acc1);
+        if (t + 1 >= T) break;
+        step(t + 1, acc1, acc0);
+    }
+}
+
 // Same pipeline with TWO rows per step (strip_row2): block j consumes the row pair its predecessor finished in the previous
 // step.  The rings hold one pair of row images each (single-buffered: a step is compute | barrier | hand over | barrier),
 // block 0 keeps two pairs of DMA buffers per wave.  Needs even band starts / lengths.
@@ -1691,6 +2019,13 @@ template <int CQ, int KB, bool RELU, int NH2>
 int launch_pipe_inst(const PipeArgs& pa, hipStream_t s) {
     using K = SK<CQ>;
     const bool two = pa.rows_per_step >= 2;
+    if (pa.rows_per_step == 4) {  // one row per step, MFMA pointwise convs
+        auto k1 = strip_pipe1m_kernel<CQ, KB, RELU, NH2>;
+        const size_t lds1 = (size_t)((KB - 1) * 2 * 132 * (K::C + 4) + 6 * K::BUF_F) * 4;
+        if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(k1)); e != hipSuccess) return (int)e;
+        const int wgs1 = pa.strips == 2 ? pa.units : (pa.units + 1) / 2;
+        return (int)launch_kernel(k1, dim3((unsigned)wgs1), dim3(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB), lds1, s, pa);
+    }
     const bool mf = pa.rows_per_step == 3;
     auto kern = mf ? strip_pipe2m_kernel<CQ, KB, RELU, NH2> : (two ? strip_pipe2_kernel<CQ, KB, RELU, NH2> : strip_pipe_kernel<CQ, KB, RELU, NH2>);
     const size_t lds_bytes = (size_t)((KB - 1) * 2 * 132 * (mf ? K::C + 4 : K::C) + (two ? 10 : 6) * K::BUF_F) * 4;
@@ -1879,14 +2214,16 @@ void strip_pack_consts_s2(int C, int Co, const float* w_dw, const float* b_dw, c
 int strip_pipe_rows_per_step(int H, int hint) {
     static const int rows_forced = getenv("MI_PIPE_ROWS") ? atoi(getenv("MI_PIPE_ROWS")) : 0;  // tuning aid
     static const bool no_mfma = getenv("MI_PIPE_NO_MFMA") != nullptr;                           // tuning aid: packed-FMA pointwise convs
-    if (rows_forced == 1 || hint == 1 || (H & 1)) return 1;
+    if (rows_forced == 1 || hint == 1) return 1;
+    if (rows_forced == 4 || hint == 4) return 4;            // one row per step, MFMA pointwise convs (any height)
+    if (H & 1) return no_mfma ? 1 : 4;
     return (no_mfma || rows_forced == 2 || hint == 2) ? 2 : 3;
 }
 
 const char* strip_pipe_label(const BlockArgs* blocks, int n, char* buf, size_t cap) {
     const int nh2 = blocks[n - 1].sh == 2 ? blocks[n - 1].Co / blocks[n - 1].C : 0;
     const int rps = strip_pipe_rows_per_step(blocks[0].H, blocks[0].pipe_rows);
-    snprintf(buf, cap, "strip_pipe%s_kernel<%d,%d,%d,%d>", rps == 3 ? "2m" : (rps == 2 ? "2" : ""), blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
+    snprintf(buf, cap, "strip_pipe%s_kernel<%d,%d,%d,%d>", rps == 4 ? "1m" : (rps == 3 ? "2m" : (rps == 2 ? "2" : "")), blocks[0].C / 4, n, blocks[0].ep.act == ACT_RELU ? 1 : 0, nh2);
     return buf;
 }
 
@@ -1912,7 +2249,7 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     rows = std::max(rows, std::min(a.H, 8 * n));
     if (forced > 0) rows = std::min(forced, a.H);
     pa.rows_per_step = strip_pipe_rows_per_step(a.H, a.pipe_rows);
-    if (nh2 || pa.rows_per_step >= 2) rows = std::min(a.H, (rows + 1) & ~1);  // bands that start on even rows
+    if (nh2 || pa.rows_per_step == 2 || pa.rows_per_step == 3) rows = std::min(a.H, (rows + 1) & ~1);  // bands that start on even rows
     pa.band_rows = rows;
     pa.bands = (a.H + rows - 1) / rows;
     pa.units = a.B * pa.bands;

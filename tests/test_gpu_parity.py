@@ -161,7 +161,8 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
     if name != "front":  # default: two rows per step, pointwise convs on v_mfma_f32_4x4x1_16b_f32 (strip_pipe2m_kernel)
         labels = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
         assert any(k.startswith("strip_pipe2m_kernel") for k in labels), labels
-    for rows, sym in ((1, "strip_pipe_kernel"), (2, "strip_pipe2_kernel")):  # one row per step (odd heights); two rows, packed-FMA pointwise convs
+    # one row per step, packed FMAs; two rows, packed-FMA pointwise convs; one row per step with the MFMA pointwise convs (the form odd heights take)
+    for rows, sym in ((1, "strip_pipe_kernel"), (2, "strip_pipe2_kernel"), (4, "strip_pipe1m_kernel")):
         m.set_option("pipe_rows", rows)
         for o, r in zip(m.run(x), chained):
             np.testing.assert_array_equal(o, r)

@@ -139,12 +139,12 @@ int main(int argc, char** argv) {
         printf("pipe x%d%s check: max |diff| %.3g, %zu of %zu outside %.0e", nb, tail ? " (stride-2 tail)" : "", md, nbad, nlast, tol);
         if (nbad) { size_t px = fi / Cl; printf("  first at frame %zu y %zu x %zu c %zu: ref %g got %g", px / ((size_t)Hl * Wl), px / Wl % Hl, px % Wl, fi % Cl, r0[fi], r1[fi]); }
         printf("\n");
-        {   // packed-FMA form of the same pipeline (pipe_rows hint 2) against the default (MFMA pointwise convs): bit for bit
+        for (int hint : {2, 4}) {   // the packed-FMA two-row form (hint 2) and the one-row MFMA form (hint 4) against the default (two rows, MFMA): bit for bit
             std::vector<BlockArgs> pv = pb;
-            for (auto& b : pv) b.pipe_rows = 2;
+            for (auto& b : pv) b.pipe_rows = hint;
             float* dpv; CK(hipMalloc(&dpv, nlast * 4)); CK(hipMemset(dpv, 0xff, nlast * 4));
             pv[nb - 1].out = dpv;
-            if (launch_strip_pipe(pv.data(), nb, s)) { printf("pipe (packed FMA) launch failed\n"); return 1; }
+            if (launch_strip_pipe(pv.data(), nb, s)) { printf("pipe (hint %d) launch failed\n", hint); return 1; }
             CK(hipStreamSynchronize(s));
             std::vector<float> r2(nlast);
             CK(hipMemcpy(r2.data(), dpv, nlast * 4, hipMemcpyDeviceToHost));
@@ -159,7 +159,7 @@ int main(int argc, char** argv) {
             for (int i = 0; i < it; i++) launch_strip_pipe(pv.data(), nb, s);
             CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
-            printf("pipe (packed FMA) x%d B %d %dx%d C %d : %.4f ms (%.4f per block)\n", nb, B, H, W, C, ms, ms / nb);
+            printf("pipe (%s) x%d B %d %dx%d C %d : %.4f ms (%.4f per block)\n", strip_pipe_label(pv.data(), nb, l1, sizeof l1), nb, B, H, W, C, ms, ms / nb);
         }
         for (int which = 0; which < 2; which++) {
             const int it = 20;
