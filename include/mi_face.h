@@ -107,8 +107,11 @@ int mi_model_debug_tensor(mi_model *m, int tensor_index, int frame, float *dst, 
 size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
 /* Tuning knobs: "chunk" (frames per pass through the net, 0 = whole batch), "graph" (0/1 hipGraph replay),
  * "fuse" (0 = op-by-op kernels, 1 = epilogue fusion, 2 = BlazeBlock fusion, 3 = + frame-resident chains of small-spatial
- * blocks, 4 = + row-pipelined chains of narrow blocks; default 4), "pipe" (blocks per row-pipelined chain, 2..4, 0 = none),
- * "pipe_rows" (1 = one row per pipeline step instead of two), "strip" (0 = LDS-ring block kernel for every block),
+ * blocks, 4 = + row-pipelined chains of narrow blocks, 5 = + stage programs, operand-layout kernels, fused edges; default 5),
+ * "pipe" (blocks per row-pipelined chain, 2..4, 0 = none), "pipe_rows" (0 = automatic: two rows per pipeline step with the 1x1 convs on
+ * the 4x4x1 MFMA, one row for odd heights; 1 / 2 = one / two rows per step with packed-FMA 1x1 convs; 4 = one row per step, MFMA),
+ * "small_chain" (frames up to which a row-pipelined chain runs one launch per block instead — what keeps a batch of one short;
+ * default 16, 0 = never), "strip" (0 = LDS-ring block kernel for every block),
  * "fork" (0 = output heads run on the trunk's stream instead of beside it), "heads" (side streams the output heads are spread
  * over, 1..4), "reuse", "lanes". Takes effect on the next run. */
 int mi_model_set_option(mi_model *m, const char *key, int value);
