@@ -1006,7 +1006,12 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         cur = b.out; cur_fs = b.out_fs;
                     }
                     if (ok) {
-                        if (labels) { char buf[96]; snprintf(buf, sizeof buf, "%s x%d%s (small batch)", strip_kernel_label(sb[0], buf + 48, 48), sb[static_cast<size_t>(nb - 1)].sh == 2 ? nb - 1 : nb, sb[static_cast<size_t>(nb - 1)].sh == 2 ? " + block_kernel" : ""); labels->back() = buf; }
+                        if (labels) {
+                            char name[48], buf[112];
+                            const bool s2 = sb[static_cast<size_t>(nb - 1)].sh == 2;
+                            snprintf(buf, sizeof buf, "%s x%d%s (small batch)", strip_kernel_label(sb[0], name, sizeof name), s2 ? nb - 1 : nb, s2 ? " + block_kernel" : "");
+                            labels->back() = buf;
+                        }
                         for (int k = 0; k < nb && rc == 0; k++) rc = sb[static_cast<size_t>(k)].sh == 1 ? launch_strip(sb[static_cast<size_t>(k)], s) : launch_block(sb[static_cast<size_t>(k)], s);
                         break;
                     }
