@@ -91,6 +91,14 @@ for c in WORKLOADS:
         grid = "x".join(str(r.get(k, "")) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
         wg = "x".join(str(r.get(k, "")) for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z"))
         per[(lab, shape, grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if c == 2:  # the rows themselves for the headline workload (a few hundred lines): what the averages above are averages of
+        t0 = min(int(r["Start_Timestamp"]) for r in rows_kt)
+        with open(os.path.join(out, "%s_kernel_trace_rows_config%d.csv" % (tag, c)), "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(["dispatch_id", "kernel", "grid_threads", "workgroup_threads", "start_ns_from_first", "duration_ns"])
+            for r in rows_kt:
+                short = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                wr.writerow([r["Dispatch_Id"], short, r["Grid_Size_X"], r["Workgroup_Size_X"], int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
     with open(os.path.join(out, "%s_kernel_trace_by_shape_config%d.csv" % (tag, c)), "w", newline="") as fh:
         wr = csv.writer(fh)
         wr.writerow(["kernel", "shape", "grid_threads", "workgroup", "dispatches", "avg_ns", "median_ns", "min_ns", "max_ns"])
