@@ -113,7 +113,9 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * "small_chain" (frames up to which a row-pipelined chain runs one launch per block instead — what keeps a batch of one short;
  * default 16, 0 = never), "strip" (0 = LDS-ring block kernel for every block),
  * "fork" (0 = output heads run on the trunk's stream instead of beside it), "heads" (side streams the output heads are spread
- * over, 1..4), "reuse", "lanes". Takes effect on the next run. */
+ * over, 1..4), "tail" (0 = no stage program takes the several-frames-per-workgroup form of round 5: the round-4 plan),
+ * "tail_g" (frames per workgroup of those programs; 0 = chosen per launch from the batch and the LDS a frame needs), "reuse",
+ * "lanes". Takes effect on the next run. */
 int mi_model_set_option(mi_model *m, const char *key, int value);
 /* Host-only: parse + lower a .tflite blob WITHOUT touching a GPU and write the launch plan text (same format as
  * mi_model_describe). Returns bytes needed (incl. NUL), 0 on error (see mi_last_error). Used by CPU-side tests. */

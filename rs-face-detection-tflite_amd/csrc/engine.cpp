@@ -43,6 +43,7 @@ Model::~Model() {
     invalidate_graphs();
     if (d_weights_) hipFree(d_weights_);
     if (d_programs_) hipFree(d_programs_);
+    if (d_tail_programs_) hipFree(d_tail_programs_);
     if (d_arena_) hipFree(d_arena_);
     if (d_small_) hipFree(d_small_);
     if (d_in_stage_) hipFree(d_in_stage_);
@@ -71,6 +72,9 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "small_chain") { small_chain_ = std::max(0, std::min(value, 64)); if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; } invalidate_graphs(); }  // frames up to which a row-pipelined chain runs one launch per block (0: never)
     else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2 || value == 4) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel), 4: one row, MFMA pointwise convs (strip_pipe1m_kernel)
     else if (key == "strip") { strip_ = value != 0; }
+    else if (key == "tail") { tail_ = value != 0; dirty_ = true; }   // 0: no stage program runs on tail_kernels.hip (the round-4 plan)
+    else if (key == "tail_pre") { tail_pre_ = std::max(0, std::min(value, 2)); }   // tail programs: 0 = chosen per launch, 1 = constants a stage ahead (one workgroup per CU), 2 = 128 registers (two per CU)
+    else if (key == "tail_g") { tail_g_ = std::max(0, std::min(value, 64)); }   // frames per workgroup of the tail stage programs (0: chosen per launch)
     else if (key == "fork") { fork_ = value != 0; }
     else if (key == "heads") { head_streams_opt_ = std::min(kHeadStreams, std::max(1, value)); dirty_ = true; }  // side streams the output heads are spread over                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
@@ -84,7 +88,7 @@ void Model::rebuild() {
     if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; }  // sized for the plan it was allocated under
     hip_check(hipSetDevice(device_), "hipSetDevice");
     invalidate_graphs();
-    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_, pipe_max_, res_budget_);
+    plan_ = build_plan(parse_tflite(blob_.data(), blob_.size()), fuse_level_, pipe_max_, res_budget_, tail_ != 0);
     const Graph& g = plan_.graph;
     if (!reuse_) {  // debugging layout: every tensor keeps its own slot
         long off = 0;
@@ -108,6 +112,8 @@ void Model::rebuild() {
     node_mwalk_.assign(NN, -1);
     res_cblob_.assign(NN, {});
     res_wblk_.assign(NN, {});
+    tail_wa_.assign(NN, {});
+    tail_wc_.assign(NN, {});
     // pointwise weights [O][1][1][I] -> MFMA A-fragment order [tile][k-chunk][lane][4]:
     // lane l = (row m = l & 31, k-half h = l >> 5) holds W[tile*32 + m][h*Cp/2 + 4*chunk + e], zero padded
     auto pack_pw = [&](int wt, int kblk = 0) {
@@ -310,6 +316,45 @@ void Model::rebuild() {
             res_cblob_[i].clear();
             continue;
         }
+        if (n.kind == Node::Resident && n.tail) {
+            // tail_kernels.hip: per stage the A operands of v_mfma_f32_16x16x4_f32 — lane (k-quarter kq = l / 16, row m = l % 16) holds, for
+            // float4 step i, W[16 tile + m][kq * Kv / 4 + 4 i .. + 3] ([O][KH][KW][I] read as [O][Kv]) — and the small constants:
+            // [bias][slope] padded to whole tiles, then for depthwise stages the taps [9][Kv] and the depthwise bias [Kv]
+            tail_wa_[i].assign(n.stages.size(), -1);
+            tail_wc_[i].assign(n.stages.size(), -1);
+            for (size_t k = 0; k < n.stages.size(); k++) {
+                const Node::Stage& sg = n.stages[k];
+                const TailStage& st = sg.tst;
+                if (st.kind == TAIL_LOAD) continue;
+                const Node& m = n.members[static_cast<size_t>(sg.member)];
+                const auto& wsrc = g.tensors[m.kind == Node::Conv ? m.w : m.w2].f32;
+                const int O = st.Co, Kv = st.Kv, nct = (O + 15) / 16, n4 = Kv / 16, K4 = Kv / 4;
+                if (wsrc.size() != static_cast<size_t>(O) * Kv) throw std::runtime_error("engine: tail stage weights do not match its shape");
+                std::vector<float> r(static_cast<size_t>(nct) * n4 * 256, 0.f);
+                for (int ct = 0; ct < nct; ct++)
+                    for (int q = 0; q < n4; q++)
+                        for (int l = 0; l < 64; l++)
+                            for (int e = 0; e < 4; e++) {
+                                const int o = 16 * ct + (l & 15), c = (l >> 4) * K4 + 4 * q + e;
+                                if (o < O) r[((static_cast<size_t>(ct) * n4 + q) * 64 + l) * 4 + e] = wsrc[static_cast<size_t>(o) * Kv + c];
+                            }
+                tail_wa_[i][k] = put(r);
+                const int bias_t = m.kind == Node::Conv ? m.b : m.b2;
+                std::vector<float> cb(static_cast<size_t>(32 * nct) + (st.kind == TAIL_DW ? static_cast<size_t>(10) * Kv : 0), 0.f);
+                for (int c = 0; c < O; c++) {
+                    cb[static_cast<size_t>(c)] = bias_t >= 0 ? g.tensors[bias_t].f32[static_cast<size_t>(c)] : 0.f;
+                    cb[static_cast<size_t>(16 * nct + c)] = m.act == ACT_PRELU ? g.tensors[m.alpha].f32[static_cast<size_t>(c)] : (m.act == ACT_NONE ? 1.f : 0.f);
+                }
+                if (st.kind == TAIL_DW) {
+                    const auto& wd = g.tensors[m.w].f32;  // [3][3][C]
+                    for (int t = 0; t < 9 * Kv; t++) cb[static_cast<size_t>(32 * nct + t)] = wd[static_cast<size_t>(t)];
+                    if (m.b >= 0)
+                        for (int c = 0; c < Kv; c++) cb[static_cast<size_t>(32 * nct + 9 * Kv + c)] = g.tensors[m.b].f32[static_cast<size_t>(c)];
+                }
+                tail_wc_[i][k] = put(cb);
+            }
+            continue;
+        }
         if (n.kind == Node::Resident) {
             for (const Node& m : n.members) {
                 MemberOff mo;
@@ -428,9 +473,33 @@ void Model::rebuild() {
             r.root_off = plan_.root_offset[st.root];
             return r;
         };
+        std::vector<TailStage> tprogs;
         for (size_t i = 0; i < NN; i++) {
             const Node& n = plan_.nodes[i];
-            if (n.kind != Node::Resident) continue;
+            if (n.kind != Node::Resident || !n.tail) continue;
+            node_prog_[i] = static_cast<long>(tprogs.size());
+            for (size_t k = 0; k < n.stages.size(); k++) {
+                const Node::Stage& sg = n.stages[k];
+                TailStage st = sg.tst;
+                if (sg.src_t >= 0) st.src_g = ref(sg.src_t);
+                if (st.kind != TAIL_LOAD) {
+                    if (sg.dst_t >= 0) st.dst_g = ref(sg.dst_t);
+                    if (sg.res_t >= 0) st.res_g = ref(sg.res_t);
+                    st.w_a = tail_wa_[i][k];
+                    st.w_c = tail_wc_[i][k];
+                }
+                tprogs.push_back(st);
+            }
+        }
+        if (d_tail_programs_) hip_check(hipFree(d_tail_programs_), "hipFree");
+        d_tail_programs_ = nullptr;
+        if (!tprogs.empty()) {
+            hip_check(hipMalloc(reinterpret_cast<void**>(&d_tail_programs_), tprogs.size() * sizeof(TailStage)), "hipMalloc programs");
+            hip_check(hipMemcpy(d_tail_programs_, tprogs.data(), tprogs.size() * sizeof(TailStage), hipMemcpyHostToDevice), "upload programs");
+        }
+        for (size_t i = 0; i < NN; i++) {
+            const Node& n = plan_.nodes[i];
+            if (n.kind != Node::Resident || n.tail) continue;
             node_prog_[i] = static_cast<long>(progs.size());
             for (const Node::Stage& sg : n.stages) {
                 ResStage st = sg.st;
@@ -602,7 +671,7 @@ std::string Model::node_label(const Node& n) const {
             const int rps = strip_pipe_rows_per_step(sin[1], pipe_rows_);
             return std::string(rps == 4 ? "strip_pipe1m_kernel<" : (rps == 3 ? "strip_pipe2m_kernel<" : (rps == 2 ? "strip_pipe2_kernel<" : "strip_pipe_kernel<"))) + std::to_string(sin.back() / 4) + "," + std::to_string(n.members.size()) + "," + (n.members[0].act == ACT_RELU ? "1" : "0") + "," + std::to_string(nh2) + ">";
         }
-        case Node::Resident: return n.xc ? "xc_kernel" : (n.dblock ? "dblock_kernel" : (n.bneck ? "bneck_kernel" : "resident_kernel"));
+        case Node::Resident: return n.xc ? "xc_kernel" : (n.dblock ? "dblock_kernel" : (n.bneck ? "bneck_kernel" : (n.tail ? "tail_kernel" : "resident_kernel")));
         case Node::Add: return "add_kernel";
         case Node::Act: return "act_kernel";
         case Node::MaxPool: return "maxpool_kernel";
@@ -867,6 +936,27 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         break;
                     }
                     rc = launch_bneck(a, s);
+                    break;
+                }
+                if (n.tail) {
+                    TailLaunch a;
+                    a.prog = d_tail_programs_ + node_prog_[i];
+                    a.nstages = static_cast<int>(n.stages.size());
+                    a.B = F;
+                    a.frame_floats = n.tail_frame_floats;
+                    a.variant = tail_pre_;
+                    // frames per workgroup: as many as keep every CU busy (a workgroup's stage costs the same few thousand cycles of
+                    // latency whether its pixel tiles are full or not), within what the CU's LDS holds
+                    const int gmax = std::max(1, (160 * 1024 - 1024) / (4 * n.tail_frame_floats));
+                    a.G = tail_g_ > 0 ? std::min(tail_g_, gmax) : std::max(1, std::min(gmax, F / device_cu_count()));
+                    for (int k = 0; k < kResBases; k++) { a.bases.p[k] = nullptr; a.bases.scale[k] = 0; a.bases.frame0[k] = 0; }
+                    a.bases.p[0] = d_arena_ + static_cast<size_t>(plan_.arena_floats_per_frame) * chunk_cap_ * arena_lane_;
+                    a.bases.scale[0] = chunk_cap_;
+                    a.bases.p[1] = const_cast<float*>(in);
+                    a.bases.frame0[1] = chunk_start;
+                    for (int k = 0; k < num_outputs() && 2 + k < kResBases; k++) { a.bases.p[2 + k] = d_out_[k]; a.bases.frame0[2 + k] = chunk_start; }
+                    a.bases.weights = d_weights_;
+                    rc = launch_tail(a, s);
                     break;
                 }
                 ResLaunch a;

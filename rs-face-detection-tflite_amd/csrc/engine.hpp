@@ -95,6 +95,11 @@ class Model {
     std::vector<std::vector<MemberOff>> chain_head_off_;  // per node, per head pair: stacked weights (w2) and bias (b2)
 
     ResStage* d_programs_ = nullptr;        // stage programs of the Resident nodes (device memory)
+    TailStage* d_tail_programs_ = nullptr;  // ... of those that run on tail_kernels.hip (Node::tail; node_prog_ indexes this array then)
+    std::vector<std::vector<long>> tail_wa_, tail_wc_;  // per tail node, per stage: A operands / small constants (-1: LOAD)
+    int tail_ = 1;                          // option "tail"
+    int tail_pre_ = 0;                      // option "tail_pre"
+    int tail_g_ = 0;                        // option "tail_g": frames per workgroup of the tail programs (0 = chosen per launch)
     std::vector<std::vector<long>> res_wblk_;   // per Resident node, per stage: K-blocked weight packing (-1: classic order)
     std::vector<std::vector<long>> res_cblob_;  // per Resident node, per stage: offset of its packed constants (-1: LOAD)
     std::vector<long> node_prog_;           // per node: first stage in d_programs_ (-1 none)

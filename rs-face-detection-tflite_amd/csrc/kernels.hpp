@@ -244,6 +244,42 @@ int resident_const_floats(const ResStage& st);  // LDS floats the stage's consta
 constexpr int kResSlabFloats = 8 * 32 * 20;        // LDS floats of the 8 waves' staging slabs (kblk stages)
 constexpr int kResConstMax = 5120;               // most constants a stage may have (10 per thread, prefetched in registers)
 
+// Stage programs with several frames per workgroup (tail_kernels.hip): the same three stage kinds on v_mfma_f32_16x16x4_f32, every
+// LDS tensor a dense [G * H * W][C + 4] array without borders (per-frame offsets, multiplied by G at run time).
+enum TailKind : int { TAIL_LOAD = 0, TAIL_GATHER = 1, TAIL_DW = 2 };
+struct TailStage {
+    int kind = TAIL_GATHER;
+    int K = 1, S = 1, pt = 0, pl = 0;  // GATHER: K x K window with stride K (1 or 2); DW: 3 x 3, stride S, TF SAME pads before the first row / column
+    int src_off = -1;                  // LDS floats per frame (-1: global memory, LOAD and DW only)
+    int src_H = 0, src_W = 0, src_C = 0;
+    ResRef src_g;
+    int Kv = 0;                        // contraction length: K * K * src_C (GATHER), src_C (DW)
+    int Ho = 0, Wo = 0, Co = 0;
+    int dst_off = -1;                  // LDS floats per frame (-1: none)
+    ResRef dst_g;                      // optional global copy, dense [Ho][Wo][Co] (base < 0: none)
+    int res_mode = RES_NONE, res_C = 0, res_W = 0;
+    int res_off = -1;                  // skip source in LDS (floats per frame), else res_g
+    ResRef res_g;
+    int act = ACT_NONE;
+    int scr_off = -1;                  // DW: the depthwise scratch [Ho * Wo][Kv + 4], LDS floats per frame
+    int pool_off = -1;                 // DW stride 2 whose skip is the 2x2 max-pool of its own source (pads 0): the depthwise phase leaves the pooled
+                                       // pixels here ([Ho * Wo][Kv + 4]: taps (0..1, 0..1) are the pool window) and the epilogue reads them as a direct skip
+    unsigned mHW = 0, mW = 0;          // tail_magic(Ho * Wo), tail_magic(Wo); LOAD: tail_magic(H * W * C / 4), tail_magic(C / 4)
+    long w_a = -1;                     // float offsets into the weights blob: A operands [tile][Kv / 16][lane][4] ...
+    long w_c = -1;                     // ... and [bias 16 nct][slope 16 nct]([9][Kv] depthwise taps, [Kv] depthwise bias)
+};
+struct TailLaunch {
+    const TailStage* prog = nullptr;   // device memory
+    int nstages = 0, B = 0;
+    int G = 1;                         // frames per workgroup
+    int frame_floats = 0;              // LDS floats per frame (activations + depthwise scratch)
+    int variant = 0;                   // 0: chosen per launch; 1: constants a stage ahead (256 registers, one workgroup per CU); 2: 128 registers, two per CU
+    ResBases bases;
+};
+int launch_tail(const TailLaunch& a, void* stream);
+bool tail_stage_ok(int kind, int K, int S, int src_C, int Kv, int Co, bool dst_lds);
+unsigned tail_magic(int d);
+
 // ---- launchers (kernels.hip). All enqueue on `stream` and return hipError_t as int (0 = success).
 int launch_conv(const ConvArgs& a, void* stream);
 const char* conv_kernel_label(const ConvArgs& a);

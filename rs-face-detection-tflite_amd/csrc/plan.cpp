@@ -528,6 +528,218 @@ bool build_resident(const Graph& g, const std::vector<Node>& ns, size_t i, size_
 }
 
 
+// Level 5, round 5: the same candidate group [i, j] as a stage program of tail_kernels.hip (several frames per workgroup, every LDS
+// tensor a dense borderless [pixels][C + 4] array, 16x16x4 MFMAs).  Also takes the frame-resident chains with their stride-2
+// neighbours (the face mesh's 24x24 -> 12x12 x2 -> 6x6 and 6x6 x3 -> 3x3 launches): a BlazeBlock updates its input tensor in place, the
+// stride-2 block in front reads its taps from global memory.  Placement by liveness, the depthwise scratch included.
+bool build_tail(const Graph& g, const std::vector<Node>& ns, size_t i, size_t j, Node* out) {
+    std::vector<Node> M;
+    for (size_t k = i; k <= j; k++) {
+        const Node& n = ns[k];
+        if (n.kind == Node::Chain) {
+            if (!n.head_pairs.empty()) return false;  // chains with output heads stay on chain_kernels.hip
+            const auto& sr = g.tensors[n.members[n.chain_pre ? 1 : 0].in[0]].shape;  // the resident frame
+            if (sr.size() != 4 || sr[1] * sr[2] > 256) return false;                  // row-pipelined chains
+            for (const Node& m : n.members) M.push_back(m);
+        } else if (n.kind == Node::Conv && n.gemm_head) {
+            return false;
+        } else if (n.kind == Node::Block || n.kind == Node::Conv) {
+            M.push_back(n);
+        } else {
+            return false;
+        }
+    }
+    auto shp = [&](int t) -> const std::vector<int>& { return g.tensors[t].shape; };
+    std::map<int, int> made;
+    for (size_t m = 0; m < M.size(); m++) made[M[m].out] = static_cast<int>(m);
+    auto external = [&](int t) {
+        if (std::find(g.outputs.begin(), g.outputs.end(), t) != g.outputs.end()) return true;
+        for (size_t k = 0; k < ns.size(); k++) {
+            if (k >= i && k <= j) continue;
+            if (std::find(ns[k].in.begin(), ns[k].in.end(), t) != ns[k].in.end() || ns[k].res == t) return true;
+        }
+        return false;
+    };
+    struct Lt { int H = 0, W = 0, C = 0, def = -1, last = -1, off = -1; bool in_lds = false; };
+    std::map<int, Lt> lt;
+    auto geom = [&](int t) -> Lt& {
+        auto it = lt.find(t);
+        if (it == lt.end()) {
+            Lt x;
+            x.H = shp(t)[1]; x.W = shp(t)[2]; x.C = shp(t)[3];
+            it = lt.emplace(t, x).first;
+        }
+        return it->second;
+    };
+    std::vector<Node::Stage> S;
+    std::vector<int> ext_in, ext_out;
+    auto add_ext_in = [&](int t) { if (std::find(ext_in.begin(), ext_in.end(), t) == ext_in.end()) ext_in.push_back(t); };
+    auto in_lds = [&](int t) { return lt.count(t) && lt[t].in_lds; };
+    auto load = [&](int t) {   // bring an external frame into LDS
+        const auto& s = shp(t);
+        if (s[3] % 4 || static_cast<long>(s[1]) * s[2] * (s[3] + 4) * 4 > 150 * 1024) return false;
+        Node::Stage ld;
+        ld.tst.kind = TAIL_LOAD;
+        ld.tst.src_H = s[1]; ld.tst.src_W = s[2]; ld.tst.src_C = s[3];
+        ld.tst.mHW = tail_magic(s[1] * s[2] * (s[3] / 4)); ld.tst.mW = tail_magic(s[3] / 4);
+        ld.src_t = t; ld.dst_t = t;
+        Lt& x = geom(t);
+        x.in_lds = true; x.def = static_cast<int>(S.size());
+        S.push_back(ld);
+        add_ext_in(t);
+        return true;
+    };
+    int min_px = 1 << 30;
+    for (size_t m = 0; m < M.size(); m++) {
+        const Node& n = M[m];
+        if (n.in.size() != 1 || n.res_after || n.ept >= 0 || n.epl >= 0) return false;
+        const int src = n.in[0];
+        if (shp(src).size() != 4 || shp(n.out).size() != 4) return false;
+        const int H = shp(src)[1], W = shp(src)[2], C = shp(src)[3];
+        const int Ho = shp(n.out)[1], Wo = shp(n.out)[2], Co = shp(n.out)[3];
+        if (C % 4 || Ho * Wo > 256 || H * W > 1024) return false;
+        Node::Stage sg;
+        TailStage& st = sg.tst;
+        sg.member = static_cast<int>(m);
+        st.src_H = H; st.src_W = W; st.src_C = C;
+        st.Ho = Ho; st.Wo = Wo; st.Co = Co;
+        st.mHW = tail_magic(Ho * Wo); st.mW = tail_magic(Wo);
+        st.act = n.act;
+        const bool src_inside = made.count(src) && made[src] < static_cast<int>(m);
+        if (src_inside && !in_lds(src)) return false;
+        // where the output goes
+        bool used_inside = false;
+        for (size_t m2 = m + 1; m2 < M.size(); m2++)
+            used_inside |= std::find(M[m2].in.begin(), M[m2].in.end(), n.out) != M[m2].in.end() || M[m2].res == n.out;
+        const bool ext = external(n.out);
+        if (!used_inside && !ext) return false;
+        if (n.kind == Node::Block && n.w >= 0) {
+            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) return false;
+            st.kind = TAIL_DW;
+            st.K = 3; st.S = n.sh; st.Kv = C;
+            st.pt = std::max(0, (Ho - 1) * n.sh + 3 - H) / 2;
+            st.pl = std::max(0, (Wo - 1) * n.sw + 3 - W) / 2;
+            if (!tail_stage_ok(TAIL_DW, 3, st.S, C, C, Co, used_inside)) return false;
+            if (!in_lds(src)) {
+                // a stride-1 block brings its frame in (its skip is the frame, and it updates it in place); a stride-2 block reads the
+                // nine taps of a pixel straight from global memory (its input is four times the frame and often does not fit)
+                if (n.sh == 1) { if (!load(src)) return false; }
+                else { sg.src_t = src; add_ext_in(src); }
+            }
+        } else {
+            int K = 1;
+            if (n.kind == Node::Conv) {
+                if (n.KH != n.KW || n.res >= 0) return false;
+                K = n.KH;
+                if (K != 1 && (K != 2 || n.sh != 2 || n.sw != 2 || H % 2 || W % 2)) return false;
+                if (K == 1 && (n.sh != 1 || n.sw != 1)) return false;
+                if (Ho != H / K || Wo != W / K) return false;
+            } else if (n.kind != Node::Block) {
+                return false;
+            }
+            st.kind = TAIL_GATHER;
+            st.K = K; st.S = K; st.Kv = K * K * C;
+            if (!tail_stage_ok(TAIL_GATHER, K, K, C, st.Kv, Co, used_inside)) return false;
+            if (!in_lds(src) && !load(src)) return false;
+        }
+        if (in_lds(src)) lt[src].last = static_cast<int>(S.size());
+        if (n.res >= 0) {
+            const auto& sr = shp(n.res);
+            if (sr.size() != 4 || sr[3] % 4 || sr[3] > Co) return false;
+            if (n.res_mode == RES_DIRECT) { if (sr[1] != Ho || sr[2] != Wo) return false; }
+            else if (n.res_mode == RES_MAXPOOL) { if (sr[1] != 2 * Ho || sr[2] != 2 * Wo) return false; }
+            else return false;
+            st.res_mode = n.res_mode; st.res_C = sr[3]; st.res_W = sr[2];
+            if (in_lds(n.res)) {
+                lt[n.res].last = static_cast<int>(S.size());
+            } else if (made.count(n.res) && made[n.res] < static_cast<int>(m)) {
+                return false;
+            } else {
+                sg.res_t = n.res;
+                add_ext_in(n.res);
+            }
+        }
+        if (used_inside) {
+            Lt& y = geom(n.out);
+            y.in_lds = true; y.def = static_cast<int>(S.size());
+        }
+        if (ext) { sg.dst_t = n.out; ext_out.push_back(n.out); }
+        min_px = std::min(min_px, Ho * Wo);
+        S.push_back(sg);
+    }
+    if (ext_out.empty() || ext_in.size() + ext_out.size() > 12) return false;
+    // ---- LDS placement in stage order (floats per frame; the kernel multiplies every offset by the frames per workgroup)
+    struct Live { int off, size, t; };   // t < 0: a depthwise scratch
+    std::vector<Live> live;
+    int high = 0;
+    auto size_of = [&](const Lt& x) { return x.H * x.W * (x.C + 4); };
+    auto place = [&](int size, int t) {
+        std::sort(live.begin(), live.end(), [](const Live& a, const Live& b) { return a.off < b.off; });
+        int off = 0;
+        for (const Live& l : live) {
+            if (off + size <= l.off) break;
+            off = std::max(off, l.off + l.size);
+        }
+        live.push_back({off, size, t});
+        high = std::max(high, off + size);
+        return off;
+    };
+    for (size_t k = 0; k < S.size(); k++) {
+        Node::Stage& sg = S[k];
+        TailStage& st = sg.tst;
+        const int src = sg.member >= 0 ? M[static_cast<size_t>(sg.member)].in[0] : sg.src_t;
+        const int dst = sg.member >= 0 ? M[static_cast<size_t>(sg.member)].out : sg.dst_t;
+        const int res = sg.member >= 0 ? M[static_cast<size_t>(sg.member)].res : -1;
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.t < 0 || lt[l.t].last < static_cast<int>(k); }), live.end());
+        if (st.kind != TAIL_LOAD && in_lds(src)) st.src_off = lt[src].off;
+        if (st.kind != TAIL_LOAD && res >= 0 && in_lds(res)) st.res_off = lt[res].off;
+        // (the output first: it outlives the stage's scratch, which then fills the space above it)
+        if (in_lds(dst) && lt[dst].def == static_cast<int>(k)) {
+            Lt& y = lt[dst];
+            if (y.last < static_cast<int>(k)) y.last = static_cast<int>(k);
+            bool placed = false;
+            // in place on the skip tensor when it dies here: the lane that stores an output quad is the one that read the skip quad at
+            // that address.  A depthwise stage may do so even when the skip is its own source (the taps went into the scratch before
+            // the stage's barrier); a pointwise stage reads its source across lanes while others store.
+            if (st.kind != TAIL_LOAD && res >= 0 && st.res_off >= 0 && st.res_mode == RES_DIRECT && (res != src || st.kind == TAIL_DW)) {
+                const Lt& r = lt[res];
+                if (r.last == static_cast<int>(k) && r.H == y.H && r.W == y.W && r.C == y.C) {
+                    y.off = r.off;
+                    for (Live& l : live) if (l.t == res) l.t = dst;
+                    placed = true;
+                }
+            }
+            if (!placed) y.off = place(size_of(y), dst);
+            st.dst_off = y.off;
+        }
+        if (st.kind == TAIL_DW) {
+            st.scr_off = place(st.Ho * st.Wo * (st.Kv + 4), -1);
+            if (st.S == 2 && st.res_mode == RES_MAXPOOL && res == src && st.pt == 0 && st.pl == 0 && st.res_C == st.Kv) {
+                const int before = high;
+                st.pool_off = place(st.Ho * st.Wo * (st.Kv + 4), -1);
+                if ((static_cast<long>(high) + 260) * 4 > 160 * 1024) { st.pool_off = -1; live.pop_back(); high = before; }   // no room: the epilogue pools from the source
+            }
+        }
+    }
+    const int frame_floats = (high + 3) & ~3;
+    if ((static_cast<long>(frame_floats) + 256) * 4 > 160 * 1024) return false;
+    Node r;
+    r.kind = Node::Resident;
+    r.tail = true;
+    r.tail_frame_floats = frame_floats;
+    r.tail_min_px = min_px;
+    r.res_lds_bytes = (frame_floats + 256) * 4;
+    r.members = std::move(M);
+    r.stages = std::move(S);
+    r.in = ext_in;
+    r.out = ext_out.back();
+    ext_out.pop_back();
+    r.extra_out = ext_out;
+    for (size_t k = i; k <= j; k++) r.src_ops.insert(r.src_ops.end(), ns[k].src_ops.begin(), ns[k].src_ops.end());
+    *out = std::move(r);
+    return true;
+}
+
 // Level 5, large frames: the bottleneck pair  r = act(PW(x));  y = act(PW(DW3x3(r)) + b + x')  (iris 32x32: 64 -> 32 -> 64
 // channels) whose frame does not fit in LDS runs as ONE launch cut into row bands: a workgroup recomputes the one-row halo of
 // r for its band, keeps r in LDS and reads x / x' and writes y in global memory — r never reaches HBM.
@@ -848,11 +1060,13 @@ bool is_fork(const std::vector<Node>& ns, const std::vector<std::vector<char>>& 
     return false;
 }
 
-std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget) {
+std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, int budget, bool tail) {
     std::vector<Node> outv;
     static const bool no_bneck = getenv("MI_NO_BNECK") != nullptr;  // development aid
     static const bool no_dblock = getenv("MI_NO_DBLOCK") != nullptr;  // development aid
     static const bool no_fork_split = getenv("MI_NO_FORK_SPLIT") != nullptr;  // development aid
+    const bool no_tail = !tail || getenv("MI_NO_TAIL") != nullptr;     // option "tail" 0 / development aid: the round-4 plan (resident_kernel / chain_kernel for every small-spatial part)
+    static const bool tail_split = getenv("MI_TAIL_SPLIT") != nullptr;  // development aid
     const std::vector<std::vector<char>> dep = dependence(ns);
     for (size_t i = 0; i < ns.size();) {
         {
@@ -885,17 +1099,26 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
         Node best;
         size_t best_j = 0;
         bool have = false;
-        for (size_t j = i; j < ns.size(); j++) {
-            Node cand;
-            {   // a stage program does not run on into an expand / contract run: that one has its own launch (xc_kernels.hip)
-                Node xn;
-                if (j > i && build_xc(g, ns, j, &xn)) break;
+        // the longest run from i in either form; the several-frames-per-workgroup form (tail_kernels.hip) wins when it reaches at
+        // least as far (it also takes frame-resident chains with stride-2 neighbours, which the classic form leaves alone)
+        for (int form = no_tail ? 1 : 0; form < 2; form++) {
+            Node fbest;
+            size_t fj = 0;
+            bool fhave = false;
+            for (size_t j = i; j < ns.size(); j++) {
+                Node cand;
+                {   // a stage program does not run on into an expand / contract run: that one has its own launch (xc_kernels.hip)
+                    Node xn;
+                    if (j > i && build_xc(g, ns, j, &xn)) break;
+                }
+                if (!(form == 0 ? build_tail(g, ns, i, j, &cand) : build_resident(g, ns, i, j, budget, &cand))) break;  // a longer run only needs more
+                fbest = std::move(cand);
+                fj = j;
+                fhave = true;
+                if (!no_fork_split && j > i && is_fork(ns, dep, j)) break;  // the launch ends where the branches part (a fork at the very start is the previous launch's business)
+                if (form == 0 && tail_split && j + 1 < ns.size() && ns[j].kind == Node::Chain && ns[j].chain_post) break;  // development aid: a launch per resolution
             }
-            if (!build_resident(g, ns, i, j, budget, &cand)) break;  // a longer run only needs more
-            best = std::move(cand);
-            best_j = j;
-            have = true;
-            if (!no_fork_split && j > i && is_fork(ns, dep, j)) break;  // the launch ends where the branches part (a fork at the very start is the previous launch's business)
+            if (fhave && (!have || fj > best_j)) { best = std::move(fbest); best_j = fj; have = true; }
         }
         // worth a launch of its own: at least two fused nodes, or a k x k convolution (otherwise the generic direct conv)
         bool take = have && (best.members.size() >= 2 || (best.members[0].kind == Node::Conv && best.members[0].KH > 1));
@@ -917,7 +1140,7 @@ std::vector<Node> group_resident(const Graph& g, const std::vector<Node>& ns, in
 }  // namespace
 
 namespace {
-Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads);
+Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads, bool tail);
 
 // The chain's output heads and the batch-GEMM heads are chosen before storage exists (placeholder pointers, 16-byte aligned); the
 // kernels need the real views 16-byte aligned with frame strides that are multiples of 4 floats.  A head whose slice of a
@@ -942,10 +1165,10 @@ bool head_views_aligned(const Plan& plan) {
 }
 }  // namespace
 
-Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes) {
-    Plan plan = build_plan_impl(graph, fuse_level, pipe_max_opt, res_budget_bytes, true);
+Plan build_plan(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool tail) {
+    Plan plan = build_plan_impl(graph, fuse_level, pipe_max_opt, res_budget_bytes, true, tail);
     if (head_views_aligned(plan)) return plan;
-    return build_plan_impl(std::move(graph), fuse_level, pipe_max_opt, res_budget_bytes, false);
+    return build_plan_impl(std::move(graph), fuse_level, pipe_max_opt, res_budget_bytes, false, tail);
 }
 
 namespace {
@@ -1192,7 +1415,7 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
     for (int& t : g.outputs) t = resolve(t);
 }
 
-Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads) {
+Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budget_bytes, bool fuse_heads, bool tail) {
     Plan plan;
     plan.graph = std::move(graph);
     plan.fuse_level = fuse_level;
@@ -1512,7 +1735,7 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
     // ---- level 5: frame-resident stage programs
     if (fuse_level >= 5) {
         reorder_branches(plan.nodes);
-        plan.nodes = group_resident(g, plan.nodes, res_budget_bytes);
+        plan.nodes = group_resident(g, plan.nodes, res_budget_bytes, tail);
     }
     // ---- tail branches: behind the LAST fork of the plan the remaining launches fall into chains that do not need each other (the
     // output heads of the iris / face mesh networks: 16 + 16 stage-program nodes).  branch[i] = chain of node i (0 = stays on the trunk
@@ -1707,6 +1930,9 @@ std::string Plan::describe() const {
                << " channels), frame resident, depthwise stages on the fly";
         } else if (n.kind == Node::Resident && n.bneck) {
             os << " x" << n.members.size() / 2 << " bottleneck blocks, wide tensor in registers, " << (n.res_bands > 1 ? std::to_string(n.res_bands) + " row bands" : std::string("frame resident"));
+        } else if (n.kind == Node::Resident && n.tail) {
+            os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, several frames per workgroup, " << n.tail_frame_floats * 4 << " B LDS per frame";
+            for (int t : n.extra_out) os << " +t" << t;
         } else if (n.kind == Node::Resident) {
             os << " x" << n.members.size() << " nodes in " << n.stages.size() << " stages, " << (n.res_bands > 1 ? "row-band resident" : "frame resident") << ", " << n.res_lds_bytes << " B LDS";
             if (n.res_bands > 1) os << ", " << n.res_bands << " bands of " << n.stages[0].st.band_rows << " rows";

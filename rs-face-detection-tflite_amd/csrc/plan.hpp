@@ -11,7 +11,8 @@
 //            launch, the intermediate rows handed from block to block through LDS (strip_kernels.hip)
 //   level 5  the small-spatial parts (outputs of <= 256 pixels) become frame-resident stage programs: independent branches are
 //            made contiguous, then maximal runs of blocks / pointwise convs / k x k stride-k convs whose live activations
-//            fit in LDS are one launch each (resident_kernels.hip)
+//            fit in LDS are one launch each (resident_kernels.hip; round 5: tail_kernels.hip where its stage forms exist, which
+//            also takes the face mesh's frame-resident chains with their stride-2 neighbours)
 #pragma once
 
 #include <string>
@@ -29,12 +30,16 @@ struct Node {
     // filled in by the engine from (src_t, dst_t, res_t) and the member's constants.
     struct Stage {
         ResStage st;
+        TailStage tst;                         // Node::tail: the stage in tail_kernels.hip's form (st is unused then)
         int member = -1;                       // index into members (-1: LOAD stage)
         int src_t = -1, dst_t = -1, res_t = -1;  // tensors behind the global references (-1: none)
     };
     std::vector<Stage> stages;
     int res_const_off = 0, res_const_floats = 0, res_lds_bytes = 0;
     int res_bands = 1;           // Resident: workgroups per frame (row bands; 1 = the whole frame is resident)
+    bool tail = false;           // Resident: the stage program runs on tail_kernels.hip (several frames per workgroup, 16x16x4 MFMAs)
+    int tail_frame_floats = 0;   // ... LDS floats one frame needs (activations + depthwise scratch, placed by liveness)
+    int tail_min_px = 0;         // ... fewest output pixels per frame among its stages (the engine picks the frames per workgroup)
     bool dblock = false;         // Resident without stages: members are the two blocks of a full_range double block (dblock_kernels.hip)
     bool xc = false;             // Resident without stages: members alternate expand / contract blocks on a tiny frame (xc_kernels.hip)
     bool bneck = false;          // Resident without stages: members are (pointwise C -> Cm, depthwise block Cm -> C + skip) pairs run by
@@ -94,6 +99,7 @@ struct Plan {
 
 // pipe_max: most blocks one row-pipelined chain may hold (level 4; 2..4, below 2 disables them)
 // res_budget_bytes: LDS a frame-resident stage program may use (level 5)
-Plan build_plan(Graph g, int fuse_level, int pipe_max = 4, int res_budget_bytes = 156 * 1024);
+// tail: stage programs take tail_kernels.hip's form where it exists (false: the round-4 plan)
+Plan build_plan(Graph g, int fuse_level, int pipe_max = 4, int res_budget_bytes = 156 * 1024, bool tail = true);
 
 }  // namespace mi

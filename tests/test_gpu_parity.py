@@ -286,6 +286,53 @@ def test_batch_size_sweep_across_kernel_thresholds(gpu, oracle, name):
     m.close()
 
 
+@pytest.mark.parametrize("name", ["landmark", "iris"])
+def test_tail_programs_frames_per_workgroup(gpu, oracle, name):
+    """Round 5: the small-spatial stage programs of the face mesh (24x24 -> 12x12 x2 -> 6x6 x3 -> 3x3, the two 3x3 branches) and the iris
+    network (the two 8x8 -> 2x2 branches) run on tail_kernel: G frames per workgroup share the 16-pixel MFMA tiles, LDS tensors without
+    borders.  Every G from 1 to what the LDS holds — with batches that leave the last workgroup partly empty and pixel tiles that
+    straddle two frames — against the oracle frame by frame, bit-identical among each other (a pixel's contraction order does not
+    depend on its tile slot), and against the round-4 kernels (option "tail" = 0: resident_kernel / chain_kernel)."""
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path(name))
+    assert "several frames per workgroup" in m.describe()
+    x = seeded_input(name, 37, 99, m.input_dims[1:3])
+    x[5] = 0.0
+    x[9, :, : x.shape[2] // 2] = x.max()
+    om = oracle.Model(model_path(name))
+    refs = om.run(x, nthreads=8)
+    labels = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+    assert "tail_kernel" in labels and "resident_kernel" not in labels or name == "iris", labels
+    base = None
+    for g in (0, 1, 2, 3, 4, 5, 8, 16):
+        m.set_option("tail_g", g)
+        outs = [o.copy() for o in m.run(x)]
+        for o, r in zip(outs, refs):
+            _raw_close(o, r)
+        if base is None:
+            base = outs
+        for o, b in zip(outs, base):
+            np.testing.assert_array_equal(o, b)
+        for nb in (1, 2, 3, 7, 36):   # (other layers of the net change kernels with the batch: tolerance, not bits)
+            for o, b in zip(m.run(x[:nb]), base):
+                _raw_close(o, b[:nb])
+    # a batch large enough for the automatic choice to pack frames (more frames than CUs)
+    m.set_option("tail_g", 0)
+    xb = np.concatenate([x] * 16)[:577]
+    for pre in (1, 2, 0):   # both register variants of the kernel (constants a stage ahead / two workgroups per CU), then the automatic choice
+        m.set_option("tail_pre", pre)
+        for o, b in zip(m.run(xb), base):   # (other layers of the net change kernels with the batch: tolerance, not bits)
+            _raw_close(o, np.concatenate([b] * 16)[:577])
+        for o, b in zip(m.run(x), base):
+            np.testing.assert_array_equal(o, b)
+    m.set_option("tail", 0)
+    labels0 = {r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)}
+    assert "tail_kernel" not in labels0, labels0
+    for o, b in zip(m.run(x), base):
+        _raw_close(o, b)
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))
