@@ -99,11 +99,21 @@ impl FaceDetection {
     /// `infer` over a batch of equally sized frames in ONE call (`mi_fd_infer_images`): u8 RGB frames cross the bus (a quarter of
     /// the f32 tensors), image_to_tensor runs on the device.  `frames` = `batch` frames of `height` rows of `stride` bytes.
     pub fn infer_batch(&self, frames: &[u8], batch: usize, width: i32, height: i32, stride: i32, cap_per_frame: usize) -> Result<Vec<Vec<Detection>>, Error> {
-        let need = (stride as usize) * (height as usize) * batch.saturating_sub(1) + (stride as usize) * (height as usize - 1) + 3 * width as usize;
-        if batch == 0 || batch > i32::MAX as usize || cap_per_frame == 0 || width <= 0 || height <= 0 || stride < 3 * width || frames.len() < need {
+        // (sizes are validated before anything is computed from them: height 0 would underflow, the products may overflow)
+        if batch == 0 || batch > i32::MAX as usize || cap_per_frame == 0 || cap_per_frame > i32::MAX as usize || width <= 0 || height <= 0 || stride <= 0
+            || (stride as i64) < 3 * width as i64
+        {
             return Err(Error::msg("frames must hold batch frames of height rows of stride bytes"));
         }
-        let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; batch * cap_per_frame];
+        let (w, h, s) = (width as usize, height as usize, stride as usize);
+        let need = s.checked_mul(h).and_then(|f| f.checked_mul(batch - 1)).and_then(|x| x.checked_add(s * (h - 1))).and_then(|x| x.checked_add(3 * w));
+        let slots = batch.checked_mul(cap_per_frame);
+        let (need, slots) = match (need, slots) {
+            (Some(n), Some(c)) if frames.len() >= n => (n, c),
+            _ => return Err(Error::msg("frames must hold batch frames of height rows of stride bytes")),
+        };
+        let _ = need;
+        let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; slots];
         let mut counts = vec![0i32; batch];
         check(unsafe {
             ffi::mi_fd_infer_images(self.handle, frames.as_ptr(), batch as i32, width, height, stride, std::ptr::null(), out.as_mut_ptr(),

@@ -111,7 +111,8 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * "pipe" (blocks per row-pipelined chain, 2..4, 0 = none), "pipe_rows" (0 = automatic: two rows per pipeline step with the 1x1 convs on
  * the 4x4x1 MFMA, one row for odd heights; 1 / 2 = one / two rows per step with packed-FMA 1x1 convs; 4 = one row per step, MFMA),
  * "small_chain" (frames up to which a row-pipelined chain runs one launch per block instead — what keeps a batch of one short;
- * default 16, 0 = never), "strip" (0 = LDS-ring block kernel for every block),
+ * default 16, 0 = never; the stand-alone stride-2 block of that form folds its depthwise bias differently, so one frame's raw
+ * outputs differ between a batch <= small_chain and a larger one within the stated 1e-4 tolerance, not bit for bit), "strip" (0 = LDS-ring block kernel for every block),
  * "fork" (0 = output heads run on the trunk's stream instead of beside it), "heads" (side streams the output heads are spread
  * over, 1..4), "tail" (0 = no stage program takes the several-frames-per-workgroup form of round 5: the round-4 plan),
  * "tail_g" (frames per workgroup of those programs; 0 = chosen per launch from the batch and the LDS a frame needs), "reuse",
@@ -171,8 +172,9 @@ int mi_fd_infer_image(mi_fd *h, const uint8_t *rgb, int width, int height, int s
 int mi_fd_infer_images(mi_fd *h, const uint8_t *frames, int batch, int width, int height, int stride, const mi_rect *rois,
                        mi_detection *out, int cap_per_frame, int *counts, int mem, void *stream);
 /* The same for a host feed, split in two so that the copy of one batch overlaps the kernels of the other: submit queues
- * H2D copy (on the slot's own stream), pre-processing, network, post-processing and the copy of the results into pinned
- * memory and returns; collect waits for that slot and hands the results out.  Two slots (0 / 1); a slot must be collected
+ * H2D copy (on the slot's own stream), pre-processing, network and post-processing — whose kernel writes detections and counts
+ * straight into the slot's pinned, mapped, coherent host block (no result copy is queued) — and returns; collect waits for that
+ * slot and hands the results out.  Two slots (0 / 1); a slot must be collected
  * before it is submitted again; `frames` must stay valid until then and should be pinned (mi_host_alloc) — a pageable
  * buffer is copied synchronously by the runtime.  Whole frames (roi = None). */
 int mi_fd_submit_images(mi_fd *h, int slot, const uint8_t *frames, int batch, int width, int height, int stride,

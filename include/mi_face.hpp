@@ -116,6 +116,9 @@ class FaceDetection {
     // bytes, host memory; rois empty (whole frames) or one per frame.  Up to cap_per_frame detections per frame are returned.
     std::vector<std::vector<Detection>> infer_batch(const std::uint8_t* frames, int batch, int width, int height, int stride,
                                                     const std::vector<Rect>& rois = {}, int cap_per_frame = 64) const {
+        if (batch < 1 || cap_per_frame < 1) throw std::invalid_argument("infer_batch: batch and cap_per_frame must be positive");
+        if (!rois.empty() && rois.size() != static_cast<std::size_t>(batch))   // (the C side reads `batch` entries)
+            throw std::invalid_argument("infer_batch: rois must be empty or hold one entry per frame");
         std::vector<mi_detection> out(static_cast<std::size_t>(batch) * cap_per_frame);
         std::vector<int> counts(static_cast<std::size_t>(batch));
         std::vector<mi_rect> r;

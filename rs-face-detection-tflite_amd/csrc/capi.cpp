@@ -149,6 +149,10 @@ struct mi_fd {
     DeviceBuf d_in, d_pad, d_out, d_counts, d_img, d_geom, d_roi;
     FdSlot slot[2];
     ~mi_fd() {
+        //  a batch that was submitted and never collected still reads the anchors and the table: wait for it before
+        // anything is freed (hipFree happens to synchronise the device; this does not rely on it)
+        for (FdSlot& sl : slot)
+            if (sl.pending && sl.done) hipEventSynchronize(sl.done);
         if (d_anchors) hipFree(d_anchors);
         if (d_lut) hipFree(d_lut);
     }
@@ -586,11 +590,10 @@ int mi_fd_submit_images(mi_fd* h, int slot, const uint8_t* frames, int batch, in
         if (nout + ncnt > sl.h_cap) {
             if (sl.h_out) hipHostFree(sl.h_out);
             sl.h_out = nullptr; sl.h_cap = 0;
-            mi::hip_check(hipHostMalloc(&sl.h_out, nout + ncnt, hipHostMallocMapped), "hipHostMalloc");
+            // (coherent: the kernel's stores must be visible to the host once `done` has fired, without a copy)
+            mi::hip_check(hipHostMalloc(&sl.h_out, nout + ncnt, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
             sl.h_cap = nout + ncnt;
         }
-        // frames: host -> device on the slot's copy stream (asynchronous when `frames` is pinned memory: mi_host_alloc);
-        // everything else on the handle's stream, behind the copy
         // frames: host -> device on the slot's copy stream (asynchronous when `frames` is pinned memory: mi_host_alloc);
         // everything else on the handle's stream, behind the copy.  The post-processing kernel writes detections and counts
         // straight into the slot's pinned host block (mapped into the device's address space): a hipMemcpyAsync of the results
@@ -603,8 +606,13 @@ int mi_fd_submit_images(mi_fd* h, int slot, const uint8_t* frames, int batch, in
         void* mapped = nullptr;
         mi::hip_check(hipHostGetDevicePointer(&mapped, sl.h_out, 0), "hipHostGetDevicePointer");
         double* d_pad = static_cast<double*>(sl.d_pad.get(sizeof(double) * 4 * batch));
-        fd_images_device(h, d_frames, batch, width, height, stride, nullptr, d_pad, static_cast<mi_detection*>(mapped), cap_per_frame,
-                         reinterpret_cast<int*>(static_cast<char*>(mapped) + nout), s);
+        try {
+            fd_images_device(h, d_frames, batch, width, height, stride, nullptr, d_pad, static_cast<mi_detection*>(mapped), cap_per_frame,
+                             reinterpret_cast<int*>(static_cast<char*>(mapped) + nout), s);
+        } catch (...) {
+            (void)hipStreamSynchronize(sl.copy);   //  the queued copy may still be reading the caller's frames: not after we return
+            throw;
+        }
         mi::hip_check(hipEventRecord(sl.done, s), "hipEventRecord");
         sl.batch = batch; sl.cap = cap_per_frame; sl.pending = true;
     });

@@ -1092,7 +1092,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                         b.in = cur; b.in_fs = cur_fs;
                         if (b.ep.res_mode != RES_NONE) { b.ep.res = cur; b.ep.res_fs = cur_fs; }
                         if (k == nb - 1) { b.out = op; b.out_fs = out_fs; } else { b.out = T[k & 1]; b.out_fs = fsz; }
-                        if (b.sh == 1) ok = strip_kernel_supports(b);
+                        ok = b.sh == 1 ? strip_kernel_supports(b) : block_kernel_supports(b);   // (the stride-2 member too, or the run fails where the row pipeline below would have taken it)
                         cur = b.out; cur_fs = b.out_fs;
                     }
                     if (ok) {

@@ -265,6 +265,7 @@ struct TailStage {
     int pool_off = -1;                 // DW stride 2 whose skip is the 2x2 max-pool of its own source (pads 0): the depthwise phase leaves the pooled
                                        // pixels here ([Ho * Wo][Kv + 4]: taps (0..1, 0..1) are the pool window) and the epilogue reads them as a direct skip
     unsigned mHW = 0, mW = 0;          // tail_magic(Ho * Wo), tail_magic(Wo); LOAD: tail_magic(H * W * C / 4), tail_magic(C / 4)
+    unsigned mHWp = 0, mWp = 0;        // DW: tail_magic(Ho * ceil(Wo / 2)), tail_magic(ceil(Wo / 2)) (the depthwise phase works on pixel pairs)
     long w_a = -1;                     // float offsets into the weights blob: A operands [tile][Kv / 16][lane][4] ...
     long w_c = -1;                     // ... and [bias 16 nct][slope 16 nct]([9][Kv] depthwise taps, [Kv] depthwise bias)
 };

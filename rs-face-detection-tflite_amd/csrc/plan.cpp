@@ -617,6 +617,7 @@ bool build_tail(const Graph& g, const std::vector<Node>& ns, size_t i, size_t j,
             if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) return false;
             st.kind = TAIL_DW;
             st.K = 3; st.S = n.sh; st.Kv = C;
+            st.mHWp = tail_magic(Ho * ((Wo + 1) / 2)); st.mWp = tail_magic((Wo + 1) / 2);
             st.pt = std::max(0, (Ho - 1) * n.sh + 3 - H) / 2;
             st.pl = std::max(0, (Wo - 1) * n.sw + 3 - W) / 2;
             if (!tail_stage_ok(TAIL_DW, 3, st.S, C, C, Co, used_inside)) return false;
@@ -1319,12 +1320,22 @@ void pad_odd_channels(Graph& g, std::vector<double>* logical_elems, std::vector<
     // a channel PAD that consumes a widened tensor must have room for the extra channels.  Marking a class changes what its
     // neighbours (and its growth group) are padded to, so the check runs to a fixpoint (a single pass could leave an
     // earlier PAD with a negative amount on crafted graphs)
+    // (a pass counts as a change only when a class really flips — a PAD whose data input is a constant can never be marked
+    // (mark() skips constants), and with a shrinking output it kept the loop spinning on crafted graphs; every flip is permanent and
+    // there are at most NT classes, so the loop ends)
     for (bool changed = true; changed;) {
         changed = false;
         for (const OpInfo& op : g.ops)
             if (op.op == BuiltinOp::Pad) {
                 const int in = op.inputs.at(0), out = op.outputs.at(0);
-                if (padded(out) - padded(in) < 0 && !(bad[find(in)] && bad[find(out)])) { mark(in); mark(out); changed = true; }
+                if (padded(out) - padded(in) >= 0) continue;
+                auto flip = [&](int t) {
+                    if (!act(t) || bad[find(t)]) return false;
+                    bad[find(t)] = 1;
+                    return true;
+                };
+                const bool a = flip(in), b = flip(out);
+                changed |= a || b;
             }
     }
     std::vector<int> newC(NT);

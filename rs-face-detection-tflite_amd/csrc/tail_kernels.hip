@@ -287,6 +287,68 @@ __global__ __launch_bounds__(512, PRE ? 2 : 4) void tail_kernel(const TailStage*
             const long sfs = st.src_g.fs;
             const float* zl = lds + zero_off + 4 * c4;
             float* pool = st.pool_off >= 0 ? lds + (long)st.pool_off * G + 4 * c4 : nullptr;   // 2x2 max-pool of the source = taps (0..1, 0..1): the skip, for the epilogue
+            if constexpr (PRE) {
+            // an item = two horizontally adjacent output pixels: they share two (stride 1) / one (stride 2) of their three tap columns, so a
+            // pair costs 12 / 15 reads instead of 18, and the reads of a pair are in flight together
+            const int Wp = (Wo + 1) >> 1, per = Ho * Wp, nitems = nf * per;
+            for (int it = prow; it < nitems; it += PP) {
+                const int f = tdiv(it, st.mHWp), r = it - f * per, oy = tdiv(r, st.mWp), ox = 2 * (r - oy * Wp);
+                const int iy0 = oy * S - st.pt, ix0 = ox * S - st.pl;
+                const int b0 = (f * sH + iy0) * sW + ix0;   // source pixel of tap (0, 0) of the first pixel, counted over the workgroup's frames (may lie outside: unused then)
+                const int p0 = f * HW + oy * Wo + ox;
+                const bool two = ox + 1 < Wo;
+                bool rok[3], cok[5];
+#pragma unroll
+                for (int k = 0; k < 3; k++) rok[k] = (unsigned)(iy0 + k) < (unsigned)sH;
+#pragma unroll
+                for (int k = 0; k < 5; k++) cok[k] = (unsigned)(ix0 + k) < (unsigned)sW;
+                float4 d[3][5];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 5; kx++) {
+                        if (kx == 4 && S == 1) continue;   // (uniform)
+                        const bool ok = rok[ky] && cok[kx];
+                        if (from_lds) {
+                            d[ky][kx] = tld4(ok ? sl + (long)(b0 + ky * sW + kx) * sPS : zl);
+                        } else {
+                            const float4 x = tld4(sg + f * sfs + (long)(ok ? (iy0 + ky) * sW + ix0 + kx : 0) * sC);
+                            d[ky][kx] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                float4 acc0 = bdw, acc1 = bdw;
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {   // (the taps of a pixel in the order of the single-pixel form: ky, kx ascending)
+                        const float4 wt = w[ky * 3 + kx], x0 = d[ky][kx];
+                        acc0.x = fmaf(x0.x, wt.x, acc0.x); acc0.y = fmaf(x0.y, wt.y, acc0.y); acc0.z = fmaf(x0.z, wt.z, acc0.z); acc0.w = fmaf(x0.w, wt.w, acc0.w);
+                    }
+                if (S == 1) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const float4 wt = w[ky * 3 + kx], x1 = d[ky][kx + 1];
+                            acc1.x = fmaf(x1.x, wt.x, acc1.x); acc1.y = fmaf(x1.y, wt.y, acc1.y); acc1.z = fmaf(x1.z, wt.z, acc1.z); acc1.w = fmaf(x1.w, wt.w, acc1.w);
+                        }
+                } else {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const float4 wt = w[ky * 3 + kx], x1 = d[ky][kx + 2];
+                            acc1.x = fmaf(x1.x, wt.x, acc1.x); acc1.y = fmaf(x1.y, wt.y, acc1.y); acc1.z = fmaf(x1.z, wt.z, acc1.z); acc1.w = fmaf(x1.w, wt.w, acc1.w);
+                        }
+                }
+                tst4(scr + (long)p0 * PSk, acc0);
+                if (two) tst4(scr + (long)(p0 + 1) * PSk, acc1);
+                if (pool) {   // (stride 2, pads 0: the 2x2 windows are columns 0..1 and 2..3 of rows 0..1)
+                    tst4(pool + (long)p0 * PSk, tmax4(d[0][0], d[0][1], d[1][0], d[1][1]));
+                    if (two) tst4(pool + (long)(p0 + 1) * PSk, tmax4(d[0][2], d[0][3], d[1][2], d[1][3]));
+                }
+            }
+            } else {   // (128 registers: one pixel per item)
             for (int p = prow; p < P; p += PP) {
                 const int f = tdiv(p, st.mHW), q = p - f * HW, oy = tdiv(q, st.mW), ox = q - oy * Wo;
                 const int iy0 = oy * S - st.pt, ix0 = ox * S - st.pl;
@@ -317,6 +379,7 @@ __global__ __launch_bounds__(512, PRE ? 2 : 4) void tail_kernel(const TailStage*
                 }
                 tst4(scr + (long)p * PSk, acc);
                 if (pool) tst4(pool + (long)p * PSk, tmax4(d[0], d[1], d[3], d[4]));
+            }
             }
             __syncthreads();
             v.bsrc = lds + (long)st.scr_off * G; v.bPS = PSk;

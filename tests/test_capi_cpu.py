@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from conftest import MODEL_FILES, ROOT, model_path
@@ -201,3 +203,32 @@ def test_absent_operand_is_refused_not_dereferenced(mi):
                 assert not bias_slot
                 refused += 1
     assert refused >= len(ops) and accepted >= 4
+
+
+def test_pad_with_constant_input_and_shrinking_output_terminates(tmp_path):
+    """the widening pass (plan.cpp pad_odd_channels) checks its channel PADs to a fixpoint; a PAD whose DATA input is a
+    constant tensor can never be marked (constants are no activation classes), and when its output is narrower than its input the
+    loop used to report a change on every pass — a crafted model hung mi_*_create_from_bytes.  The lowering runs in a child process
+    under a timeout: it must come back (accepting or refusing the graph), with or without an odd-width neighbour that makes the pass
+    do real work."""
+    import subprocess, sys
+    import synth_tflite as st
+
+    for variant in range(3):
+        gb = st.GraphBuilder(7, [1, 8, 8, 8])
+        x = gb.conv(gb.input, 6 if variant else 8)            # 6 channels: the pass has something to widen
+        x = gb.relu(x)
+        c = gb.const(np.zeros((1, 8, 8, 12), np.float32), "const_in")
+        pads = gb.const(np.array([[0, 0], [0, 0], [0, 0], [0, -4 if variant < 2 else 0]]), "pads", dtype=2)
+        y = gb._act([1, 8, 8, 8 if variant < 2 else 12], "pad_of_const")
+        gb.ops.append((st.PAD, [c, pads], [y], st.OPT_PAD, []))
+        x8 = gb.conv(x, y and gb.shape(y)[3])
+        z = gb.add(x8, y)
+        gb.outputs = [gb.relu(z)]
+        path = tmp_path / ("pad_const_%d.tflite" % variant)
+        path.write_bytes(gb.finish())
+        code = ("import sys; sys.path.insert(0, %r); import rs_face_detection_tflite_amd as mi\n"
+                "try:\n    mi.plan_describe(open(%r, 'rb').read(), 5); print('accepted')\n"
+                "except mi.MiError as e:\n    print('refused')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(path)))
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0 and p.stdout.strip() in ("accepted", "refused"), (variant, p.returncode, p.stdout, p.stderr[-400:])

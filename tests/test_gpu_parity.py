@@ -186,7 +186,7 @@ def test_strip_and_pipeline_kernels_agree(gpu, name):
 @pytest.mark.parametrize("name", ["back", "landmark"])
 def test_small_batch_chains_run_block_by_block(gpu, oracle, name):
     """A row pipeline is a chain of dependent steps whose length does not shrink with the batch (88 us per launch for ONE BackCamera
-    frame): up to `small_chain` frames (default 8) the members of such a chain run as one strip-kernel launch each through a
+    frame): up to `small_chain` frames (default 16; the test sets 8) the members of such a chain run as one strip-kernel launch each through a
     ping-pong scratch — FaceDetection::infer(&Mat) is a batch of one (face_detection.rs:205-267).  Batches 1, 3 and 8 against the
     oracle, against the pipelined form (tolerance: the stride-2 block that ends a chain folds its depthwise bias differently in the
     stand-alone block kernel), batch 9 back on the pipelines, and the launch labels of both."""
