@@ -155,3 +155,23 @@ def test_launcher_parent_stays_clear_of_torch_and_hip():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "clean" in r.stdout, r.stderr[-2000:]
     assert '"n_gpus": 1' in r.stdout
+
+
+def test_secondary_configs_run_before_the_gpu_is_touched_and_flag_failures():
+    """the child runs of configs 1 / 3 / 5 behind the headline line are started by bench.py's main() while the
+    process has not imported torch nor made a HIP call, and a child that fails leaves an explicit error record (the line's top-level
+    `secondary_errors` counts them).  Without a GPU every child fails at its device check (status 2): three error records, and the
+    parent still has not loaded torch."""
+    import subprocess, sys, json
+    code = ("import sys, json; sys.path.insert(0, %r); import bench, argparse\n"
+            "a = argparse.Namespace(steps=1, warmup=0)\n"
+            "r = bench.run_secondary_configs(a)\n"
+            "print(json.dumps({'r': r, 'torch': 'torch' in sys.modules}))\n" % ROOT)
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-500:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["torch"] is False
+    assert sorted(d["r"]) == ["config 1", "config 3", "config 5"]
+    for v in d["r"].values():
+        assert "error" in v and "status" in v["error"], v

@@ -916,6 +916,94 @@ def _oracle_pipeline(oracle, models, img, kind="back"):
     return res
 
 
+def test_config5_pipeline_128_frames_originals_vs_oracle(gpu, oracle, man_image):
+    """BASELINE config 5 at its per-GPU size WITH an oracle (the full-size case was property-only): 128 frames of 192x192 =
+    8 distinct frames x 16 in shuffled order through mi_pipeline_run (full-range detector -> faces[0] ROI -> mesh -> 2 x iris on the
+    device); every copy equals its original bit for bit wherever it sits in the batch, and the 8 originals agree with the oracle's
+    frame-by-frame flow (lib.rs:18-40) at the tensor-path tolerances, as configs 2 and 3 are checked at their full sizes."""
+    torch = pytest.importorskip("torch")
+    from PIL import Image
+    img = np.asarray(Image.fromarray(man_image).resize((192, 192)))
+    rs = np.random.RandomState(5)
+    originals = [img, np.roll(img, (7, -5), axis=(0, 1)), img[:, ::-1].copy(), (img.astype(np.float32) * 0.7).astype(np.uint8),
+                 np.roll(img, (-9, 11), axis=(0, 1)), np.clip(img.astype(np.int32) + 30, 0, 255).astype(np.uint8),
+                 rs.randint(0, 256, img.shape).astype(np.uint8), np.zeros_like(img)]
+    order = rs.permutation(128) % 8
+    order[:8] = np.arange(8)                      # the originals first, then 120 copies in random order
+    frames = np.stack([originals[k] for k in order])
+    pipe = gpu.Pipeline(gpu.FaceDetectionModel.Full)
+    out = {k: v.cpu().numpy() for k, v in pipe.run(torch.from_numpy(frames).cuda()).items()}
+    for k, v in out.items():
+        for b in range(8, 128):
+            np.testing.assert_array_equal(v[b], v[order[b]], err_msg="%s frame %d (copy of %d)" % (k, b, order[b]))
+    models = (oracle.Model(model_path("full")), oracle.Model(model_path("landmark")), oracle.Model(model_path("iris")))
+    n_faces = n_mesh = 0
+    for b in range(8):
+        ref = _oracle_pipeline(oracle, models, frames[b], "full")
+        assert out["face_counts"][b] == ref["count"], b
+        if ref["face"] is None:
+            assert out["present"][b] == 0 and not out["faces"][b].any() and not out["landmarks"][b].any() and not out["eyes"][b].any()
+            continue
+        n_faces += 1
+        assert _iou(out["faces"][b][:4], ref["face"][:4]) >= 0.999
+        np.testing.assert_allclose(out["faces"][b], ref["face"], atol=2e-5)
+        assert out["present"][b] == (ref["landmarks"] is not None)
+        if ref["landmarks"] is not None:
+            n_mesh += 1
+            np.testing.assert_allclose(out["landmarks"][b], ref["landmarks"], atol=2e-5)
+            np.testing.assert_allclose(out["eyes"][b], ref["eyes"], atol=1e-4)   # third stage of the chain, see test_full_pipeline_on_man_jpg
+    assert n_faces >= 5 and n_mesh >= 5
+    pipe.close()
+
+
+@pytest.mark.parametrize("jpg", ["russ_cox_1.jpg", "russ_cox_2.jpg"])
+def test_pipeline_on_the_reference_other_pictures(gpu, oracle, jpg):
+    """The reference's two other test pictures (test_data/russ_cox_1.jpg 400x400, russ_cox_2.jpg 200x225 — a PORTRAIT source: the
+    letterbox goes left / right instead of top / bottom) from their JPEG bytes through the whole lib.rs:18-40 flow: convert_image_to_mat
+    on the device, FaceDetection::infer with all five model types, then faces[0] -> FaceLandmark::infer -> both IrisLandmark::infer
+    calls, each against the oracle's restatement of the same call (these pictures were only opened by the JPEG tests)."""
+    data = open(os.path.join(GOLDEN, jpg), "rb").read()
+    image = gpu.convert_image_to_mat(data)
+    np.testing.assert_array_equal(image, oracle.jpeg_decode_rgb(data))            # bit-exact decode (pinned against libjpeg-turbo in test_jpeg.py)
+    H, W = image.shape[:2]
+    found = 0
+    for kind, name in KINDS:
+        fd = gpu.FaceDetection(getattr(gpu.FaceDetectionModel, kind))
+        faces = fd.infer(image, None)
+        iw, ih = fd.input_size
+        t, pad = oracle.image_to_tensor(image, None, (iw, ih), True, (-1., 1.), False)
+        if H > W:
+            assert pad[0] > 0 and pad[2] > 0 and pad[1] == 0 and pad[3] == 0      # left / right letterbox
+        rb, rs = oracle.Model(model_path(name)).run(t[None])
+        ref = oracle.fd_postprocess(rb[0], rs[0], oracle.ssd_anchors(getattr(oracle, ORC_KIND[name])), float(ih), pad)
+        assert len(faces) == len(ref), (kind, len(faces), len(ref))
+        for f, r in zip(faces, ref):
+            got = np.concatenate([f.data.reshape(-1), [f.score]])
+            assert _iou(got[:4], r[:4]) >= 0.999
+            np.testing.assert_allclose(got, r, atol=2e-5)
+        fd.close()
+        if not len(ref):
+            continue
+        found += 1
+        # the rest of the chain from THIS detector's first face, against the oracle's chain from ITS first face
+        models = (oracle.Model(model_path(name)), oracle.Model(model_path("landmark")), oracle.Model(model_path("iris")))
+        want = _oracle_pipeline(oracle, models, image, name)
+        roi = gpu.face_detection_to_roi(faces[0], (W, H))
+        lms = gpu.FaceLandmark().infer(image, roi)
+        if want["landmarks"] is None:
+            assert lms == []
+            continue
+        assert len(lms) == 468
+        np.testing.assert_allclose(np.array([[l.x, l.y, l.z] for l in lms]), want["landmarks"], atol=2e-5)
+        left, right = gpu.iris_roi_from_face_landmarks(lms, (W, H))
+        iris = gpu.IrisLandmark()
+        for k, (r, is_right) in enumerate(((left, False), (right, True))):
+            res = iris.infer(image, r, is_right)
+            got = np.array([[p.x, p.y, p.z] for p in list(res.contour) + list(res.iris)])
+            np.testing.assert_allclose(got, want["eyes"][k], atol=1e-4)            # third stage of the chain, see test_full_pipeline_on_man_jpg
+    assert found >= 3, "a face is in both pictures: most detectors must find it"
+
+
 @pytest.mark.parametrize("kind,name", [("BackCamera", "back"), ("Full", "full"), ("Short", "short")])
 def test_batched_device_pipeline_vs_oracle(gpu, oracle, man_image, kind, name):
     """BASELINE config 5 shape at test size (Full = the detector config 5 names): frames -> detector -> faces[0] ROI -> mesh ->

@@ -13,8 +13,9 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 tools/bench_configs.py > "$OUT/configs.log" 2>&1; echo configs done
 for m in "back 256" "front 256" "full 128" "landmark 512" "iris 1024"; do set -- $m; python3 tools/profile_model.py $1 $2 2>/dev/null | grep -v amdgpu > "$OUT/launches_$1.txt"; done; echo launches done
-for c in 2 1 3 5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --steps 30 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --no-event-profile --single-window > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
+CONFIGS=${CONFIGS:-"2 1 3 5"}   # (CONFIGS="3" for a quick partial collection)
+for c in $CONFIGS; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --warmup 10 --steps 100 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --no-event-profile --single-window > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window > "$OUT/fetch_c$c.log" 2>&1; echo fetch $c done
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window > "$OUT/write_c$c.log" 2>&1; echo write $c done
   i=0
@@ -24,7 +25,7 @@ for c in 2 1 3 5; do
   done
 done
 python3 tools/summarize_profiles.py "$TAG" "$OUT/summary" > "$OUT/summarize.log" 2>&1 || { tail -5 "$OUT/summarize.log"; exit 1; }
-for c in 2 1 3 5; do
+for c in $CONFIGS; do
   MI_PMC_SUMMARY="$OUT/summary/pmc_summary.json" python3 bench.py --config $c --no-secondary > "$OUT/bench_c$c.json" 2> "$OUT/bench_c$c.err"; echo bench $c done
 done
 python3 tools/summarize_profiles.py "$TAG" "$OUT/summary" > "$OUT/summarize.log" 2>&1   # again: picks the bench lines up

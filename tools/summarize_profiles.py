@@ -64,6 +64,8 @@ for c in WORKLOADS:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats_config%d.csv" % (tag, c)))
 
 
+STEADY = {}   # per config: kernel label -> steady-state nanoseconds per launch
+
 # ---- the kernel-trace rows the per-symbol averages of --stats come from, per (kernel, grid size): a symbol that runs on two shapes (the
 # 128^2 and 64^2 row pipelines) is two lines here
 for c in WORKLOADS:
@@ -101,9 +103,26 @@ for c in WORKLOADS:
                 wr.writerow([r["Dispatch_Id"], short, r["Grid_Size_X"], r["Workgroup_Size_X"], int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
     with open(os.path.join(out, "%s_kernel_trace_by_shape_config%d.csv" % (tag, c)), "w", newline="") as fh:
         wr = csv.writer(fh)
-        wr.writerow(["kernel", "shape", "grid_threads", "workgroup", "dispatches", "avg_ns", "median_ns", "min_ns", "max_ns"])
+        wr.writerow(["kernel", "shape", "grid_threads", "workgroup", "dispatches", "avg_ns", "median_ns", "min_ns", "max_ns", "steady_median_ns"])
         for (lab, shape, grid, wg), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            wr.writerow([lab, shape, grid, wg, len(v), round(statistics.mean(v)), round(statistics.median(v)), min(v), max(v)])
+            # steady state = without the dispatches of the first two steps (the chip's clocks ramp up over them)
+            wr.writerow([lab, shape, grid, wg, len(v), round(statistics.mean(v)), round(statistics.median(v)), min(v), max(v), round(statistics.median(v[2:] or v))])
+    # per SYMBOL (what `rocprofv3 --stats` and the bench line's `roofline` report): launches per step, the --stats average, and the
+    # steady-state figure = mean over the symbol's launches of a step of each launch's median without its first two dispatches
+    by_sym = collections.defaultdict(list)
+    for (lab, shape, grid, wg), v in per.items():
+        by_sym[lab].append(v)
+    STEADY[c] = {}
+    with open(os.path.join(out, "%s_kernel_steady_config%d.csv" % (tag, c)), "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(["kernel", "launches_per_step", "dispatches", "avg_ns_all_dispatches", "steady_ns_per_launch"])
+        for lab, vs in sorted(by_sym.items(), key=lambda kv: -sum(sum(v) for v in kv[1])):
+            # (order[lab] lists the symbol's launches of one step; a shape launched twice per step owns two of them)
+            lps = max(len(order.get(lab, [])), len(vs))
+            n_all = sum(len(v) for v in vs)
+            steady = sum(statistics.median(v[2 * max(1, round(len(v) * lps / n_all)):] or v) * len(v) for v in vs) / n_all
+            STEADY[c][lab] = steady
+            wr.writerow([lab, lps, n_all, round(sum(sum(v) for v in vs) / n_all), round(steady)])
 
 
 def load(d):
@@ -142,6 +161,7 @@ for c, workload in WORKLOADS.items():
     for r in crow:
         by_label[r["label"]].append(r)
     entries += [{"round": tag, "workload": workload, "kernel": lab, "source_hash": bench.kernel_source_hash(), "rocprof_avg_ns": avg.get(lab),
+                 "rocprof_steady_ns": STEADY.get(c, {}).get(lab),
                  "hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / sum(r["dispatches"] for r in rs)),
                  "note": "reads = %d x FETCH_SIZE (gfx950: FETCH_SIZE counts half of a 16 B/lane stream) + WRITE_SIZE, KiB -> bytes; separate --pmc passes" % rs[0]["fetch_correction"]}
                 for lab, rs in by_label.items()]
