@@ -57,6 +57,46 @@ impl FaceLandmark {
     }
 }
 
+impl FaceLandmark {
+    /// `infer` over a batch (`mi_fl_infer_images`): `frames` holds `batch` 8UC3 RGB frames of `height` rows of `stride` bytes; item `i`
+    /// reads frame `i / items_per_frame` with ROI `rois[i]` (`rois` empty: whole frames, `items_per_frame` 1).  One `Vec` per item,
+    /// empty where the face flag fails.  The warp to 192x192 runs on the device: only the frames and the ROIs cross the bus.
+    pub fn infer_batch(&self, frames: &[u8], batch: usize, width: i32, height: i32, stride: i32, rois: &[Rect], items_per_frame: usize)
+        -> Result<Vec<Vec<Landmark>>, Error> {
+        if batch == 0 || items_per_frame == 0 || width <= 0 || height <= 0 || stride <= 0 || (stride as i64) < 3 * width as i64 {
+            return Err(Error::msg("frames must hold batch frames of height rows of stride bytes"));
+        }
+        let n = batch.checked_mul(items_per_frame).filter(|n| *n <= i32::MAX as usize).ok_or_else(|| Error::msg("too many items"))?;
+        if (rois.is_empty() && items_per_frame != 1) || (!rois.is_empty() && rois.len() != n) {
+            return Err(Error::msg("rois must hold one entry per item"));
+        }
+        let (w, h, s) = (width as usize, height as usize, stride as usize);
+        let need = s.checked_mul(h).and_then(|f| f.checked_mul(batch - 1)).and_then(|x| x.checked_add(s * (h - 1))).and_then(|x| x.checked_add(3 * w));
+        if need.map_or(true, |x| frames.len() < x) {
+            return Err(Error::msg("frames must hold batch frames of height rows of stride bytes"));
+        }
+        let c_rois: Vec<ffi::mi_rect> = rois.iter().map(|r| r.to_mi()).collect();
+        let mut lm = vec![0f32; n * 3 * ffi::MI_NUM_FACE_LANDMARKS];
+        let mut present = vec![0i32; n];
+        check(unsafe {
+            ffi::mi_fl_infer_images(self.handle, frames.as_ptr(), batch as i32, width, height, stride,
+                                    if c_rois.is_empty() { std::ptr::null() } else { c_rois.as_ptr() }, items_per_frame as i32, lm.as_mut_ptr(),
+                                    present.as_mut_ptr(), std::ptr::null_mut(), ffi::MI_MEM_HOST, std::ptr::null_mut())
+        })?;
+        Ok((0..n)
+            .map(|i| {
+                if present[i] == 0 {
+                    return Vec::new();
+                }
+                lm[i * 3 * ffi::MI_NUM_FACE_LANDMARKS..(i + 1) * 3 * ffi::MI_NUM_FACE_LANDMARKS]
+                    .chunks_exact(3)
+                    .map(|v| Landmark::new(v[0] as f64, v[1] as f64, v[2] as f64))
+                    .collect()
+            })
+            .collect())
+    }
+}
+
 impl Drop for FaceLandmark {
     fn drop(&mut self) {
         unsafe { ffi::mi_fl_free(self.handle) }

@@ -73,12 +73,18 @@ extern "C" {
                              out: *mut mi_landmark, cap: c_int, count: *mut c_int) -> c_int;
     pub fn mi_fl_infer_tensor(h: *mut mi_fl, input: *const c_float, batch: c_int, rois: *const mi_rect, image_sizes: *const c_int,
                               landmarks: *mut c_float, present: *mut c_int, raw_flags: *mut c_float, mem: c_int, stream: *mut c_void) -> c_int;
+    pub fn mi_fl_infer_images(h: *mut mi_fl, frames: *const u8, batch: c_int, width: c_int, height: c_int, stride: c_int, rois: *const mi_rect,
+                              items_per_frame: c_int, landmarks: *mut c_float, present: *mut c_int, raw_flags: *mut c_float, mem: c_int,
+                              stream: *mut c_void) -> c_int;
 
     // IrisLandmark — iris_landmark.rs:130-248
     pub fn mi_iris_create(model_path: *const c_char, device: c_int, out: *mut *mut mi_iris) -> c_int;
     pub fn mi_iris_free(h: *mut mi_iris);
     pub fn mi_iris_infer_image(h: *mut mi_iris, rgb: *const u8, width: c_int, height: c_int, stride: c_int, roi: *const mi_rect,
                                is_right_eye: c_int, contour71: *mut mi_landmark, iris5: *mut mi_landmark) -> c_int;
+    pub fn mi_iris_infer_images(h: *mut mi_iris, frames: *const u8, batch: c_int, width: c_int, height: c_int, stride: c_int, rois: *const mi_rect,
+                                is_right_eye: *const c_int, items_per_frame: c_int, contour: *mut c_float, iris: *mut c_float, mem: c_int,
+                                stream: *mut c_void) -> c_int;
 
     // helpers the reference exports next to the three structs
     pub fn mi_face_detection_to_roi(det: *const mi_detection, image_w: c_int, image_h: c_int, out: *mut mi_rect) -> c_int;

@@ -79,6 +79,44 @@ impl IrisLandmark {
     }
 }
 
+impl IrisLandmark {
+    /// `infer` over a batch (`mi_iris_infer_images`): item `i` reads frame `i / items_per_frame` with eye ROI `rois[i]` and flip
+    /// `is_right_eye[i]` (`is_right_eye` empty: no flips; `rois` empty: whole frames, `items_per_frame` 1) — iris_landmark.rs:158-248
+    /// per item, the warp to 64x64 on the device.
+    pub fn infer_batch(&self, frames: &[u8], batch: usize, width: i32, height: i32, stride: i32, rois: &[Rect], is_right_eye: &[bool],
+                       items_per_frame: usize) -> Result<Vec<IrisResults>, Error> {
+        if batch == 0 || items_per_frame == 0 || width <= 0 || height <= 0 || stride <= 0 || (stride as i64) < 3 * width as i64 {
+            return Err(Error::msg("frames must hold batch frames of height rows of stride bytes"));
+        }
+        let n = batch.checked_mul(items_per_frame).filter(|n| *n <= i32::MAX as usize).ok_or_else(|| Error::msg("too many items"))?;
+        if (rois.is_empty() && items_per_frame != 1) || (!rois.is_empty() && rois.len() != n) || (!is_right_eye.is_empty() && is_right_eye.len() != n) {
+            return Err(Error::msg("rois / is_right_eye must hold one entry per item"));
+        }
+        let (w, h, s) = (width as usize, height as usize, stride as usize);
+        let need = s.checked_mul(h).and_then(|f| f.checked_mul(batch - 1)).and_then(|x| x.checked_add(s * (h - 1))).and_then(|x| x.checked_add(3 * w));
+        if need.map_or(true, |x| frames.len() < x) {
+            return Err(Error::msg("frames must hold batch frames of height rows of stride bytes"));
+        }
+        let c_rois: Vec<ffi::mi_rect> = rois.iter().map(|r| r.to_mi()).collect();
+        let flips: Vec<i32> = is_right_eye.iter().map(|b| *b as i32).collect();
+        let mut contour = vec![0f32; n * 3 * ffi::MI_NUM_EYE_LANDMARKS];
+        let mut iris = vec![0f32; n * 3 * ffi::MI_NUM_IRIS_LANDMARKS];
+        check(unsafe {
+            ffi::mi_iris_infer_images(self.handle, frames.as_ptr(), batch as i32, width, height, stride,
+                                      if c_rois.is_empty() { std::ptr::null() } else { c_rois.as_ptr() },
+                                      if flips.is_empty() { std::ptr::null() } else { flips.as_ptr() }, items_per_frame as i32,
+                                      contour.as_mut_ptr(), iris.as_mut_ptr(), ffi::MI_MEM_HOST, std::ptr::null_mut())
+        })?;
+        let lms = |v: &[f32]| v.chunks_exact(3).map(|p| Landmark::new(p[0] as f64, p[1] as f64, p[2] as f64)).collect::<Vec<_>>();
+        Ok((0..n)
+            .map(|i| {
+                IrisResults::new(lms(&contour[i * 3 * ffi::MI_NUM_EYE_LANDMARKS..(i + 1) * 3 * ffi::MI_NUM_EYE_LANDMARKS]),
+                                 lms(&iris[i * 3 * ffi::MI_NUM_IRIS_LANDMARKS..(i + 1) * 3 * ffi::MI_NUM_IRIS_LANDMARKS]))
+            })
+            .collect())
+    }
+}
+
 impl Drop for IrisLandmark {
     fn drop(&mut self) {
         unsafe { ffi::mi_iris_free(self.handle) }

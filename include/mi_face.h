@@ -206,6 +206,15 @@ mi_model *mi_fl_model(mi_fl *h);
  *   raw_flags    optional [batch] raw flag logits (may be NULL) */
 int mi_fl_infer_tensor(mi_fl *h, const float *in, int batch, const mi_rect *rois, const int *image_sizes,
                        float *landmarks, int *present, float *raw_flags, int mem, void *stream);
+/* FaceLandmark::infer(&Mat, Option<Rect>) over a batch (face_landmark.rs:232-306): frames as the reference's callers hold them
+ * (8UC3 RGB, `batch` frames of `height` rows of `stride` bytes, stride*height bytes apart) and one ROI per item — item i reads
+ * frame i / items_per_frame (several faces of one frame: items_per_frame > 1).  image_to_tensor(frame, roi, (192,192),
+ * keep_aspect_ratio = false, (0,1)) runs on the device (transform.rs:188-309, bit-exact), then the network, the face flag and
+ * project_landmarks: no f32 crop crosses the bus (442 KB per ROI through mi_fl_infer_tensor).  rois NULL (whole frames;
+ * items_per_frame must be 1) or [batch * items_per_frame]; frames / rois / results follow `mem`; results as mi_fl_infer_tensor
+ * with batch * items_per_frame items. */
+int mi_fl_infer_images(mi_fl *h, const uint8_t *frames, int batch, int width, int height, int stride, const mi_rect *rois,
+                       int items_per_frame, float *landmarks, int *present, float *raw_flags, int mem, void *stream);
 /* FaceLandmark::infer(&Mat, Option<Rect>) — face_landmark.rs:232-306. out = 468 landmarks; *count = 0 or 468. */
 int mi_fl_infer_image(mi_fl *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
                       mi_landmark *out, int cap, int *count);
@@ -229,6 +238,13 @@ mi_model *mi_iris_model(mi_iris *h);
 int mi_iris_infer_tensor(mi_iris *h, const float *in, int batch, const mi_rect *rois, const int *image_sizes,
                          const double *padding, const int *is_right_eye, float *contour, float *iris, int mem,
                          void *stream);
+/* IrisLandmark::infer(&Mat, Option<Rect>, Option<bool>) over a batch (iris_landmark.rs:158-248): u8 frames + one eye ROI (+
+ * is_right_eye) per item, item i reads frame i / items_per_frame (2 = the two eyes of a face).  image_to_tensor(frame, roi,
+ * (64,64), keep_aspect_ratio = true, (0,1), flip = is_right_eye) on the device, network, both project_landmarks calls (the
+ * letterbox padding of every item stays on the device).  rois NULL (whole frames, items_per_frame 1) or [batch * items_per_frame];
+ * is_right_eye NULL (no flips) or int [batch * items_per_frame]; contour f32 [N][71][3], iris f32 [N][5][3]. */
+int mi_iris_infer_images(mi_iris *h, const uint8_t *frames, int batch, int width, int height, int stride, const mi_rect *rois,
+                         const int *is_right_eye, int items_per_frame, float *contour, float *iris, int mem, void *stream);
 /* IrisLandmark::infer(&Mat, Option<Rect>, Option<bool>) — iris_landmark.rs:158-248 -> IrisResults {contour, iris}. */
 int mi_iris_infer_image(mi_iris *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
                         int is_right_eye, mi_landmark *contour71, mi_landmark *iris5);

@@ -165,6 +165,30 @@ class FaceLandmark {
         return lm;
     }
 
+    // infer() over a batch (mi_fl_infer_images): `frames` = batch x height rows of `stride` bytes, host memory; item i reads frame
+    // i / items_per_frame with ROI rois[i] (rois empty: whole frames, items_per_frame 1).  One entry per item; empty where the
+    // face flag fails, like infer().
+    std::vector<std::vector<Landmark>> infer_batch(const std::uint8_t* frames, int batch, int width, int height, int stride,
+                                                   const std::vector<Rect>& rois = {}, int items_per_frame = 1) const {
+        if (batch < 1 || items_per_frame < 1) throw std::invalid_argument("infer_batch: batch and items_per_frame must be positive");
+        const std::size_t n = static_cast<std::size_t>(batch) * items_per_frame;
+        if (rois.empty() ? items_per_frame != 1 : rois.size() != n) throw std::invalid_argument("infer_batch: rois must hold one entry per item");
+        std::vector<mi_rect> r;
+        for (const Rect& x : rois) r.push_back(x.c());
+        std::vector<float> lm(n * 3 * MI_NUM_FACE_LANDMARKS);
+        std::vector<int> present(n);
+        detail::check(mi_fl_infer_images(h_, frames, batch, width, height, stride, r.empty() ? nullptr : r.data(), items_per_frame, lm.data(),
+                                         present.data(), nullptr, MI_MEM_HOST, nullptr));
+        std::vector<std::vector<Landmark>> res(n);
+        for (std::size_t i = 0; i < n; i++)
+            if (present[i])
+                for (int k = 0; k < MI_NUM_FACE_LANDMARKS; k++) {
+                    const float* v = &lm[(i * MI_NUM_FACE_LANDMARKS + k) * 3];
+                    res[i].push_back(Landmark{v[0], v[1], v[2]});
+                }
+        return res;
+    }
+
    private:
     mi_fl* h_ = nullptr;
 };
@@ -188,6 +212,28 @@ class IrisLandmark {
         IrisResults res;
         for (const auto& v : c) res.contour.push_back(Landmark{v.x, v.y, v.z});
         for (const auto& v : i5) res.iris.push_back(Landmark{v.x, v.y, v.z});
+        return res;
+    }
+
+    // infer() over a batch (mi_iris_infer_images): item i reads frame i / items_per_frame with ROI rois[i] and flip is_right_eye[i]
+    // (empty: no flips); rois empty: whole frames, items_per_frame 1.
+    std::vector<IrisResults> infer_batch(const std::uint8_t* frames, int batch, int width, int height, int stride, const std::vector<Rect>& rois = {},
+                                         const std::vector<bool>& is_right_eye = {}, int items_per_frame = 1) const {
+        if (batch < 1 || items_per_frame < 1) throw std::invalid_argument("infer_batch: batch and items_per_frame must be positive");
+        const std::size_t n = static_cast<std::size_t>(batch) * items_per_frame;
+        if (rois.empty() ? items_per_frame != 1 : rois.size() != n) throw std::invalid_argument("infer_batch: rois must hold one entry per item");
+        if (!is_right_eye.empty() && is_right_eye.size() != n) throw std::invalid_argument("infer_batch: is_right_eye must hold one entry per item");
+        std::vector<mi_rect> r;
+        for (const Rect& x : rois) r.push_back(x.c());
+        std::vector<int> flip(is_right_eye.begin(), is_right_eye.end());
+        std::vector<float> c(n * 3 * MI_NUM_EYE_LANDMARKS), i5(n * 3 * MI_NUM_IRIS_LANDMARKS);
+        detail::check(mi_iris_infer_images(h_, frames, batch, width, height, stride, r.empty() ? nullptr : r.data(), flip.empty() ? nullptr : flip.data(),
+                                           items_per_frame, c.data(), i5.data(), MI_MEM_HOST, nullptr));
+        std::vector<IrisResults> res(n);
+        for (std::size_t i = 0; i < n; i++) {
+            for (int k = 0; k < MI_NUM_EYE_LANDMARKS; k++) res[i].contour.push_back(Landmark{c[(i * MI_NUM_EYE_LANDMARKS + k) * 3], c[(i * MI_NUM_EYE_LANDMARKS + k) * 3 + 1], c[(i * MI_NUM_EYE_LANDMARKS + k) * 3 + 2]});
+            for (int k = 0; k < MI_NUM_IRIS_LANDMARKS; k++) res[i].iris.push_back(Landmark{i5[(i * MI_NUM_IRIS_LANDMARKS + k) * 3], i5[(i * MI_NUM_IRIS_LANDMARKS + k) * 3 + 1], i5[(i * MI_NUM_IRIS_LANDMARKS + k) * 3 + 2]});
+        }
         return res;
     }
 

@@ -34,8 +34,8 @@ EXPORTS = [
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
     "mi_fd_collect", "mi_host_alloc", "mi_host_free",
-    "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_image",
-    "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor",
+    "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_images", "mi_fl_infer_image",
+    "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor", "mi_iris_infer_images",
     "mi_iris_infer_image",
     "mi_pipeline_create", "mi_pipeline_create_from_bytes", "mi_pipeline_model", "mi_pipeline_free", "mi_pipeline_set_option", "mi_pipeline_run",
     "mi_bbox_to_roi", "mi_bbox_from_landmarks", "mi_face_detection_to_roi", "mi_iris_roi_from_face_landmarks", "mi_update_face_landmarks_with_iris_results", "mi_image_to_tensor", "mi_jpeg_info", "mi_jpeg_decode_rgb",
@@ -172,6 +172,7 @@ def lib():
     L.mi_fl_model.argtypes = [vp]
     L.mi_fl_model.restype = vp
     L.mi_fl_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.mi_fl_infer_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp]
     L.mi_fl_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(CLandmark), C.c_int, ip]
     L.mi_iris_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.mi_iris_create_from_bytes.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
@@ -180,6 +181,7 @@ def lib():
     L.mi_iris_model.argtypes = [vp]
     L.mi_iris_model.restype = vp
     L.mi_iris_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+    L.mi_iris_infer_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_int, vp]
     L.mi_iris_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.c_int, C.POINTER(CLandmark),
                                       C.POINTER(CLandmark)]
     L.mi_pipeline_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
@@ -345,6 +347,33 @@ def _image_args(image):
         raise ValueError("image must be uint8 [H,W,3] RGB")
     h, w = image.shape[:2]
     return image, w, h, image.strides[0]
+
+
+
+def _frames_and_rois(frames, rois, items_per_frame, device):
+    """(pointer, mem, B, H, W, stride, rois pointer, keep-alive) for the batched u8 entry points: frames uint8 [B,H,W,3] (numpy, or a
+    contiguous torch CUDA tensor); rois None, a sequence of B * items_per_frame Rect (host frames) or a device tensor holding them."""
+    p, mem = _ptr(frames)
+    B, H, W = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    N = B * items_per_frame
+    if rois is None and items_per_frame != 1:
+        raise ValueError("several items per frame need their ROIs")
+    if mem == MI_MEM_DEVICE:
+        import torch
+        if frames.dtype != torch.uint8 or not frames.is_contiguous() or frames.shape[3] != 3:
+            raise ValueError("frames must be a contiguous uint8 [B,H,W,3] tensor")
+        _device_ready(frames, device, None, dtype="uint8")
+        rp = C.c_void_p(rois.data_ptr()) if rois is not None else None
+        return p, mem, B, H, W, 3 * W, rp, frames
+    frames = np.ascontiguousarray(frames, np.uint8)
+    if frames.ndim != 4 or frames.shape[3] != 3:
+        raise ValueError("frames must be uint8 [B,H,W,3]")
+    rarr = None
+    if rois is not None:
+        if len(rois) != N:
+            raise ValueError("expected %d rois" % N)
+        rarr = (Rect * N)(*rois)
+    return C.c_void_p(frames.ctypes.data), mem, B, H, W, frames.strides[1], (C.cast(rarr, C.c_void_p) if rarr is not None else None), (frames, rarr)
 
 
 class PinnedBuffer:
@@ -568,6 +597,24 @@ class FaceLandmark:
         return lm, present, flags
 
 
+    def infer_images(self, frames, rois=None, items_per_frame=1, stream=None):
+        """Batched FaceLandmark::infer on u8 RGB frames [B,H,W,3] with one ROI per item (item i reads frame i // items_per_frame): device
+        image_to_tensor + network + face flag + projection in one call.  Returns (landmarks [N,468,3], present [N], flags [N]) in the
+        memory space of `frames`, N = B * items_per_frame."""
+        p, mem, B, H, W, stride, rp, keep = _frames_and_rois(frames, rois, items_per_frame, self.device)
+        N = B * items_per_frame
+        if mem == MI_MEM_DEVICE:
+            import torch
+            lm = torch.zeros((N, NUM_FACE_LANDMARKS, 3), dtype=torch.float32, device=frames.device)
+            present = torch.zeros((N,), dtype=torch.int32, device=frames.device)
+            flags = torch.zeros((N,), dtype=torch.float32, device=frames.device)
+        else:
+            lm, present, flags = np.zeros((N, NUM_FACE_LANDMARKS, 3), np.float32), np.zeros((N,), np.int32), np.zeros((N,), np.float32)
+        _check(self.L.mi_fl_infer_images(self.h, p, B, W, H, stride, rp, items_per_frame, _ptr(lm)[0], _ptr(present)[0], _ptr(flags)[0], mem,
+                                         C.c_void_p(stream or 0)))
+        return lm, present, flags
+
+
 class IrisLandmark:
     """Iris / eye-contour model — mirrors iris_landmark.rs:130-248."""
 
@@ -632,6 +679,28 @@ class IrisLandmark:
                 is_right_eye = np.ascontiguousarray(is_right_eye, np.int32).reshape(B)
                 fp_ = C.c_void_p(is_right_eye.ctypes.data)
         _check(self.L.mi_iris_infer_tensor(self.h, p, B, rp, sp, pp, fp_, _ptr(contour)[0], _ptr(iris)[0], mem,
+                                           C.c_void_p(stream or 0)))
+        return contour, iris
+
+
+    def infer_images(self, frames, rois=None, is_right_eye=None, items_per_frame=1, stream=None):
+        """Batched IrisLandmark::infer on u8 RGB frames [B,H,W,3] with one eye ROI (+ is_right_eye) per item (item i reads frame
+        i // items_per_frame).  Returns (contour [N,71,3], iris [N,5,3]) in the memory space of `frames`."""
+        p, mem, B, H, W, stride, rp, keep = _frames_and_rois(frames, rois, items_per_frame, self.device)
+        N = B * items_per_frame
+        fp_ = None
+        if mem == MI_MEM_DEVICE:
+            import torch
+            contour = torch.zeros((N, NUM_EYE_LANDMARKS, 3), dtype=torch.float32, device=frames.device)
+            iris = torch.zeros((N, NUM_IRIS_LANDMARKS, 3), dtype=torch.float32, device=frames.device)
+            if is_right_eye is not None:
+                fp_ = C.c_void_p(is_right_eye.data_ptr())
+        else:
+            contour, iris = np.zeros((N, NUM_EYE_LANDMARKS, 3), np.float32), np.zeros((N, NUM_IRIS_LANDMARKS, 3), np.float32)
+            if is_right_eye is not None:
+                is_right_eye = np.ascontiguousarray(is_right_eye, np.int32).reshape(N)
+                fp_ = C.c_void_p(is_right_eye.ctypes.data)
+        _check(self.L.mi_iris_infer_images(self.h, p, B, W, H, stride, rp, fp_, items_per_frame, _ptr(contour)[0], _ptr(iris)[0], mem,
                                            C.c_void_p(stream or 0)))
         return contour, iris
 

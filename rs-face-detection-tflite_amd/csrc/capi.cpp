@@ -161,7 +161,8 @@ struct mi_fd {
 struct mi_fl {
     mi_model model;
     int in_w = 0, in_h = 0;
-    DeviceBuf d_in, d_roi, d_size, d_lm, d_present, d_flag, d_img;
+    DeviceBuf d_in, d_roi, d_size, d_lm, d_present, d_flag, d_img, d_geom, d_sizes_b;
+    int sizes_N = 0, sizes_w = 0, sizes_h = 0;  // what d_sizes_b holds (mi_fl_infer_images: uploaded when the batch geometry changes)
 };
 
 struct mi_pipeline {
@@ -176,7 +177,8 @@ struct mi_pipeline {
 struct mi_iris {
     mi_model model;
     int in_w = 0, in_h = 0;
-    DeviceBuf d_in, d_roi, d_size, d_pad, d_flip, d_contour, d_iris, d_img;
+    DeviceBuf d_in, d_roi, d_size, d_pad, d_flip, d_contour, d_iris, d_img, d_geom, d_sizes_b;
+    int sizes_N = 0, sizes_w = 0, sizes_h = 0;
 };
 
 extern "C" {
@@ -741,6 +743,84 @@ int mi_fl_infer_tensor(mi_fl* h, const float* in, int batch, const mi_rect* rois
     });
 }
 
+// (w, h) of the source image for every item of a batch of equally sized frames, on the device; re-uploaded only when the batch geometry changes
+static int* batch_image_sizes(DeviceBuf& buf, int& have_N, int& have_w, int& have_h, int N, int width, int height, hipStream_t s) {
+    int* d = static_cast<int*>(buf.get(sizeof(int) * 2 * N));
+    if (have_N != N || have_w != width || have_h != height) {
+        std::vector<int> hs(2 * static_cast<size_t>(N));
+        for (int i = 0; i < N; i++) { hs[2 * i] = width; hs[2 * i + 1] = height; }
+        have_N = 0;
+        mi::hip_check(hipMemcpyAsync(d, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D sizes");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
+        have_N = N; have_w = width; have_h = height;
+    }
+    return d;
+}
+
+// FaceLandmark::infer(&Mat, Option<Rect>) for a batch of (frame, ROI) items (face_landmark.rs:232-306): image_to_tensor(frame, roi,
+// (192,192), keep_aspect_ratio = false, (0,1)) on the device, network, face flag, project_landmarks.  Item i reads frame
+// i / items_per_frame.  Only u8 frames and ROIs cross the bus (the f32 crops of mi_fl_infer_tensor are 442 KB per ROI).
+int mi_fl_infer_images(mi_fl* h, const uint8_t* frames, int batch, int width, int height, int stride, const mi_rect* rois, int items_per_frame,
+                       float* landmarks, int* present, float* raw_flags, int mem, void* stream) {
+    return guarded([&] {
+        require(h && frames && landmarks && present, "null argument");
+        require(batch > 0 && items_per_frame > 0 && width > 0 && height > 0 && stride >= 3 * width, "bad frame geometry");
+        require(rois || items_per_frame == 1, "several items per frame need their ROIs");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        require(static_cast<long long>(batch) * items_per_frame <= (1 << 24), "too many items");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
+        const int N = batch * items_per_frame;
+        const uint8_t* d_frames = frames;
+        const mi::RectD* d_rois = reinterpret_cast<const mi::RectD*>(rois);
+        if (mem == MI_MEM_HOST) {
+            d_frames = static_cast<const uint8_t*>(h->d_img.get(static_cast<size_t>(stride) * height * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, frames_bytes(batch, width, height, stride), hipMemcpyHostToDevice, s), "H2D frames");
+            if (rois) {
+                d_rois = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect) * N));
+                mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_rois), rois, sizeof(mi_rect) * N, hipMemcpyHostToDevice, s), "H2D rois");
+            }
+        }
+        mi::PreItems it{};
+        it.frames = d_frames; it.frame_bytes = static_cast<long>(stride) * height; it.width = width; it.height = height; it.stride = stride;
+        it.rois = d_rois; it.items_per_frame = items_per_frame; it.N = N; it.out_w = h->in_w; it.out_h = h->in_h; it.keep_aspect = 0;
+        it.range_min = 0.0; it.range_max = 1.0;
+        auto* d_geom = static_cast<mi::PreGeom*>(h->d_geom.get(sizeof(mi::PreGeom) * N));
+        float* d_in = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float) * N));
+        mi::launch_pre_geom(it, d_geom, nullptr, s);
+        mi::launch_pre_tensor(it, d_geom, d_in, s);
+        const size_t lm_bytes = sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * N;
+        mi::ProjArgs a;
+        a.B = N; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = h->in_w; a.tensor_h = h->in_h;
+        a.roi = d_rois;
+        a.image_size = d_rois ? batch_image_sizes(h->d_sizes_b, h->sizes_N, h->sizes_w, h->sizes_h, N, width, height, s) : nullptr;
+        if (mem == MI_MEM_HOST) {
+            a.out = static_cast<float*>(h->d_lm.get(lm_bytes));
+            a.present = static_cast<int*>(h->d_present.get(sizeof(int) * N));
+            a.raw_flag_out = static_cast<float*>(h->d_flag.get(sizeof(float) * N));
+        } else {
+            a.out = landmarks; a.present = present; a.raw_flag_out = raw_flags;
+        }
+        m.run_device(d_in, N, s);
+        a.raw = m.output_device(0);
+        a.raw_fs = static_cast<long>(m.output_elems(0));
+        a.flag = m.output_device(1) + (m.output_elems(1) - 1);
+        a.flag_fs = static_cast<long>(m.output_elems(1));
+        int rc = mi::launch_project(a, s);
+        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (mem == MI_MEM_HOST) {
+            mi::hip_check(hipMemcpyAsync(landmarks, a.out, lm_bytes, hipMemcpyDeviceToHost, s), "D2H landmarks");
+            mi::hip_check(hipMemcpyAsync(present, a.present, sizeof(int) * N, hipMemcpyDeviceToHost, s), "D2H present");
+            if (raw_flags) mi::hip_check(hipMemcpyAsync(raw_flags, a.raw_flag_out, sizeof(float) * N, hipMemcpyDeviceToHost, s), "D2H flags");
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        } else if (!stream) {
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+    });
+}
+
 int mi_fl_infer_image(mi_fl* h, const uint8_t* rgb, int width, int height, int stride, const mi_rect* roi, mi_landmark* out,
                       int cap, int* count) {
     return guarded([&] {
@@ -887,6 +967,62 @@ int mi_iris_infer_tensor(mi_iris* h, const float* in, int batch, const mi_rect* 
         mi::hip_check(hipMemcpyAsync(contour, dc, cb, hipMemcpyDeviceToHost, s), "D2H contour");
         mi::hip_check(hipMemcpyAsync(iris, di, ib, hipMemcpyDeviceToHost, s), "D2H iris");
         mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    });
+}
+
+// IrisLandmark::infer(&Mat, Option<Rect>, Option<bool>) for a batch of (frame, eye ROI) items (iris_landmark.rs:158-248):
+// image_to_tensor(frame, roi, (64,64), keep_aspect_ratio = true, (0,1), flip = is_right_eye) on the device, network, both
+// project_landmarks calls.  Item i reads frame i / items_per_frame (2 = the two eyes of a face).
+int mi_iris_infer_images(mi_iris* h, const uint8_t* frames, int batch, int width, int height, int stride, const mi_rect* rois, const int* is_right_eye,
+                         int items_per_frame, float* contour, float* iris, int mem, void* stream) {
+    return guarded([&] {
+        require(h && frames && contour && iris, "null argument");
+        require(batch > 0 && items_per_frame > 0 && width > 0 && height > 0 && stride >= 3 * width, "bad frame geometry");
+        require(rois || items_per_frame == 1, "several items per frame need their ROIs");
+        require(mem == MI_MEM_HOST || mem == MI_MEM_DEVICE, "mem must be MI_MEM_HOST or MI_MEM_DEVICE");
+        require(static_cast<long long>(batch) * items_per_frame <= (1 << 24), "too many items");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m.stream();
+        Use use(h->model, s);
+        const int N = batch * items_per_frame;
+        const uint8_t* d_frames = frames;
+        const mi::RectD* d_rois = reinterpret_cast<const mi::RectD*>(rois);
+        const int* d_flip = is_right_eye;
+        if (mem == MI_MEM_HOST) {
+            d_frames = static_cast<const uint8_t*>(h->d_img.get(static_cast<size_t>(stride) * height * batch));
+            mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, frames_bytes(batch, width, height, stride), hipMemcpyHostToDevice, s), "H2D frames");
+            if (rois) {
+                d_rois = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect) * N));
+                mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_rois), rois, sizeof(mi_rect) * N, hipMemcpyHostToDevice, s), "H2D rois");
+            }
+            if (is_right_eye) {
+                d_flip = static_cast<const int*>(h->d_flip.get(sizeof(int) * N));
+                mi::hip_check(hipMemcpyAsync(const_cast<int*>(d_flip), is_right_eye, sizeof(int) * N, hipMemcpyHostToDevice, s), "H2D flip");
+            }
+        }
+        mi::PreItems it{};
+        it.frames = d_frames; it.frame_bytes = static_cast<long>(stride) * height; it.width = width; it.height = height; it.stride = stride;
+        it.rois = d_rois; it.flip = d_flip; it.items_per_frame = items_per_frame; it.N = N; it.out_w = h->in_w; it.out_h = h->in_h; it.keep_aspect = 1;
+        it.range_min = 0.0; it.range_max = 1.0;
+        auto* d_geom = static_cast<mi::PreGeom*>(h->d_geom.get(sizeof(mi::PreGeom) * N));
+        double* d_pad = static_cast<double*>(h->d_pad.get(sizeof(double) * 4 * N));
+        float* d_in = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float) * N));
+        mi::launch_pre_geom(it, d_geom, d_pad, s);
+        mi::launch_pre_tensor(it, d_geom, d_in, s);
+        const int* d_size = d_rois ? batch_image_sizes(h->d_sizes_b, h->sizes_N, h->sizes_w, h->sizes_h, N, width, height, s) : nullptr;
+        const size_t cb = sizeof(float) * 3 * MI_NUM_EYE_LANDMARKS * N, ib = sizeof(float) * 3 * MI_NUM_IRIS_LANDMARKS * N;
+        float* dc = mem == MI_MEM_DEVICE ? contour : static_cast<float*>(h->d_contour.get(cb));
+        float* di = mem == MI_MEM_DEVICE ? iris : static_cast<float*>(h->d_iris.get(ib));
+        m.run_device(d_in, N, s);
+        iris_project(h, N, d_rois, d_size, d_pad, d_flip, dc, di, s);
+        if (mem == MI_MEM_HOST) {
+            mi::hip_check(hipMemcpyAsync(contour, dc, cb, hipMemcpyDeviceToHost, s), "D2H contour");
+            mi::hip_check(hipMemcpyAsync(iris, di, ib, hipMemcpyDeviceToHost, s), "D2H iris");
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        } else if (!stream) {
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
     });
 }
 

@@ -97,6 +97,13 @@ def test_batched_u8_entry_points_refuse_bad_arguments_without_gpu(mi):
     assert L.mi_host_alloc(0, C.byref(p)) == -1 and not p.value
     assert L.mi_host_alloc(16, None) == -1
     L.mi_host_free(None)            # a no-op
+    # round 5: the batched u8 entries of the mesh and the iris network
+    lm = (C.c_float * (3 * 468))()
+    present = C.c_int()
+    assert L.mi_fl_infer_images(None, buf, 1, 2, 2, 6, None, 1, lm, C.byref(present), None, 0, None) == -1
+    assert b"null" in L.mi_last_error()
+    assert L.mi_iris_infer_images(None, buf, 1, 2, 2, 6, None, None, 1, lm, lm, 0, None) == -1
+    assert b"null" in L.mi_last_error()
 
 
 def test_header_is_plain_c99(tmp_path):

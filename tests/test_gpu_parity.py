@@ -700,6 +700,63 @@ def test_image_to_tensor_vs_oracle(gpu, oracle, gold, man_image):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_fl_and_iris_infer_images_vs_tensor_entries(gpu, oracle, gold, man_image):
+    """Round 5: mi_fl_infer_images / mi_iris_infer_images take the frames as the reference's callers hold them (8UC3) plus one ROI (and
+    is_right_eye) per item and warp on the device (face_landmark.rs:250, iris_landmark.rs:188-189).  On the 25-ROI set of
+    test_image_to_tensor_vs_oracle (rotated, off-image, non-normalised ROIs on a landscape and a portrait source) the results equal
+    the tensor entries fed with the ORACLE's image_to_tensor crops of the same items bit for bit; several items per frame, host and
+    device memory, whole frames (roi = None)."""
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(21)
+    tall = rs.randint(0, 256, (300, 171, 3)).astype(np.uint8)
+    rois = [gold["man_face_roi"], gold["man_eye_right_roi"], gold["man_eye_left_roi"], np.array([300.0, 150.0, 333.0, 217.0, -0.7, 0]),
+            np.array([0.5, 0.5, 0.4, 0.6, 0.2, 1]), np.array([0.05, 0.1, 0.5, 0.45, 2.4, 1]), np.array([0.5, 0.5, 0.3556, 0.5333, 0.0, 1]),
+            np.array([0.4, 0.6, 0.7, 0.5, -1.1, 1])]
+    for k in range(17):
+        rois.append(np.array([rs.uniform(0.2, 0.8), rs.uniform(0.2, 0.8), rs.uniform(0.1, 0.9), rs.uniform(0.1, 0.9), rs.uniform(-3.1, 3.1), 1]))
+    assert len(rois) == 25
+    fl, iris = gpu.FaceLandmark(), gpu.IrisLandmark()
+    for img in (man_image, tall):
+        H, W = img.shape[:2]
+        G = [gpu.Rect(*[float(v) for v in r[:5]], int(r[5])) for r in rois]
+        O = [oracle.Rect(*[float(v) for v in r[:5]], int(r[5])) for r in rois]
+        sizes = np.array([[W, H]] * 25, np.int32)
+        # ---- face mesh: 5 frames (copies of the picture) x 5 ROIs each
+        frames = np.stack([img] * 5)
+        crops = np.stack([oracle.image_to_tensor(img, o, (192, 192), False, (0., 1.), False)[0] for o in O])
+        want = fl.infer_tensor(crops, G, sizes)
+        got = fl.infer_images(frames, G, items_per_frame=5)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+        assert got[1].sum() >= 1                      # (the face ROI passes the flag)
+        # device memory: frames and ROIs resident, results left on the device
+        roi_dev = torch.from_numpy(np.frombuffer(bytes((gpu.Rect * 25)(*G)), np.uint8).copy()).cuda()
+        got_d = fl.infer_images(torch.from_numpy(frames).cuda(), roi_dev, items_per_frame=5)
+        for a, b in zip(got_d, want):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+        # ---- iris: the same ROIs as eye crops, every third one a right eye (flipped in, x -> 1 - x out)
+        flips = np.array([k % 3 == 0 for k in range(25)], np.int32)
+        both = [oracle.image_to_tensor(img, o, (64, 64), True, (0., 1.), bool(f)) for o, f in zip(O, flips)]
+        crops = np.stack([t for t, _ in both])
+        pads = np.array([p for _, p in both], np.float64)
+        want = iris.infer_tensor(crops, G, sizes, pads, flips)
+        got = iris.infer_images(frames, G, flips, items_per_frame=5)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+        # ---- whole frames (Option<Rect> = None), one item per frame
+        want = fl.infer_tensor(np.stack([oracle.image_to_tensor(img, None, (192, 192), False, (0., 1.), False)[0]] * 2))
+        got = fl.infer_images(frames[:2])
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+        t, p = oracle.image_to_tensor(img, None, (64, 64), True, (0., 1.), False)
+        want = iris.infer_tensor(np.stack([t] * 2), None, None, np.array([p, p], np.float64), None)
+        got = iris.infer_images(frames[:2])
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+    fl.close()
+    iris.close()
+
+
 def test_full_pipeline_on_man_jpg(gpu, oracle, gold, man_image):
     """README.md:27-46 flow through the reference-shaped API; pinned by the reference's own rendering (+-2 px)."""
     H, W = man_image.shape[:2]

@@ -110,3 +110,52 @@ with torch.cuda.stream(hs):
     hs.synchronize(); dc = (time.perf_counter() - t) / 10
 print(json.dumps({"config": "BackCamera 256 u8 frames from pinned HOST memory, two slots (copy of batch n+1 overlaps the kernels of batch n)", "ms_per_batch": round(dt * 1e3, 3),
                   "frames_per_s": round(256 / dt), "faces_in_last_batch": int((counts > 0).sum()), "h2d_copy_alone_ms": round(dc * 1e3, 3), "h2d_GBps": round(u8.nbytes / dc / 1e9, 1)}))
+
+# round 5: the mesh and the iris network from u8 frames + ROIs (mi_fl_infer_images / mi_iris_infer_images: the warp to 192x192 / 64x64 on
+# the device) against their f32-crop entries from host memory.  512 ROIs = 64 camera frames of 540x360 with 8 face ROIs each (the
+# frames and the ROIs are what crosses the bus: 37 MB instead of 226 MB); then 512 frames of 192x192 with one ROI each.
+man = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "man.jpg")).convert("RGB"))
+Hm, Wm = man.shape[:2]
+rsr = np.random.RandomState(3)
+base = gold["man_face_roi"]
+def jitter(k):
+    r = base.copy()
+    r[0] += rsr.uniform(-0.02, 0.02); r[1] += rsr.uniform(-0.02, 0.02); r[4] += rsr.uniform(-0.3, 0.3)
+    return mi.Rect(*[float(v) for v in r[:5]], int(r[5]))
+rois = [jitter(k) for k in range(512)]
+frames64 = np.stack([np.roll(man, (int(rsr.randint(-6, 7)), int(rsr.randint(-6, 7))), axis=(0, 1)) for _ in range(64)])
+pin = mi.PinnedBuffer(frames64.shape); pin.array[...] = frames64
+for _ in range(3): lm, pres, _f = fl.infer_images(pin.array, rois, items_per_frame=8)
+t = time.perf_counter()
+for _ in range(20): lm, pres, _f = fl.infer_images(pin.array, rois, items_per_frame=8)
+dt = (time.perf_counter() - t) / 20
+print(json.dumps({"config": "FaceLandmark 512 ROIs on 64 u8 frames 540x360 from pinned HOST memory (mi_fl_infer_images: H2D 37 MB + device warp + net + projection + D2H)",
+                  "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(512 / dt), "faces_present": int(pres.sum())}))
+crops = np.stack([mi.image_to_tensor(man, rois[k], (192, 192), False, (0., 1.), False)[0] for k in range(0, 512, 8)] * 8)
+sizes = np.array([[Wm, Hm]] * 512, np.int32)
+cp = torch.from_numpy(crops).pin_memory().numpy()
+for _ in range(2): fl.infer_tensor(cp, rois, sizes)
+t = time.perf_counter()
+for _ in range(5): fl.infer_tensor(cp, rois, sizes)
+dt = (time.perf_counter() - t) / 5
+print(json.dumps({"config": "FaceLandmark 512 f32 crops from pinned HOST memory (mi_fl_infer_tensor: H2D 226 MB + net + projection + D2H)", "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(512 / dt)}))
+f192 = np.stack([np.asarray(Image.fromarray(man).resize((192, 192)))] * 512)
+pin2 = mi.PinnedBuffer(f192.shape); pin2.array[...] = f192
+r192 = [mi.Rect(0.5, 0.42, 0.5, 0.75, 0.0, 1)] * 512
+for _ in range(3): fl.infer_images(pin2.array, r192)
+t = time.perf_counter()
+for _ in range(20): fl.infer_images(pin2.array, r192)
+dt = (time.perf_counter() - t) / 20
+print(json.dumps({"config": "FaceLandmark 512 ROIs on 512 u8 frames 192x192 from pinned HOST memory (mi_fl_infer_images: H2D 57 MB + device warp + net + projection + D2H)",
+                  "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(512 / dt)}))
+fdev = torch.from_numpy(frames64).cuda()
+rdev = torch.from_numpy(np.frombuffer(bytes((mi.Rect * 512)(*rois)), np.uint8).copy()).cuda()
+dt = timeit(lambda: fl.infer_images(fdev, rdev, items_per_frame=8))
+print(json.dumps({"config": "FaceLandmark 512 ROIs on 64 u8 frames resident in HBM (mi_fl_infer_images)", "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(512 / dt)}))
+eye_rois = [mi.Rect(*[float(v) for v in gold["man_eye_left_roi" if k % 2 == 0 else "man_eye_right_roi"][:5]], int(gold["man_eye_left_roi"][5])) for k in range(1024)]
+flips = np.array([k % 2 for k in range(1024)], np.int32)
+for _ in range(3): ir.infer_images(pin.array, eye_rois, flips, items_per_frame=16)
+t = time.perf_counter()
+for _ in range(20): ir.infer_images(pin.array, eye_rois, flips, items_per_frame=16)
+dt = (time.perf_counter() - t) / 20
+print(json.dumps({"config": "IrisLandmark 1024 eye ROIs on 64 u8 frames 540x360 from pinned HOST memory (mi_iris_infer_images)", "ms_per_batch": round(dt * 1e3, 3), "eyes_per_s": round(1024 / dt)}))

@@ -47,7 +47,7 @@ def label(name):
         args = args[:5]
     if m.group(1) == "chain_kernel":
         args = args[:1]   # the label carries the tile count only (not the unit-split flag)
-    if m.group(1) in ("bneck_kernel", "dblock_kernel"):
+    if m.group(1) in ("bneck_kernel", "dblock_kernel", "tail_kernel"):
         return m.group(1)
     if m.group(1) == "stem_conv_kernel":
         return "stem_conv_kernel"
@@ -55,7 +55,7 @@ def label(name):
 
 
 WORKLOADS = {1: "short128_b256", 2: "back256_b256", 3: "landmark192_b512", 5: "pipeline192_b128"}
-WIDE = ("block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "strip_pipe2m_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel", "ms2_kernel", "xc_kernel")
+WIDE = ("tail_kernel", "block_kernel", "strip_kernel", "strip_pipe_kernel", "strip_pipe2_kernel", "strip_pipe2m_kernel", "chain_kernel", "bneck_kernel", "dblock_kernel", "mstrip_kernel", "mdblock_kernel", "mbneck_kernel", "mwalk_kernel", "ms2_kernel", "xc_kernel")
 
 # ---- kernel stats per config
 for c in WORKLOADS:
