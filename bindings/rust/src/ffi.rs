@@ -99,6 +99,10 @@ extern "C" {
     pub fn mi_jpeg_decode_rgb(device: c_int, bytes: *const u8, nbytes: usize, rgb: *mut u8, cap_bytes: usize, width: *mut c_int,
                               height: *mut c_int, mem: c_int, stream: *mut c_void) -> c_int;
 
+    // multi-GPU: the frozen .tflite bytes from `root` to every rank over RCCL (one process per GPU)
+    pub fn mi_dist_broadcast_bytes(id_path: *const c_char, rank: c_int, world: c_int, root: c_int, device: c_int, buf: *mut u8, nbytes: usize,
+                                   timeout_ms: c_int) -> c_int;
+
     // batched detector -> mesh -> iris flow on the device (no counterpart in the reference: lib.rs:24-40 per frame)
     pub fn mi_pipeline_create(fd_kind: c_int, model_dir: *const c_char, device: c_int, out: *mut *mut mi_pipeline) -> c_int;
     pub fn mi_pipeline_free(p: *mut mi_pipeline);

@@ -311,6 +311,17 @@ int mi_image_to_tensor(int device, const uint8_t *rgb, int width, int height, in
                        int out_w, int out_h, int keep_aspect_ratio, double range_min, double range_max,
                        int flip_horizontal, float *out, double padding_out[4], int mem, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: the one exchange of the sharded path — the frozen .tflite bytes go once from `root` to
+ * every rank over RCCL (ncclBroadcast, ncclUint8, xGMI inside a node); every rank then builds its handles with
+ * mi_*_create_from_bytes (the counterpart of FlatBufferModel::build_from_file, face_detection.rs:188, on ranks that have no
+ * file).  One process per GPU; no PyTorch needed (librccl is loaded at call time).  Rendezvous: `root` writes the ncclUniqueId
+ * to `id_path` (a file every rank of the node can read, e.g. under /dev/shm; a fresh name per broadcast), the other ranks wait
+ * up to timeout_ms (< 0: for ever) for it.  buf: HOST memory of nbytes on every rank — the data on `root`, the receive
+ * buffer elsewhere.  device: this rank's GPU ordinal.  Collective: every rank of `world` must call it. */
+int mi_dist_broadcast_bytes(const char *id_path, int rank, int world, int root, int device, uint8_t *buf, size_t nbytes,
+                            int timeout_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ EXPORTS = [
     "mi_last_error", "mi_device_count", "mi_version",
     "mi_model_load_file", "mi_model_load_bytes", "mi_model_free", "mi_model_input_dims", "mi_model_num_outputs",
     "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
-    "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_profile",
+    "mi_dist_broadcast_bytes", "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
     "mi_fd_collect", "mi_host_alloc", "mi_host_free",
@@ -212,6 +212,19 @@ def _check(rc):
 
 def device_count():
     return lib().mi_device_count()
+
+
+def dist_broadcast_bytes(id_path, rank, world, root, data, nbytes=None, device=0, timeout_ms=60000) -> bytes:
+    """mi_dist_broadcast_bytes: `data` (bytes) on the root rank, None elsewhere (then `nbytes` says how much to receive).  Returns the
+    bytes every rank now holds.  Collective over `world` ranks, one process per GPU, RCCL directly (no torch.distributed)."""
+    n = len(data) if data is not None else int(nbytes)
+    buf = (C.c_uint8 * n)()
+    if data is not None:
+        C.memmove(buf, data, n)
+    L = lib()
+    L.mi_dist_broadcast_bytes.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+    _check(L.mi_dist_broadcast_bytes(os.fsencode(id_path), rank, world, root, device, buf, n, timeout_ms))
+    return bytes(buf)
 
 
 def plan_describe(tflite_bytes: bytes, fuse_level=4) -> str:

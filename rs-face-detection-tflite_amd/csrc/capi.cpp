@@ -12,6 +12,12 @@
 #include <vector>
 
 #include "../../include/mi_face.h"
+#include <dlfcn.h>
+
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
 #include "engine.hpp"
 #include "host_glue.hpp"
 #include "kernels.hpp"
@@ -1228,6 +1234,96 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         } else if (!stream) {
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
         }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU: weight broadcast
+// The one exchange of the sharded path: the frozen .tflite bytes travel once from `root` to every rank over RCCL, then
+// each rank builds its handles with mi_*_create_from_bytes.  A Rust host (north_star) has no torch.distributed: this entry speaks to
+// librccl directly (loaded at call time, so the library itself does not depend on it).  Rendezvous = the ncclUniqueId in a file every
+// rank of the node can read: `root` writes it (temporary name + rename), the others wait for it.
+namespace {
+struct UniqueId { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value like the original
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+
+int mi_dist_broadcast_bytes(const char* id_path, int rank, int world, int root, int device, uint8_t* buf, size_t nbytes, int timeout_ms) {
+    return guarded([&] {
+        require(id_path && buf, "null argument");
+        require(world >= 1 && rank >= 0 && rank < world && root >= 0 && root < world, "rank / root outside [0, world)");
+        require(nbytes > 0 && nbytes <= (static_cast<size_t>(1) << 31), "nbytes must be in (0, 2 GiB]");
+        mi::hip_check(hipSetDevice(device), "hipSetDevice");
+        static std::mutex mu;
+        static Rccl R;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!R.lib) {
+                void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+                if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+                if (!lib) throw ApiError(MI_EDEVICE, std::string("librccl is not loadable: ") + dlerror());
+                auto sym = [&](const char* n) {
+                    void* p = dlsym(lib, n);
+                    if (!p) throw ApiError(MI_EDEVICE, std::string("librccl lacks ") + n);
+                    return p;
+                };
+                R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+                R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+                R.Broadcast = reinterpret_cast<decltype(R.Broadcast)>(sym("ncclBroadcast"));
+                R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+                R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+                R.lib = lib;
+            }
+        }
+        auto nccl = [&](int rc, const char* what) {
+            if (rc != 0) throw ApiError(MI_EDEVICE, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(rc) : "rccl error"));
+        };
+        UniqueId id{};
+        const std::string path = id_path, tmp = path + ".tmp";
+        if (rank == root) {
+            nccl(R.GetUniqueId(&id), "ncclGetUniqueId");
+            {
+                std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
+                if (!f || !f.write(id.internal, sizeof id.internal)) throw ApiError(MI_EIO, "cannot write the rendezvous file '" + tmp + "'");
+            }
+            if (std::rename(tmp.c_str(), path.c_str()) != 0) throw ApiError(MI_EIO, "cannot publish the rendezvous file '" + path + "'");
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                std::ifstream f(path, std::ios::binary);
+                if (f && f.read(id.internal, sizeof id.internal) && f.gcount() == static_cast<std::streamsize>(sizeof id.internal)) break;
+                if (timeout_ms >= 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms))
+                    throw ApiError(MI_EIO, "no rendezvous file '" + path + "' from the root rank within the timeout");
+                std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+        }
+        void* comm = nullptr;
+        uint8_t* d = nullptr;
+        hipStream_t s = nullptr;
+        try {
+            nccl(R.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+            if (rank == root) std::remove(path.c_str());   // every rank has read it: CommInitRank is collective
+            mi::hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+            mi::hip_check(hipMalloc(reinterpret_cast<void**>(&d), nbytes), "hipMalloc");
+            if (rank == root) mi::hip_check(hipMemcpyAsync(d, buf, nbytes, hipMemcpyHostToDevice, s), "H2D model bytes");
+            nccl(R.Broadcast(d, d, nbytes, /* ncclUint8 */ 1, root, comm, s), "ncclBroadcast");
+            if (rank != root) mi::hip_check(hipMemcpyAsync(buf, d, nbytes, hipMemcpyDeviceToHost, s), "D2H model bytes");
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        } catch (...) {
+            if (d) hipFree(d);
+            if (s) hipStreamDestroy(s);
+            if (comm) R.CommDestroy(comm);
+            throw;
+        }
+        hipFree(d);
+        hipStreamDestroy(s);
+        nccl(R.CommDestroy(comm), "ncclCommDestroy");
     });
 }
 
