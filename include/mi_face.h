@@ -114,7 +114,7 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * default 16, 0 = never; the stand-alone stride-2 block of that form folds its depthwise bias differently, so one frame's raw
  * outputs differ between a batch <= small_chain and a larger one within the stated 1e-4 tolerance, not bit for bit), "strip" (0 = LDS-ring block kernel for every block),
  * "fork" (0 = output heads run on the trunk's stream instead of beside it), "heads" (side streams the output heads are spread
- * over, 1..4), "tail" (0 = no stage program takes the several-frames-per-workgroup form of round 5: the round-4 plan),
+ * over, 1..4), "mchain" (0 = the 32x32x48 blocks run one launch each instead of one launch per run), "tail" (0 = no stage program takes the several-frames-per-workgroup form of round 5: the round-4 plan),
  * "tail_g" (frames per workgroup of those programs; 0 = chosen per launch from the batch and the LDS a frame needs), "reuse",
  * "lanes". Takes effect on the next run. */
 int mi_model_set_option(mi_model *m, const char *key, int value);

@@ -72,6 +72,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "small_chain") { small_chain_ = std::max(0, std::min(value, 64)); if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; } invalidate_graphs(); }  // frames up to which a row-pipelined chain runs one launch per block (0: never)
     else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2 || value == 4) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel), 4: one row, MFMA pointwise convs (strip_pipe1m_kernel)
     else if (key == "strip") { strip_ = value != 0; }
+    else if (key == "mchain") { mchain_ = value != 0; }   // 0: the 32x32x48 blocks run one launch each (mstrip_kernel) instead of one launch per run
     else if (key == "tail") { tail_ = value != 0; dirty_ = true; }   // 0: no stage program runs on tail_kernels.hip (the round-4 plan)
     else if (key == "tail_pre") { tail_pre_ = std::max(0, std::min(value, 2)); }   // tail programs: 0 = chosen per launch, 1 = constants a stage ahead (one workgroup per CU), 2 = 128 registers (two per CU)
     else if (key == "tail_g") { tail_g_ = std::max(0, std::min(value, 64)); }   // frames per workgroup of the tail stage programs (0: chosen per launch)
@@ -761,6 +762,18 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
     }
     profile_inner_ = 1;
     (void)saved_chunk;
+    // plan nodes that ran inside the launch before them (a run of blocks on mstrip_chain_kernel): their work belongs to that launch
+    for (size_t i = 1; i < stats.size();) {
+        if (stats[i].kernel == "(fused into previous launch)") {
+            stats[i - 1].ms += stats[i].ms; stats[i - 1].bytes += stats[i].bytes; stats[i - 1].macs += stats[i].macs;
+            const size_t arrow = stats[i].detail.find("->");
+            const size_t parrow = stats[i - 1].detail.find("->");
+            if (arrow != std::string::npos && parrow != std::string::npos) stats[i - 1].detail = stats[i - 1].detail.substr(0, parrow) + stats[i].detail.substr(arrow);
+            stats.erase(stats.begin() + static_cast<long>(i));
+        } else {
+            i++;
+        }
+    }
     return stats;
 }
 
@@ -786,9 +799,17 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         if (!head_events_[k]) hip_check(hipEventCreateWithFlags(&head_events_[k], hipEventDisableTiming), "hipEventCreate");
         return head_events_[k];
     };
+    int fused_behind = 0;   // plan nodes that ran inside the launch just made (a run of 32x32x48 blocks on mstrip_chain_kernel)
     for (size_t i = 0; i < plan_.nodes.size(); i++) {
         const Node& n = plan_.nodes[i];
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;  // views
+        if (fused_behind > 0) {
+            fused_behind--;
+            if (labels) labels->push_back("(fused into previous launch)");
+            if (fork && event_after_[i]) hip_check(record_event(node_event(i), trunk), "hipEventRecord");
+            mark();
+            continue;
+        }
         s = trunk;
         if (fork && head_slot_[i] >= 0) {
             while (static_cast<int>(head_streams_.size()) <= head_slot_[i]) {
@@ -1137,6 +1158,46 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 }
                 const bool strip = strip_ && strip_kernel_supports(a);
                 const bool mstrip = strip_ && !strip && mstrip_kernel_supports(a);
+                if (mstrip && mchain_ && lanes_ == 1) {
+                    // the blocks behind this one that the same kernel takes, each reading its predecessor's output: ONE launch for the run
+                    // (every intermediate tensor keeps its arena slot; a workgroup per frame walks through the blocks)
+                    std::vector<BlockArgs> run{a};
+                    for (size_t j = i + 1; j < plan_.nodes.size() && run.size() < 8; j++) {
+                        const Node& m = plan_.nodes[j];
+                        if (m.kind != Node::Block || m.w < 0 || m.in.size() != 1 || m.in[0] != plan_.nodes[j - 1].out || node_strip_[j] < 0 || head_slot_[j] >= 0) break;
+                        const auto& mi_ = g.tensors[m.in[0]].shape;
+                        const auto& mo_ = g.tensors[m.out].shape;
+                        if (mi_.size() != 4 || mo_ != mi_) break;
+                        BlockArgs bb;
+                        bb.in = tensor_ptr(m.in[0], in, chunk_start, &bb.in_fs);
+                        bb.out = tensor_ptr_mut(m.out, chunk_start, &bb.out_fs);
+                        bb.has_dw = 1;
+                        bb.w_dw = d_weights_ + node_w_[j];
+                        bb.b_dw = node_b_[j] >= 0 ? d_weights_ + node_b_[j] : nullptr;
+                        bb.w_pw = d_weights_ + node_w2_[j];
+                        bb.w_strip = d_weights_ + node_strip_[j];
+                        bb.B = F; bb.H = mi_[1]; bb.W = mi_[2]; bb.C = mi_[3]; bb.Ho = mo_[1]; bb.Wo = mo_[2]; bb.Co = mo_[3];
+                        bb.sh = m.sh; bb.sw = m.sw;
+                        if (m.padding == Padding::Same) { same_pad(bb.H, 3, bb.sh, bb.Ho, &bb.pt); same_pad(bb.W, 3, bb.sw, bb.Wo, &bb.pl); }
+                        if (m.ept >= 0) break;
+                        bb.ep.bias = node_b2_[j] >= 0 ? d_weights_ + node_b2_[j] : nullptr;
+                        bb.ep.alpha = node_alpha_[j] >= 0 ? d_weights_ + node_alpha_[j] : nullptr;
+                        bb.ep.act = m.act;
+                        if (m.res >= 0) {
+                            if (m.res != m.in[0] || m.res_mode != RES_DIRECT || m.res_after) break;
+                            bb.ep.res = bb.in; bb.ep.res_fs = bb.in_fs; bb.ep.res_mode = RES_DIRECT; bb.ep.res_C = bb.C;
+                            bb.ep.res_H = bb.H; bb.ep.res_W = bb.W;
+                        }
+                        run.push_back(bb);
+                        if (!mstrip_chain_supports(run.data(), static_cast<int>(run.size()))) { run.pop_back(); break; }
+                    }
+                    if (run.size() >= 2) {
+                        if (labels) { char buf[96]; snprintf(buf, sizeof buf, "mstrip_chain_kernel<%d,%d>", a.C / 4, a.ep.act == ACT_RELU ? 1 : 0); labels->back() = buf; }
+                        rc = launch_mstrip_chain(run.data(), static_cast<int>(run.size()), s);
+                        fused_behind = static_cast<int>(run.size()) - 1;
+                        break;
+                    }
+                }
                 if (labels) { char buf[96]; labels->back() = strip ? strip_kernel_label(a, buf, sizeof buf) : (mstrip ? mstrip_kernel_label(a, buf, sizeof buf) : block_kernel_label(a, buf, sizeof buf)); }
                 rc = strip ? launch_strip(a, s) : (mstrip ? launch_mstrip(a, s) : launch_block(a, s));
                 break;

@@ -97,6 +97,7 @@ class Model {
     ResStage* d_programs_ = nullptr;        // stage programs of the Resident nodes (device memory)
     TailStage* d_tail_programs_ = nullptr;  // ... of those that run on tail_kernels.hip (Node::tail; node_prog_ indexes this array then)
     std::vector<std::vector<long>> tail_wa_, tail_wc_;  // per tail node, per stage: A operands / small constants (-1: LOAD)
+    int mchain_ = 1;                        // option "mchain"
     int tail_ = 1;                          // option "tail"
     int tail_pre_ = 0;                      // option "tail_pre"
     int tail_g_ = 0;                        // option "tail_g": frames per workgroup of the tail programs (0 = chosen per launch)

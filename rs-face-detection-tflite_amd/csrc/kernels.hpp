@@ -318,6 +318,9 @@ bool mstrip_shape_ok(int C, int Co);
 int mstrip_consts_floats(int C);
 void mstrip_pack_consts(int C, const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst);
 const char* mstrip_kernel_label(const BlockArgs& a, char* buf, size_t cap);
+// a run of 2..8 such blocks (each reading its predecessor's output, 32 x 32 frames) as ONE launch: a workgroup per frame, a barrier between blocks
+bool mstrip_chain_supports(const BlockArgs* blocks, int n);
+int launch_mstrip_chain(const BlockArgs* blocks, int n, void* stream);
 // row-pipelined chain of 2..4 strip-eligible blocks (blocks[k+1].in == blocks[k].out, which never reaches HBM)
 bool strip_pipe_supports(const BlockArgs* blocks, int n);
 bool strip_pipe_shape_ok(int C, int W);  // host-only shape tests for the planner

@@ -220,17 +220,27 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     x[5] = 0.0                       # an all-zero frame: biases only
     x[9, :, :128] = -1.0             # half-saturated frame
     outs = [o.copy() for o in m.run(x)]
-    labels = {r["kernel"] for r in m.profile(__import__("torch").from_numpy(x).cuda(), reps=1)}
-    assert any(k.startswith("mstrip_kernel") for k in labels), labels
+    recs = m.profile(__import__("torch").from_numpy(x).cuda(), reps=1)
+    labels = {r["kernel"] for r in recs}
+    # round 5: the run of seven blocks is ONE launch (mstrip_chain_kernel: a workgroup per frame, a barrier between blocks, every
+    # intermediate tensor still written to its arena slot)
+    assert any(k.startswith("mstrip_chain_kernel") for k in labels) and sum(r["kernel"].startswith("mstrip") for r in recs) == 1, labels
     om = oracle.Model(model_path("back"))
     refs = om.run(x, nthreads=8)
     for o, r in zip(outs, refs):
         _raw_close(o, r)
     for o, r in zip(m.run(x[7:8]), outs):
         _raw_close(o[0], r[7])
+    # one launch per block (option "mchain" = 0: mstrip_kernel x 7) computes the same bits: same row code, same order of every sum
+    m.set_option("mchain", 0)
+    recs1 = m.profile(__import__("torch").from_numpy(x).cuda(), reps=1)
+    assert sum(r["kernel"].startswith("mstrip_kernel") for r in recs1) == 7, [r["kernel"] for r in recs1]
+    for o, r in zip(m.run(x), outs):
+        np.testing.assert_array_equal(o, r)
+    m.set_option("mchain", 1)
     m.set_option("strip", 0)
     labels0 = {r["kernel"] for r in m.profile(__import__("torch").from_numpy(x).cuda(), reps=1)}
-    assert not any(k.startswith("mstrip_kernel") for k in labels0)
+    assert not any(k.startswith("mstrip") for k in labels0)
     for o, r in zip(m.run(x), outs):
         _raw_close(o, r)
     m.close()
