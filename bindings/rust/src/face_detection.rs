@@ -38,6 +38,15 @@ impl FaceDetection {
         Ok(FaceDetection { handle })
     }
 
+    /// The handle from the model's BYTES instead of a file (`mi_fd_create_from_bytes`): what a rank that received the frozen
+    /// `.tflite` over RCCL (`mi_dist_broadcast_bytes`) builds its detector from — the counterpart of
+    /// `FlatBufferModel::build_from_file` (face_detection.rs:188) on ranks that hold no file.
+    pub fn from_bytes(model_type: FaceDetectionModel, tflite: &[u8], device: i32) -> Result<FaceDetection, Error> {
+        let mut handle: *mut ffi::mi_fd = std::ptr::null_mut();
+        check(unsafe { ffi::mi_fd_create_from_bytes(model_type as i32, tflite.as_ptr(), tflite.len(), device, &mut handle) })?;
+        Ok(FaceDetection { handle })
+    }
+
     /// `infer(&self, image: &Mat, roi) -> Result<Vec<Detection>>` — face_detection.rs:205-267.  `image` is anything that turns
     /// into an `Image` view: `&Mat` (feature `opencv`), `&RgbImage`, `&Image` or an `Image` — so the reference's call
     /// `face_detection.infer(&mat, None)` compiles unchanged.  Flow: image_to_tensor (letterbox to the
