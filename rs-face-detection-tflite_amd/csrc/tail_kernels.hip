@@ -112,7 +112,7 @@ unsigned long long* g_tail_stamps = nullptr;  // [workgroup][stage][4]: stage st
 // (compile time: with run-time predicates around the steps the compiler waited for every LDS read right behind its issue).  The stage
 // programs run every instruction a few times per stage: code size counts (a version with three tile-group sizes and the constants of the
 // depthwise stage prefetched too was 120 KB of code and ran three times slower than this one).
-template <int N4, int NPT, bool PRE>
+template <int N4, int NPT>
 __device__ __forceinline__ void tail_group(const TailView& v, float4 (&A)[8], bool a0, const float* wa, const float4& bias, const float4& slope, int ch, int tb, int t1,
                                            int nkb) {
     const int lane = threadIdx.x & 63, kq = lane >> 4, n = lane & 15;
@@ -133,22 +133,10 @@ __device__ __forceinline__ void tail_group(const TailView& v, float4 (&A)[8], bo
     tf32x4 D[NPT];
 #pragma unroll
     for (int u = 0; u < NPT; u++) D[u] = tf32x4{0.f, 0.f, 0.f, 0.f};
-    // long contractions (the 2x2 stride-2 convolutions: 2 - 4 k-blocks): in the one-CU variant the next k-block's A operands travel
-    // while the current block's MFMAs run (32 more registers; the 128-register variant streams them block by block)
-    float4 An[PRE && N4 == 8 ? 8 : 1];
     for (int kb = 0; kb < nkb; kb++) {
         if (kb > 0 || !a0) {
-            if (PRE && N4 == 8 && kb > 0) {
 #pragma unroll
-                for (int i = 0; i < N4; i++) A[i] = An[PRE && N4 == 8 ? i : 0];
-            } else {
-#pragma unroll
-                for (int i = 0; i < N4; i++) A[i] = tld4(wa + 256 * (kb * N4 + i));
-            }
-        }
-        if (PRE && N4 == 8 && kb + 1 < nkb) {
-#pragma unroll
-            for (int i = 0; i < N4; i++) An[PRE && N4 == 8 ? i : 0] = tld4(wa + 256 * ((kb + 1) * N4 + i));
+            for (int i = 0; i < N4; i++) A[i] = tld4(wa + 256 * (kb * N4 + i));
         }
         float4 b[NPT][2];   // the B operands of step i + 1 are on their way while step i's MFMAs run
 #pragma unroll
@@ -216,23 +204,22 @@ __device__ __forceinline__ void tail_group(const TailView& v, float4 (&A)[8], bo
 
 // One output-channel tile x the pixel tiles [t0, t1) of the stage on this wave, in pairs (two independent MFMA chains share every A
 // register), a last odd tile alone.
-template <int N4, bool PRE>
+template <int N4>
 __device__ __forceinline__ void tail_tile_n(const TailView& v, float4 (&A)[8], const float4& bias, const float4& slope, int ct, int t0, int t1, int nkb) {
     const int lane = threadIdx.x & 63, kq = lane >> 4;
     const int ch = 16 * ct + 4 * kq;
     const float* wa = v.wa + ((long)ct * v.n4 * 64 + lane) * 4;
     int tb = t0;
     bool a0 = true;
-    for (; tb + 1 < t1; tb += 2) { tail_group<N4, 2, PRE>(v, A, a0, wa, bias, slope, ch, tb, t1, nkb); a0 = nkb == 1; }
-    if (tb < t1) tail_group<N4, 1, PRE>(v, A, a0, wa, bias, slope, ch, tb, t1, nkb);
+    for (; tb + 1 < t1; tb += 2) { tail_group<N4, 2>(v, A, a0, wa, bias, slope, ch, tb, t1, nkb); a0 = nkb == 1; }
+    if (tb < t1) tail_group<N4, 1>(v, A, a0, wa, bias, slope, ch, tb, t1, nkb);
 }
-template <bool PRE>
 __device__ __forceinline__ void tail_tile(const TailView& v, float4 (&A)[8], const float4& bias, const float4& slope, int ct, int t0, int t1, int n4b, int nkb) {
     switch (n4b) {
-        case 1: tail_tile_n<1, PRE>(v, A, bias, slope, ct, t0, t1, nkb); break;
-        case 2: tail_tile_n<2, PRE>(v, A, bias, slope, ct, t0, t1, nkb); break;
-        case 4: tail_tile_n<4, PRE>(v, A, bias, slope, ct, t0, t1, nkb); break;
-        default: tail_tile_n<8, PRE>(v, A, bias, slope, ct, t0, t1, nkb); break;
+        case 1: tail_tile_n<1>(v, A, bias, slope, ct, t0, t1, nkb); break;
+        case 2: tail_tile_n<2>(v, A, bias, slope, ct, t0, t1, nkb); break;
+        case 4: tail_tile_n<4>(v, A, bias, slope, ct, t0, t1, nkb); break;
+        default: tail_tile_n<8>(v, A, bias, slope, ct, t0, t1, nkb); break;
     }
 }
 
@@ -430,14 +417,14 @@ __global__ __launch_bounds__(512, PRE ? 2 : 4) void tail_kernel(const TailStage*
         const int parts = nct >= 8 ? 1 : 8 / nct, part = nct >= 8 ? 0 : wave / nct;
         const int t0 = part * ntl / parts, t1 = (part + 1) * ntl / parts;
         if (part < parts && t0 < t1) {
-            tail_tile<PRE>(v, A, bias, slope, ct0, t0, t1, n4b, nkb);
+            tail_tile(v, A, bias, slope, ct0, t0, t1, n4b, nkb);
             for (int ct = ct0 + 8; ct < nct; ct += 8) {   // stages of more than 128 output channels: the further tiles fetch their constants themselves
                 const float* wa = v.wa + ((long)ct * n4 * 64 + lane) * 4;
 #pragma unroll
                 for (int i = 0; i < 8; i++) A[i] = tld4(wa + 256 * i);
                 bias = tld4(v.wc + 16 * ct + 4 * kq);
                 slope = tld4(v.wc + 16 * nct + 16 * ct + 4 * kq);
-                tail_tile<PRE>(v, A, bias, slope, ct, t0, t1, n4b, nkb);
+                tail_tile(v, A, bias, slope, ct, t0, t1, n4b, nkb);
             }
         }
         MI_TAIL_STAMP(2)
