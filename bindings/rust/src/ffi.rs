@@ -77,6 +77,10 @@ extern "C" {
                               items_per_frame: c_int, landmarks: *mut c_float, present: *mut c_int, raw_flags: *mut c_float, mem: c_int,
                               stream: *mut c_void) -> c_int;
 
+    pub fn mi_fl_submit_images(h: *mut mi_fl, slot: c_int, frames: *const u8, batch: c_int, width: c_int, height: c_int, stride: c_int,
+                               rois: *const mi_rect, items_per_frame: c_int) -> c_int;
+    pub fn mi_fl_collect(h: *mut mi_fl, slot: c_int, landmarks: *mut c_float, present: *mut c_int, raw_flags: *mut c_float) -> c_int;
+
     // IrisLandmark — iris_landmark.rs:130-248
     pub fn mi_iris_create(model_path: *const c_char, device: c_int, out: *mut *mut mi_iris) -> c_int;
     pub fn mi_iris_free(h: *mut mi_iris);

@@ -215,6 +215,14 @@ int mi_fl_infer_tensor(mi_fl *h, const float *in, int batch, const mi_rect *rois
  * with batch * items_per_frame items. */
 int mi_fl_infer_images(mi_fl *h, const uint8_t *frames, int batch, int width, int height, int stride, const mi_rect *rois,
                        int items_per_frame, float *landmarks, int *present, float *raw_flags, int mem, void *stream);
+/* The same for a continuous host feed, in two halves like mi_fd_submit_images / mi_fd_collect: submit queues the H2D copy of the
+ * frames (on the slot's own stream), the warp, the network and the projection — whose kernel writes into the slot's pinned, mapped,
+ * coherent host block — and returns; collect waits for that slot and hands the results out (raw_flags may be NULL).  Two slots
+ * (0 / 1): the copy of one batch runs beside the kernels of the other.  A slot must be collected before it is submitted again;
+ * `frames` must stay valid until then and should be pinned (mi_host_alloc).  Host memory only. */
+int mi_fl_submit_images(mi_fl *h, int slot, const uint8_t *frames, int batch, int width, int height, int stride,
+                        const mi_rect *rois, int items_per_frame);
+int mi_fl_collect(mi_fl *h, int slot, float *landmarks, int *present, float *raw_flags);
 /* FaceLandmark::infer(&Mat, Option<Rect>) — face_landmark.rs:232-306. out = 468 landmarks; *count = 0 or 468. */
 int mi_fl_infer_image(mi_fl *h, const uint8_t *rgb, int width, int height, int stride, const mi_rect *roi,
                       mi_landmark *out, int cap, int *count);

@@ -34,7 +34,7 @@ EXPORTS = [
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
     "mi_fd_collect", "mi_host_alloc", "mi_host_free",
-    "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_images", "mi_fl_infer_image",
+    "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_images", "mi_fl_submit_images", "mi_fl_collect", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor", "mi_iris_infer_images",
     "mi_iris_infer_image",
     "mi_pipeline_create", "mi_pipeline_create_from_bytes", "mi_pipeline_model", "mi_pipeline_free", "mi_pipeline_set_option", "mi_pipeline_run",
@@ -173,6 +173,8 @@ def lib():
     L.mi_fl_model.restype = vp
     L.mi_fl_infer_tensor.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp]
     L.mi_fl_infer_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp]
+    L.mi_fl_submit_images.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+    L.mi_fl_collect.argtypes = [vp, C.c_int, vp, vp, vp]
     L.mi_fl_infer_image.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(Rect), C.POINTER(CLandmark), C.c_int, ip]
     L.mi_iris_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     L.mi_iris_create_from_bytes.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp)]
@@ -385,7 +387,7 @@ def _frames_and_rois(frames, rois, items_per_frame, device):
     if rois is not None:
         if len(rois) != N:
             raise ValueError("expected %d rois" % N)
-        rarr = (Rect * N)(*rois)
+        rarr = rois if isinstance(rois, C.Array) else (Rect * N)(*rois)
     return C.c_void_p(frames.ctypes.data), mem, B, H, W, frames.strides[1], (C.cast(rarr, C.c_void_p) if rarr is not None else None), (frames, rarr)
 
 
@@ -625,6 +627,30 @@ class FaceLandmark:
             lm, present, flags = np.zeros((N, NUM_FACE_LANDMARKS, 3), np.float32), np.zeros((N,), np.int32), np.zeros((N,), np.float32)
         _check(self.L.mi_fl_infer_images(self.h, p, B, W, H, stride, rp, items_per_frame, _ptr(lm)[0], _ptr(present)[0], _ptr(flags)[0], mem,
                                          C.c_void_p(stream or 0)))
+        return lm, present, flags
+
+
+    def submit_images(self, slot, frames, rois=None, items_per_frame=1):
+        """Queues one batch of host frames (numpy uint8 [B,H,W,3], pinned for the copy to overlap the other slot's kernels) with their ROIs
+        and returns at once; `collect(slot)` hands the results out."""
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3 or not frames.flags["C_CONTIGUOUS"]:
+            raise ValueError("frames must be a C-contiguous uint8 [B,H,W,3] array")
+        B, H, W = frames.shape[:3]
+        N = B * items_per_frame
+        rarr = None
+        if rois is not None:
+            rarr = rois if isinstance(rois, C.Array) else (Rect * N)(*rois)
+            if len(rarr) != N:
+                raise ValueError("expected %d rois" % N)
+        _check(self.L.mi_fl_submit_images(self.h, slot, C.c_void_p(frames.ctypes.data), B, W, H, frames.strides[1],
+                                          C.cast(rarr, C.c_void_p) if rarr is not None else None, items_per_frame))
+        self._slot_shape = getattr(self, "_slot_shape", {})
+        self._slot_shape[slot] = (N, frames, rarr)   # keeps frames and ROIs alive until collect()
+
+    def collect(self, slot):
+        N, _, _ = self._slot_shape.pop(slot)
+        lm, present, flags = np.zeros((N, NUM_FACE_LANDMARKS, 3), np.float32), np.zeros((N,), np.int32), np.zeros((N,), np.float32)
+        _check(self.L.mi_fl_collect(self.h, slot, C.c_void_p(lm.ctypes.data), C.c_void_p(present.ctypes.data), C.c_void_p(flags.ctypes.data)))
         return lm, present, flags
 
 

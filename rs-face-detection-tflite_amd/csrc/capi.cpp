@@ -164,11 +164,35 @@ struct mi_fd {
     }
 };
 
+// One of the two slots of the mesh's host-fed batch form (mi_fl_submit_images / mi_fl_collect), like FdSlot: its own copy stream, device
+// frames and ROIs, and a pinned + mapped host block that the projection kernel writes the results into.
+struct FlSlot {
+    hipStream_t copy = nullptr;
+    hipEvent_t copied = nullptr, done = nullptr;
+    DeviceBuf d_frames, d_rois;
+    void* h_out = nullptr;      // [N][468][3] landmarks, [N] present, [N] raw flags
+    size_t h_cap = 0;
+    int N = 0;
+    bool pending = false;
+    ~FlSlot() {
+        if (pending && done) hipEventSynchronize(done);
+        if (copy) hipStreamDestroy(copy);
+        if (copied) hipEventDestroy(copied);
+        if (done) hipEventDestroy(done);
+        if (h_out) hipHostFree(h_out);
+    }
+};
+
 struct mi_fl {
     mi_model model;
     int in_w = 0, in_h = 0;
     DeviceBuf d_in, d_roi, d_size, d_lm, d_present, d_flag, d_img, d_geom, d_sizes_b;
     int sizes_N = 0, sizes_w = 0, sizes_h = 0;  // what d_sizes_b holds (mi_fl_infer_images: uploaded when the batch geometry changes)
+    FlSlot slot[2];
+    ~mi_fl() {
+        for (FlSlot& sl : slot)
+            if (sl.pending && sl.done) hipEventSynchronize(sl.done);   // its kernels still read the handle's buffers
+    }
 };
 
 struct mi_pipeline {
@@ -824,6 +848,97 @@ int mi_fl_infer_images(mi_fl* h, const uint8_t* frames, int batch, int width, in
         } else if (!stream) {
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
         }
+    });
+}
+
+// The same for a continuous host feed, split in two like the detector's (mi_fd_submit_images / mi_fd_collect): submit queues the H2D copy
+// of the frames on the slot's own stream, then warp + network + projection on the handle's stream behind it, and returns; the projection
+// kernel writes into the slot's pinned, mapped host block; collect waits for the slot and hands the results out.
+int mi_fl_submit_images(mi_fl* h, int slot, const uint8_t* frames, int batch, int width, int height, int stride, const mi_rect* rois, int items_per_frame) {
+    return guarded([&] {
+        require(h && frames, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        require(batch > 0 && items_per_frame > 0 && width > 0 && height > 0 && stride >= 3 * width, "bad frame geometry");
+        require(rois || items_per_frame == 1, "several items per frame need their ROIs");
+        require(static_cast<long long>(batch) * items_per_frame <= (1 << 24), "too many items");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        hipStream_t s = m.stream();
+        Use use(h->model, s);
+        FlSlot& sl = h->slot[slot];
+        if (sl.pending) throw ApiError(MI_EINVAL, "slot still holds an uncollected batch (call mi_fl_collect first)");
+        if (!sl.copy) mi::hip_check(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking), "hipStreamCreate");
+        if (!sl.copied) mi::hip_check(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate");
+        if (!sl.done) mi::hip_check(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate");
+        const int N = batch * items_per_frame;
+        const size_t lm_bytes = sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * N, total = lm_bytes + (sizeof(int) + sizeof(float)) * N;
+        if (total > sl.h_cap) {
+            if (sl.h_out) hipHostFree(sl.h_out);
+            sl.h_out = nullptr; sl.h_cap = 0;
+            mi::hip_check(hipHostMalloc(&sl.h_out, total, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+            sl.h_cap = total;
+        }
+        const size_t frame_bytes = static_cast<size_t>(stride) * height;
+        auto* d_frames = static_cast<uint8_t*>(sl.d_frames.get(frame_bytes * batch));
+        mi::hip_check(hipMemcpyAsync(d_frames, frames, frames_bytes(batch, width, height, stride), hipMemcpyHostToDevice, sl.copy), "H2D frames");
+        const mi::RectD* d_rois = nullptr;
+        if (rois) {   // (the ROIs are small and usually pageable: the runtime stages them before the call returns)
+            d_rois = static_cast<const mi::RectD*>(sl.d_rois.get(sizeof(mi_rect) * N));
+            mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_rois), rois, sizeof(mi_rect) * N, hipMemcpyHostToDevice, sl.copy), "H2D rois");
+        }
+        mi::hip_check(hipEventRecord(sl.copied, sl.copy), "hipEventRecord");
+        void* mapped = nullptr;
+        mi::hip_check(hipHostGetDevicePointer(&mapped, sl.h_out, 0), "hipHostGetDevicePointer");
+        try {
+            const int* d_sizes = d_rois ? batch_image_sizes(h->d_sizes_b, h->sizes_N, h->sizes_w, h->sizes_h, N, width, height, s) : nullptr;
+            mi::hip_check(hipStreamWaitEvent(s, sl.copied, 0), "hipStreamWaitEvent");
+            mi::PreItems it{};
+            it.frames = d_frames; it.frame_bytes = static_cast<long>(frame_bytes); it.width = width; it.height = height; it.stride = stride;
+            it.rois = d_rois; it.items_per_frame = items_per_frame; it.N = N; it.out_w = h->in_w; it.out_h = h->in_h; it.keep_aspect = 0;
+            it.range_min = 0.0; it.range_max = 1.0;
+            auto* d_geom = static_cast<mi::PreGeom*>(h->d_geom.get(sizeof(mi::PreGeom) * N));
+            float* d_in = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float) * N));
+            mi::launch_pre_geom(it, d_geom, nullptr, s);
+            mi::launch_pre_tensor(it, d_geom, d_in, s);
+            mi::ProjArgs a;
+            a.B = N; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = h->in_w; a.tensor_h = h->in_h;
+            a.roi = d_rois; a.image_size = d_sizes;
+            a.out = static_cast<float*>(mapped);
+            a.present = reinterpret_cast<int*>(static_cast<char*>(mapped) + lm_bytes);
+            a.raw_flag_out = reinterpret_cast<float*>(static_cast<char*>(mapped) + lm_bytes + sizeof(int) * N);
+            m.run_device(d_in, N, s);
+            a.raw = m.output_device(0);
+            a.raw_fs = static_cast<long>(m.output_elems(0));
+            a.flag = m.output_device(1) + (m.output_elems(1) - 1);
+            a.flag_fs = static_cast<long>(m.output_elems(1));
+            int rc = mi::launch_project(a, s);
+            if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        } catch (...) {
+            (void)hipStreamSynchronize(sl.copy);   // the queued copy may still be reading the caller's frames
+            throw;
+        }
+        mi::hip_check(hipEventRecord(sl.done, s), "hipEventRecord");
+        sl.N = N; sl.pending = true;
+    });
+}
+
+int mi_fl_collect(mi_fl* h, int slot, float* landmarks, int* present, float* raw_flags) {
+    return guarded([&] {
+        require(h && landmarks && present, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        FlSlot& sl = h->slot[slot];
+        {
+            std::lock_guard<std::mutex> g(h->model.mu);
+            if (!sl.pending) throw ApiError(MI_EINVAL, "nothing was submitted to this slot");
+        }
+        mi::hip_check(hipSetDevice(h->model.m->device()), "hipSetDevice");
+        mi::hip_check(hipEventSynchronize(sl.done), "hipEventSynchronize");
+        std::lock_guard<std::mutex> g(h->model.mu);
+        const size_t lm_bytes = sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * sl.N;
+        std::memcpy(landmarks, sl.h_out, lm_bytes);
+        std::memcpy(present, static_cast<char*>(sl.h_out) + lm_bytes, sizeof(int) * sl.N);
+        if (raw_flags) std::memcpy(raw_flags, static_cast<char*>(sl.h_out) + lm_bytes + sizeof(int) * sl.N, sizeof(float) * sl.N);
+        sl.pending = false;
     });
 }
 

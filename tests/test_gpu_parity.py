@@ -773,6 +773,45 @@ def test_fl_and_iris_infer_images_vs_tensor_entries(gpu, oracle, gold, man_image
     iris.close()
 
 
+def test_fl_submit_collect_two_slots(gpu, gold, man_image):
+    """mi_fl_submit_images / mi_fl_collect (round 5): the two-slot host feed of the face mesh, like the detector's.  Batches that
+    alternate between the slots give what mi_fl_infer_images gives for the same frames and ROIs, bit for bit; protocol errors
+    (collect before submit, submit on a pending slot) are MI_EINVAL."""
+    fl = gpu.FaceLandmark()
+    base = gold["man_face_roi"]
+    rs = np.random.RandomState(4)
+    def batch(k):
+        frames = np.stack([np.roll(man_image, (int(rs.randint(-5, 6)), int(rs.randint(-5, 6))), axis=(0, 1)) for _ in range(3)])
+        rois = []
+        for i in range(3 * 4):
+            r = base.copy(); r[0] += rs.uniform(-0.02, 0.02); r[4] += rs.uniform(-0.4, 0.4)
+            rois.append(gpu.Rect(*[float(v) for v in r[:5]], int(r[5])))
+        return frames, rois
+    batches = [batch(k) for k in range(5)]
+    want = [fl.infer_images(f, r, items_per_frame=4) for f, r in batches]
+    pins = [gpu.PinnedBuffer(batches[0][0].shape) for _ in range(2)]
+    import ctypes as C
+    lm0, pr0 = np.zeros((12, 468, 3), np.float32), np.zeros((12,), np.int32)
+    assert gpu.lib().mi_fl_collect(fl.h, 0, C.c_void_p(lm0.ctypes.data), C.c_void_p(pr0.ctypes.data), None) == -1   # MI_EINVAL: nothing was submitted
+    got = []
+    for k, (f, r) in enumerate(batches):
+        pins[k & 1].array[...] = f
+        fl.submit_images(k & 1, pins[k & 1].array, r, items_per_frame=4)
+        if k == 0:
+            with pytest.raises(gpu.MiError):
+                fl.submit_images(0, pins[0].array, r, items_per_frame=4)      # slot 0 is pending
+        if k >= 1:
+            got.append(fl.collect((k - 1) & 1))
+    got.append(fl.collect((len(batches) - 1) & 1))
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            np.testing.assert_array_equal(a, b)
+    assert sum(int(g[1].sum()) for g in got) >= 50
+    for p in pins:
+        p.close()
+    fl.close()
+
+
 def test_full_pipeline_on_man_jpg(gpu, oracle, gold, man_image):
     """README.md:27-46 flow through the reference-shaped API; pinned by the reference's own rendering (+-2 px)."""
     H, W = man_image.shape[:2]

@@ -148,6 +148,20 @@ for _ in range(20): fl.infer_images(pin2.array, r192)
 dt = (time.perf_counter() - t) / 20
 print(json.dumps({"config": "FaceLandmark 512 ROIs on 512 u8 frames 192x192 from pinned HOST memory (mi_fl_infer_images: H2D 57 MB + device warp + net + projection + D2H)",
                   "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(512 / dt)}))
+pinb = [mi.PinnedBuffer(frames64.shape) for _ in range(2)]
+for pb in pinb: pb.array[...] = frames64
+import ctypes as _C
+rarr = (mi.Rect * 512)(*rois)
+nb = 40
+fl.submit_images(0, pinb[0].array, rarr, items_per_frame=8)
+t = time.perf_counter()
+for b in range(1, nb + 1):
+    fl.submit_images(b & 1, pinb[b & 1].array, rarr, items_per_frame=8)
+    lm, pres, _f = fl.collect((b - 1) & 1)
+dt = (time.perf_counter() - t) / nb
+fl.collect(nb & 1)
+print(json.dumps({"config": "FaceLandmark 512 ROIs on 64 u8 frames 540x360 from pinned HOST memory, two slots (mi_fl_submit_images / mi_fl_collect: the copy of batch n+1 beside the kernels of batch n)",
+                  "ms_per_batch": round(dt * 1e3, 3), "rois_per_s": round(512 / dt), "faces_present": int(pres.sum())}))
 fdev = torch.from_numpy(frames64).cuda()
 rdev = torch.from_numpy(np.frombuffer(bytes((mi.Rect * 512)(*rois)), np.uint8).copy()).cuda()
 dt = timeit(lambda: fl.infer_images(fdev, rdev, items_per_frame=8))
