@@ -53,7 +53,7 @@ struct MS2 {
     static constexpr int QP = CK + 1, PS = 4 * QP;
     static_assert(QP % 2 == 1, "odd number of float4 slots per pixel");
     static constexpr int IMG_F = (WI + 1) * PS;                 // input pixels 0 .. WI - 1 and the zero column WI
-    static constexpr int DPX = QP <= 16 ? 4 : 2, ACTIVE = DPX * QP;   // LDS-DMA: pixels per instruction; four instructions (one source base) per group
+    static constexpr int DPX = QP <= 6 ? 8 : (QP <= 16 ? 4 : 2), ACTIVE = DPX * QP;   // LDS-DMA: pixels per instruction (more than half a wave of lanes); four instructions (one source base) per group
     static_assert(ACTIVE > 32 && ACTIVE <= 64 && 3 * DPX * C * 4 < 4096, "DMA shape");
     static constexpr int OFF_A = 0, A_F = CK * MT * 64, OFF_TAP = A_F, TAP_F = CK * 48, OFF_BIAS = OFF_TAP + TAP_F, OFF_SLOPE = OFF_BIAS + 16 * MT, TOTAL = OFF_SLOPE + 16 * MT;
     static constexpr int LDS_F = TOTAL + NF * 4 * IMG_F;
@@ -290,6 +290,7 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void ms2_kernel(Ms2Args a) 
 using MS2a = MS2<8, 4, 64, 2, 24, 2, true, false>;    // face mesh: 48 x 48 x 32 -> 24 x 24 x 64, max-pool skip, two frames per workgroup
 using MS2b = MS2<8, 1, 12, 3, 48, 1, false, false>;   // full_range: 96 x 96 x 32 -> 48 x 48 x 12
 using MS2c = MS2<16, 2, 24, 2, 24, 1, false, true>;   // full_range: 48 x 48 x 64 -> 24 x 24 x 24, taps in LDS
+using MS2d = MS2<4, 2, 32, 3, 48, 2, true, false>;    // face mesh (round 5): 96 x 96 x 16 -> 48 x 48 x 32, max-pool skip, two frames per workgroup
 
 template <class K>
 void ms2_pack(const float* w_dw, const float* b_dw, const float* w_pw, const float* bias, const float* alpha, int act, float* dst) {
@@ -340,13 +341,14 @@ int ms2_launch(const BlockArgs& a, hipStream_t s) {
     return (int)launch_kernel(kern, grid, dim3(K::NF * K::NWV * 64), lds_bytes, s, ma);
 }
 
-// 0: none; 1: 48 wide 32 -> 64 with the max-pool skip; 2: 96 wide 32 -> 12, no skip; 3: 48 wide 64 -> 24, no skip  (W = INPUT width)
+// 0: none; 1: 48 wide 32 -> 64 with the max-pool skip; 2: 96 wide 32 -> 12, no skip; 3: 48 wide 64 -> 24, no skip; 4: 96 wide 16 -> 32 with the skip  (W = INPUT width)
 int ms2_shape(int W, int C, int Co, bool skip) {
     static const bool off = getenv("MI_NO_MS2") != nullptr;  // tuning aid: the block kernel instead
     if (off) return 0;
     if (W == 48 && C == 32 && Co == 64 && skip) return 1;
     if (W == 96 && C == 32 && Co == 12 && !skip) return 2;
     if (W == 48 && C == 64 && Co == 24 && !skip) return 3;
+    if (W == 96 && C == 16 && Co == 32 && skip) return 4;
     return 0;
 }
 
@@ -359,6 +361,7 @@ int ms2_consts_floats(int W, int C, int Co, bool skip) {
         case 1: return MS2a::TOTAL;
         case 2: return MS2b::TOTAL;
         case 3: return MS2c::TOTAL;
+        case 4: return MS2d::TOTAL;
     }
     return 0;
 }
@@ -369,6 +372,7 @@ void ms2_pack_consts(int W, int C, int Co, bool skip, const float* w_dw, const f
         case 1: ms2_pack<MS2a>(w_dw, b_dw, w_pw, bias, alpha, act, dst); break;
         case 2: ms2_pack<MS2b>(w_dw, b_dw, w_pw, bias, alpha, act, dst); break;
         case 3: ms2_pack<MS2c>(w_dw, b_dw, w_pw, bias, alpha, act, dst); break;
+        case 4: ms2_pack<MS2d>(w_dw, b_dw, w_pw, bias, alpha, act, dst); break;
     }
 }
 
@@ -399,6 +403,7 @@ int launch_ms2(const BlockArgs& a, void* stream) {
         case 1: return ms2_launch<MS2a>(a, s);
         case 2: return ms2_launch<MS2b>(a, s);
         case 3: return ms2_launch<MS2c>(a, s);
+        case 4: return ms2_launch<MS2d>(a, s);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -246,7 +246,7 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<pair>", "ms2_kernel<8,4,2>"]), ("iris", ["mbneck_kernel"])])
+@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<pair>", "ms2_kernel<8,4,2>", "ms2_kernel<4,2,3>"]), ("iris", ["mbneck_kernel"])])
 def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, kernels):
     """The row-walking MFMA kernels of round 3 (mdblock / mwalk / ms2 / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand
     layout) take the wide double blocks and stride-2 blocks of full_range, the 48x48x32 / 24x24x64 blocks, the 96x96x16 block pair and the
