@@ -263,7 +263,8 @@ __global__ __launch_bounds__(K::NF * K::NWV * 64, 2) void ms2_kernel(Ms2Args a) 
     // rows of step s + 2.  "The rows of step s have landed" = at most the DMA issued at the end of step s - 1 is outstanding.
     auto step = [&](auto emit, int s) {
         constexpr bool EMIT = decltype(emit)::value;
-        const int s0 = 2 * (s & 1);
+        const int s0 = 2 * ((s - y0) & 1);   // band-relative: the prologue put step y0's rows into images 0 / 1 (round 5: a band that starts on an odd
+                                              // output row — odd band sizes, first met at 70 ROIs — read the wrong pair)
         const bool dm = s == y0 || s + 1 <= y1;   // step y0: the prologue's second pair of rows is behind the first
         ms2_wait_le(dm ? 8 * ngrp : 0);           // (step s - 1's stores are older than its DMA: they are waited for as well)
         fix_row(2 * s, s0);

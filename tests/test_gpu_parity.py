@@ -290,7 +290,8 @@ def test_batch_size_sweep_across_kernel_thresholds(gpu, oracle, name):
     for o, r in zip(ref, om.run(x[[0, 31, 64, 129]], nthreads=4)):
         _raw_close(o[[0, 31, 64, 129]], r)
     m.set_option("strip", 1)
-    for nb in (1, 2, 5, 31, 32, 33, 63, 95, 96, 97, 128, 129, 130):
+    # (37 / 70 frames: the band sizes the launchers pick there are odd — ms2_kernel's bands then start on odd output rows, which round 5 found broken)
+    for nb in (1, 2, 5, 31, 32, 33, 37, 63, 70, 95, 96, 97, 128, 129, 130):
         for o, r in zip(m.run(x[:nb]), ref):
             _raw_close(o, r[:nb])
     m.close()
