@@ -379,6 +379,10 @@ CASES = {
     "iris_16x16_c64_run": (lambda: iris_like(12, 32, 32, 64, 32, 3), 32, 32),             # 64-channel frame-resident run of 3 pairs
     "iris_12x20_c128": (lambda: iris_like(13, 24, 40, 128, 64, 2, down=False), 24, 40),   # 240 pixels: partial last pixel group
     "iris_24x24_fallback": (lambda: iris_like(14, 48, 48, 64, 32, 1), 48, 48),            # band rows do not tile 32-pixel groups: stage programs
+    # round 5 (tail_kernels.hip): 256-channel stages = 16 output tiles (two per wave) and a 1x1 contraction over 256 values (two k-blocks
+    # streamed through the A registers), on 6 x 10 frames (pixel tiles that straddle frames when several frames share a workgroup)
+    "iris_6x10_c256_tail": (lambda: iris_like(15, 12, 20, 256, 64, 2, down=False), 12, 20),
+    "iris_4x4_c128_down_tail": (lambda: iris_like(16, 8, 8, 128, 32, 1), 8, 8),           # 4 x 4 x 128 -> stride-2 block to 2 x 2 x 256 -> bottleneck 256 <-> 64
     "back_96": (lambda: back_like(21, 96), 96, 96),                                        # chains at 12x12x96 / 6x6x96 with edges and heads
     "back_160_c16": (lambda: back_like(22, 160, 16, 2, 4), 160, 160),                      # 16-channel pipelines, 20x20 / 10x10 chains
     "back_48_odd_head_slices": (lambda: back_like(24, 48, coarse_first=True), 48, 48),     # 3x3 heads first: the 6x6 classifier's slice of the concatenation starts at float 54 (not 16-byte aligned: stored float by float by the chain's fused heads)

@@ -344,6 +344,33 @@ def test_tail_programs_frames_per_workgroup(gpu, oracle, name):
     m.close()
 
 
+@pytest.mark.parametrize("case", ["iris_6x10_c256_tail", "iris_4x4_c128_down_tail", "mesh_160", "iris_32x20_ragged_bands"])
+def test_tail_programs_on_other_shapes(gpu, oracle, synth_models, case):
+    """tail_kernel on shapes the shipped graphs do not contain (tests/synth_tflite.py): 256-channel stages (sixteen output tiles: two per
+    wave; a 1x1 contraction over 256 values streamed in two k-blocks), 6 x 10 / 5 x 5 / 10 x 16 frames whose pixels do not fill whole
+    16-pixel tiles (tiles straddle frames when several frames share a workgroup; odd widths in the pixel-pair depthwise phase), a
+    stride-2 block down to 2 x 2.  Every G against the oracle frame by frame and bit-identical among each other, both register variants."""
+    path, h, w = synth_models[case]
+    m = gpu.Model(path)
+    assert "several frames per workgroup" in m.describe()
+    om = oracle.Model(path)
+    x = np.random.RandomState(77).uniform(-1, 1, (23, h, w, 3)).astype(np.float32)
+    refs = om.run(x, nthreads=8)
+    base = None
+    for pre in (1, 2):
+        m.set_option("tail_pre", pre)
+        for g in (1, 2, 3, 5, 8):
+            m.set_option("tail_g", g)
+            outs = [o.copy() for o in m.run(x)]
+            for o, r in zip(outs, refs):
+                _raw_close(o, r)
+            if base is None:
+                base = outs
+            for o, b in zip(outs, base):
+                np.testing.assert_array_equal(o, b)
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))
