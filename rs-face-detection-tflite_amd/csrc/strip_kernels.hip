@@ -2045,7 +2045,10 @@ int strips_band_rows(const BlockArgs& a, int strips) {
     long bands = std::max<long>(1, (3072 + per_row_waves / 2) / per_row_waves);
     int rows = (int)((a.H + bands - 1) / bands);
     // ... as long as that leaves enough waves to fill the chip: small batches (the 64 ROIs of the device pipeline) take shorter bands
-    const int floor_rows = per_row_waves * ((a.H + 11) / 12) >= 2048 ? 12 : (per_row_waves * ((a.H + 7) / 8) >= 1024 ? 8 : 4);
+    // (round 5: down to ONE row per band for a handful of frames — a band costs two priming rows, but a batch of one is latency: 128x128x24 at
+    // one frame, four blocks: 53.6 us with 4-row bands, 38.9 with 2, 31.4 with 1; at 16 frames 90 / 84 / 91)
+    const int floor_rows = per_row_waves * ((a.H + 11) / 12) >= 2048 ? 12
+                         : (per_row_waves * ((a.H + 7) / 8) >= 1024 ? 8 : (per_row_waves * ((a.H + 3) / 4) >= 2048 ? 4 : (per_row_waves * ((a.H + 1) / 2) >= 2048 ? 2 : 1)));
     rows = std::max(rows, std::min(a.H, floor_rows));
     return rows;
 }
