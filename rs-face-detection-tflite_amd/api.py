@@ -15,6 +15,7 @@ import ctypes as C
 import enum
 import os
 from dataclasses import dataclass
+from collections.abc import Sequence
 
 import numpy as np
 
@@ -93,6 +94,43 @@ class Landmark:
     x: float
     y: float
     z: float
+
+
+class LandmarkList(Sequence):
+    """Vec<Landmark> the way the C ABI filled it: one [n,3] f64 array (`.array`: x, y, z per row, types.rs:176-187).  It reads like the list of Landmark the
+    reference returns (len, index, slice, iteration, ==); the Landmark objects are made on access, not per call — building 468 Python
+    objects costs about as much as a third of the whole single-image mesh call (tools/latency_probe.py)."""
+    __slots__ = ("array",)
+
+    def __init__(self, array):
+        self.array = array
+
+    def __len__(self):
+        return len(self.array)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return LandmarkList(self.array[i])
+        x, y, z = self.array[i].tolist()
+        return Landmark(x, y, z)
+
+    def __iter__(self):
+        it = iter(self.array.ravel().tolist())
+        return map(Landmark, it, it, it)
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        return "LandmarkList(%d landmarks)" % len(self)
+
+
+def _landmarks_from(carray, n):
+    """n CLandmark structs -> LandmarkList over its own copy of their floats"""
+    return LandmarkList(np.frombuffer(carray, np.float64, 3 * n).reshape(n, 3).copy())
 
 
 @dataclass
@@ -581,7 +619,7 @@ class FaceLandmark:
         n = C.c_int()
         _check(self.L.mi_fl_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
                                         C.byref(roi) if roi is not None else None, out, NUM_FACE_LANDMARKS, C.byref(n)))
-        return [Landmark(out[i].x, out[i].y, out[i].z) for i in range(n.value)]
+        return _landmarks_from(out, n.value)
 
     def infer_tensor(self, x, rois=None, image_sizes=None, stream=None):
         """x [B,192,192,3] in [0,1]. rois: list of Rect (host path) . Returns (landmarks [B,468,3], present [B], flags [B])."""
@@ -686,7 +724,7 @@ class IrisLandmark:
         i5 = (CLandmark * NUM_IRIS_LANDMARKS)()
         _check(self.L.mi_iris_infer_image(self.h, C.c_void_p(image.ctypes.data), w, h, stride,
                                           C.byref(roi) if roi is not None else None, int(bool(is_right_eye)), c, i5))
-        return IrisResults([Landmark(v.x, v.y, v.z) for v in c], [Landmark(v.x, v.y, v.z) for v in i5])
+        return IrisResults(_landmarks_from(c, NUM_EYE_LANDMARKS), _landmarks_from(i5, NUM_IRIS_LANDMARKS))
 
     def infer_tensor(self, x, rois=None, image_sizes=None, padding=None, is_right_eye=None, stream=None):
         p, mem = _ptr(x)

@@ -11,7 +11,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-result -I"$HERE/../include" ${MI_EXTRA_FLAGS:-})
 OBJ=()
 mkdir -p "$BUILD"
-for f in tflite_graph.cpp plan.cpp host_glue.cpp jpeg.cpp engine.cpp capi.cpp jpeg_kernels.hip kernels.hip block_kernels.hip strip_kernels.hip chain_kernels.hip resident_kernels.hip bneck_kernels.hip dblock_kernels.hip xc_kernels.hip mstrip_kernels.hip mdblock_kernels.hip mwalk_kernels.hip ms2_kernels.hip tail_kernels.hip preproc.hip; do
+for f in tflite_graph.cpp plan.cpp host_glue.cpp jpeg.cpp engine.cpp capi.cpp jpeg_kernels.hip kernels.hip block_kernels.hip strip_kernels.hip chain_kernels.hip resident_kernels.hip bneck_kernels.hip dblock_kernels.hip xc_kernels.hip mstrip_kernels.hip mdblock_kernels.hip mwalk_kernels.hip ms2_kernels.hip tail_kernels.hip bandnet_kernels.hip preproc.hip; do
   o="$BUILD/${f%.*}.o"
   if [[ ! -f "$o" || "$SRC/$f" -nt "$o" || -n "$(find "$SRC" -name '*.hpp' -newer "$o" -print -quit)" || "$HERE/../include/mi_face.h" -nt "$o" ]]; then
     echo "  hipcc $f"

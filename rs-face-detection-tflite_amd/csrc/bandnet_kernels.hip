@@ -1,0 +1,381 @@
+// bandnet_kernels.hip — one launch for a whole BlazeBlock network, for the few frames of a single-image call.
+//
+// The reference's only operating point is one Mat per call (/root/reference/src/face_detection_lite/face_detection.rs:205-267).
+// At one frame the fused per-block launches of the batched plan are 5 - 16 us each, most of it dispatch latency and the start-up
+// of a launch that holds a few thousand MACs per lane, and the 16x16x96 chain keeps one CU of 256 busy for 150 us.  Here the
+// network behind the first convolution is ONE launch of NW workgroups per frame:
+//
+//   * a stage is one BlazeBlock (DW3x3 -> PW1x1 -> [+ skip] -> activation) or one 1x1 convolution (the SSD heads);
+//   * every stage cuts its output rows into bands; workgroup w owns band w >> wshift of the stages it is active in (the bands get
+//     thinner towards the 16x16 and 8x8 stages, where only every 8th / 16th workgroup still has a row), and the owner of output
+//     row r owns input row S r: a workgroup's own part of every tensor stays in LDS (two tiles, used in turn);
+//   * only the rows another workgroup needs — the halo of the 3x3 window — go through global memory, as 16-byte packets
+//     {value, tag, value, tag} stored with sc0 sc1 (write-through; the workgroups of a frame sit on all eight XCDs, whose L2s are
+//     not coherent with each other).  The reader polls the packets themselves (sc0 sc1 loads) until both tags are the producer
+//     stage's: one memory round trip per hand-over, no wait for the stores, no flag.  Measured on MI355X
+//     (tools/probes/flag_sync_probe.hip): stores + s_waitcnt + flag + poll + loads cost 2 - 3 us per hand-over, an agent-scope
+//     release / acquire pair (L2 write-back + invalidate) 6 - 80 us;
+//   * a tag is 64 x generation + stage + 1; the generation is kept in sync[0] and advanced by the last workgroup to finish, and every
+//     stage has a packet buffer of its own: nothing has to be cleared between launches and a stale packet never carries the tag a
+//     reader waits for;
+//   * every wait is bounded: a launch whose workgroups are not all resident (CUs taken by someone else) runs out of iterations,
+//     raises *fail and drains; the host repeats that call on the batched plan.
+//
+// Per stage and band: [A operands -> registers, small constants -> LDS] [halo rows: packets -> LDS] | DW3x3 on the VALU, one
+// thread per (pixel, channel quad) -> LDS | v_mfma_f32_16x16x4_f32 per (16 pixels x 16 output channels) tile, depthwise
+// results from LDS, bias / skip / activation in the MFMA result layout -> the other LDS tile, the packet buffer (halo rows), the
+// graph output.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+
+#include "kernels.hpp"
+#include "launch.hpp"
+
+namespace mi {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 512;
+constexpr int kSpinLimit = 1 << 18;   // polls of a packet before the launch gives up (a poll is a memory round trip, ~1 us: ~0.3 s)
+constexpr int kMaxN16 = 8;            // C <= 128
+constexpr int kConstFloats = 2048;    // LDS floats of a stage's small constants (32 nct + 10 C <= 1536)
+
+__device__ __forceinline__ void ld_sc1(f32x4& dst, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void st_sc1(float* p, const f32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned poll(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// n / d for 0 <= n < 2^16 through d's magic number m = ceil(2^32 / d) (0 stands for d = 1)
+__device__ __forceinline__ int mdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
+
+#ifdef MI_BAND_STAMPS
+// diagnostic builds only (tools/band_stamps.py): 10 s_memtime stamps per (workgroup of frame 0, stage)
+unsigned long long* g_band_stamps = nullptr;
+#define MI_BAND_STAMP(k) if (a.stamps && f == 0 && tid == 0) { __builtin_amdgcn_sched_barrier(0); a.stamps[((long)w * 64 + s) * 10 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define MI_BAND_STAMP(k)
+#endif
+
+// A stage descriptor in scalar registers.  The program is copied to LDS once (a descriptor read from global memory at the top of a
+// stage is a dependent round trip in front of everything else); a descriptor is then ONE LDS read per lane (dword `lane` of it) and a
+// v_readlane per field.
+struct StageRegs {
+    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats;
+    int wpc_shift, per_ct;
+    unsigned mC4, mWo, mrowq;
+    long src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
+};
+static_assert(sizeof(BandStage) <= 64 * 4, "a descriptor is read as one dword per lane");
+static_assert(sizeof(BandStage) % 16 == 0, "the program is copied 16 bytes at a time");
+#define MI_BAND_WORD(name) __builtin_amdgcn_readlane(word, (int)(offsetof(BandStage, name) / 4))
+#define MI_BAND_FIELD(name) r.name = MI_BAND_WORD(name)
+#define MI_BAND_FIELDU(name) r.name = (unsigned)MI_BAND_WORD(name)
+#define MI_BAND_FIELD64(name) \
+    r.name = (long)(((unsigned long)(unsigned)__builtin_amdgcn_readlane(word, (int)(offsetof(BandStage, name) / 4 + 1)) << 32) | (unsigned long)(unsigned)MI_BAND_WORD(name))
+__device__ __forceinline__ StageRegs stage_regs(const BandStage* p, int lane) {
+    const int word = reinterpret_cast<const int*>(p)[lane < (int)(sizeof(BandStage) / 4) ? lane : 0];
+    StageRegs r;
+    MI_BAND_FIELD(kind); MI_BAND_FIELD(S); MI_BAND_FIELD(H); MI_BAND_FIELD(W); MI_BAND_FIELD(C); MI_BAND_FIELD(Ho); MI_BAND_FIELD(Wo); MI_BAND_FIELD(Co);
+    MI_BAND_FIELD(R); MI_BAND_FIELD(wshift); MI_BAND_FIELD(nbands); MI_BAND_FIELD(dep); MI_BAND_FIELD(Rin);
+    MI_BAND_FIELD(src_tile); MI_BAND_FIELD(dst_tile); MI_BAND_FIELD(pub_lo); MI_BAND_FIELD(pub_hi);
+    MI_BAND_FIELD(src_base); MI_BAND_FIELD(dst_base); MI_BAND_FIELD(res_mode); MI_BAND_FIELD(act); MI_BAND_FIELD(c_floats);
+    MI_BAND_FIELD(wpc_shift); MI_BAND_FIELD(per_ct);
+    MI_BAND_FIELDU(mC4); MI_BAND_FIELDU(mWo); MI_BAND_FIELDU(mrowq);
+    MI_BAND_FIELD64(src_off); MI_BAND_FIELD64(dst_off); MI_BAND_FIELD64(src_fs); MI_BAND_FIELD64(dst_fs);
+    MI_BAND_FIELD64(src_ll); MI_BAND_FIELD64(dst_ll); MI_BAND_FIELD64(w_a); MI_BAND_FIELD64(w_c);
+    return r;
+}
+
+__global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x, f = blockIdx.y;
+    // (no static LDS: the launch may ask for all 160 KB as dynamic LDS.  The generation only changes when the launch has drained.)
+    const unsigned base = (unsigned)uni((int)poll(a.sync)) * 64u;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float* const ws = a.base[0] + (long)f * a.ws_frame_floats;
+    float* const dwb = lds + 2 * a.tile_floats;
+    float* const lC = dwb + a.dw_floats;
+    const BandStage* const lprog = reinterpret_cast<const BandStage*>(lC + kConstFloats);
+    {
+        const f32x4* gp = reinterpret_cast<const f32x4*>(a.prog);
+        f32x4* lp = reinterpret_cast<f32x4*>(lC + kConstFloats);
+        for (int i = tid; i < a.nstages * (int)(sizeof(BandStage) / 16); i += kThreads) lp[i] = gp[i];
+    }
+    __syncthreads();
+    // the next stage after `from` that this workgroup takes part in (workgroup w owns band w >> wshift where its low wshift bits are 0)
+    auto next_active = [&](int from) {
+        int k = from + 1;
+        for (; k < a.nstages; k++) {
+            const int sh = uni(lprog[k].wshift), nb = uni(lprog[k].nbands);
+            if ((w & ((1 << sh) - 1)) == 0 && (w >> sh) < nb) break;
+        }
+        return k;
+    };
+    // a stage's A operands for this wave (it keeps one 16-channel output tile for the whole stage) and its small constants
+    auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, f32x4& creg) {
+        const int nct = (st.Co + 15) >> 4, n16 = st.C >> 4, has8 = (st.C & 15) == 8;
+        const int myct = wave >> st.wpc_shift;
+        const float* ga = a.consts + st.w_a + (myct < nct ? myct : 0) * st.per_ct;
+#pragma unroll
+        for (int j = 0; j < kMaxN16; j++) A[j] = j < n16 ? *reinterpret_cast<const f32x4*>(ga + (j * 64 + lane) * 4) : zero4;
+        A8 = has8 ? *reinterpret_cast<const f32x2*>(ga + n16 * 256 + lane * 2) : f32x2{0.f, 0.f};
+        creg = tid < (st.c_floats >> 2) ? reinterpret_cast<const f32x4*>(a.consts + st.w_c)[tid] : zero4;   // c_floats <= 4 x 512
+    };
+
+    int s = next_active(-1);
+    StageRegs st{};
+    f32x4 A[kMaxN16], creg = zero4;
+    f32x2 A8 = {0.f, 0.f};
+    if (s < a.nstages) {
+        st = stage_regs(lprog + s, lane);
+        fetch(st, A, A8, creg);
+    }
+    while (s < a.nstages) {
+        MI_BAND_STAMP(0)
+        const bool blk = st.kind == BAND_BLOCK;
+        const int S = st.S, C = st.C, Cs = C + 4, C4 = C >> 2, Co = st.Co, Wo = st.Wo, W = st.W, TW = W + 2;
+        const int bi = w >> st.wshift;
+        const int r0 = bi * st.R, nro = min(st.Ho, r0 + st.R) - r0, npx = nro * Wo;
+        const int p0 = S * r0;                     // first input row of the band; tile row of input row y: y - p0 + 1
+        const int Rin = st.dep >= 0 ? min(st.Rin, st.H - p0) : 0;
+        const int ya = blk && S == 1 ? p0 - 1 : p0;
+        const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : p0 + nro;
+        float* const tile = lds + st.src_tile * a.tile_floats;
+        const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C & 15) == 8;
+        const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
+        const int wpc = 1 << st.wpc_shift, myct = wave >> st.wpc_shift;    // wpc = 8 / nct rounded down to a power of two (nct <= 8)
+        const bool wave_on = myct < nct;
+
+        // ---- the rows of the input that this workgroup does not own: above [ya, p0) and below [p0 + Rin, yb)
+        const int nA = p0 - ya, nH = nA + (yb - (p0 + Rin));
+        const int rowq = W * C4, total = nH * rowq;
+        if (st.dep >= 0 && total > 0) {
+            // From the producers' packets: at most four elements (eight packets) per lane, all requested at once and again until every tag
+            // is the producer stage's.  The loads are unconditional — a lane without an element reads the buffer's first packets — and
+            // nothing touches their destination registers before the s_waitcnt: the compiler does not know that they are in flight.
+            const float* ll = ws + st.src_ll;
+            int dsto[4];
+            bool real[4];
+            const float* pk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = tid + u * kThreads, ic = min(i, total - 1);
+                const int hr = mdiv(ic, st.mrowq), e = ic - hr * rowq, px = mdiv(e, st.mC4), q = e - px * C4;
+                const int y = hr < nA ? ya + hr : p0 + Rin + (hr - nA);
+                dsto[u] = i < total ? ((y - p0 + 1) * TW + px + 1) * Cs + 4 * q : -1;
+                real[u] = i < total && y >= 0 && y < st.H;
+                pk[u] = ll + (real[u] ? ((y * W + px) * C4 + q) * 8 : 0);
+            }
+            f32x4 pa[4], pb[4];
+            int it = 0;
+            for (;;) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { ld_sc1(pa[u], pk[u]); ld_sc1(pb[u], pk[u] + 4); }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pb[0]), "+v"(pa[1]), "+v"(pb[1]), "+v"(pa[2]), "+v"(pb[2]), "+v"(pa[3]), "+v"(pb[3])::"memory");
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    ok = ok && (!real[u] || (bits(pa[u].y) == tag_in && bits(pa[u].w) == tag_in && bits(pb[u].y) == tag_in && bits(pb[u].w) == tag_in));
+                if (ok) break;
+                if (++it > kSpinLimit) { *a.fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (dsto[u] >= 0) { const f32x4 v = {pa[u].x, pa[u].z, pb[u].x, pb[u].z}; *reinterpret_cast<f32x4*>(tile + dsto[u]) = real[u] ? v : zero4; }
+        } else if (st.dep < 0) {
+            // the program's input: plain memory, complete before the launch
+            const float* src = a.base[st.src_base] + st.src_off + (long)f * st.src_fs;
+            for (int i = tid; i < total; i += kThreads) {
+                const int hr = mdiv(i, st.mrowq), e = i - hr * rowq, px = mdiv(e, st.mC4), q = e - px * C4;
+                const int y = hr < nA ? ya + hr : p0 + Rin + (hr - nA);
+                f32x4 v = zero4;
+                if (y >= 0 && y < st.H) v = *reinterpret_cast<const f32x4*>(src + ((long)y * W + px) * C + 4 * q);
+                *reinterpret_cast<f32x4*>(tile + ((y - p0 + 1) * TW + px + 1) * Cs + 4 * q) = v;
+            }
+            for (int i = tid; i < (yb - ya) * 2 * C4; i += kThreads) {   // nobody wrote this tile's border pixels
+                const int rr = i / (2 * C4), e = i - rr * 2 * C4, side = e / C4, q = e - side * C4;
+                *reinterpret_cast<f32x4*>(tile + ((ya + rr - p0 + 1) * TW + (side ? W + 1 : 0)) * Cs + 4 * q) = zero4;
+            }
+        }
+        if (tid < (st.c_floats >> 2)) reinterpret_cast<f32x4*>(lC)[tid] = creg;
+        MI_BAND_STAMP(1)
+        __syncthreads();
+        MI_BAND_STAMP(2)
+        // ---- which stage comes next, its descriptor, A operands and constants: their L2 round trip runs under this stage's arithmetic
+        const int sn = next_active(s);
+        MI_BAND_STAMP(6)
+        StageRegs stn{};
+        f32x4 An[kMaxN16], cregn = zero4;
+        f32x2 A8n = {0.f, 0.f};
+        if (sn < a.nstages) {
+            stn = stage_regs(lprog + sn, lane);
+            MI_BAND_STAMP(7)
+            fetch(stn, An, A8n, cregn);
+        }
+        MI_BAND_STAMP(8)
+        // ---- depthwise 3x3: one thread per (output pixel, channel quad); taps at tile rows trow + S oy + ky
+        const int trow = blk && S == 1 ? 0 : 1;
+        if (blk) {
+            const float* wdw = lC + 32 * nct;
+            const float* bdw = wdw + 9 * C;
+            for (int i = tid; i < npx * C4; i += kThreads) {
+                const int px = mdiv(i, st.mC4), q = i - px * C4, oy = mdiv(px, st.mWo), ox = px - oy * Wo;
+                const float* t = tile + ((trow + S * oy) * TW + S * ox + (S - 1)) * Cs + 4 * q;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(t + (ky * TW + kx) * Cs);
+                        const f32x4 k = *reinterpret_cast<const f32x4*>(wdw + (ky * 3 + kx) * C + 4 * q);
+                        acc.x = fmaf(d.x, k.x, acc.x);
+                        acc.y = fmaf(d.y, k.y, acc.y);
+                        acc.z = fmaf(d.z, k.z, acc.z);
+                        acc.w = fmaf(d.w, k.w, acc.w);
+                    }
+                *reinterpret_cast<f32x4*>(dwb + px * Cs + 4 * q) = acc;
+            }
+            __syncthreads();
+        }
+        MI_BAND_STAMP(3)
+        // ---- pointwise: (16 pixels x 16 output channels) tiles; the wave keeps its output-channel tile and walks over the pixel tiles
+        {
+            const int npt = (npx + 15) >> 4;
+            const int n = lane & 15, kq = lane >> 4;
+            const int Cso = Co + 4, TWo = Wo + 2;
+            float* const dtile = st.dst_tile >= 0 ? lds + st.dst_tile * a.tile_floats : nullptr;
+            float* const gout = st.dst_base >= 0 ? a.base[st.dst_base] + st.dst_off + (long)f * st.dst_fs + (long)r0 * Wo * Co : nullptr;
+            float* const llo = st.dst_ll >= 0 ? ws + st.dst_ll : nullptr;
+            const float hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
+            const float tagf = __uint_as_float(tag_out);
+            if (dtile)   // the output band's border pixels
+                for (int i = tid; i < (st.R + 3) * 2 * (Co >> 2); i += kThreads) {
+                    const int rr = i / (2 * (Co >> 2)), e = i - rr * 2 * (Co >> 2), side = e / (Co >> 2), q = e - side * (Co >> 2);
+                    *reinterpret_cast<f32x4*>(dtile + (rr * TWo + (side ? Wo + 1 : 0)) * Cso + 4 * q) = zero4;
+                }
+            if (wave_on)
+                for (int pt = wave & (wpc - 1); pt < npt; pt += wpc) {
+                    const int px = 16 * pt + n, pxc = min(px, npx - 1);
+                    const int oy = mdiv(pxc, st.mWo), ox = pxc - oy * Wo;
+                    const float* bp = blk ? dwb + pxc * Cs : tile + ((1 + oy) * TW + ox + 1) * Cs;
+                    f32x4 D = zero4;
+#pragma unroll
+                    for (int j = 0; j < kMaxN16; j++)
+                        if (j < n16) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 16 * j + 4 * kq);
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].x, bv.x, D, 0, 0, 0);
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].y, bv.y, D, 0, 0, 0);
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].z, bv.z, D, 0, 0, 0);
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].w, bv.w, D, 0, 0, 0);
+                        }
+                    if (has8) {
+                        const f32x2 bv = *reinterpret_cast<const f32x2*>(bp + 16 * n16 + 2 * kq);
+                        D = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.x, bv.x, D, 0, 0, 0);
+                        D = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.y, bv.y, D, 0, 0, 0);
+                    }
+                    // D[i] = output channel 16 ct + 4 kq + i of pixel px
+                    const int c0 = 16 * myct + 4 * kq;
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);
+                    f32x4 sk = zero4;
+                    if (st.res_mode == RES_DIRECT) {
+                        sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // Co == C
+                    } else if (st.res_mode == RES_MAXPOOL && c0 < C) {
+                        const float* t0 = tile + ((1 + 2 * oy) * TW + 2 * ox + 1) * Cs + c0;
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(t0), s1 = *reinterpret_cast<const f32x4*>(t0 + Cs);
+                        const f32x4 s2 = *reinterpret_cast<const f32x4*>(t0 + TW * Cs), s3 = *reinterpret_cast<const f32x4*>(t0 + TW * Cs + Cs);
+                        sk.x = fmaxf(fmaxf(s0.x, s1.x), fmaxf(s2.x, s3.x));
+                        sk.y = fmaxf(fmaxf(s0.y, s1.y), fmaxf(s2.y, s3.y));
+                        sk.z = fmaxf(fmaxf(s0.z, s1.z), fmaxf(s2.z, s3.z));
+                        sk.w = fmaxf(fmaxf(s0.w, s1.w), fmaxf(s2.w, s3.w));
+                    }
+                    f32x4 v;
+                    v.x = D.x + bb.x + sk.x; v.y = D.y + bb.y + sk.y; v.z = D.z + bb.z + sk.z; v.w = D.w + bb.w + sk.w;
+                    v.x = fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), hi);
+                    v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), hi);
+                    v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), hi);
+                    v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), hi);
+                    if (px < npx && c0 < Co) {
+                        if (llo && (oy < st.pub_lo || oy >= nro - st.pub_hi)) {   // a row some other workgroup reads
+                            float* pk = llo + (((r0 + oy) * Wo + ox) * (Co >> 2) + (c0 >> 2)) * 8;
+                            const f32x4 q0 = {v.x, tagf, v.y, tagf}, q1 = {v.z, tagf, v.w, tagf};
+                            st_sc1(pk, q0);
+                            st_sc1(pk + 4, q1);
+                        }
+                        if (dtile) *reinterpret_cast<f32x4*>(dtile + ((1 + oy) * TWo + ox + 1) * Cso + c0) = v;
+                        if (gout) {
+                            float* o = gout + (long)px * Co + c0;
+                            if ((Co & 3) == 0) {
+                                *reinterpret_cast<f32x4*>(o) = v;
+                            } else {
+                                o[0] = v.x;
+                                if (c0 + 1 < Co) o[1] = v.y;
+                                if (c0 + 2 < Co) o[2] = v.z;
+                                if (c0 + 3 < Co) o[3] = v.w;
+                            }
+                        }
+                    }
+                }
+        }
+        MI_BAND_STAMP(4)
+        __syncthreads();   // the output band is complete in its tile; the input tile, the depthwise result and the constants are free
+        MI_BAND_STAMP(5)
+        s = sn;
+        st = stn;
+#pragma unroll
+        for (int j = 0; j < kMaxN16; j++) A[j] = An[j];
+        A8 = A8n;
+        creg = cregn;
+    }
+    // ---- the last workgroup to finish moves the generation on
+    if (tid == 0) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == total - 1) {
+            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync, base / 64u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+int bandnet_tile_floats(int R, int W, int C) { return (R + 3) * (W + 2) * (C + 4); }
+int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
+int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
+int bandnet_lds_bytes(int tile_floats, int dw_floats, int nstages) { return (2 * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandStage); }
+
+int launch_bandnet(const BandLaunch& a, void* stream) {
+    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (bandnet_lds_bytes(a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
+    if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
+    auto kern = bandnet_kernel;
+    if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
+#ifdef MI_BAND_STAMPS
+    BandLaunch b = a;
+    b.stamps = g_band_stamps;
+    return (int)launch_kernel(kern, dim3((unsigned)a.NW, (unsigned)a.F), dim3(kThreads), (size_t)a.lds_bytes, (hipStream_t)stream, b);
+#else
+    return (int)launch_kernel(kern, dim3((unsigned)a.NW, (unsigned)a.F), dim3(kThreads), (size_t)a.lds_bytes, (hipStream_t)stream, a);
+#endif
+}
+
+}  // namespace mi
+
+#ifdef MI_BAND_STAMPS
+// stamps build only (tools/band_stamps.py)
+extern "C" void mi_debug_set_band_stamps(unsigned long long* p) { mi::g_band_stamps = p; }
+#endif

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -19,6 +20,7 @@
 #include <thread>
 
 #include "engine.hpp"
+#include "launch.hpp"
 #include "host_glue.hpp"
 #include "kernels.hpp"
 #include "jpeg.hpp"
@@ -83,6 +85,52 @@ struct DeviceBuf {
         if (p) hipFree(p);
     }
 };
+
+// The single-image entries (one picture per call: the reference's only operating point, face_detection.rs:205) keep every small
+// operand and every result of a call in ONE pinned host block that is mapped into the device's address space: the kernels read the
+// padding / ROI / flags from it and write their results into it.  A call is then: one copy of the picture, the pre-processing launch,
+// the network's graph, the post-processing launch and ONE synchronisation, with no small copies either way.
+struct OneShot {
+    void* host = nullptr;
+    void* dev = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (host) hipHostFree(host);
+        host = dev = nullptr;
+        cap = 0;
+        // (coherent: the kernels' stores must be visible to the host once the stream has been synchronised, without a copy)
+        mi::hip_check(hipHostMalloc(&host, bytes, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+        mi::hip_check(hipHostGetDevicePointer(&dev, host, 0), "hipHostGetDevicePointer");
+        cap = bytes;
+    }
+    template <class T> T* h(size_t off) const { return reinterpret_cast<T*>(static_cast<char*>(host) + off); }
+    template <class T> T* d(size_t off) const { return reinterpret_cast<T*>(static_cast<char*>(dev) + off); }
+    ~OneShot() {
+        if (host) hipHostFree(host);
+    }
+};
+// A single-launch run (bandnet_kernels.hip) needs every one of its workgroups resident, one per CU, until it has finished: the handles of
+// a process share the device's CUs through this count.  A call that does not get its CUs runs on the batched plan instead — it never waits.
+std::atomic<int> g_band_cus[64];
+struct BandClaim {
+    int dev = 0, n = 0;
+    bool ok = false;
+    BandClaim(mi::Model& m, int batch) {
+        dev = m.device();
+        n = m.band_workgroups(batch);
+        if (n <= 0 || dev < 0 || dev >= 64) return;
+        if (g_band_cus[dev].fetch_add(n) + n <= mi::device_cu_count()) ok = true;
+        else g_band_cus[dev].fetch_sub(n);
+    }
+    ~BandClaim() {
+        if (ok) g_band_cus[dev].fetch_sub(n);
+    }
+    BandClaim(const BandClaim&) = delete;
+    BandClaim& operator=(const BandClaim&) = delete;
+};
+// offsets of the small operands inside the block; results start at kOneResults
+constexpr size_t kOnePad = 0, kOneRoi = 64, kOneSize = 128, kOneFlip = 136, kOneCount = 192, kOneResults = 256;
 
 void require(bool ok, const char* msg) {
     if (!ok) throw ApiError(MI_EINVAL, msg);
@@ -153,6 +201,7 @@ struct mi_fd {
     float* d_anchors = nullptr;
     float* d_lut = nullptr;  // u8 -> f32 in (-1, 1), 256 entries (frames of the network's own size feed the first convolution as bytes)
     DeviceBuf d_in, d_pad, d_out, d_counts, d_img, d_geom, d_roi;
+    OneShot one;
     FdSlot slot[2];
     ~mi_fd() {
         //  a batch that was submitted and never collected still reads the anchors and the table: wait for it before
@@ -188,6 +237,7 @@ struct mi_fl {
     int in_w = 0, in_h = 0;
     DeviceBuf d_in, d_roi, d_size, d_lm, d_present, d_flag, d_img, d_geom, d_sizes_b;
     int sizes_N = 0, sizes_w = 0, sizes_h = 0;  // what d_sizes_b holds (mi_fl_infer_images: uploaded when the batch geometry changes)
+    OneShot one;
     FlSlot slot[2];
     ~mi_fl() {
         for (FlSlot& sl : slot)
@@ -209,6 +259,7 @@ struct mi_iris {
     int in_w = 0, in_h = 0;
     DeviceBuf d_in, d_roi, d_size, d_pad, d_flip, d_contour, d_iris, d_img, d_geom, d_sizes_b;
     int sizes_N = 0, sizes_w = 0, sizes_h = 0;
+    OneShot one;
 };
 
 extern "C" {
@@ -517,11 +568,25 @@ int mi_fd_infer_image(mi_fd* h, const uint8_t* rgb, int width, int height, int s
         hipStream_t s = m.stream();
         Use use(h->model, s);
         float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
-        double pad[4];
+        const size_t nout = sizeof(mi_detection) * static_cast<size_t>(cap);
+        OneShot& o = h->one;
+        o.reserve(kOneResults + nout);
         // image_to_tensor(image, roi, (w,h), keep_aspect_ratio = true, (-1,1), flip = false) — face_detection.rs:219
-        mi::image_to_tensor_device(rgb, width, height, stride, roi, h->in_w, h->in_h, true, -1.0, 1.0, false, d_t, pad, h->d_img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, h->in_w, h->in_h, true)), s);
-        m.run_device(d_t, 1, s);
-        fd_post(h, m.output_device(0), m.output_device(1), 1, pad, out, cap, count, MI_MEM_HOST, s);
+        mi::image_to_tensor_enqueue(rgb, width, height, stride, roi, h->in_w, h->in_h, true, -1.0, 1.0, false, d_t, o.h<double>(kOnePad),
+                                    static_cast<uint8_t*>(h->d_img.get(static_cast<size_t>(stride) * height)), s);
+        BandClaim claim(m, 1);
+        auto network = [&](bool one_shot) {
+            std::memset(o.h<char>(kOneResults), 0, nout);  // slots beyond the count read as zeros
+            m.run_device(d_t, 1, s, one_shot);
+            fd_post(h, m.output_device(0), m.output_device(1), 1, o.d<double>(kOnePad), o.d<mi_detection>(kOneResults), cap, o.d<int>(kOneCount),
+                    MI_MEM_DEVICE, s);
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        };
+        network(claim.ok);
+        if (claim.ok && m.band_failed()) network(false);  // the single launch did not get its CUs (someone else's kernels hold them): the batched plan
+        *count = *o.h<int>(kOneCount);
+        std::memcpy(out, o.h<char>(kOneResults), nout);
+        if (*count < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
     });
 }
 
@@ -954,31 +1019,38 @@ int mi_fl_infer_image(mi_fl* h, const uint8_t* rgb, int width, int height, int s
         Use use(h->model, s);
         float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
         double pad[4];
+        OneShot& o = h->one;
+        const size_t lm_bytes = sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS;
+        o.reserve(kOneResults + lm_bytes);
         // image_to_tensor(image, roi, (192,192), keep_aspect_ratio = false, (0,1), false) — face_landmark.rs:250
-        mi::image_to_tensor_device(rgb, width, height, stride, roi, h->in_w, h->in_h, false, 0.0, 1.0, false, d_t, pad, h->d_img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, h->in_w, h->in_h, false)), s);
-        std::vector<float> lm(3 * MI_NUM_FACE_LANDMARKS);
-        int present = 0;
-        int size[2] = {width, height};
+        mi::image_to_tensor_enqueue(rgb, width, height, stride, roi, h->in_w, h->in_h, false, 0.0, 1.0, false, d_t, pad,
+                                    static_cast<uint8_t*>(h->d_img.get(static_cast<size_t>(stride) * height)), s);
         mi::ProjArgs a;
         a.B = 1; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = h->in_w; a.tensor_h = h->in_h;
         if (roi) {
-            a.roi = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect)));
-            mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(a.roi), roi, sizeof(mi_rect), hipMemcpyHostToDevice, s), "H2D roi");
-            a.image_size = static_cast<const int*>(h->d_size.get(sizeof(int) * 2));
-            mi::hip_check(hipMemcpyAsync(const_cast<int*>(a.image_size), size, sizeof(size), hipMemcpyHostToDevice, s), "H2D size");
+            std::memcpy(o.h<char>(kOneRoi), roi, sizeof(mi_rect));
+            o.h<int>(kOneSize)[0] = width;
+            o.h<int>(kOneSize)[1] = height;
+            a.roi = o.d<mi::RectD>(kOneRoi);
+            a.image_size = o.d<int>(kOneSize);
         }
-        a.out = static_cast<float*>(h->d_lm.get(sizeof(float) * lm.size()));
-        a.present = static_cast<int*>(h->d_present.get(sizeof(int)));
-        m.run_device(d_t, 1, s);
-        a.raw = m.output_device(0);
-        a.raw_fs = static_cast<long>(m.output_elems(0));
-        a.flag = m.output_device(1) + (m.output_elems(1) - 1);
-        a.flag_fs = static_cast<long>(m.output_elems(1));
-        int rc = mi::launch_project(a, s);
-        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-        mi::hip_check(hipMemcpyAsync(lm.data(), a.out, sizeof(float) * lm.size(), hipMemcpyDeviceToHost, s), "D2H landmarks");
-        mi::hip_check(hipMemcpyAsync(&present, a.present, sizeof(int), hipMemcpyDeviceToHost, s), "D2H present");
-        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        a.out = o.d<float>(kOneResults);
+        a.present = o.d<int>(kOneCount);
+        BandClaim claim(m, 1);
+        auto network = [&](bool one_shot) {
+            m.run_device(d_t, 1, s, one_shot);
+            a.raw = m.output_device(0);
+            a.raw_fs = static_cast<long>(m.output_elems(0));
+            a.flag = m.output_device(1) + (m.output_elems(1) - 1);
+            a.flag_fs = static_cast<long>(m.output_elems(1));
+            int rc = mi::launch_project(a, s);
+            if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        };
+        network(claim.ok);
+        if (claim.ok && m.band_failed()) network(false);
+        const float* lm = o.h<float>(kOneResults);
+        const int present = *o.h<int>(kOneCount);
         *count = 0;
         if (present) {
             for (int i = 0; i < MI_NUM_FACE_LANDMARKS; i++) out[i] = mi_landmark{lm[3 * i], lm[3 * i + 1], lm[3 * i + 2]};
@@ -1157,30 +1229,31 @@ int mi_iris_infer_image(mi_iris* h, const uint8_t* rgb, int width, int height, i
         hipStream_t s = m.stream();
         Use use(h->model, s);
         float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
-        double pad[4];
+        OneShot& o = h->one;
+        constexpr size_t kContour = kOneResults, kIris = kOneResults + sizeof(float) * 3 * MI_NUM_EYE_LANDMARKS;
+        o.reserve(kIris + sizeof(float) * 3 * MI_NUM_IRIS_LANDMARKS);
         // image_to_tensor(image, roi, (64,64), keep_aspect_ratio = true, (0,1), is_right_eye) — iris_landmark.rs:188-189
-        mi::image_to_tensor_device(rgb, width, height, stride, roi, h->in_w, h->in_h, true, 0.0, 1.0, is_right_eye != 0, d_t, pad, h->d_img.get(mi::image_to_tensor_scratch_bytes(width, height, stride, roi, h->in_w, h->in_h, true)), s);
-        int size[2] = {width, height}, flip = is_right_eye != 0;
+        mi::image_to_tensor_enqueue(rgb, width, height, stride, roi, h->in_w, h->in_h, true, 0.0, 1.0, is_right_eye != 0, d_t,
+                                    o.h<double>(kOnePad), static_cast<uint8_t*>(h->d_img.get(static_cast<size_t>(stride) * height)), s);
         const mi::RectD* d_roi = nullptr;
         const int* d_size = nullptr;
         if (roi) {
-            d_roi = static_cast<const mi::RectD*>(h->d_roi.get(sizeof(mi_rect)));
-            mi::hip_check(hipMemcpyAsync(const_cast<mi::RectD*>(d_roi), roi, sizeof(mi_rect), hipMemcpyHostToDevice, s), "H2D roi");
-            d_size = static_cast<const int*>(h->d_size.get(sizeof(int) * 2));
-            mi::hip_check(hipMemcpyAsync(const_cast<int*>(d_size), size, sizeof(size), hipMemcpyHostToDevice, s), "H2D size");
+            std::memcpy(o.h<char>(kOneRoi), roi, sizeof(mi_rect));
+            o.h<int>(kOneSize)[0] = width;
+            o.h<int>(kOneSize)[1] = height;
+            d_roi = o.d<mi::RectD>(kOneRoi);
+            d_size = o.d<int>(kOneSize);
         }
-        double* d_pad = static_cast<double*>(h->d_pad.get(sizeof(double) * 4));
-        mi::hip_check(hipMemcpyAsync(d_pad, pad, sizeof(pad), hipMemcpyHostToDevice, s), "H2D padding");
-        int* d_flip = static_cast<int*>(h->d_flip.get(sizeof(int)));
-        mi::hip_check(hipMemcpyAsync(d_flip, &flip, sizeof(int), hipMemcpyHostToDevice, s), "H2D flip");
-        float* dc = static_cast<float*>(h->d_contour.get(sizeof(float) * 3 * MI_NUM_EYE_LANDMARKS));
-        float* di = static_cast<float*>(h->d_iris.get(sizeof(float) * 3 * MI_NUM_IRIS_LANDMARKS));
-        m.run_device(d_t, 1, s);
-        iris_project(h, 1, d_roi, d_size, d_pad, d_flip, dc, di, s);
-        float c[3 * MI_NUM_EYE_LANDMARKS], ir[3 * MI_NUM_IRIS_LANDMARKS];
-        mi::hip_check(hipMemcpyAsync(c, dc, sizeof(c), hipMemcpyDeviceToHost, s), "D2H contour");
-        mi::hip_check(hipMemcpyAsync(ir, di, sizeof(ir), hipMemcpyDeviceToHost, s), "D2H iris");
-        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        *o.h<int>(kOneFlip) = is_right_eye != 0;
+        BandClaim claim(m, 1);
+        auto network = [&](bool one_shot) {
+            m.run_device(d_t, 1, s, one_shot);
+            iris_project(h, 1, d_roi, d_size, o.d<double>(kOnePad), o.d<int>(kOneFlip), o.d<float>(kContour), o.d<float>(kIris), s);
+            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        };
+        network(claim.ok);
+        if (claim.ok && m.band_failed()) network(false);
+        const float *c = o.h<float>(kContour), *ir = o.h<float>(kIris);
         for (int i = 0; i < MI_NUM_EYE_LANDMARKS; i++) contour71[i] = mi_landmark{c[3 * i], c[3 * i + 1], c[3 * i + 2]};
         for (int i = 0; i < MI_NUM_IRIS_LANDMARKS; i++) iris5[i] = mi_landmark{ir[3 * i], ir[3 * i + 1], ir[3 * i + 2]};
     });

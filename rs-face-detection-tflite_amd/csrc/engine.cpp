@@ -47,6 +47,7 @@ Model::~Model() {
     if (d_arena_) hipFree(d_arena_);
     if (d_small_) hipFree(d_small_);
     if (d_in_stage_) hipFree(d_in_stage_);
+    free_bandnet();
     for (float* p : d_out_)
         if (p) hipFree(p);
     for (hipStream_t st : side_streams_) hipStreamDestroy(st);
@@ -76,6 +77,8 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "tail") { tail_ = value != 0; dirty_ = true; }   // 0: no stage program runs on tail_kernels.hip (the round-4 plan)
     else if (key == "tail_pre") { tail_pre_ = std::max(0, std::min(value, 2)); }   // tail programs: 0 = chosen per launch, 1 = constants a stage ahead (one workgroup per CU), 2 = 128 registers (two per CU)
     else if (key == "tail_g") { tail_g_ = std::max(0, std::min(value, 64)); }   // frames per workgroup of the tail stage programs (0: chosen per launch)
+    else if (key == "band") { band_ = std::max(0, std::min(value, 2)); dirty_ = true; }   // single-launch plan: 0 never, 1 one_shot runs (the single-image entries), 2 every run of few enough frames
+    else if (key == "band_nw") { band_nw_ = std::max(8, std::min(value, 256)); dirty_ = true; }   // its workgroups per frame
     else if (key == "fork") { fork_ = value != 0; }
     else if (key == "heads") { head_streams_opt_ = std::min(kHeadStreams, std::max(1, value)); dirty_ = true; }  // side streams the output heads are spread over                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
     else if (key == "reuse") { reuse_ = value != 0; dirty_ = true; }
@@ -591,8 +594,254 @@ void Model::rebuild() {
             if (prod >= 0) event_after_[static_cast<size_t>(prod)] = 1;
         }
     }
+    build_bandnet();
     dirty_ = false;
     chunk_cap_ = 0;
+}
+
+void Model::free_bandnet() {
+    if (d_band_prog_) hipFree(d_band_prog_);
+    if (d_band_consts_) hipFree(d_band_consts_);
+    if (d_band_ws_) hipFree(d_band_ws_);
+    if (d_band_sync_) hipFree(d_band_sync_);
+    if (h_band_fail_) hipHostFree(h_band_fail_);
+    d_band_prog_ = nullptr; d_band_consts_ = nullptr; d_band_ws_ = nullptr; d_band_sync_ = nullptr; h_band_fail_ = nullptr; d_band_fail_ = nullptr;
+    band_ready_ = false;
+}
+
+// The single-launch plan (bandnet_kernels.hip).  It is made from the level-2 lowering of the same graph — one node per BlazeBlock /
+// convolution — when that is: a first convolution (which keeps its launch of the batched plan), then nothing but 3x3 BlazeBlocks whose
+// skip is their own input, pointwise blocks and 1x1 convolutions, each reading the tensor of an earlier one.  Anything else (full_range's
+// double blocks and resizes, the mesh's and the iris network's 2x2 convolutions and PReLU stacks, channel counts off the 8-grid)
+// leaves band_ready_ false and the handle on the batched plan.
+void Model::build_bandnet() {
+    free_bandnet();
+    if (!band_ || fuse_level_ < 2) return;
+    const Plan p2 = build_plan(parse_tflite(blob_.data(), blob_.size()), 2);
+    const Graph& g = p2.graph;
+    auto is_view = [](const Node& n) { return n.kind == Node::Reshape || n.kind == Node::Concat; };
+    // the first launch of both plans must be the same convolution
+    size_t i5 = 0, i2 = 0;
+    while (i5 < plan_.nodes.size() && is_view(plan_.nodes[i5])) i5++;
+    while (i2 < p2.nodes.size() && is_view(p2.nodes[i2])) i2++;
+    if (i5 >= plan_.nodes.size() || i2 >= p2.nodes.size()) return;
+    const Node &stem5 = plan_.nodes[i5], &stem2 = p2.nodes[i2];
+    if (stem5.kind != Node::Conv || stem2.kind != Node::Conv || stem5.out != stem2.out || stem5.gemm_head) return;
+    band_stem_out_ = stem2.out;
+    if (plan_.storage[band_stem_out_].root != band_stem_out_ || plan_.storage[band_stem_out_].offset != 0) return;
+    band_first_ = static_cast<int>(i5) + 1;
+    while (band_first_ < static_cast<int>(plan_.nodes.size()) && is_view(plan_.nodes[static_cast<size_t>(band_first_)])) band_first_++;
+    if (band_first_ >= static_cast<int>(plan_.nodes.size())) return;
+    const int NW = band_nw_;
+    band_max_frames_ = std::max(0, device_cu_count() / NW);
+    if (band_max_frames_ < 1) return;
+
+    std::vector<BandStage> prog;
+    std::vector<const Node*> nodes;
+    std::vector<float> consts;
+    std::vector<int> producer(g.tensors.size(), -1);
+    std::vector<int> out_root;
+    for (int o : g.outputs) out_root.push_back(p2.storage[o].root);
+    if (2 + out_root.size() > static_cast<size_t>(kBandBases)) return;
+    band_out_base_.clear();
+    for (size_t k = 0; k < out_root.size(); k++) band_out_base_.push_back(2 + static_cast<int>(k));
+    auto put = [&](const std::vector<float>& v) {
+        const long off = align_up(static_cast<long>(consts.size()), 64);
+        consts.resize(static_cast<size_t>(off) + v.size(), 0.f);
+        std::copy(v.begin(), v.end(), consts.begin() + off);
+        return off;
+    };
+    // ---- pass 1: one stage per node, its shape, bands, source and constants
+    for (size_t i = i2 + 1; i < p2.nodes.size(); i++) {
+        const Node& n = p2.nodes[i];
+        if (is_view(n)) continue;
+        const bool pw_block = n.kind == Node::Block && n.w < 0;
+        const bool dw_block = n.kind == Node::Block && n.w >= 0;
+        const bool conv1 = n.kind == Node::Conv && n.KH == 1 && n.KW == 1 && n.sh == 1 && n.sw == 1 && !n.gemm_head;
+        if (!pw_block && !dw_block && !conv1) return;
+        if (n.in.size() != 1 || n.ept >= 0 || n.res_after) return;
+        const auto& si = g.tensors[n.in[0]].shape;
+        const auto& so = g.tensors[n.out].shape;
+        if (si.size() != 4 || so.size() != 4) return;
+        BandStage st;
+        st.kind = dw_block ? BAND_BLOCK : BAND_PW;
+        st.H = si[1]; st.W = si[2]; st.C = si[3]; st.Ho = so[1]; st.Wo = so[2]; st.Co = so[3];
+        if (st.C % 8 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) return;
+        st.S = 1;
+        if (dw_block) {
+            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) return;
+            st.S = n.sh;
+            if (st.S == 2 && ((st.H & 1) || (st.W & 1))) return;
+            if (st.Ho != st.H / st.S || st.Wo != st.W / st.S) return;
+        } else if (st.Ho != st.H || st.Wo != st.W) {
+            return;
+        }
+        st.act = n.act;
+        if (n.act != ACT_NONE && n.act != ACT_RELU && n.act != ACT_RELU6 && n.act != ACT_PRELU) return;
+        st.res_mode = RES_NONE;
+        if (n.res >= 0) {
+            if (!dw_block || n.res != n.in[0]) return;
+            if (n.res_mode == RES_DIRECT && st.S == 1 && st.Co == st.C) st.res_mode = RES_DIRECT;
+            else if (n.res_mode == RES_MAXPOOL && st.S == 2 && st.Co >= st.C) st.res_mode = RES_MAXPOOL;
+            else return;
+        }
+        // bands: whole rows per workgroup while there are at least NW rows, one row for every (NW / rows)-th workgroup below that
+        auto log2_exact = [](int v) { int k = 0; while ((1 << k) < v) k++; return (1 << k) == v ? k : -1; };
+        if (st.Ho >= NW) {
+            if (st.Ho % NW) return;
+            st.R = st.Ho / NW; st.wshift = 0; st.nbands = NW;
+        } else {
+            if (NW % st.Ho || log2_exact(NW / st.Ho) < 0) return;
+            st.R = 1; st.wshift = log2_exact(NW / st.Ho); st.nbands = st.Ho;
+        }
+        if (n.in[0] == band_stem_out_) {
+            st.src_base = 1; st.src_off = 0; st.dep = -1; st.Rin = 0;
+            st.src_fs = plan_.storage[band_stem_out_].frame_stride;
+            if (st.src_fs & 3) return;
+        } else {
+            const int d = producer[static_cast<size_t>(n.in[0])];
+            if (d < 0) return;
+            const BandStage& pd = prog[static_cast<size_t>(d)];
+            st.dep = d;
+            st.Rin = pd.R;
+            // the owner of output row r must own input row S r, and the rows it lacks must be at most one above and two below its own
+            for (int b = 0; b < st.nbands; b++) {
+                const int r0 = b * st.R, nro = std::min(st.Ho, r0 + st.R) - r0, p0 = st.S * r0;
+                if (((p0 / pd.R) << pd.wshift) != (b << st.wshift) || p0 % pd.R) return;
+                const int rin = std::min(pd.R, st.H - p0);
+                const int yb = dw_block ? (st.S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : p0 + nro;
+                const int below = yb - (p0 + rin);
+                if (below < 0 || below > 2) return;
+                if (((dw_block && st.S == 1 ? 1 : 0) + below) * st.W * (st.C / 4) > 4 * 512) return;   // the halo rows: four 16-byte elements per lane
+            }
+        }
+        // a plain copy of the output where it is a graph output (through the reshape / concatenation views behind it)
+        const Storage& so_st = p2.storage[n.out];
+        for (size_t k = 0; k < out_root.size(); k++)
+            if (out_root[k] == so_st.root) { st.dst_base = 2 + static_cast<int>(k); st.dst_off = so_st.offset; st.dst_fs = so_st.frame_stride; }
+        if (st.dst_base < 0 && so_st.root != n.out) return;
+        if (st.dst_base < 0 && st.Co % 4) return;
+        if ((st.dst_off & 3) || (st.dst_fs & 3)) {
+            if (st.Co % 4 == 0) return;   // 16-byte stores need the alignment; the ragged heads store floats
+        }
+        // constants
+        const int wt = n.kind == Node::Conv ? n.w : n.w2, bt = n.kind == Node::Conv ? n.b : n.b2;
+        const auto& wsrc = g.tensors[wt].f32;
+        const int C = st.C, Co = st.Co, nct = (Co + 15) / 16, n16 = C / 16, has8 = (C % 16) == 8, per_ct = n16 * 256 + has8 * 128;
+        if (wsrc.size() != static_cast<size_t>(Co) * C) return;
+        std::vector<float> A(static_cast<size_t>(nct) * per_ct, 0.f);
+        for (int ct = 0; ct < nct; ct++)
+            for (int l = 0; l < 64; l++) {
+                const int o = 16 * ct + (l & 15), kq = l >> 4;
+                if (o >= Co) continue;
+                for (int j = 0; j < n16; j++)
+                    for (int e = 0; e < 4; e++) A[static_cast<size_t>(ct) * per_ct + (j * 64 + l) * 4 + e] = wsrc[static_cast<size_t>(o) * C + 16 * j + 4 * kq + e];
+                if (has8)
+                    for (int e = 0; e < 2; e++) A[static_cast<size_t>(ct) * per_ct + n16 * 256 + l * 2 + e] = wsrc[static_cast<size_t>(o) * C + 16 * n16 + 2 * kq + e];
+            }
+        st.c_floats = bandnet_const_floats(st);
+        st.per_ct = per_ct;
+        if (nct > 8) return;
+        st.wpc_shift = nct == 1 ? 3 : (nct == 2 ? 2 : (nct <= 4 ? 1 : 0));
+        std::vector<float> cb(static_cast<size_t>(st.c_floats), 0.f);
+        for (int c = 0; c < Co; c++) {
+            cb[static_cast<size_t>(c)] = bt >= 0 ? g.tensors[bt].f32[static_cast<size_t>(c)] : 0.f;
+            cb[static_cast<size_t>(16 * nct + c)] = n.act == ACT_PRELU ? g.tensors[n.alpha].f32[static_cast<size_t>(c)] : (n.act == ACT_NONE ? 1.f : 0.f);
+        }
+        if (dw_block) {
+            const auto& wd = g.tensors[n.w].f32;  // [1][3][3][C]
+            if (wd.size() != static_cast<size_t>(9) * C) return;
+            for (int t = 0; t < 9 * C; t++) cb[static_cast<size_t>(32 * nct + t)] = wd[static_cast<size_t>(t)];
+            if (n.b >= 0)
+                for (int c = 0; c < C; c++) cb[static_cast<size_t>(32 * nct + 9 * C + c)] = g.tensors[n.b].f32[static_cast<size_t>(c)];
+        }
+        st.w_a = put(A);
+        st.w_c = put(cb);
+        auto magic = [](int d) { return d <= 1 ? 0u : static_cast<unsigned>((0x100000000ull + static_cast<unsigned long long>(d) - 1) / static_cast<unsigned long long>(d)); };
+        st.mC4 = magic(st.C / 4); st.mWo = magic(st.Wo); st.mrowq = magic(st.W * (st.C / 4));
+        if (static_cast<long>(st.R + 3) * st.W * (st.C / 4) >= 65536 || st.R * st.Wo * std::max(st.C, st.Co) / 4 >= 65536) return;   // the magic divisions' range
+        producer[static_cast<size_t>(n.out)] = static_cast<int>(prog.size());
+        prog.push_back(st);
+        nodes.push_back(&n);
+    }
+    if (prog.empty() || prog.size() > 63) return;
+    // every graph output must be written, whole, by the band program (the first convolution writes none of them)
+    for (size_t k = 0; k < out_root.size(); k++) {
+        size_t written = 0;
+        for (const BandStage& st : prog)
+            if (st.dst_base == 2 + static_cast<int>(k)) written += static_cast<size_t>(st.Ho) * st.Wo * st.Co;
+        if (written != g.tensors[g.outputs[k]].elems()) return;
+    }
+    // ---- pass 2: who reads what -> LDS tiles (two, used in turn), packet buffers for the rows other workgroups read
+    const int NS = static_cast<int>(prog.size());
+    std::vector<int> last_reader(static_cast<size_t>(NS), -1);
+    for (int k = 0; k < NS; k++)
+        if (prog[static_cast<size_t>(k)].dep >= 0) {
+            BandStage& pd = prog[static_cast<size_t>(prog[static_cast<size_t>(k)].dep)];
+            last_reader[static_cast<size_t>(prog[static_cast<size_t>(k)].dep)] = k;
+            if (prog[static_cast<size_t>(k)].kind == BAND_BLOCK && pd.nbands > 1) {
+                pd.pub_lo = 1;
+                if (prog[static_cast<size_t>(k)].S == 1 && pd.R > 1) pd.pub_hi = 1;
+            }
+        }
+    long ws = 0;
+    int tile_floats = 0, dw_floats = 0;
+    int holder[2] = {-2, -2};   // stage whose output a tile holds (-1: the program's input, -2: nothing)
+    for (int k = 0; k < NS; k++) {
+        BandStage& st = prog[static_cast<size_t>(k)];
+        if (st.dep < 0) {
+            // the program's input comes from global memory into tile 0: only its first reader may be such a stage
+            if (holder[0] != -2) return;
+            holder[0] = -1;
+            st.src_tile = 0;
+            const int rows = st.kind == BAND_BLOCK ? (st.S == 1 ? st.R + 2 : 2 * st.R + 2) : st.R + 1;
+            tile_floats = std::max(tile_floats, rows * (st.W + 2) * (st.C + 4));
+        } else {
+            if (holder[0] == st.dep) st.src_tile = 0;
+            else if (holder[1] == st.dep) st.src_tile = 1;
+            else return;   // its input is no longer in LDS
+            st.src_ll = prog[static_cast<size_t>(st.dep)].dst_ll;
+            if (st.kind == BAND_BLOCK && st.nbands > 1 && st.src_ll < 0) return;
+        }
+        if (last_reader[static_cast<size_t>(k)] >= 0) {
+            st.dst_tile = 1 - st.src_tile;
+            const int victim = holder[st.dst_tile];
+            if (victim >= 0 && last_reader[static_cast<size_t>(victim)] > k) return;   // someone still reads what this tile holds
+            if (victim == -1) {   // (the program's input: any later reader?)
+                for (int j = k + 1; j < NS; j++)
+                    if (prog[static_cast<size_t>(j)].dep < 0) return;
+            }
+            holder[st.dst_tile] = k;
+            tile_floats = std::max(tile_floats, bandnet_tile_floats(st.R, st.Wo, st.Co));
+            if (st.pub_lo || st.pub_hi) {
+                st.dst_ll = ws;
+                ws += align_up(2 * static_cast<long>(st.Ho) * st.Wo * st.Co, 64);
+            }
+        }
+        dw_floats = std::max(dw_floats, bandnet_dw_floats(st));
+    }
+    tile_floats = static_cast<int>(align_up(tile_floats, 4));
+    dw_floats = static_cast<int>(align_up(dw_floats, 4));
+    band_tile_floats_ = tile_floats;
+    band_dw_floats_ = dw_floats;
+    band_lds_bytes_ = bandnet_lds_bytes(tile_floats, dw_floats, NS);
+    if (band_lds_bytes_ > 160 * 1024) return;
+    band_ws_frame_floats_ = std::max<long>(ws, 64);
+    band_nstages_ = NS;
+    consts.resize(consts.size() + 64, 0.f);
+    hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_prog_), prog.size() * sizeof(BandStage)), "hipMalloc band program");
+    hip_check(hipMemcpy(d_band_prog_, prog.data(), prog.size() * sizeof(BandStage), hipMemcpyHostToDevice), "upload band program");
+    hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_consts_), consts.size() * sizeof(float)), "hipMalloc band constants");
+    hip_check(hipMemcpy(d_band_consts_, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice), "upload band constants");
+    const size_t ws_bytes = static_cast<size_t>(band_ws_frame_floats_) * band_max_frames_ * sizeof(float);
+    hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_ws_), ws_bytes), "hipMalloc band workspace");
+    hip_check(hipMemset(d_band_ws_, 0, ws_bytes), "hipMemset");   // no packet carries a tag yet (tags start at 1)
+    hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_sync_), 64 * sizeof(unsigned)), "hipMalloc band generation");
+    hip_check(hipMemset(d_band_sync_, 0, 64 * sizeof(unsigned)), "hipMemset");
+    hip_check(hipHostMalloc(reinterpret_cast<void**>(&h_band_fail_), 64, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc");
+    *h_band_fail_ = 0;
+    hip_check(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_band_fail_), h_band_fail_, 0), "hipHostGetDevicePointer");
+    band_ready_ = true;
 }
 
 void Model::ensure_capacity(int batch) {
@@ -745,6 +994,7 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
     // one untimed pass first: the first launch of a kernel symbol in a process loads its code object (about a millisecond,
     // which averaged over a few reps made the first layer of every kernel type look 3x slower than its twins)
     profile_inner_ = 4;
+    band_use_ = band_ == 2 && band_usable(batch);
     for (int r = -1; r < reps; r++) {
         marks.clear();
         std::vector<std::string> labels;
@@ -761,6 +1011,7 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
         for (hipEvent_t ev : marks) hipEventDestroy(ev);
     }
     profile_inner_ = 1;
+    band_use_ = false;
     (void)saved_chunk;
     // plan nodes that ran inside the launch before them (a run of blocks on mstrip_chain_kernel): their work belongs to that launch
     for (size_t i = 1; i < stats.size();) {
@@ -791,7 +1042,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
     // heads beside the trunk (not while profiling: the per-launch events there assume one stream)
     // (with several lanes the chunks already overlap; the head streams and node events are one set per model, and sharing
     // them between concurrently captured lanes crashes hipGraph capture)
-    const bool fork = fork_ && !marks && lanes_ == 1;
+    const bool fork = fork_ && !marks && lanes_ == 1 && !band_use_;
     hipStream_t const trunk = s;
     unsigned used_heads = 0;
     auto node_event = [&](size_t k) {
@@ -800,9 +1051,32 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
         return head_events_[k];
     };
     int fused_behind = 0;   // plan nodes that ran inside the launch just made (a run of 32x32x48 blocks on mstrip_chain_kernel)
+    const bool band = band_use_ && chunk_start == 0;
     for (size_t i = 0; i < plan_.nodes.size(); i++) {
         const Node& n = plan_.nodes[i];
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;  // views
+        if (band && static_cast<int>(i) >= band_first_) {
+            // the single-launch plan: everything behind the first convolution is this one launch (bandnet_kernels.hip)
+            if (static_cast<int>(i) > band_first_) {
+                if (labels) labels->push_back("(fused into previous launch)");
+                mark();
+                continue;
+            }
+            if (labels) labels->push_back("bandnet_kernel");
+            BandLaunch a;
+            a.prog = d_band_prog_; a.nstages = band_nstages_; a.NW = band_nw_; a.F = F; a.lds_bytes = band_lds_bytes_;
+            a.tile_floats = band_tile_floats_; a.dw_floats = band_dw_floats_; a.ws_frame_floats = band_ws_frame_floats_;
+            long fs = 0;
+            a.base[0] = d_band_ws_;
+            a.base[1] = const_cast<float*>(tensor_ptr(band_stem_out_, in, chunk_start, &fs));
+            for (size_t k = 0; k < band_out_base_.size(); k++) a.base[band_out_base_[k]] = d_out_[k];
+            a.consts = d_band_consts_; a.sync = d_band_sync_; a.fail = d_band_fail_;
+            int rc = 0;
+            for (int rep_ = 0; rep_ < (marks ? profile_inner_ : 1) && rc == 0; rep_++) rc = launch_bandnet(a, trunk);
+            if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+            mark();
+            continue;
+        }
         if (fused_behind > 0) {
             fused_behind--;
             if (labels) labels->push_back("(fused into previous launch)");
@@ -1323,12 +1597,36 @@ void Model::run_device_u8(const uint8_t* frames, long frame_bytes, int row_bytes
     u8_ = U8Input{};
 }
 
-void Model::run_device(const float* in, int batch, hipStream_t stream) {
+void Model::run_device(const float* in, int batch, hipStream_t stream, bool one_shot) {
     if (batch <= 0) throw std::runtime_error("batch must be positive");
     hip_check(hipSetDevice(device_), "hipSetDevice");
     if (dirty_) rebuild();
     ensure_capacity(batch);
-    run_graph_or_eager(in, batch, stream ? stream : stream_, GraphKey{in, batch, 0, 0});
+    band_use_ = band_usable(batch) && (band_ == 2 || one_shot);
+    GraphKey key{in, batch, 0, 0};
+    key.band = band_use_;
+    try {
+        run_graph_or_eager(in, batch, stream ? stream : stream_, key);
+    } catch (...) {
+        band_use_ = false;
+        throw;
+    }
+    band_use_ = false;
+}
+
+bool Model::band_usable(int batch) const {
+    return band_ready_ && band_ > 0 && lanes_ == 1 && batch <= band_max_frames_ && batch <= chunk_cap_;
+}
+
+int Model::band_workgroups(int batch) {
+    if (dirty_) rebuild();
+    return band_ready_ && band_ > 0 && lanes_ == 1 && batch <= band_max_frames_ ? batch * band_nw_ : 0;
+}
+
+bool Model::band_failed() {
+    if (!h_band_fail_ || !*h_band_fail_) return false;
+    *h_band_fail_ = 0;
+    return true;
 }
 
 void Model::run_graph_or_eager(const float* in, int batch, hipStream_t s, const GraphKey& key) {

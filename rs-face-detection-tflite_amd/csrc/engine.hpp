@@ -36,7 +36,13 @@ class Model {
 
     // Enqueue the network for `batch` frames. `in` is a DEVICE pointer [batch, H, W, C]. Results land in the
     // model-owned device buffers returned by output_device(i) ([batch, output_elems(i)]).
-    void run_device(const float* in, int batch, hipStream_t stream);
+    // one_shot: the caller is a single-image entry — it synchronises `stream` before anything else uses this model and then asks
+    // band_failed(); such calls may run on the single-launch plan (bandnet_kernels.hip)
+    void run_device(const float* in, int batch, hipStream_t stream, bool one_shot = false);
+    // true when the last single-launch run gave up waiting (its results are void; the flag is cleared): repeat the call with one_shot = false
+    bool band_failed();
+    // workgroups a one_shot run of `batch` frames would occupy, one per CU for the whole launch (0: it would not use the single-launch plan)
+    int band_workgroups(int batch);
     // Full boundary call (host or device user buffers).
     void run(const float* in, int batch, float* const* outs, int mem, hipStream_t stream);
     float* output_device(int i) const { return d_out_.at(i); }
@@ -61,6 +67,9 @@ class Model {
 
    private:
     void rebuild();                       // (re)lower + upload weights for the current options
+    void build_bandnet();                 // the single-launch plan of the same graph, when its operators have band stages
+    void free_bandnet();
+    bool band_usable(int batch) const;
     void ensure_capacity(int batch);
     void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s, std::vector<hipEvent_t>* marks = nullptr,
                        std::vector<std::string>* labels = nullptr);
@@ -113,6 +122,23 @@ class Model {
     size_t in_stage_floats_ = 0;
     int last_chunk_frames_ = 0;
 
+    // single-launch plan for one_shot runs (bandnet_kernels.hip): the first convolution as in the batched plan, everything behind it ONE launch
+    int band_ = 1;                  // option "band": 0 never, 1 one_shot runs, 2 every run of few enough frames (tests, profiling)
+    int band_nw_ = 128;             // option "band_nw": workgroups per frame
+    bool band_ready_ = false;       // the graph has a single-launch form
+    bool band_use_ = false;         // the run being enqueued takes it
+    int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it)
+    int band_stem_out_ = -1;        // tensor the first convolution writes = the band program's input
+    int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_tile_floats_ = 0, band_dw_floats_ = 0;
+    long band_ws_frame_floats_ = 0;
+    std::vector<int> band_out_base_;  // graph output k -> BandLaunch::base index
+    BandStage* d_band_prog_ = nullptr;
+    float* d_band_consts_ = nullptr;
+    float* d_band_ws_ = nullptr;
+    unsigned* d_band_sync_ = nullptr;
+    int* h_band_fail_ = nullptr;    // pinned + mapped: the kernel raises it, band_failed() reads it without a copy
+    int* d_band_fail_ = nullptr;
+
     hipStream_t stream_ = nullptr;
     int small_chain_ = 16;          // option "small_chain" (measured on BackCamera: block by block wins up to ~24 frames, tools/small_batch_probe.py)
     float* d_small_ = nullptr;      // [2][small_chain_][largest chain frame] ping-pong scratch
@@ -122,11 +148,13 @@ class Model {
         int batch;
         long u8_frame_bytes;  // 0: f32 input
         int u8_row_bytes;
+        int band = 0;         // 1: the single-launch plan
         bool operator<(const GraphKey& o) const {
             if (in != o.in) return in < o.in;
             if (batch != o.batch) return batch < o.batch;
             if (u8_frame_bytes != o.u8_frame_bytes) return u8_frame_bytes < o.u8_frame_bytes;
-            return u8_row_bytes < o.u8_row_bytes;
+            if (u8_row_bytes != o.u8_row_bytes) return u8_row_bytes < o.u8_row_bytes;
+            return band < o.band;
         }
     };
     struct U8Input {  // set by run_device_u8 for the duration of the enqueue

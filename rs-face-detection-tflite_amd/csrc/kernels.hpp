@@ -431,6 +431,62 @@ int launch_copy_strided(const EltArgs& a, void* stream);
 int launch_postprocess(const PostArgs& a, void* stream);
 int launch_project(const ProjArgs& a, void* stream);
 
+// ---- bandnet_kernels.hip: a whole BlazeBlock network behind its first convolution as ONE launch, for the handful of frames of a
+// single-image call (face_detection.rs:205: one Mat per call).  NW workgroups per frame; every stage (one BlazeBlock or one 1x1
+// convolution) cuts its output into row bands, one per active workgroup, which keeps its band in LDS for the next stage; only the
+// rows a neighbour needs (the 3x3 halo) travel through global memory, as 16-byte packets {value, tag, value, tag} (sc0 sc1: the
+// workgroups of a frame sit on all eight XCDs, whose L2s are not coherent with each other) that the reader polls until both tags are
+// the producer stage's — no flag round trip, no wait for the stores, no launch boundary and no grid-wide barrier between blocks.
+enum BandKind : int { BAND_BLOCK = 0, BAND_PW = 1 };
+constexpr int kBandBases = 6;
+struct alignas(16) BandStage {
+    int kind = BAND_BLOCK;
+    int S = 1;                   // BLOCK: DW3x3 stride (1: pad 1; 2: TF SAME on an even size, taps at 2o .. 2o+2)
+    int H = 0, W = 0, C = 0;     // input  (C % 8 == 0, C <= 128)
+    int Ho = 0, Wo = 0, Co = 0;  // output (Co <= 128)
+    int R = 1;                   // output rows per band
+    int wshift = 0;              // workgroup w runs the stage when its low wshift bits are 0; it owns band w >> wshift (the owner of output row r
+                                 // also owns input row S r: its part of the input is still in LDS)
+    int nbands = 0;
+    int dep = -1;                // stage that produces the input (-1: in global memory, complete before the launch)
+    int Rin = 0;                 // input rows of this band that the workgroup owns (dep >= 0: the producer's R), from row S r0 on
+    int src_tile = 0;            // LDS tile (0 / 1) that holds the input band: rows [S r0 - 1, S r0 + Rin + 2) at tile rows 0 .., one zero pixel left and right
+    int dst_tile = -1;           // LDS tile the output band is left in for the stages that read it (-1: nobody does)
+    int pub_lo = 0, pub_hi = 0;  // the first pub_lo and last pub_hi rows of the band also go to the packet buffer (other workgroups read them)
+    int src_base = 0, dst_base = -1;  // BandLaunch::base index of the input (dep < 0) / of a plain copy of the output (-1: none; graph outputs)
+    int res_mode = RES_NONE;     // RES_DIRECT: the input itself (S == 1, Co == C); RES_MAXPOOL: 2x2 max of the input, channels >= C zero (S == 2)
+    int act = ACT_NONE;
+    long src_off = 0, dst_off = 0;   // floats from the base to frame 0 of the tensor
+    long src_fs = 0, dst_fs = 0;     // floats between frames
+    long src_ll = -1, dst_ll = -1;   // packet buffers of the input / output tensor inside base[0] (floats from the frame's workspace; 2 x the tensor)
+    long w_a = 0;                // BandLaunch::consts offset: A operands of v_mfma_f32_16x16x4_f32, per 16-channel output tile
+                                 //   [C/16 chunks][64 lanes][4] then (C % 16 == 8) [64 lanes][2]: lane (kq = l / 16, m = l % 16) holds W[16 t + m][16 j + 4 kq + e]
+                                 //   (8-chunk: W[16 t + m][16 (C/16) + 2 kq + e])
+    long w_c = 0;                // [bias 16 nct][slope 16 nct] then BLOCK: [taps 9 C][depthwise bias C]
+    int c_floats = 0;
+    int wpc_shift = 0;           // log2 of the waves per 16-channel output tile (8 / nct rounded down to a power of two)
+    int per_ct = 0;              // floats of A operands per output tile
+    unsigned mC4 = 0, mWo = 0, mrowq = 0;   // magic numbers ceil(2^32 / d) of C / 4, Wo, W C / 4 (0: d = 1): n / d = umulhi(n, m) for n < 2^16
+};
+struct BandLaunch {
+    const BandStage* prog = nullptr;
+    int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
+    int tile_floats = 0;            // LDS: [tile 0][tile 1][depthwise result][small constants]
+    int dw_floats = 0;
+    long ws_frame_floats = 0;       // base[0]: floats between the frames' workspaces
+    float* base[kBandBases] = {};   // 0: the launch's own workspace (packet buffers), 1: the first stage's input, 2..: graph outputs
+    const float* consts = nullptr;
+    unsigned* sync = nullptr;       // [0] generation (tags are 64 x generation + stage + 1), [1] workgroups finished
+    int* fail = nullptr;            // set to 1 when a wait ran out of iterations (host-visible): the results of that launch are void
+    unsigned long long* stamps = nullptr;  // diagnostic builds only (MI_BAND_STAMPS)
+};
+int launch_bandnet(const BandLaunch& a, void* stream);
+// LDS floats of a band of R rows of a W x C tensor (with its halo rows and border pixels) / of a stage's depthwise result / small constants
+int bandnet_tile_floats(int R, int W, int C);
+int bandnet_dw_floats(const BandStage& st);
+int bandnet_const_floats(const BandStage& st);
+int bandnet_lds_bytes(int tile_floats, int dw_floats, int nstages);
+
 // Pointwise weight packing for the fused block kernel: [Co][C] (TFLite [O,1,1,I]) -> [Cop][Cp] zero padded.
 void block_weight_dims(int C, int Co, int* Cp, int* Cop);
 

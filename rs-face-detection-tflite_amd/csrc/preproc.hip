@@ -278,16 +278,12 @@ __global__ __launch_bounds__(64) void pre_geom_kernel(PreItems it, PreGeom* geom
 
 // One thread per output pixel: flip + `(pixel as f64 * (max - min) / 255.0 + min) as f32` (transform.rs:282-301) of the
 // image produced by warp -> [border (+ resize)] -> [resize].
-__global__ __launch_bounds__(256) void pre_tensor_kernel(PreItems it, const PreGeom* __restrict__ geom, float* __restrict__ out) {
-    const int i = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= it.out_w * it.out_h) return;
+__device__ __forceinline__ void pre_tensor_px(const PreItems& it, const PreGeom& g, int i, bool flip, int idx, float* __restrict__ out) {
     const int y = idx / it.out_w, x = idx - y * it.out_w;
     float* o = out + ((long)i * it.out_h * it.out_w + idx) * 3;
-    const PreGeom g = geom[i];
     if (!g.valid) { o[0] = o[1] = o[2] = 0.f; return; }
     const uint8_t* src = it.frames + (long)(i / it.items_per_frame) * it.frame_bytes;
-    const int sx_out = (it.flip && it.flip[i]) ? it.out_w - 1 - x : x;   // cv::flip(…, 1) of the final image
+    const int sx_out = flip ? it.out_w - 1 - x : x;   // cv::flip(…, 1) of the final image
     const int sw = it.width, sh = it.height, ss = it.stride;
     auto warped = [&](int yy, int xx) { return warp_px(g, src, sw, sh, ss, yy, xx); };
     auto bordered = [&](int yy, int xx) {  // copyMakeBorder(top = bottom = pad_v, left = right = pad_h, 0)
@@ -311,6 +307,21 @@ __global__ __launch_bounds__(256) void pre_tensor_kernel(PreItems it, const PreG
     o[0] = (float)((double)p.r * k / 255.0 + it.range_min);
     o[1] = (float)((double)p.g * k / 255.0 + it.range_min);
     o[2] = (float)((double)p.b * k / 255.0 + it.range_min);
+}
+
+__global__ __launch_bounds__(256) void pre_tensor_kernel(PreItems it, const PreGeom* __restrict__ geom, float* __restrict__ out) {
+    const int i = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= it.out_w * it.out_h) return;
+    const PreGeom g = geom[i];
+    pre_tensor_px(it, g, i, it.flip && it.flip[i], idx, out);
+}
+
+// One picture, its geometry and flip flag as kernel arguments (the single-image entries: nothing to upload but the picture)
+__global__ __launch_bounds__(256) void pre_tensor_one_kernel(PreItems it, PreGeom g, int flip, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= it.out_w * it.out_h) return;
+    pre_tensor_px(it, g, 0, flip != 0, idx, out);
 }
 
 // ---------------------------------------------------------------------------------------------- ROI maths (device)
@@ -429,6 +440,24 @@ void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int 
     launch_pre_tensor(it, d_geom, d_out, s);
     // the H2D copies above read host stack variables: make sure they are consumed before returning
     hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    padding[0] = g.pad_x; padding[1] = g.pad_y; padding[2] = g.pad_x; padding[3] = g.pad_y;
+}
+
+void image_to_tensor_enqueue(const uint8_t* rgb_host, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
+                             bool keep_aspect, double range_min, double range_max, bool flip, float* d_out, double padding[4],
+                             uint8_t* d_img, hipStream_t s) {
+    RectD r;
+    if (roi) std::memcpy(&r, roi, sizeof r);
+    const PreGeom g = compute_geom(width, height, roi ? &r : nullptr, out_w, out_h, keep_aspect);  // same code as the device path
+    if (!g.valid) throw std::runtime_error("ROI is empty or degenerate (singular perspective transform)");
+    // the caller's last row owns 3 * width bytes, not a whole stride (a cv::Mat ROI view ends there)
+    hip_check(hipMemcpyAsync(d_img, rgb_host, static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width, hipMemcpyHostToDevice, s), "H2D image");
+    PreItems it{};
+    it.frames = d_img; it.frame_bytes = 0; it.width = width; it.height = height; it.stride = stride;
+    it.items_per_frame = 1; it.N = 1; it.out_w = out_w; it.out_h = out_h; it.keep_aspect = keep_aspect;
+    it.range_min = range_min; it.range_max = range_max;
+    hipLaunchKernelGGL(pre_tensor_one_kernel, dim3((out_w * out_h + 255) / 256), dim3(256), 0, s, it, g, flip ? 1 : 0, d_out);
+    hip_check(hipGetLastError(), "pre_tensor kernel launch");
     padding[0] = g.pad_x; padding[1] = g.pad_y; padding[2] = g.pad_x; padding[3] = g.pad_y;
 }
 

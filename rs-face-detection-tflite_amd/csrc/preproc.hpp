@@ -46,6 +46,11 @@ void launch_pre_tensor(const PreItems& it, const PreGeom* d_geom, float* d_out, 
 void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
                             bool keep_aspect_ratio, double range_min, double range_max, bool flip_horizontal, float* d_out,
                             double padding[4], void* d_scratch, hipStream_t stream);
+// The same without a host synchronisation and without small uploads: geometry and flip flag travel as kernel arguments, the picture
+// is copied into d_img (>= stride * height bytes) on `stream`.  `rgb_host` must stay valid until the caller has synchronised `stream`.
+void image_to_tensor_enqueue(const uint8_t* rgb_host, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
+                             bool keep_aspect_ratio, double range_min, double range_max, bool flip_horizontal, float* d_out,
+                             double padding[4], uint8_t* d_img, hipStream_t stream);
 size_t image_to_tensor_scratch_bytes(int width, int height, int stride, const mi_rect* roi, int out_w, int out_h, bool keep_aspect_ratio);
 
 // Device-side ROI maths between pipeline stages (face_landmark.rs:180-198, iris_landmark.rs:268-292).

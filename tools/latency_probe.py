@@ -46,6 +46,44 @@ def measure(n=300):
     return out
 
 
+def measure_c_abi(n=300):
+    """The same three calls timed at the C ABI itself (arguments marshalled once, outside the timed region): what a Rust / C++ caller of
+    include/mi_face.h sees, without the Python wrapper's per-call conversion of the results into Detection / Landmark objects."""
+    import ctypes as C
+    from PIL import Image
+    from rs_face_detection_tflite_amd import api
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "man.jpg")).convert("RGB")))
+    h, w = img.shape[:2]
+    p = C.c_void_p(img.ctypes.data)
+    out = {}
+    for kind in ("BackCamera", "Short", "Full"):
+        fd = mi.FaceDetection(getattr(mi.FaceDetectionModel, kind))
+        dets, cnt = (api.CDetection * 256)(), C.c_int()
+        def call():
+            rc = fd.L.mi_fd_infer_image(fd.h, p, w, h, 3 * w, None, dets, 256, C.byref(cnt))
+            assert rc == 0
+        out["mi_fd_infer_image %s" % kind] = timed(call, n)
+        fd.close()
+    fl = mi.FaceLandmark()
+    roi = mi.Rect(*[float(v) for v in gold["man_face_roi"][:5]], int(gold["man_face_roi"][5]))
+    lms, cnt = (api.CLandmark * api.NUM_FACE_LANDMARKS)(), C.c_int()
+    def call_fl():
+        rc = fl.L.mi_fl_infer_image(fl.h, p, w, h, 3 * w, C.byref(roi), lms, api.NUM_FACE_LANDMARKS, C.byref(cnt))
+        assert rc == 0
+    out["mi_fl_infer_image"] = timed(call_fl, n)
+    ir = mi.IrisLandmark()
+    eye = mi.Rect(*[float(v) for v in gold["man_eye_left_roi"][:5]], int(gold["man_eye_left_roi"][5]))
+    c71, i5 = (api.CLandmark * 71)(), (api.CLandmark * 5)()
+    def call_ir():
+        rc = ir.L.mi_iris_infer_image(ir.h, p, w, h, 3 * w, C.byref(eye), 0, c71, i5)
+        assert rc == 0
+    out["mi_iris_infer_image"] = timed(call_ir, n)
+    return out
+
+
 if __name__ == "__main__":
     for k, v in measure().items():
         print(json.dumps({"call": k, **v}))
+    for k, v in measure_c_abi().items():
+        print(json.dumps({"call": k, "timed_at": "C ABI", **v}))
