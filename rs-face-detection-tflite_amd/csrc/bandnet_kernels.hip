@@ -125,13 +125,14 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         return k;
     };
     // a stage's A operands for this wave (it keeps one 16-channel output tile for the whole stage) and its small constants
-    auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, f32x4& creg) {
-        const int nct = (st.Co + 15) >> 4, n16 = st.C >> 4, has8 = (st.C & 15) == 8;
+    auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, float& A4, f32x4& creg) {
+        const int nct = (st.Co + 15) >> 4, n16 = st.C >> 4, has8 = (st.C >> 3) & 1, has4 = (st.C >> 2) & 1;
         const int myct = wave >> st.wpc_shift;
         const float* ga = a.consts + st.w_a + (myct < nct ? myct : 0) * st.per_ct;
 #pragma unroll
         for (int j = 0; j < kMaxN16; j++) A[j] = j < n16 ? *reinterpret_cast<const f32x4*>(ga + (j * 64 + lane) * 4) : zero4;
         A8 = has8 ? *reinterpret_cast<const f32x2*>(ga + n16 * 256 + lane * 2) : f32x2{0.f, 0.f};
+        A4 = has4 ? ga[n16 * 256 + has8 * 128 + lane] : 0.f;
         creg = tid < (st.c_floats >> 2) ? reinterpret_cast<const f32x4*>(a.consts + st.w_c)[tid] : zero4;   // c_floats <= 4 x 512
     };
 
@@ -139,9 +140,10 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     StageRegs st{};
     f32x4 A[kMaxN16], creg = zero4;
     f32x2 A8 = {0.f, 0.f};
+    float A4 = 0.f;
     if (s < a.nstages) {
         st = stage_regs(lprog + s, lane);
-        fetch(st, A, A8, creg);
+        fetch(st, A, A8, A4, creg);
     }
     while (s < a.nstages) {
         MI_BAND_STAMP(0)
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         const int ya = blk && S == 1 ? p0 - 1 : p0;
         const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : p0 + nro;
         float* const tile = lds + st.src_tile * a.tile_floats;
-        const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C & 15) == 8;
+        const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C >> 3) & 1, has4 = (C >> 2) & 1;
         const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
         const int wpc = 1 << st.wpc_shift, myct = wave >> st.wpc_shift;    // wpc = 8 / nct rounded down to a power of two (nct <= 8)
         const bool wave_on = myct < nct;
@@ -221,10 +223,11 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         StageRegs stn{};
         f32x4 An[kMaxN16], cregn = zero4;
         f32x2 A8n = {0.f, 0.f};
+        float A4n = 0.f;
         if (sn < a.nstages) {
             stn = stage_regs(lprog + sn, lane);
             MI_BAND_STAMP(7)
-            fetch(stn, An, A8n, cregn);
+            fetch(stn, An, A8n, A4n, cregn);
         }
         MI_BAND_STAMP(8)
         // ---- depthwise 3x3: one thread per (output pixel, channel quad); taps at tile rows trow + S oy + ky
@@ -287,12 +290,13 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                         D = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.x, bv.x, D, 0, 0, 0);
                         D = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.y, bv.y, D, 0, 0, 0);
                     }
+                    if (has4) D = __builtin_amdgcn_mfma_f32_16x16x4f32(A4, bp[16 * n16 + 8 * has8 + kq], D, 0, 0, 0);
                     // D[i] = output channel 16 ct + 4 kq + i of pixel px
                     const int c0 = 16 * myct + 4 * kq;
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);
                     f32x4 sk = zero4;
                     if (st.res_mode == RES_DIRECT) {
-                        sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // Co == C
+                        if (c0 < C) sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // channels >= C: the zero pad of a widening block
                     } else if (st.res_mode == RES_MAXPOOL && c0 < C) {
                         const float* t0 = tile + ((1 + 2 * oy) * TW + 2 * ox + 1) * Cs + c0;
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(t0), s1 = *reinterpret_cast<const f32x4*>(t0 + Cs);
@@ -338,6 +342,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 #pragma unroll
         for (int j = 0; j < kMaxN16; j++) A[j] = An[j];
         A8 = A8n;
+        A4 = A4n;
         creg = cregn;
     }
     // ---- the last workgroup to finish moves the generation on

@@ -632,7 +632,14 @@ void Model::build_bandnet() {
     band_first_ = static_cast<int>(i5) + 1;
     while (band_first_ < static_cast<int>(plan_.nodes.size()) && is_view(plan_.nodes[static_cast<size_t>(band_first_)])) band_first_++;
     if (band_first_ >= static_cast<int>(plan_.nodes.size())) return;
-    const int NW = band_nw_;
+    // workgroups per frame: one per row of the first tensor, at most band_nw_ (the bands of the later, smaller tensors are one row of every
+    // 2nd, 4th ... workgroup)
+    const auto& stem_shape = g.tensors[band_stem_out_].shape;
+    if (stem_shape.size() != 4) return;
+    int NW = band_nw_;
+    while (NW > 1 && (stem_shape[1] % NW) && (NW % stem_shape[1])) NW--;
+    if (stem_shape[1] < NW) NW = stem_shape[1];
+    band_nw_used_ = NW;
     band_max_frames_ = std::max(0, device_cu_count() / NW);
     if (band_max_frames_ < 1) return;
 
@@ -666,7 +673,7 @@ void Model::build_bandnet() {
         BandStage st;
         st.kind = dw_block ? BAND_BLOCK : BAND_PW;
         st.H = si[1]; st.W = si[2]; st.C = si[3]; st.Ho = so[1]; st.Wo = so[2]; st.Co = so[3];
-        if (st.C % 8 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) return;
+        if (st.C % 4 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) return;
         st.S = 1;
         if (dw_block) {
             if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) return;
@@ -681,7 +688,7 @@ void Model::build_bandnet() {
         st.res_mode = RES_NONE;
         if (n.res >= 0) {
             if (!dw_block || n.res != n.in[0]) return;
-            if (n.res_mode == RES_DIRECT && st.S == 1 && st.Co == st.C) st.res_mode = RES_DIRECT;
+            if (n.res_mode == RES_DIRECT && st.S == 1 && st.Co >= st.C) st.res_mode = RES_DIRECT;   // (Co > C: the skip is zero-padded to Co channels)
             else if (n.res_mode == RES_MAXPOOL && st.S == 2 && st.Co >= st.C) st.res_mode = RES_MAXPOOL;
             else return;
         }
@@ -727,7 +734,7 @@ void Model::build_bandnet() {
         // constants
         const int wt = n.kind == Node::Conv ? n.w : n.w2, bt = n.kind == Node::Conv ? n.b : n.b2;
         const auto& wsrc = g.tensors[wt].f32;
-        const int C = st.C, Co = st.Co, nct = (Co + 15) / 16, n16 = C / 16, has8 = (C % 16) == 8, per_ct = n16 * 256 + has8 * 128;
+        const int C = st.C, Co = st.Co, nct = (Co + 15) / 16, n16 = C / 16, has8 = (C / 8) & 1, has4 = (C / 4) & 1, per_ct = n16 * 256 + has8 * 128 + has4 * 64;
         if (wsrc.size() != static_cast<size_t>(Co) * C) return;
         std::vector<float> A(static_cast<size_t>(nct) * per_ct, 0.f);
         for (int ct = 0; ct < nct; ct++)
@@ -738,6 +745,7 @@ void Model::build_bandnet() {
                     for (int e = 0; e < 4; e++) A[static_cast<size_t>(ct) * per_ct + (j * 64 + l) * 4 + e] = wsrc[static_cast<size_t>(o) * C + 16 * j + 4 * kq + e];
                 if (has8)
                     for (int e = 0; e < 2; e++) A[static_cast<size_t>(ct) * per_ct + n16 * 256 + l * 2 + e] = wsrc[static_cast<size_t>(o) * C + 16 * n16 + 2 * kq + e];
+                if (has4) A[static_cast<size_t>(ct) * per_ct + n16 * 256 + has8 * 128 + l] = wsrc[static_cast<size_t>(o) * C + 16 * n16 + 8 * has8 + kq];
             }
         st.c_floats = bandnet_const_floats(st);
         st.per_ct = per_ct;
@@ -771,6 +779,42 @@ void Model::build_bandnet() {
         for (const BandStage& st : prog)
             if (st.dst_base == 2 + static_cast<int>(k)) written += static_cast<size_t>(st.Ho) * st.Wo * st.Co;
         if (written != g.tensors[g.outputs[k]].elems()) return;
+    }
+    // ---- the output heads (stages nobody reads) move up behind the first other reader of their input: the two LDS tiles hold a tensor
+    // only until the trunk has moved on twice, and a head costs its workgroups two microseconds wherever it stands
+    {
+        const int N0 = static_cast<int>(prog.size());
+        std::vector<char> read(static_cast<size_t>(N0), 0), placed(static_cast<size_t>(N0), 0);
+        for (const BandStage& st : prog)
+            if (st.dep >= 0) read[static_cast<size_t>(st.dep)] = 1;
+        std::vector<int> order;
+        for (int k = 0; k < N0; k++) {
+            if (placed[static_cast<size_t>(k)]) continue;
+            const bool head = !read[static_cast<size_t>(k)] && prog[static_cast<size_t>(k)].kind == BAND_PW;
+            if (head) continue;   // placed behind a sibling, or at the end
+            order.push_back(k);
+            placed[static_cast<size_t>(k)] = 1;
+            for (int j = 0; j < N0; j++)
+                if (!placed[static_cast<size_t>(j)] && !read[static_cast<size_t>(j)] && prog[static_cast<size_t>(j)].kind == BAND_PW &&
+                    prog[static_cast<size_t>(j)].dep == prog[static_cast<size_t>(k)].dep && prog[static_cast<size_t>(j)].dep >= 0) {
+                    order.push_back(j);
+                    placed[static_cast<size_t>(j)] = 1;
+                }
+        }
+        for (int k = 0; k < N0; k++)
+            if (!placed[static_cast<size_t>(k)]) order.push_back(k);
+        std::vector<int> new_index(static_cast<size_t>(N0), -1);
+        for (int k = 0; k < N0; k++) new_index[static_cast<size_t>(order[static_cast<size_t>(k)])] = k;
+        std::vector<BandStage> re;
+        for (int k = 0; k < N0; k++) {
+            BandStage st = prog[static_cast<size_t>(order[static_cast<size_t>(k)])];
+            if (st.dep >= 0) {
+                st.dep = new_index[static_cast<size_t>(st.dep)];
+                if (st.dep >= k) return;   // (cannot happen: a head only moves down to behind a reader of its own input)
+            }
+            re.push_back(st);
+        }
+        prog.swap(re);
     }
     // ---- pass 2: who reads what -> LDS tiles (two, used in turn), packet buffers for the rows other workgroups read
     const int NS = static_cast<int>(prog.size());
@@ -1064,7 +1108,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             }
             if (labels) labels->push_back("bandnet_kernel");
             BandLaunch a;
-            a.prog = d_band_prog_; a.nstages = band_nstages_; a.NW = band_nw_; a.F = F; a.lds_bytes = band_lds_bytes_;
+            a.prog = d_band_prog_; a.nstages = band_nstages_; a.NW = band_nw_used_; a.F = F; a.lds_bytes = band_lds_bytes_;
             a.tile_floats = band_tile_floats_; a.dw_floats = band_dw_floats_; a.ws_frame_floats = band_ws_frame_floats_;
             long fs = 0;
             a.base[0] = d_band_ws_;
@@ -1620,7 +1664,7 @@ bool Model::band_usable(int batch) const {
 
 int Model::band_workgroups(int batch) {
     if (dirty_) rebuild();
-    return band_ready_ && band_ > 0 && lanes_ == 1 && batch <= band_max_frames_ ? batch * band_nw_ : 0;
+    return band_ready_ && band_ > 0 && lanes_ == 1 && batch <= band_max_frames_ ? batch * band_nw_used_ : 0;
 }
 
 bool Model::band_failed() {

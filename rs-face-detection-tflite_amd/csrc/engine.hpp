@@ -124,7 +124,8 @@ class Model {
 
     // single-launch plan for one_shot runs (bandnet_kernels.hip): the first convolution as in the batched plan, everything behind it ONE launch
     int band_ = 1;                  // option "band": 0 never, 1 one_shot runs, 2 every run of few enough frames (tests, profiling)
-    int band_nw_ = 128;             // option "band_nw": workgroups per frame
+    int band_nw_ = 128;             // option "band_nw": most workgroups per frame
+    int band_nw_used_ = 0;          // ... of the program that was built
     bool band_ready_ = false;       // the graph has a single-launch form
     bool band_use_ = false;         // the run being enqueued takes it
     int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it)

@@ -442,7 +442,7 @@ constexpr int kBandBases = 6;
 struct alignas(16) BandStage {
     int kind = BAND_BLOCK;
     int S = 1;                   // BLOCK: DW3x3 stride (1: pad 1; 2: TF SAME on an even size, taps at 2o .. 2o+2)
-    int H = 0, W = 0, C = 0;     // input  (C % 8 == 0, C <= 128)
+    int H = 0, W = 0, C = 0;     // input  (C % 4 == 0, C <= 128)
     int Ho = 0, Wo = 0, Co = 0;  // output (Co <= 128)
     int R = 1;                   // output rows per band
     int wshift = 0;              // workgroup w runs the stage when its low wshift bits are 0; it owns band w >> wshift (the owner of output row r
@@ -454,14 +454,14 @@ struct alignas(16) BandStage {
     int dst_tile = -1;           // LDS tile the output band is left in for the stages that read it (-1: nobody does)
     int pub_lo = 0, pub_hi = 0;  // the first pub_lo and last pub_hi rows of the band also go to the packet buffer (other workgroups read them)
     int src_base = 0, dst_base = -1;  // BandLaunch::base index of the input (dep < 0) / of a plain copy of the output (-1: none; graph outputs)
-    int res_mode = RES_NONE;     // RES_DIRECT: the input itself (S == 1, Co == C); RES_MAXPOOL: 2x2 max of the input, channels >= C zero (S == 2)
+    int res_mode = RES_NONE;     // RES_DIRECT: the input itself (S == 1), RES_MAXPOOL: 2x2 max of the input (S == 2); channels >= C: zero (Co >= C)
     int act = ACT_NONE;
     long src_off = 0, dst_off = 0;   // floats from the base to frame 0 of the tensor
     long src_fs = 0, dst_fs = 0;     // floats between frames
     long src_ll = -1, dst_ll = -1;   // packet buffers of the input / output tensor inside base[0] (floats from the frame's workspace; 2 x the tensor)
     long w_a = 0;                // BandLaunch::consts offset: A operands of v_mfma_f32_16x16x4_f32, per 16-channel output tile
                                  //   [C/16 chunks][64 lanes][4] then (C % 16 == 8) [64 lanes][2]: lane (kq = l / 16, m = l % 16) holds W[16 t + m][16 j + 4 kq + e]
-                                 //   (8-chunk: W[16 t + m][16 (C/16) + 2 kq + e])
+                                 //   (8-chunk: W[16 t + m][16 (C/16) + 2 kq + e]); then (C % 8 == 4) [64 lanes]: W[16 t + m][C - 4 + kq]
     long w_c = 0;                // [bias 16 nct][slope 16 nct] then BLOCK: [taps 9 C][depthwise bias C]
     int c_floats = 0;
     int wpc_shift = 0;           // log2 of the waves per 16-channel output tile (8 / nct rounded down to a power of two)

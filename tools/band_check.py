@@ -6,7 +6,7 @@ import numpy as np
 import rs_face_detection_tflite_amd as mi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = {"back": "face_detection_back.tflite", "front": "face_detection_front.tflite", "full": "face_detection_full_range.tflite",
+FILES = {"back": "face_detection_back.tflite", "front": "face_detection_front.tflite", "short": "face_detection_short_range.tflite", "full": "face_detection_full_range.tflite",
          "landmark": "face_landmark.tflite", "iris": "iris_landmark.tflite"}
 name = sys.argv[1]
 rng = np.random.default_rng(5)

@@ -5,7 +5,7 @@ import torch
 import rs_face_detection_tflite_amd as mi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = {"back": "face_detection_back.tflite", "front": "face_detection_front.tflite", "full": "face_detection_full_range.tflite",
+FILES = {"back": "face_detection_back.tflite", "front": "face_detection_front.tflite", "short": "face_detection_short_range.tflite", "full": "face_detection_full_range.tflite",
          "sparse": "face_detection_full_range_sparse.tflite", "landmark": "face_landmark.tflite", "iris": "iris_landmark.tflite"}
 name, B = sys.argv[1], int(sys.argv[2])
 m = mi.Model(os.path.join(ROOT, "models", FILES[name]))
