@@ -129,6 +129,11 @@ size_t mi_model_profile(mi_model *m, const float *in_device, int batch, int reps
 /* Algorithmic traffic of the launch plan per frame (bytes read+written by the kernels as launched, weights
  * included once) and MACs per frame; used by bench.py for the roofline figure. */
 int mi_model_plan_stats(const mi_model *m, double *bytes_per_frame, double *macs_per_frame, int *launches);
+/* The single-image entries (mi_fd_infer_image ...: one Mat per call, face_detection.rs:205) run a graph that is a first convolution
+ * followed by BlazeBlocks / 1x1 convolutions as ONE launch behind that convolution (bandnet_kernels.hip) instead of the batched
+ * plan's launches.  Returns the workgroups (= CUs held for the launch) such a call of `batch` frames occupies, 0 when the graph has
+ * no such form or `batch` is too large for it, negative on error.  Engine option "band" = 0 turns the form off. */
+int mi_model_single_launch_workgroups(mi_model *m, int batch);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * L1 — FaceDetection (face_detection.rs:146-362)

@@ -31,7 +31,7 @@ EXPORTS = [
     "mi_last_error", "mi_device_count", "mi_version",
     "mi_model_load_file", "mi_model_load_bytes", "mi_model_free", "mi_model_input_dims", "mi_model_num_outputs",
     "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
-    "mi_dist_broadcast_bytes", "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_profile",
+    "mi_dist_broadcast_bytes", "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
     "mi_fd_collect", "mi_host_alloc", "mi_host_free",
@@ -183,6 +183,7 @@ def lib():
     L.mi_plan_describe.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
     L.mi_plan_describe.restype = C.c_size_t
     L.mi_model_plan_stats.argtypes = [vp, dp, dp, ip]
+    L.mi_model_single_launch_workgroups.argtypes = [vp, C.c_int]
     L.mi_model_profile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     L.mi_model_profile.restype = C.c_size_t
     L.mi_fd_create.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(vp)]
@@ -354,6 +355,13 @@ class Model:
         b, m, n = C.c_double(), C.c_double(), C.c_int()
         _check(self.L.mi_model_plan_stats(self.h, C.byref(b), C.byref(m), C.byref(n)))
         return b.value, m.value, n.value
+
+    def single_launch_workgroups(self, batch=1):
+        """Workgroups a single-image call of `batch` frames occupies on the single-launch plan (0: the graph has none / batch too large)."""
+        n = self.L.mi_model_single_launch_workgroups(self.h, int(batch))
+        if n < 0:
+            _check(n)
+        return n
 
     def profile(self, x_device, reps=5):
         """Per-launch HIP-event timing (x_device: torch CUDA tensor). Returns a list of dicts."""

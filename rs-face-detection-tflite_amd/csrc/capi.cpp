@@ -399,6 +399,18 @@ size_t mi_model_profile(mi_model* m, const float* in_device, int batch, int reps
     return rc == MI_OK ? need : 0;
 }
 
+int mi_model_single_launch_workgroups(mi_model* m, int batch) {
+    int n = 0;
+    int rc = guarded([&] {
+        require(m && m->m, "null argument");
+        require(batch > 0, "batch must be positive");
+        std::lock_guard<std::mutex> g(m->mu);
+        mi::hip_check(hipSetDevice(m->m->device()), "hipSetDevice");
+        n = m->m->band_workgroups(batch);
+    });
+    return rc == MI_OK ? n : rc;
+}
+
 int mi_model_plan_stats(const mi_model* m, double* bytes_per_frame, double* macs_per_frame, int* launches) {
     return guarded([&] {
         require(m, "null argument");

@@ -78,6 +78,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "tail_pre") { tail_pre_ = std::max(0, std::min(value, 2)); }   // tail programs: 0 = chosen per launch, 1 = constants a stage ahead (one workgroup per CU), 2 = 128 registers (two per CU)
     else if (key == "tail_g") { tail_g_ = std::max(0, std::min(value, 64)); }   // frames per workgroup of the tail stage programs (0: chosen per launch)
     else if (key == "band") { band_ = std::max(0, std::min(value, 2)); dirty_ = true; }   // single-launch plan: 0 never, 1 one_shot runs (the single-image entries), 2 every run of few enough frames
+    else if (key == "band_test_fail") { band_test_fail_ = value != 0; }   // test hook: the next single-launch run reports that it gave up
     else if (key == "band_nw") { band_nw_ = std::max(8, std::min(value, 256)); dirty_ = true; }   // its workgroups per frame
     else if (key == "fork") { fork_ = value != 0; }
     else if (key == "heads") { head_streams_opt_ = std::min(kHeadStreams, std::max(1, value)); dirty_ = true; }  // side streams the output heads are spread over                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
@@ -1647,6 +1648,7 @@ void Model::run_device(const float* in, int batch, hipStream_t stream, bool one_
     if (dirty_) rebuild();
     ensure_capacity(batch);
     band_use_ = band_usable(batch) && (band_ == 2 || one_shot);
+    band_ran_ = band_use_;
     GraphKey key{in, batch, 0, 0};
     key.band = band_use_;
     try {
@@ -1668,6 +1670,8 @@ int Model::band_workgroups(int batch) {
 }
 
 bool Model::band_failed() {
+    if (band_test_fail_ && band_ran_) { band_test_fail_ = false; band_ran_ = false; return true; }
+    band_ran_ = false;
     if (!h_band_fail_ || !*h_band_fail_) return false;
     *h_band_fail_ = 0;
     return true;

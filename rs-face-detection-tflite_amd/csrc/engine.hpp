@@ -128,6 +128,8 @@ class Model {
     int band_nw_used_ = 0;          // ... of the program that was built
     bool band_ready_ = false;       // the graph has a single-launch form
     bool band_use_ = false;         // the run being enqueued takes it
+    bool band_ran_ = false;         // the last run_device took it
+    bool band_test_fail_ = false;   // option "band_test_fail"
     int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it)
     int band_stem_out_ = -1;        // tensor the first convolution writes = the band program's input
     int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_tile_floats_ = 0, band_dw_floats_ = 0;

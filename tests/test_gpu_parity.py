@@ -371,6 +371,105 @@ def test_tail_programs_on_other_shapes(gpu, oracle, synth_models, case):
     m.close()
 
 
+@pytest.mark.parametrize("name,frames", [("back", 2), ("front", 4), ("short", 4)])
+def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames):
+    """Round 5: the single-image plan (bandnet_kernels.hip) — everything behind the first convolution ONE launch, a row band per workgroup
+    kept in LDS, halo rows handed over as tagged packets.  Option "band" = 2 runs it for every call of few enough frames: against the
+    oracle frame by frame, against the batched plan (band = 0), run-to-run bit-identical (the arithmetic does not depend on who arrives
+    first), eager and as a replayed graph, with one and with several rows per band, and one frame beyond what a launch takes."""
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path(name))
+    assert m.single_launch_workgroups(1) > 0 and m.single_launch_workgroups(frames) == frames * m.single_launch_workgroups(1)
+    assert m.single_launch_workgroups(frames + 1) == 0
+    x = seeded_input(name, frames + 1, 77, m.input_dims[1:3])
+    x[0, : x.shape[1] // 3] = 0.0                       # rows of zeros at the top (the zero halo and real zeros must agree)
+    x[1, :, x.shape[2] // 2:] = x.max()
+    om = oracle.Model(model_path(name))
+    refs = om.run(x, nthreads=8)
+    m.set_option("band", 0)
+    batched = [o.copy() for o in m.run(x)]
+    m.set_option("band", 2)
+    for graph in (1, 0):
+        m.set_option("graph", graph)
+        for nb in range(1, frames + 2):
+            outs = [o.copy() for o in m.run(x[:nb])]
+            for o, r, b in zip(outs, refs, batched):
+                _raw_close(o, r[:nb])
+                _raw_close(o, b[:nb])
+            for rep in range(3):
+                for o, o2 in zip(outs, m.run(x[:nb])):
+                    np.testing.assert_array_equal(o, o2)
+    m.set_option("graph", 1)
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
+    assert labels[1:] == ["bandnet_kernel"], labels
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert "bandnet_kernel" not in labels, labels
+    # fewer workgroups per frame: several rows per band (both edge rows of a band travel), more frames per launch
+    one = [o.copy() for o in m.run(x[:1])]
+    for nw in (32,) if name != "back" else (128,):
+        m.set_option("band_nw", nw)
+        assert m.single_launch_workgroups(1) == nw
+        for nb in (1, 3):
+            for o, r in zip(m.run(x[:nb]), refs):
+                _raw_close(o, r[:nb])
+        for o, o1 in zip(m.run(x[:1]), one):   # the band height does not enter a pixel's arithmetic
+            np.testing.assert_array_equal(o, o1)
+    m.set_option("band", 1)   # the default: only the single-image entries take it
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
+    assert "bandnet_kernel" not in labels, labels
+    m.close()
+
+
+def test_single_launch_plan_only_where_the_graph_has_one(gpu):
+    for name in ("full", "landmark", "iris"):
+        m = gpu.Model(model_path(name))
+        assert m.single_launch_workgroups(1) == 0, name
+        m.close()
+
+
+def test_single_image_entry_on_the_single_launch_plan(gpu, oracle, man_image):
+    """mi_fd_infer_image (one Mat per call, face_detection.rs:205) takes the single-launch plan: the same detections as a handle with the
+    plan turned off, a run that reports it gave up is repeated on the batched plan, and handles on several threads share the device's CUs
+    (256 CUs, 128 workgroups per BackCamera call: the third concurrent call runs on the batched plan instead of waiting)."""
+    import threading
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    assert fd.model.single_launch_workgroups(1) == 128
+    off = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    off.model.set_option("band", 0)
+    assert off.model.single_launch_workgroups(1) == 0
+    want = off.infer(man_image, None)
+    assert len(want) >= 1
+
+    def same(got):
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert np.abs(g.data - w.data).max() <= 1e-5 and abs(g.score - w.score) <= 1e-5
+
+    same(fd.infer(man_image, None))
+    fd.model.set_option("band_test_fail", 1)   # the next single launch "gives up": the call must repeat itself on the batched plan
+    same(fd.infer(man_image, None))
+    same(fd.infer(man_image, None))
+    errors = []
+
+    def worker():
+        try:
+            h = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+            for _ in range(40):
+                same(h.infer(man_image, None))
+            h.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    fd.close()
+    off.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))
