@@ -46,16 +46,16 @@ constexpr int kSpinLimit = 1 << 18;   // polls of a packet before the launch giv
 constexpr int kMaxN16 = 8;            // C <= 128
 constexpr int kConstFloats = 2048;    // LDS floats of a stage's small constants (32 nct + 10 C <= 1536)
 
-__device__ __forceinline__ void ld_sc1(f32x4& dst, const float* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void st_sc1(float* p, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+// Packets travel with sc0 sc1 (write-through stores, loads served by memory, not by this XCD's L2), as buffer instructions: hipcc
+// counts those itself, so other work may stand between a request and its use (aux: 1 = sc0, 16 = sc1).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPacketAux = 17;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t packet_buffer(float* base, long floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(floats * 4), 0x00020000);
 }
 __device__ __forceinline__ unsigned poll(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ unsigned bits(float v) { return __float_as_uint(v); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // n / d for 0 <= n < 2^16 through d's magic number m = ceil(2^32 / d) (0 stands for d = 1)
 __device__ __forceinline__ int mdiv(int n, unsigned m) { return m ? (int)__umulhi((unsigned)n, m) : n; }
@@ -68,33 +68,34 @@ unsigned long long* g_band_stamps = nullptr;
 #define MI_BAND_STAMP(k)
 #endif
 
-// A stage descriptor in scalar registers.  The program is copied to LDS once (a descriptor read from global memory at the top of a
-// stage is a dependent round trip in front of everything else); a descriptor is then ONE LDS read per lane (dword `lane` of it) and a
-// v_readlane per field.
+// A stage descriptor in scalar registers.  The program (BandPacked, 20 dwords a stage) is copied to LDS once — a descriptor read from
+// global memory at the top of a stage is a dependent round trip in front of everything else — and a descriptor is then ONE LDS read
+// per lane (dword `lane` of it), a v_readlane per dword and scalar bit-field extracts.
 struct StageRegs {
     int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats;
     int wpc_shift, per_ct;
     unsigned mC4, mWo, mrowq;
-    long src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
+    int src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
 };
-static_assert(sizeof(BandStage) <= 64 * 4, "a descriptor is read as one dword per lane");
-static_assert(sizeof(BandStage) % 16 == 0, "the program is copied 16 bytes at a time");
-#define MI_BAND_WORD(name) __builtin_amdgcn_readlane(word, (int)(offsetof(BandStage, name) / 4))
-#define MI_BAND_FIELD(name) r.name = MI_BAND_WORD(name)
-#define MI_BAND_FIELDU(name) r.name = (unsigned)MI_BAND_WORD(name)
-#define MI_BAND_FIELD64(name) \
-    r.name = (long)(((unsigned long)(unsigned)__builtin_amdgcn_readlane(word, (int)(offsetof(BandStage, name) / 4 + 1)) << 32) | (unsigned long)(unsigned)MI_BAND_WORD(name))
-__device__ __forceinline__ StageRegs stage_regs(const BandStage* p, int lane) {
-    const int word = reinterpret_cast<const int*>(p)[lane < (int)(sizeof(BandStage) / 4) ? lane : 0];
+// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:1 dst_tile+1:2 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:3 wpc_shift:2
+// word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:16 per_ct:16
+// words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)
+__host__ __device__ inline unsigned bf(unsigned v, int lo, int n) { return (v >> lo) & ((1u << n) - 1u); }
+__device__ __forceinline__ StageRegs stage_regs(const BandPacked* p, int lane) {
+    const int word = reinterpret_cast<const int*>(p)[lane < kBandPackedWords ? lane : 0];
+    unsigned w[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
     StageRegs r;
-    MI_BAND_FIELD(kind); MI_BAND_FIELD(S); MI_BAND_FIELD(H); MI_BAND_FIELD(W); MI_BAND_FIELD(C); MI_BAND_FIELD(Ho); MI_BAND_FIELD(Wo); MI_BAND_FIELD(Co);
-    MI_BAND_FIELD(R); MI_BAND_FIELD(wshift); MI_BAND_FIELD(nbands); MI_BAND_FIELD(dep); MI_BAND_FIELD(Rin);
-    MI_BAND_FIELD(src_tile); MI_BAND_FIELD(dst_tile); MI_BAND_FIELD(pub_lo); MI_BAND_FIELD(pub_hi);
-    MI_BAND_FIELD(src_base); MI_BAND_FIELD(dst_base); MI_BAND_FIELD(res_mode); MI_BAND_FIELD(act); MI_BAND_FIELD(c_floats);
-    MI_BAND_FIELD(wpc_shift); MI_BAND_FIELD(per_ct);
-    MI_BAND_FIELDU(mC4); MI_BAND_FIELDU(mWo); MI_BAND_FIELDU(mrowq);
-    MI_BAND_FIELD64(src_off); MI_BAND_FIELD64(dst_off); MI_BAND_FIELD64(src_fs); MI_BAND_FIELD64(dst_fs);
-    MI_BAND_FIELD64(src_ll); MI_BAND_FIELD64(dst_ll); MI_BAND_FIELD64(w_a); MI_BAND_FIELD64(w_c);
+    r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
+    r.src_tile = bf(w[0], 12, 1); r.dst_tile = (int)bf(w[0], 13, 2) - 1; r.pub_lo = bf(w[0], 15, 1); r.pub_hi = bf(w[0], 16, 1);
+    r.src_base = bf(w[0], 17, 3); r.dst_base = (int)bf(w[0], 20, 3) - 1; r.wpc_shift = bf(w[0], 23, 2);
+    r.R = bf(w[1], 0, 8); r.Rin = bf(w[1], 8, 8); r.dep = (int)bf(w[1], 16, 8) - 1; r.nbands = bf(w[1], 24, 8);
+    r.H = bf(w[2], 0, 16); r.W = bf(w[2], 16, 16); r.Ho = bf(w[3], 0, 16); r.Wo = bf(w[3], 16, 16); r.C = bf(w[4], 0, 16); r.Co = bf(w[4], 16, 16);
+    r.c_floats = bf(w[5], 0, 16); r.per_ct = bf(w[5], 16, 16);
+    r.mC4 = w[6]; r.mWo = w[7]; r.mrowq = w[8];
+    r.src_off = (int)w[9]; r.dst_off = (int)w[10]; r.src_fs = (int)w[11]; r.dst_fs = (int)w[12];
+    r.src_ll = (int)w[13]; r.dst_ll = (int)w[14]; r.w_a = (int)w[15]; r.w_c = (int)w[16];
     return r;
 }
 
@@ -108,21 +109,24 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     float* const ws = a.base[0] + (long)f * a.ws_frame_floats;
     float* const dwb = lds + 2 * a.tile_floats;
     float* const lC = dwb + a.dw_floats;
-    const BandStage* const lprog = reinterpret_cast<const BandStage*>(lC + kConstFloats);
+    const BandPacked* const lprog = reinterpret_cast<const BandPacked*>(lC + kConstFloats);
     {
         const f32x4* gp = reinterpret_cast<const f32x4*>(a.prog);
         f32x4* lp = reinterpret_cast<f32x4*>(lC + kConstFloats);
-        for (int i = tid; i < a.nstages * (int)(sizeof(BandStage) / 16); i += kThreads) lp[i] = gp[i];
+        for (int i = tid; i < a.nstages * (int)(sizeof(BandPacked) / 16); i += kThreads) lp[i] = gp[i];
     }
     __syncthreads();
-    // the next stage after `from` that this workgroup takes part in (workgroup w owns band w >> wshift where its low wshift bits are 0)
-    auto next_active = [&](int from) {
-        int k = from + 1;
-        for (; k < a.nstages; k++) {
-            const int sh = uni(lprog[k].wshift), nb = uni(lprog[k].nbands);
-            if ((w & ((1 << sh) - 1)) == 0 && (w >> sh) < nb) break;
-        }
-        return k;
+    // the stages this workgroup takes part in (workgroup w owns band w >> wshift of a stage where its low wshift bits are 0), as a bit mask:
+    // lane k looks at stage k
+    unsigned long long amask;
+    {
+        const int k = lane < a.nstages ? lane : 0;
+        const int sh = (int)bf(lprog[k].w[0], 3, 4), nb = (int)bf(lprog[k].w[1], 24, 8);
+        amask = __ballot(lane < a.nstages && (w & ((1 << sh) - 1)) == 0 && (w >> sh) < nb);
+    }
+    auto next_active = [&](int from) {   // the next such stage after `from` (nstages: none)
+        const unsigned long long rest = from + 1 < 64 ? amask >> (from + 1) : 0ull;
+        return rest ? from + 1 + (int)__builtin_ctzll(rest) : a.nstages;
     };
     // a stage's A operands for this wave (it keeps one 16-channel output tile for the whole stage) and its small constants
     auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, float& A4, f32x4& creg) {
@@ -164,14 +168,14 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         // ---- the rows of the input that this workgroup does not own: above [ya, p0) and below [p0 + Rin, yb)
         const int nA = p0 - ya, nH = nA + (yb - (p0 + Rin));
         const int rowq = W * C4, total = nH * rowq;
-        if (st.dep >= 0 && total > 0) {
-            // From the producers' packets: at most four elements (eight packets) per lane, all requested at once and again until every tag
-            // is the producer stage's.  The loads are unconditional — a lane without an element reads the buffer's first packets — and
-            // nothing touches their destination registers before the s_waitcnt: the compiler does not know that they are in flight.
-            const float* ll = ws + st.src_ll;
-            int dsto[4];
-            bool real[4];
-            const float* pk[4];
+        // From the producers' packets: at most four elements (eight packets) per lane, all requested at once and again until every tag is
+        // the producer stage's.  While the first answers travel, the scalar work of finding the next stage and its descriptor is done.
+        const bool packets = st.dep >= 0 && total > 0;
+        int dsto[4], pko[4];
+        bool real[4];
+        u32x4 pa[4], pb[4];
+        __amdgpu_buffer_rsrc_t lsrc = packet_buffer(ws + (packets ? st.src_ll : 0), packets ? 2L * st.H * W * C : 0);
+        if (packets) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = tid + u * kThreads, ic = min(i, total - 1);
@@ -179,25 +183,35 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                 const int y = hr < nA ? ya + hr : p0 + Rin + (hr - nA);
                 dsto[u] = i < total ? ((y - p0 + 1) * TW + px + 1) * Cs + 4 * q : -1;
                 real[u] = i < total && y >= 0 && y < st.H;
-                pk[u] = ll + (real[u] ? ((y * W + px) * C4 + q) * 8 : 0);
+                pko[u] = real[u] ? ((y * W + px) * C4 + q) * 32 : 0;   // bytes
             }
-            f32x4 pa[4], pb[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                pa[u] = __builtin_amdgcn_raw_buffer_load_b128(lsrc, pko[u], 0, kPacketAux);
+                pb[u] = __builtin_amdgcn_raw_buffer_load_b128(lsrc, pko[u] + 16, 0, kPacketAux);
+            }
+        }
+        if (packets) {
             int it = 0;
             for (;;) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) { ld_sc1(pa[u], pk[u]); ld_sc1(pb[u], pk[u] + 4); }
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pa[0]), "+v"(pb[0]), "+v"(pa[1]), "+v"(pb[1]), "+v"(pa[2]), "+v"(pb[2]), "+v"(pa[3]), "+v"(pb[3])::"memory");
                 bool ok = true;
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-                    ok = ok && (!real[u] || (bits(pa[u].y) == tag_in && bits(pa[u].w) == tag_in && bits(pb[u].y) == tag_in && bits(pb[u].w) == tag_in));
+                for (int u = 0; u < 4; u++) ok = ok && (!real[u] || (pa[u].y == tag_in && pa[u].w == tag_in && pb[u].y == tag_in && pb[u].w == tag_in));
                 if (ok) break;
                 if (++it > kSpinLimit) { *a.fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    pa[u] = __builtin_amdgcn_raw_buffer_load_b128(lsrc, pko[u], 0, kPacketAux);
+                    pb[u] = __builtin_amdgcn_raw_buffer_load_b128(lsrc, pko[u] + 16, 0, kPacketAux);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if (dsto[u] >= 0) { const f32x4 v = {pa[u].x, pa[u].z, pb[u].x, pb[u].z}; *reinterpret_cast<f32x4*>(tile + dsto[u]) = real[u] ? v : zero4; }
+                if (dsto[u] >= 0) {
+                    const f32x4 v = {__uint_as_float(pa[u].x), __uint_as_float(pa[u].z), __uint_as_float(pb[u].x), __uint_as_float(pb[u].z)};
+                    *reinterpret_cast<f32x4*>(tile + dsto[u]) = real[u] ? v : zero4;
+                }
         } else if (st.dep < 0) {
             // the program's input: plain memory, complete before the launch
             const float* src = a.base[st.src_base] + st.src_off + (long)f * st.src_fs;
@@ -217,19 +231,6 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         MI_BAND_STAMP(1)
         __syncthreads();
         MI_BAND_STAMP(2)
-        // ---- which stage comes next, its descriptor, A operands and constants: their L2 round trip runs under this stage's arithmetic
-        const int sn = next_active(s);
-        MI_BAND_STAMP(6)
-        StageRegs stn{};
-        f32x4 An[kMaxN16], cregn = zero4;
-        f32x2 A8n = {0.f, 0.f};
-        float A4n = 0.f;
-        if (sn < a.nstages) {
-            stn = stage_regs(lprog + sn, lane);
-            MI_BAND_STAMP(7)
-            fetch(stn, An, A8n, A4n, cregn);
-        }
-        MI_BAND_STAMP(8)
         // ---- depthwise 3x3: one thread per (output pixel, channel quad); taps at tile rows trow + S oy + ky
         const int trow = blk && S == 1 ? 0 : 1;
         if (blk) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             float* const gout = st.dst_base >= 0 ? a.base[st.dst_base] + st.dst_off + (long)f * st.dst_fs + (long)r0 * Wo * Co : nullptr;
             float* const llo = st.dst_ll >= 0 ? ws + st.dst_ll : nullptr;
             const float hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
-            const float tagf = __uint_as_float(tag_out);
+            __amdgpu_buffer_rsrc_t osrc = packet_buffer(ws + (llo ? st.dst_ll : 0), llo ? 2L * st.Ho * Wo * Co : 0);
             if (dtile)   // the output band's border pixels
                 for (int i = tid; i < (st.R + 3) * 2 * (Co >> 2); i += kThreads) {
                     const int rr = i / (2 * (Co >> 2)), e = i - rr * 2 * (Co >> 2), side = e / (Co >> 2), q = e - side * (Co >> 2);
@@ -314,10 +315,10 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), hi);
                     if (px < npx && c0 < Co) {
                         if (llo && (oy < st.pub_lo || oy >= nro - st.pub_hi)) {   // a row some other workgroup reads
-                            float* pk = llo + (((r0 + oy) * Wo + ox) * (Co >> 2) + (c0 >> 2)) * 8;
-                            const f32x4 q0 = {v.x, tagf, v.y, tagf}, q1 = {v.z, tagf, v.w, tagf};
-                            st_sc1(pk, q0);
-                            st_sc1(pk + 4, q1);
+                            const int pko = (((r0 + oy) * Wo + ox) * (Co >> 2) + (c0 >> 2)) * 32;
+                            const u32x4 q0 = {__float_as_uint(v.x), tag_out, __float_as_uint(v.y), tag_out}, q1 = {__float_as_uint(v.z), tag_out, __float_as_uint(v.w), tag_out};
+                            __builtin_amdgcn_raw_buffer_store_b128(q0, osrc, pko, 0, kPacketAux);
+                            __builtin_amdgcn_raw_buffer_store_b128(q1, osrc, pko + 16, 0, kPacketAux);
                         }
                         if (dtile) *reinterpret_cast<f32x4*>(dtile + ((1 + oy) * TWo + ox + 1) * Cso + c0) = v;
                         if (gout) {
@@ -335,15 +336,20 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                 }
         }
         MI_BAND_STAMP(4)
+        // ---- the next stage's A operands and constants: requested here, needed behind its halo rows
+        const int sn = next_active(s);
+        MI_BAND_STAMP(6)
+        StageRegs stn{};
+        if (sn < a.nstages) {
+            stn = stage_regs(lprog + sn, lane);
+            MI_BAND_STAMP(7)
+            fetch(stn, A, A8, A4, creg);
+        }
+        MI_BAND_STAMP(8)
         __syncthreads();   // the output band is complete in its tile; the input tile, the depthwise result and the constants are free
         MI_BAND_STAMP(5)
         s = sn;
         st = stn;
-#pragma unroll
-        for (int j = 0; j < kMaxN16; j++) A[j] = An[j];
-        A8 = A8n;
-        A4 = A4n;
-        creg = cregn;
     }
     // ---- the last workgroup to finish moves the generation on
     if (tid == 0) {
@@ -361,7 +367,32 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 int bandnet_tile_floats(int R, int W, int C) { return (R + 3) * (W + 2) * (C + 4); }
 int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
 int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
-int bandnet_lds_bytes(int tile_floats, int dw_floats, int nstages) { return (2 * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandStage); }
+int bandnet_lds_bytes(int tile_floats, int dw_floats, int nstages) { return (2 * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked); }
+
+bool bandnet_pack(const BandStage& st, BandPacked* out) {
+    auto fits = [](long v, int bits) { return v >= 0 && v < (1L << bits); };
+    const long offs[8] = {st.src_off, st.dst_off, st.src_fs, st.dst_fs, st.src_ll, st.dst_ll, st.w_a, st.w_c};
+    for (long v : offs)
+        if (v < -1 || v > 0x7fffffffL) return false;
+    if (!fits(st.kind, 1) || !fits(st.S, 2) || !fits(st.wshift, 4) || !fits(st.res_mode, 2) || !fits(st.act, 3) || !fits(st.src_tile, 1) || !fits(st.dst_tile + 1, 2) ||
+        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 3) || !fits(st.wpc_shift, 2) || !fits(st.R, 8) || !fits(st.Rin, 8) ||
+        !fits(st.dep + 1, 8) || !fits(st.nbands, 8) || !fits(st.H, 16) || !fits(st.W, 16) || !fits(st.Ho, 16) || !fits(st.Wo, 16) || !fits(st.C, 16) || !fits(st.Co, 16) ||
+        !fits(st.c_floats, 16) || !fits(st.per_ct, 16))
+        return false;
+    BandPacked p{};
+    p.w[0] = (unsigned)st.kind | (unsigned)st.S << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
+             (unsigned)(st.dst_tile + 1) << 13 | (unsigned)st.pub_lo << 15 | (unsigned)st.pub_hi << 16 | (unsigned)st.src_base << 17 | (unsigned)(st.dst_base + 1) << 20 |
+             (unsigned)st.wpc_shift << 23;
+    p.w[1] = (unsigned)st.R | (unsigned)st.Rin << 8 | (unsigned)(st.dep + 1) << 16 | (unsigned)st.nbands << 24;
+    p.w[2] = (unsigned)st.H | (unsigned)st.W << 16;
+    p.w[3] = (unsigned)st.Ho | (unsigned)st.Wo << 16;
+    p.w[4] = (unsigned)st.C | (unsigned)st.Co << 16;
+    p.w[5] = (unsigned)st.c_floats | (unsigned)st.per_ct << 16;
+    p.w[6] = st.mC4; p.w[7] = st.mWo; p.w[8] = st.mrowq;
+    for (int k = 0; k < 8; k++) p.w[9 + k] = (unsigned)(int)offs[k];
+    *out = p;
+    return true;
+}
 
 int launch_bandnet(const BandLaunch& a, void* stream) {
     if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;

@@ -874,8 +874,11 @@ void Model::build_bandnet() {
     band_ws_frame_floats_ = std::max<long>(ws, 64);
     band_nstages_ = NS;
     consts.resize(consts.size() + 64, 0.f);
-    hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_prog_), prog.size() * sizeof(BandStage)), "hipMalloc band program");
-    hip_check(hipMemcpy(d_band_prog_, prog.data(), prog.size() * sizeof(BandStage), hipMemcpyHostToDevice), "upload band program");
+    std::vector<BandPacked> packed(prog.size());
+    for (size_t k = 0; k < prog.size(); k++)
+        if (!bandnet_pack(prog[k], &packed[k])) return;
+    hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_prog_), packed.size() * sizeof(BandPacked)), "hipMalloc band program");
+    hip_check(hipMemcpy(d_band_prog_, packed.data(), packed.size() * sizeof(BandPacked), hipMemcpyHostToDevice), "upload band program");
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_consts_), consts.size() * sizeof(float)), "hipMalloc band constants");
     hip_check(hipMemcpy(d_band_consts_, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice), "upload band constants");
     const size_t ws_bytes = static_cast<size_t>(band_ws_frame_floats_) * band_max_frames_ * sizeof(float);

@@ -135,7 +135,7 @@ class Model {
     int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_tile_floats_ = 0, band_dw_floats_ = 0;
     long band_ws_frame_floats_ = 0;
     std::vector<int> band_out_base_;  // graph output k -> BandLaunch::base index
-    BandStage* d_band_prog_ = nullptr;
+    BandPacked* d_band_prog_ = nullptr;
     float* d_band_consts_ = nullptr;
     float* d_band_ws_ = nullptr;
     unsigned* d_band_sync_ = nullptr;

@@ -468,8 +468,15 @@ struct alignas(16) BandStage {
     int per_ct = 0;              // floats of A operands per output tile
     unsigned mC4 = 0, mWo = 0, mrowq = 0;   // magic numbers ceil(2^32 / d) of C / 4, Wo, W C / 4 (0: d = 1): n / d = umulhi(n, m) for n < 2^16
 };
+// A stage as the kernel reads it: 20 dwords (one LDS read per lane, one v_readlane per dword; the full descriptor costs twice that)
+constexpr int kBandPackedWords = 20;
+struct alignas(16) BandPacked {
+    unsigned w[kBandPackedWords];
+};
+// false: a field does not fit its bits (offsets are 32-bit, shapes 16-bit)
+bool bandnet_pack(const BandStage& st, BandPacked* out);
 struct BandLaunch {
-    const BandStage* prog = nullptr;
+    const BandPacked* prog = nullptr;
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
     int tile_floats = 0;            // LDS: [tile 0][tile 1][depthwise result][small constants]
     int dw_floats = 0;

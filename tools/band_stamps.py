@@ -28,7 +28,7 @@ for _ in range(3):
     torch.cuda.synchronize()
 a = buf.cpu().numpy().astype(np.int64).reshape(NWMAX, NST, 10)
 TICK = 2.4e3   # s_memtime ticks per microsecond on these boxes (about)
-print("stage: workgroups | recv  barrier  dw(+prefetch)  pw  barrier | stage total | gap to the next stage of the same workgroup   (microseconds, medians)")
+print("stage: workgroups | recv  barrier  dw  pw  next-stage prep + barrier | stage total | gap to the next stage of the same workgroup   (microseconds, medians)")
 tot = 0.0
 first = a[:, :, 0]
 start = first[first > 0].min()
@@ -39,9 +39,9 @@ for s in range(NST):
         continue
     d = a[on, s, :]
     ph = np.median(d[:, 1:6] - d[:, :5], axis=0) / TICK
-    sub = [np.median(d[:, 6] - d[:, 2]) / TICK, np.median(d[:, 7] - d[:, 6]) / TICK, np.median(d[:, 8] - d[:, 7]) / TICK, np.median(d[:, 3] - d[:, 8]) / TICK]
+    sub = [np.median(d[:, 6] - d[:, 0]) / TICK, np.median(d[:, 7] - d[:, 6]) / TICK, np.median(d[:, 1] - d[:, 7]) / TICK, np.median(d[:, 8] - d[:, 4]) / TICK]
     t = np.median(d[:, 5] - d[:, 0]) / TICK
-    print("  %2d: %3d | %5.2f %5.2f %5.2f %5.2f %5.2f | %5.2f | dw phase = next_active %5.2f + descriptor %5.2f + fetch %5.2f + depthwise %5.2f" % (
+    print("  %2d: %3d | %5.2f %5.2f %5.2f %5.2f %5.2f | %5.2f | recv = requests + next_active %5.2f + descriptor %5.2f + wait, check, LDS %5.2f; fetch %5.2f" % (
         s, int(on.sum()), ph[0], ph[1], ph[2], ph[3], ph[4], t, sub[0], sub[1], sub[2], sub[3]))
     tot += t
 print("sum of stage medians %.1f us; first stamp to last stamp %.1f us" % (tot, (end - start) / TICK))

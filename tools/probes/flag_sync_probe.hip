@@ -16,6 +16,11 @@ __device__ __forceinline__ void st_sc1(float4* p, float4 v) {
     f4v x = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
 }
+__device__ __forceinline__ float4 ld_sc0(const float4* p) {
+    f4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float4 ld_sc1(const float4* p) {
     f4v v;
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
@@ -24,7 +29,9 @@ __device__ __forceinline__ float4 ld_sc1(const float4* p) {
 
 template <int MODE>
 __global__ __launch_bounds__(512) void probe(float4* buf, int* flags, int f4_per_band, int rounds, int epoch, int* fail) {
-    const int w = blockIdx.x, nw = gridDim.x, tid = threadIdx.x;
+    const int nw = gridDim.x, tid = threadIdx.x;
+    // modes 2, 3: neighbouring bands on the same XCD (workgroup i is dispatched to XCD i % 8)
+    const int w = (MODE >= 2 && nw % 8 == 0) ? (blockIdx.x % 8) * (nw / 8) + blockIdx.x / 8 : blockIdx.x;
     float4 acc = make_float4(0, 0, 0, 0);
     for (int r = 0; r < rounds; r++) {
         float4* mine = buf + ((long)(r & 1) * nw + w) * f4_per_band;
@@ -52,7 +59,7 @@ __global__ __launch_bounds__(512) void probe(float4* buf, int* flags, int f4_per
             if (nb < 0 || nb >= nw) continue;
             const float4* theirs = buf + ((long)(r & 1) * nw + nb) * f4_per_band;
             for (int i = tid; i < f4_per_band; i += 512) {
-                float4 v = MODE == 0 ? theirs[i] : ld_sc1(theirs + i);
+                float4 v = MODE == 0 ? theirs[i] : (MODE == 3 ? ld_sc0(theirs + i) : ld_sc1(theirs + i));
                 acc.x += v.w * 1e-9f;
                 if (v.y != (float)nb || v.z != (float)i) *fail = 2;
             }
@@ -72,15 +79,16 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int epoch = 0;
-    for (int mode = 0; mode < 2; mode++)
-        for (int nw : {8, 32, 64, 128, 256})
+    for (int mode = 1; mode < 4; mode++)
+        for (int nw : {8, 64, 128})
             for (int kb : {4, 24, 48}) {
                 const int f4 = kb * 1024 / 16;
                 float best = 1e9;
                 for (int rep = 0; rep < 5; rep++) {
                     CK(hipEventRecord(e0));
-                    if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(nw), dim3(512), 0, 0, buf, flags, f4, rounds, epoch, fail);
-                    else hipLaunchKernelGGL(probe<1>, dim3(nw), dim3(512), 0, 0, buf, flags, f4, rounds, epoch, fail);
+                    if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(nw), dim3(512), 0, 0, buf, flags, f4, rounds, epoch, fail);
+                    else if (mode == 2) hipLaunchKernelGGL(probe<2>, dim3(nw), dim3(512), 0, 0, buf, flags, f4, rounds, epoch, fail);
+                    else hipLaunchKernelGGL(probe<3>, dim3(nw), dim3(512), 0, 0, buf, flags, f4, rounds, epoch, fail);
                     CK(hipEventRecord(e1));
                     CK(hipEventSynchronize(e1));
                     epoch += rounds;
@@ -88,7 +96,7 @@ int main() {
                     if (ms < best) best = ms;
                 }
                 int f; CK(hipMemcpy(&f, fail, sizeof f, hipMemcpyDeviceToHost));
-                printf("%s nw=%3d band=%2d KB: %.2f us/round (launch of %d rounds %.1f us) fail=%d\n", mode ? "sc1  " : "fence", nw, kb, best * 1000.f / rounds, rounds, best * 1000.f, f);
+                printf("%s nw=%3d band=%2d KB: %.2f us/round (launch of %d rounds %.1f us) fail=%d\n", mode == 1 ? "sc1       " : (mode == 2 ? "sc1 +xcd  " : "sc0 +xcd  "), nw, kb, best * 1000.f / rounds, rounds, best * 1000.f, f);
             }
     return 0;
 }
