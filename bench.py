@@ -665,6 +665,8 @@ def run_rank(args):
             try:
                 import latency_probe
                 result["single_image_latency_us"] = latency_probe.measure(n=args.latency_calls)
+                # the same calls timed at the C ABI (arguments marshalled once): what a Rust / C++ host sees, without the Python wrapper
+                result["single_image_latency_us_c_abi"] = latency_probe.measure_c_abi(n=args.latency_calls)
             except Exception as e:  # noqa: BLE001
                 result["single_image_latency_us"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1 and args.config in (1, 2):  # CPU baseline: rank 0 at N = 1 only

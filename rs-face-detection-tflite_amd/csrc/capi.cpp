@@ -1356,6 +1356,12 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
             p->sizes_B = B; p->sizes_w = width; p->sizes_h = height;
         }
+        // A picture or two from host memory (lib.rs:24-40 on one image): the detector may take its single-launch plan — this call holds
+        // the CUs until its synchronisation below, and repeats itself on the batched plan should that launch have given up.
+        std::unique_ptr<BandClaim> claim;
+        if (mem == MI_MEM_HOST) claim = std::make_unique<BandClaim>(fdm, B);
+        for (int attempt = 0; attempt < 2; attempt++) {
+        const bool one_shot = claim && claim->ok && attempt == 0;
         // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
         mi::PreItems it{};
         it.frames = d_frames; it.frame_bytes = static_cast<long>(frame_bytes); it.width = width; it.height = height; it.stride = stride;
@@ -1365,7 +1371,7 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         float* d_in_det = static_cast<float*>(p->in_det.get(fdm.input_elems() * sizeof(float) * B));
         mi::launch_pre_geom(it, d_geom, d_pad_det, s);
         mi::launch_pre_tensor(it, d_geom, d_in_det, s);
-        fdm.run_device(d_in_det, B, s);
+        fdm.run_device(d_in_det, B, s, one_shot);
         float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
         mi::hip_check(hipMemsetAsync(d_dets, 0, sizeof(mi_detection) * cap * B, s), "hipMemsetAsync");  // frames without a face report zeros
         int* d_counts = mem == MI_MEM_DEVICE ? face_counts : static_cast<int*>(p->counts.get(sizeof(int) * B));
@@ -1427,12 +1433,15 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
             mi::hip_check(hipMemcpyAsync(present, d_present, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H present");
             mi::hip_check(hipMemcpyAsync(eyes, d_eyes, sizeof(float) * eye_fs * 2 * B, hipMemcpyDeviceToHost, s), "D2H eyes");
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+            if (one_shot && fdm.band_failed()) continue;
             for (int b = 0; b < B; b++) {
                 if (face_counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
                 if (face_counts[b] == 0) std::memset(&faces[b], 0, sizeof(mi_detection));
             }
         } else if (!stream) {
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        }
+        break;
         }
     });
 }

@@ -43,6 +43,11 @@ def measure(n=300):
     ir = mi.IrisLandmark()
     eye = mi.Rect(*[float(v) for v in gold["man_eye_left_roi"][:5]], int(gold["man_eye_left_roi"][5]))
     out["IrisLandmark::infer (man.jpg, left-eye ROI)"] = timed(lambda: ir.infer(img, eye, False), n)
+    # the whole flow of lib.rs:24-40 on one picture: detector -> mesh of the first face -> both eyes, one call, every stage on the device
+    pipe = mi.Pipeline(mi.FaceDetectionModel.BackCamera)
+    one = np.ascontiguousarray(img[None])
+    out["lib.rs flow on one picture: mi_pipeline_run, batch 1 (detector -> mesh -> 2 x iris)"] = timed(lambda: pipe.run(one), n)
+    pipe.close()
     return out
 
 
