@@ -276,22 +276,24 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     const int px = 16 * pt + n, pxc = min(px, npx - 1);
                     const int oy = mdiv(pxc, st.mWo), ox = pxc - oy * Wo;
                     const float* bp = blk ? dwb + pxc * Cs : tile + ((1 + oy) * TW + ox + 1) * Cs;
-                    f32x4 D = zero4;
+                    // four accumulators, one per k-step of a 16-channel chunk: a chain of dependent MFMAs runs at a quarter of the issue rate
+                    f32x4 D = zero4, D1 = zero4, D2 = zero4, D3 = zero4;
 #pragma unroll
                     for (int j = 0; j < kMaxN16; j++)
                         if (j < n16) {
                             const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 16 * j + 4 * kq);
                             D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].x, bv.x, D, 0, 0, 0);
-                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].y, bv.y, D, 0, 0, 0);
-                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].z, bv.z, D, 0, 0, 0);
-                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].w, bv.w, D, 0, 0, 0);
+                            D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].y, bv.y, D1, 0, 0, 0);
+                            D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].z, bv.z, D2, 0, 0, 0);
+                            D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].w, bv.w, D3, 0, 0, 0);
                         }
                     if (has8) {
                         const f32x2 bv = *reinterpret_cast<const f32x2*>(bp + 16 * n16 + 2 * kq);
                         D = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.x, bv.x, D, 0, 0, 0);
-                        D = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.y, bv.y, D, 0, 0, 0);
+                        D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.y, bv.y, D1, 0, 0, 0);
                     }
-                    if (has4) D = __builtin_amdgcn_mfma_f32_16x16x4f32(A4, bp[16 * n16 + 8 * has8 + kq], D, 0, 0, 0);
+                    if (has4) D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A4, bp[16 * n16 + 8 * has8 + kq], D2, 0, 0, 0);
+                    D = (D + D1) + (D2 + D3);
                     // D[i] = output channel 16 ct + 4 kq + i of pixel px
                     const int c0 = 16 * myct + 4 * kq;
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);

@@ -22,6 +22,8 @@ CASES = {
     # round 5: the stage programs with several frames per workgroup — both register variants spill-free (a version with spills ran 15 % slower),
     # and the 128-register variant really is one: two workgroups per CU depend on it
     "tail_kernels.hip": ([], [""]),
+    # round 5: the single-launch plan — one workgroup per CU, 256 registers a lane available, none of them in scratch
+    "bandnet_kernels.hip": ([], [""]),
     # the row pipelines of BASELINE config 2 (four stages, 24 channels, plain and with either stride-2 tail)
     "strip_kernels.hip": (["-DMI_DEV_ONE"], ["strip_pipe2m_kernel<6, 4, true, 0>", "strip_pipe2m_kernel<6, 4, true, 1>", "strip_pipe2m_kernel<6, 4, true, 2>"]),
 }

@@ -29,6 +29,17 @@ for c in $CONFIGS; do
   MI_PMC_SUMMARY="$OUT/summary/pmc_summary.json" python3 bench.py --config $c --no-secondary > "$OUT/bench_c$c.json" 2> "$OUT/bench_c$c.err"; echo bench $c done
 done
 python3 tools/summarize_profiles.py "$TAG" "$OUT/summary" > "$OUT/summarize.log" 2>&1   # again: picks the bench lines up
+# ---- the single-image calls (the reference's operating point): per-launch lists at one frame, the latency probe, and a kernel trace of it
+{
+  echo "# per-launch HIP-event times at a batch of ONE frame (tools/profile_model.py <model> 1): the batched plan, and for the graphs that have one"
+  echo "# the single-launch plan the single-image entries take (option band=2 makes every small run take it)"
+  for m in back front short full landmark iris; do echo "== $m 1 (batched plan)"; python3 tools/profile_model.py $m 1 band=0 2>/dev/null | grep -v amdgpu; done
+  for m in back front short; do echo "== $m 1 (single-launch plan)"; python3 tools/profile_model.py $m 1 band=2 2>/dev/null | grep -v amdgpu; done
+  echo; echo "# tools/latency_probe.py: per call, host Mat in, results out (us); then the same calls timed at the C ABI"
+  python3 tools/latency_probe.py 2>/dev/null | grep -v amdgpu
+} > "$OUT/summary/${TAG}_launches_batch1.txt"; echo batch-1 lists done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -- python3 tools/latency_probe.py > "$OUT/trace_single.log" 2>&1; echo trace single done
+f=$(find "$OUT/trace_single" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/summary/${TAG}_kernel_stats_single_image.csv"
 # keep what gpurun merges back small: counter CSVs, stats and the summaries only
 find "$OUT" -name "*.db" -delete 2>/dev/null || true
 find "$OUT" -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null || true
