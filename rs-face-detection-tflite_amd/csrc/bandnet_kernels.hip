@@ -72,12 +72,12 @@ unsigned long long* g_band_stamps = nullptr;
 // global memory at the top of a stage is a dependent round trip in front of everything else — and a descriptor is then ONE LDS read
 // per lane (dword `lane` of it), a v_readlane per dword and scalar bit-field extracts.
 struct StageRegs {
-    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats;
+    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, res_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats;
     int wpc_shift, per_ct;
     unsigned mC4, mWo, mrowq;
     int src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
 };
-// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:1 dst_tile+1:2 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:3 wpc_shift:2
+// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3
 // word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:16 per_ct:16
 // words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)
 __host__ __device__ inline unsigned bf(unsigned v, int lo, int n) { return (v >> lo) & ((1u << n) - 1u); }
@@ -88,8 +88,8 @@ __device__ __forceinline__ StageRegs stage_regs(const BandPacked* p, int lane) {
     for (int k = 0; k < 17; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
     StageRegs r;
     r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
-    r.src_tile = bf(w[0], 12, 1); r.dst_tile = (int)bf(w[0], 13, 2) - 1; r.pub_lo = bf(w[0], 15, 1); r.pub_hi = bf(w[0], 16, 1);
-    r.src_base = bf(w[0], 17, 3); r.dst_base = (int)bf(w[0], 20, 3) - 1; r.wpc_shift = bf(w[0], 23, 2);
+    r.src_tile = bf(w[0], 12, 2); r.dst_tile = (int)bf(w[0], 14, 3) - 1; r.pub_lo = bf(w[0], 17, 1); r.pub_hi = bf(w[0], 18, 1);
+    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1;
     r.R = bf(w[1], 0, 8); r.Rin = bf(w[1], 8, 8); r.dep = (int)bf(w[1], 16, 8) - 1; r.nbands = bf(w[1], 24, 8);
     r.H = bf(w[2], 0, 16); r.W = bf(w[2], 16, 16); r.Ho = bf(w[3], 0, 16); r.Wo = bf(w[3], 16, 16); r.C = bf(w[4], 0, 16); r.Co = bf(w[4], 16, 16);
     r.c_floats = bf(w[5], 0, 16); r.per_ct = bf(w[5], 16, 16);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     const unsigned base = (unsigned)uni((int)poll(a.sync)) * 64u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float* const ws = a.base[0] + (long)f * a.ws_frame_floats;
-    float* const dwb = lds + 2 * a.tile_floats;
+    float* const dwb = lds + a.ntiles * a.tile_floats;
     float* const lC = dwb + a.dw_floats;
     const BandPacked* const lprog = reinterpret_cast<const BandPacked*>(lC + kConstFloats);
     {
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     const int c0 = 16 * myct + 4 * kq;
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);
                     f32x4 sk = zero4;
-                    if (st.res_mode == RES_DIRECT) {
+                    if (st.res_mode == RES_DIRECT && st.res_tile >= 0) {   // a tensor of Co channels on the same rows, in another tile
+                        sk = *reinterpret_cast<const f32x4*>(lds + st.res_tile * a.tile_floats + ((1 + oy) * TW + ox + 1) * Cso + c0);
+                    } else if (st.res_mode == RES_DIRECT) {
                         if (c0 < C) sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // channels >= C: the zero pad of a widening block
                     } else if (st.res_mode == RES_MAXPOOL && c0 < C) {
                         const float* t0 = tile + ((1 + 2 * oy) * TW + 2 * ox + 1) * Cs + c0;
@@ -369,22 +371,23 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 int bandnet_tile_floats(int R, int W, int C) { return (R + 3) * (W + 2) * (C + 4); }
 int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
 int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
-int bandnet_lds_bytes(int tile_floats, int dw_floats, int nstages) { return (2 * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked); }
+int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages) { return (ntiles * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked); }
 
 bool bandnet_pack(const BandStage& st, BandPacked* out) {
     auto fits = [](long v, int bits) { return v >= 0 && v < (1L << bits); };
     const long offs[8] = {st.src_off, st.dst_off, st.src_fs, st.dst_fs, st.src_ll, st.dst_ll, st.w_a, st.w_c};
     for (long v : offs)
         if (v < -1 || v > 0x7fffffffL) return false;
-    if (!fits(st.kind, 1) || !fits(st.S, 2) || !fits(st.wshift, 4) || !fits(st.res_mode, 2) || !fits(st.act, 3) || !fits(st.src_tile, 1) || !fits(st.dst_tile + 1, 2) ||
-        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 3) || !fits(st.wpc_shift, 2) || !fits(st.R, 8) || !fits(st.Rin, 8) ||
+    if (!fits(st.kind, 1) || !fits(st.S, 2) || !fits(st.wshift, 4) || !fits(st.res_mode, 2) || !fits(st.act, 3) || !fits(st.src_tile, 2) || !fits(st.dst_tile + 1, 3) ||
+        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 4) || !fits(st.wpc_shift, 2) || !fits(st.res_tile + 1, 3) ||
+        st.src_tile >= kBandTiles || st.dst_tile >= kBandTiles || st.res_tile >= kBandTiles || st.dst_base >= kBandBases || !fits(st.R, 8) || !fits(st.Rin, 8) ||
         !fits(st.dep + 1, 8) || !fits(st.nbands, 8) || !fits(st.H, 16) || !fits(st.W, 16) || !fits(st.Ho, 16) || !fits(st.Wo, 16) || !fits(st.C, 16) || !fits(st.Co, 16) ||
         !fits(st.c_floats, 16) || !fits(st.per_ct, 16))
         return false;
     BandPacked p{};
     p.w[0] = (unsigned)st.kind | (unsigned)st.S << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
-             (unsigned)(st.dst_tile + 1) << 13 | (unsigned)st.pub_lo << 15 | (unsigned)st.pub_hi << 16 | (unsigned)st.src_base << 17 | (unsigned)(st.dst_base + 1) << 20 |
-             (unsigned)st.wpc_shift << 23;
+             (unsigned)(st.dst_tile + 1) << 14 | (unsigned)st.pub_lo << 17 | (unsigned)st.pub_hi << 18 | (unsigned)st.src_base << 19 | (unsigned)(st.dst_base + 1) << 22 |
+             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28;
     p.w[1] = (unsigned)st.R | (unsigned)st.Rin << 8 | (unsigned)(st.dep + 1) << 16 | (unsigned)st.nbands << 24;
     p.w[2] = (unsigned)st.H | (unsigned)st.W << 16;
     p.w[3] = (unsigned)st.Ho | (unsigned)st.Wo << 16;
@@ -397,8 +400,8 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
 }
 
 int launch_bandnet(const BandLaunch& a, void* stream) {
-    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
-    if (bandnet_lds_bytes(a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
+    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles) return (int)hipErrorInvalidValue;
+    if (bandnet_lds_bytes(a.ntiles, a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
     auto kern = bandnet_kernel;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;

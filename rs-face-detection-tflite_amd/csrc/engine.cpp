@@ -5,7 +5,10 @@
 #include <mutex>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 
 namespace mi {
@@ -612,12 +615,17 @@ void Model::free_bandnet() {
 
 // The single-launch plan (bandnet_kernels.hip).  It is made from the level-2 lowering of the same graph — one node per BlazeBlock /
 // convolution — when that is: a first convolution (which keeps its launch of the batched plan), then nothing but 3x3 BlazeBlocks whose
-// skip is their own input, pointwise blocks and 1x1 convolutions, each reading the tensor of an earlier one.  Anything else (full_range's
-// double blocks and resizes, the mesh's and the iris network's 2x2 convolutions and PReLU stacks, channel counts off the 8-grid)
-// leaves band_ready_ false and the handle on the batched plan.
+// skip is their own input (or, without a stride, another tensor of the program: the iris network's bottlenecks), pointwise blocks and
+// 1x1 convolutions, each reading the tensor of an earlier one.  The program stops in front of the first node that is none of these
+// (the face mesh's two whole-frame convolutions, the iris network's first 2x2 convolution): the plan nodes from there on keep their
+// launches of the batched plan, behind the band launch, and the tensors they read are written to their arena storage by the band
+// program — provided no launch of the batched plan straddles the cut.  Graphs whose FIRST block is already something else (full_range's
+// double blocks) leave band_ready_ false and the handle on the batched plan.
+// MI_BAND_DEBUG=1 names the line at which a graph was found to have no single-launch form
+#define BAND_GIVE_UP do { if (std::getenv("MI_BAND_DEBUG")) std::fprintf(stderr, "bandnet: no single-launch plan (engine.cpp:%d)\n", __LINE__); return; } while (0)
 void Model::build_bandnet() {
     free_bandnet();
-    if (!band_ || fuse_level_ < 2) return;
+    if (!band_ || fuse_level_ < 2) BAND_GIVE_UP;
     const Plan p2 = build_plan(parse_tflite(blob_.data(), blob_.size()), 2);
     const Graph& g = p2.graph;
     auto is_view = [](const Node& n) { return n.kind == Node::Reshape || n.kind == Node::Concat; };
@@ -625,24 +633,24 @@ void Model::build_bandnet() {
     size_t i5 = 0, i2 = 0;
     while (i5 < plan_.nodes.size() && is_view(plan_.nodes[i5])) i5++;
     while (i2 < p2.nodes.size() && is_view(p2.nodes[i2])) i2++;
-    if (i5 >= plan_.nodes.size() || i2 >= p2.nodes.size()) return;
+    if (i5 >= plan_.nodes.size() || i2 >= p2.nodes.size()) BAND_GIVE_UP;
     const Node &stem5 = plan_.nodes[i5], &stem2 = p2.nodes[i2];
-    if (stem5.kind != Node::Conv || stem2.kind != Node::Conv || stem5.out != stem2.out || stem5.gemm_head) return;
+    if (stem5.kind != Node::Conv || stem2.kind != Node::Conv || stem5.out != stem2.out || stem5.gemm_head) BAND_GIVE_UP;
     band_stem_out_ = stem2.out;
-    if (plan_.storage[band_stem_out_].root != band_stem_out_ || plan_.storage[band_stem_out_].offset != 0) return;
+    if (plan_.storage[band_stem_out_].root != band_stem_out_ || plan_.storage[band_stem_out_].offset != 0) BAND_GIVE_UP;
     band_first_ = static_cast<int>(i5) + 1;
     while (band_first_ < static_cast<int>(plan_.nodes.size()) && is_view(plan_.nodes[static_cast<size_t>(band_first_)])) band_first_++;
-    if (band_first_ >= static_cast<int>(plan_.nodes.size())) return;
+    if (band_first_ >= static_cast<int>(plan_.nodes.size())) BAND_GIVE_UP;
     // workgroups per frame: one per row of the first tensor, at most band_nw_ (the bands of the later, smaller tensors are one row of every
     // 2nd, 4th ... workgroup)
     const auto& stem_shape = g.tensors[band_stem_out_].shape;
-    if (stem_shape.size() != 4) return;
+    if (stem_shape.size() != 4) BAND_GIVE_UP;
     int NW = band_nw_;
     while (NW > 1 && (stem_shape[1] % NW) && (NW % stem_shape[1])) NW--;
     if (stem_shape[1] < NW) NW = stem_shape[1];
     band_nw_used_ = NW;
     band_max_frames_ = std::max(0, device_cu_count() / NW);
-    if (band_max_frames_ < 1) return;
+    if (band_max_frames_ < 1) BAND_GIVE_UP;
 
     std::vector<BandStage> prog;
     std::vector<const Node*> nodes;
@@ -650,9 +658,17 @@ void Model::build_bandnet() {
     std::vector<int> producer(g.tensors.size(), -1);
     std::vector<int> out_root;
     for (int o : g.outputs) out_root.push_back(p2.storage[o].root);
-    if (2 + out_root.size() > static_cast<size_t>(kBandBases)) return;
-    band_out_base_.clear();
-    for (size_t k = 0; k < out_root.size(); k++) band_out_base_.push_back(2 + static_cast<int>(k));
+    band_ext_.clear();
+    auto ext_slot = [&](int out_k, int tensor) {   // BandLaunch::base index of a graph output / an arena tensor (-1: no slot left)
+        for (size_t j = 0; j < band_ext_.size(); j++)
+            if (band_ext_[j].out_k == out_k && band_ext_[j].tensor == tensor) return 2 + static_cast<int>(j);
+        if (2 + band_ext_.size() >= static_cast<size_t>(kBandBases)) return -1;
+        BandExt e; e.out_k = out_k; e.tensor = tensor;
+        band_ext_.push_back(e);
+        return 1 + static_cast<int>(band_ext_.size());
+    };
+    std::vector<char> band_op(g.ops.size(), 0);   // .tflite operators the band program computes
+    size_t cut = p2.nodes.size();                 // first p2 node the program does not take
     auto put = [&](const std::vector<float>& v) {
         const long off = align_up(static_cast<long>(consts.size()), 64);
         consts.resize(static_cast<size_t>(off) + v.size(), 0.f);
@@ -666,77 +682,89 @@ void Model::build_bandnet() {
         const bool pw_block = n.kind == Node::Block && n.w < 0;
         const bool dw_block = n.kind == Node::Block && n.w >= 0;
         const bool conv1 = n.kind == Node::Conv && n.KH == 1 && n.KW == 1 && n.sh == 1 && n.sw == 1 && !n.gemm_head;
-        if (!pw_block && !dw_block && !conv1) return;
-        if (n.in.size() != 1 || n.ept >= 0 || n.res_after) return;
+        if (!pw_block && !dw_block && !conv1) { cut = i; break; }
+        if (n.in.size() != 1 || n.ept >= 0 || n.res_after) BAND_GIVE_UP;
         const auto& si = g.tensors[n.in[0]].shape;
         const auto& so = g.tensors[n.out].shape;
-        if (si.size() != 4 || so.size() != 4) return;
+        if (si.size() != 4 || so.size() != 4) BAND_GIVE_UP;
         BandStage st;
         st.kind = dw_block ? BAND_BLOCK : BAND_PW;
         st.H = si[1]; st.W = si[2]; st.C = si[3]; st.Ho = so[1]; st.Wo = so[2]; st.Co = so[3];
-        if (st.C % 4 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) return;
+        if (st.C % 4 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) BAND_GIVE_UP;
         st.S = 1;
         if (dw_block) {
-            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) return;
+            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) BAND_GIVE_UP;
             st.S = n.sh;
-            if (st.S == 2 && ((st.H & 1) || (st.W & 1))) return;
-            if (st.Ho != st.H / st.S || st.Wo != st.W / st.S) return;
+            if (st.S == 2 && ((st.H & 1) || (st.W & 1))) BAND_GIVE_UP;
+            if (st.Ho != st.H / st.S || st.Wo != st.W / st.S) BAND_GIVE_UP;
         } else if (st.Ho != st.H || st.Wo != st.W) {
-            return;
+            BAND_GIVE_UP;
         }
         st.act = n.act;
-        if (n.act != ACT_NONE && n.act != ACT_RELU && n.act != ACT_RELU6 && n.act != ACT_PRELU) return;
+        if (n.act != ACT_NONE && n.act != ACT_RELU && n.act != ACT_RELU6 && n.act != ACT_PRELU) BAND_GIVE_UP;
         st.res_mode = RES_NONE;
         if (n.res >= 0) {
-            if (!dw_block || n.res != n.in[0]) return;
-            if (n.res_mode == RES_DIRECT && st.S == 1 && st.Co >= st.C) st.res_mode = RES_DIRECT;   // (Co > C: the skip is zero-padded to Co channels)
+            if (!dw_block) BAND_GIVE_UP;
+            if (n.res != n.in[0]) {
+                // the skip is another tensor of the program, with the output's shape (its rows then have the output's owners)
+                const auto& sr = g.tensors[n.res].shape;
+                if (n.res_mode != RES_DIRECT || st.S != 1 || sr.size() != 4 || sr[1] != st.Ho || sr[2] != st.Wo || sr[3] != st.Co) BAND_GIVE_UP;
+                if (n.res == band_stem_out_) st.res_dep = -1;
+                else if (producer[static_cast<size_t>(n.res)] >= 0) st.res_dep = producer[static_cast<size_t>(n.res)];
+                else BAND_GIVE_UP;
+                st.res_mode = RES_DIRECT;
+            }
+            else if (n.res_mode == RES_DIRECT && st.S == 1 && st.Co >= st.C) st.res_mode = RES_DIRECT;   // (Co > C: the skip is zero-padded to Co channels)
             else if (n.res_mode == RES_MAXPOOL && st.S == 2 && st.Co >= st.C) st.res_mode = RES_MAXPOOL;
-            else return;
+            else BAND_GIVE_UP;
         }
         // bands: whole rows per workgroup while there are at least NW rows, one row for every (NW / rows)-th workgroup below that
         auto log2_exact = [](int v) { int k = 0; while ((1 << k) < v) k++; return (1 << k) == v ? k : -1; };
         if (st.Ho >= NW) {
-            if (st.Ho % NW) return;
+            if (st.Ho % NW) BAND_GIVE_UP;
             st.R = st.Ho / NW; st.wshift = 0; st.nbands = NW;
         } else {
-            if (NW % st.Ho || log2_exact(NW / st.Ho) < 0) return;
+            if (NW % st.Ho || log2_exact(NW / st.Ho) < 0) BAND_GIVE_UP;
             st.R = 1; st.wshift = log2_exact(NW / st.Ho); st.nbands = st.Ho;
         }
         if (n.in[0] == band_stem_out_) {
             st.src_base = 1; st.src_off = 0; st.dep = -1; st.Rin = 0;
             st.src_fs = plan_.storage[band_stem_out_].frame_stride;
-            if (st.src_fs & 3) return;
+            if (st.src_fs & 3) BAND_GIVE_UP;
         } else {
             const int d = producer[static_cast<size_t>(n.in[0])];
-            if (d < 0) return;
+            if (d < 0) BAND_GIVE_UP;
             const BandStage& pd = prog[static_cast<size_t>(d)];
             st.dep = d;
             st.Rin = pd.R;
             // the owner of output row r must own input row S r, and the rows it lacks must be at most one above and two below its own
             for (int b = 0; b < st.nbands; b++) {
                 const int r0 = b * st.R, nro = std::min(st.Ho, r0 + st.R) - r0, p0 = st.S * r0;
-                if (((p0 / pd.R) << pd.wshift) != (b << st.wshift) || p0 % pd.R) return;
+                if (((p0 / pd.R) << pd.wshift) != (b << st.wshift) || p0 % pd.R) BAND_GIVE_UP;
                 const int rin = std::min(pd.R, st.H - p0);
                 const int yb = dw_block ? (st.S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : p0 + nro;
                 const int below = yb - (p0 + rin);
-                if (below < 0 || below > 2) return;
-                if (((dw_block && st.S == 1 ? 1 : 0) + below) * st.W * (st.C / 4) > 4 * 512) return;   // the halo rows: four 16-byte elements per lane
+                if (below < 0 || below > 2) BAND_GIVE_UP;
+                if (((dw_block && st.S == 1 ? 1 : 0) + below) * st.W * (st.C / 4) > 4 * 512) BAND_GIVE_UP;   // the halo rows: four 16-byte elements per lane
             }
         }
         // a plain copy of the output where it is a graph output (through the reshape / concatenation views behind it)
         const Storage& so_st = p2.storage[n.out];
         for (size_t k = 0; k < out_root.size(); k++)
-            if (out_root[k] == so_st.root) { st.dst_base = 2 + static_cast<int>(k); st.dst_off = so_st.offset; st.dst_fs = so_st.frame_stride; }
-        if (st.dst_base < 0 && so_st.root != n.out) return;
-        if (st.dst_base < 0 && st.Co % 4) return;
+            if (out_root[k] == so_st.root) {
+                st.dst_base = ext_slot(static_cast<int>(k), -1); st.dst_off = so_st.offset; st.dst_fs = so_st.frame_stride;
+                if (st.dst_base < 0) BAND_GIVE_UP;
+            }
+        if (st.dst_base < 0 && so_st.root != n.out) BAND_GIVE_UP;
+        if (st.dst_base < 0 && st.Co % 4) BAND_GIVE_UP;
         if ((st.dst_off & 3) || (st.dst_fs & 3)) {
-            if (st.Co % 4 == 0) return;   // 16-byte stores need the alignment; the ragged heads store floats
+            if (st.Co % 4 == 0) BAND_GIVE_UP;   // 16-byte stores need the alignment; the ragged heads store floats
         }
         // constants
         const int wt = n.kind == Node::Conv ? n.w : n.w2, bt = n.kind == Node::Conv ? n.b : n.b2;
         const auto& wsrc = g.tensors[wt].f32;
         const int C = st.C, Co = st.Co, nct = (Co + 15) / 16, n16 = C / 16, has8 = (C / 8) & 1, has4 = (C / 4) & 1, per_ct = n16 * 256 + has8 * 128 + has4 * 64;
-        if (wsrc.size() != static_cast<size_t>(Co) * C) return;
+        if (wsrc.size() != static_cast<size_t>(Co) * C) BAND_GIVE_UP;
         std::vector<float> A(static_cast<size_t>(nct) * per_ct, 0.f);
         for (int ct = 0; ct < nct; ct++)
             for (int l = 0; l < 64; l++) {
@@ -750,7 +778,7 @@ void Model::build_bandnet() {
             }
         st.c_floats = bandnet_const_floats(st);
         st.per_ct = per_ct;
-        if (nct > 8) return;
+        if (nct > 8) BAND_GIVE_UP;
         st.wpc_shift = nct == 1 ? 3 : (nct == 2 ? 2 : (nct <= 4 ? 1 : 0));
         std::vector<float> cb(static_cast<size_t>(st.c_floats), 0.f);
         for (int c = 0; c < Co; c++) {
@@ -759,7 +787,7 @@ void Model::build_bandnet() {
         }
         if (dw_block) {
             const auto& wd = g.tensors[n.w].f32;  // [1][3][3][C]
-            if (wd.size() != static_cast<size_t>(9) * C) return;
+            if (wd.size() != static_cast<size_t>(9) * C) BAND_GIVE_UP;
             for (int t = 0; t < 9 * C; t++) cb[static_cast<size_t>(32 * nct + t)] = wd[static_cast<size_t>(t)];
             if (n.b >= 0)
                 for (int c = 0; c < C; c++) cb[static_cast<size_t>(32 * nct + 9 * C + c)] = g.tensors[n.b].f32[static_cast<size_t>(c)];
@@ -768,26 +796,97 @@ void Model::build_bandnet() {
         st.w_c = put(cb);
         auto magic = [](int d) { return d <= 1 ? 0u : static_cast<unsigned>((0x100000000ull + static_cast<unsigned long long>(d) - 1) / static_cast<unsigned long long>(d)); };
         st.mC4 = magic(st.C / 4); st.mWo = magic(st.Wo); st.mrowq = magic(st.W * (st.C / 4));
-        if (static_cast<long>(st.R + 3) * st.W * (st.C / 4) >= 65536 || st.R * st.Wo * std::max(st.C, st.Co) / 4 >= 65536) return;   // the magic divisions' range
+        if (static_cast<long>(st.R + 3) * st.W * (st.C / 4) >= 65536 || st.R * st.Wo * std::max(st.C, st.Co) / 4 >= 65536) BAND_GIVE_UP;   // the magic divisions' range
         producer[static_cast<size_t>(n.out)] = static_cast<int>(prog.size());
         prog.push_back(st);
         nodes.push_back(&n);
+        for (int o : n.src_ops) band_op[static_cast<size_t>(o)] = 1;
     }
-    if (prog.empty() || prog.size() > 63) return;
-    // every graph output must be written, whole, by the band program (the first convolution writes none of them)
+    if (prog.empty() || prog.size() > 63) BAND_GIVE_UP;
+    // ---- the cut: a plan node behind the first convolution either lies wholly inside the band program (the band launch stands for it) or wholly
+    // behind it (it keeps its launch); a tensor such a launch reads from the program is written to its arena storage by the producing stage
+    band_node_runs_.assign(plan_.nodes.size(), 0);
+    if (g.ops.size() != plan_.graph.ops.size() || g.tensors.size() > plan_.storage.size()) BAND_GIVE_UP;
+    {
+        std::vector<int> op_producer(g.tensors.size(), -1);
+        for (size_t o = 0; o < g.ops.size(); o++)
+            for (int t : g.ops[o].outputs)
+                if (t >= 0) op_producer[static_cast<size_t>(t)] = static_cast<int>(o);
+        std::function<void(const Node&, std::vector<int>&)> reads = [&](const Node& n, std::vector<int>& v) {
+            for (int t : n.in) v.push_back(t);
+            if (n.res >= 0) v.push_back(n.res);
+            for (const Node& m : n.members) reads(m, v);
+            for (const Node& m : n.head_nodes) reads(m, v);
+            for (const Node::Stage& sg : n.stages) { if (sg.src_t >= 0) v.push_back(sg.src_t); if (sg.res_t >= 0) v.push_back(sg.res_t); }
+        };
+        bool any_band = false;
+        for (size_t i = static_cast<size_t>(band_first_); i < plan_.nodes.size(); i++) {
+            const Node& n = plan_.nodes[i];
+            if (is_view(n)) continue;
+            size_t inside = 0;
+            for (int o : n.src_ops) inside += band_op[static_cast<size_t>(o)] ? 1 : 0;
+            if (n.src_ops.empty() || (inside != 0 && inside != n.src_ops.size())) BAND_GIVE_UP;   // a launch of the batched plan straddles the cut
+            if (inside) { any_band = true; continue; }
+            band_node_runs_[i] = 1;
+            std::vector<int> rd;
+            reads(n, rd);
+            for (int t : rd) {
+                const int o = op_producer[static_cast<size_t>(t)];
+                if (o < 0 || !band_op[static_cast<size_t>(o)]) continue;   // a constant, the graph input, or a tensor of another launch behind the cut
+                const int d = producer[static_cast<size_t>(t)];
+                if (d < 0) BAND_GIVE_UP;   // a tensor inside one of the program's blocks
+                const Storage& sp = plan_.storage[static_cast<size_t>(t)];
+                if (sp.root < 0 || (sp.offset & 3) || (sp.frame_stride & 3)) BAND_GIVE_UP;
+                bool is_out = false;
+                for (int go : g.outputs) is_out = is_out || plan_.storage[static_cast<size_t>(go)].root == sp.root;
+                if (is_out) { if (prog[static_cast<size_t>(d)].dst_base < 0) BAND_GIVE_UP; continue; }   // (already written where the launch reads it)
+                if (plan_.root_offset[static_cast<size_t>(sp.root)] < 0 || (plan_.root_offset[static_cast<size_t>(sp.root)] & 3)) BAND_GIVE_UP;
+                BandStage& pd = prog[static_cast<size_t>(d)];
+                if (pd.dst_base >= 0 || (pd.Co & 3)) BAND_GIVE_UP;
+                pd.dst_base = ext_slot(-1, t); pd.dst_off = 0; pd.dst_fs = sp.frame_stride;
+                if (pd.dst_base < 0) BAND_GIVE_UP;
+            }
+        }
+        if (!any_band || band_node_runs_[static_cast<size_t>(band_first_)]) BAND_GIVE_UP;
+        // the band launch writes its tensors EARLIER than the batched plan's launches would have: a launch that keeps its place in front of the
+        // last node the program stands for may only write graph outputs (an arena slot it writes might be one the program's tensors live in)
+        size_t last_inside = 0;
+        for (size_t i = static_cast<size_t>(band_first_); i < plan_.nodes.size(); i++)
+            if (!is_view(plan_.nodes[i]) && !band_node_runs_[i]) last_inside = i;
+        for (size_t i = static_cast<size_t>(band_first_); i < last_inside; i++) {
+            if (!band_node_runs_[i]) continue;
+            std::vector<int> outs = plan_.nodes[i].extra_out;
+            outs.push_back(plan_.nodes[i].out);
+            for (int t : outs) {
+                bool is_out = false;
+                for (int go : g.outputs) is_out = is_out || plan_.storage[static_cast<size_t>(go)].root == plan_.storage[static_cast<size_t>(t)].root;
+                if (!is_out) BAND_GIVE_UP;
+            }
+        }
+        // the nodes in front of the cut in the level-2 lowering must be exactly the program (nothing the batched plan computes is skipped)
+        for (size_t i = cut; i < p2.nodes.size(); i++)
+            for (int o : p2.nodes[i].src_ops)
+                if (band_op[static_cast<size_t>(o)]) BAND_GIVE_UP;
+    }
+    // every graph output must be written, whole, by the band program or by a launch behind it (the first convolution writes none of them)
     for (size_t k = 0; k < out_root.size(); k++) {
         size_t written = 0;
         for (const BandStage& st : prog)
-            if (st.dst_base == 2 + static_cast<int>(k)) written += static_cast<size_t>(st.Ho) * st.Wo * st.Co;
-        if (written != g.tensors[g.outputs[k]].elems()) return;
+            if (st.dst_base >= 2 && band_ext_[static_cast<size_t>(st.dst_base - 2)].out_k == static_cast<int>(k)) written += static_cast<size_t>(st.Ho) * st.Wo * st.Co;
+        bool later = false;
+        for (size_t i = static_cast<size_t>(band_first_); i < plan_.nodes.size(); i++)
+            if (band_node_runs_[i] && plan_.storage[static_cast<size_t>(plan_.nodes[i].out)].root == out_root[k]) later = true;
+        if (!later && written != g.tensors[g.outputs[k]].elems()) BAND_GIVE_UP;
     }
     // ---- the output heads (stages nobody reads) move up behind the first other reader of their input: the two LDS tiles hold a tensor
     // only until the trunk has moved on twice, and a head costs its workgroups two microseconds wherever it stands
     {
         const int N0 = static_cast<int>(prog.size());
         std::vector<char> read(static_cast<size_t>(N0), 0), placed(static_cast<size_t>(N0), 0);
-        for (const BandStage& st : prog)
+        for (const BandStage& st : prog) {
             if (st.dep >= 0) read[static_cast<size_t>(st.dep)] = 1;
+            if (st.res_dep >= 0) read[static_cast<size_t>(st.res_dep)] = 1;
+        }
         std::vector<int> order;
         for (int k = 0; k < N0; k++) {
             if (placed[static_cast<size_t>(k)]) continue;
@@ -811,52 +910,83 @@ void Model::build_bandnet() {
             BandStage st = prog[static_cast<size_t>(order[static_cast<size_t>(k)])];
             if (st.dep >= 0) {
                 st.dep = new_index[static_cast<size_t>(st.dep)];
-                if (st.dep >= k) return;   // (cannot happen: a head only moves down to behind a reader of its own input)
+                if (st.dep >= k) BAND_GIVE_UP;   // (cannot happen: a head only moves down to behind a reader of its own input)
+            }
+            if (st.res_dep >= 0) {
+                st.res_dep = new_index[static_cast<size_t>(st.res_dep)];
+                if (st.res_dep >= k) BAND_GIVE_UP;
             }
             re.push_back(st);
         }
         prog.swap(re);
     }
-    // ---- pass 2: who reads what -> LDS tiles (two, used in turn), packet buffers for the rows other workgroups read
+    // ---- pass 2: who reads what -> LDS tiles (placed by liveness; a straight chain uses two in turn), packet buffers for the rows other
+    // workgroups read
     const int NS = static_cast<int>(prog.size());
     std::vector<int> last_reader(static_cast<size_t>(NS), -1);
-    for (int k = 0; k < NS; k++)
-        if (prog[static_cast<size_t>(k)].dep >= 0) {
-            BandStage& pd = prog[static_cast<size_t>(prog[static_cast<size_t>(k)].dep)];
-            last_reader[static_cast<size_t>(prog[static_cast<size_t>(k)].dep)] = k;
-            if (prog[static_cast<size_t>(k)].kind == BAND_BLOCK && pd.nbands > 1) {
+    int input_last_reader = -1;   // ... of the program's input
+    for (int k = 0; k < NS; k++) {
+        const BandStage& st = prog[static_cast<size_t>(k)];
+        if (st.dep >= 0) {
+            BandStage& pd = prog[static_cast<size_t>(st.dep)];
+            last_reader[static_cast<size_t>(st.dep)] = k;
+            if (st.kind == BAND_BLOCK && pd.nbands > 1) {
                 pd.pub_lo = 1;
-                if (prog[static_cast<size_t>(k)].S == 1 && pd.R > 1) pd.pub_hi = 1;
+                if (st.S == 1 && pd.R > 1) pd.pub_hi = 1;
             }
+        } else {
+            input_last_reader = k;
         }
+        if (st.res_dep >= 0) last_reader[static_cast<size_t>(st.res_dep)] = k;
+        if (st.res_dep == -1) input_last_reader = k;
+    }
     long ws = 0;
-    int tile_floats = 0, dw_floats = 0;
-    int holder[2] = {-2, -2};   // stage whose output a tile holds (-1: the program's input, -2: nothing)
+    int tile_floats = 0, dw_floats = 0, ntiles = 2;
+    int holder[kBandTiles];   // stage whose output a tile holds (-1: the program's input, -2: nothing)
+    for (int& h : holder) h = -2;
+    auto tile_of = [&](int stage) {
+        for (int t = 0; t < kBandTiles; t++)
+            if (holder[t] == stage) return t;
+        return -1;
+    };
     for (int k = 0; k < NS; k++) {
         BandStage& st = prog[static_cast<size_t>(k)];
         if (st.dep < 0) {
-            // the program's input comes from global memory into tile 0: only its first reader may be such a stage
-            if (holder[0] != -2) return;
+            // the program's input comes from global memory into tile 0: only its first reader may be such a stage (a skip may read it there later)
+            if (holder[0] != -2) BAND_GIVE_UP;
             holder[0] = -1;
             st.src_tile = 0;
             const int rows = st.kind == BAND_BLOCK ? (st.S == 1 ? st.R + 2 : 2 * st.R + 2) : st.R + 1;
             tile_floats = std::max(tile_floats, rows * (st.W + 2) * (st.C + 4));
         } else {
-            if (holder[0] == st.dep) st.src_tile = 0;
-            else if (holder[1] == st.dep) st.src_tile = 1;
-            else return;   // its input is no longer in LDS
+            st.src_tile = tile_of(st.dep);
+            if (st.src_tile < 0) BAND_GIVE_UP;   // its input is no longer in LDS
             st.src_ll = prog[static_cast<size_t>(st.dep)].dst_ll;
-            if (st.kind == BAND_BLOCK && st.nbands > 1 && st.src_ll < 0) return;
+            if (st.kind == BAND_BLOCK && st.nbands > 1 && st.src_ll < 0) BAND_GIVE_UP;
+        }
+        if (st.res_dep >= -1) {
+            st.res_tile = tile_of(st.res_dep);
+            if (st.res_tile < 0) BAND_GIVE_UP;
+            // the skip is read at the output's pixel positions: its band must have the output's rows (same shape, same owners)
+            if (st.res_dep >= 0) {
+                const BandStage& rd = prog[static_cast<size_t>(st.res_dep)];
+                if (rd.Ho != st.Ho || rd.Wo != st.Wo || rd.Co != st.Co || rd.R != st.R || rd.wshift != st.wshift) BAND_GIVE_UP;
+            } else {
+                const BandStage& first = prog[0];   // (the stage that loaded the program's input: own rows at tile rows 1 ..)
+                if (first.dep >= 0 || first.H != st.Ho || first.W != st.Wo || first.C != st.Co || first.R != st.R || first.wshift != st.wshift || first.S != 1) BAND_GIVE_UP;
+            }
         }
         if (last_reader[static_cast<size_t>(k)] >= 0) {
-            st.dst_tile = 1 - st.src_tile;
-            const int victim = holder[st.dst_tile];
-            if (victim >= 0 && last_reader[static_cast<size_t>(victim)] > k) return;   // someone still reads what this tile holds
-            if (victim == -1) {   // (the program's input: any later reader?)
-                for (int j = k + 1; j < NS; j++)
-                    if (prog[static_cast<size_t>(j)].dep < 0) return;
+            int pick = -1;
+            for (int t = 0; t < kBandTiles && pick < 0; t++) {
+                if (t == st.src_tile || t == st.res_tile) continue;
+                const int h = holder[t];
+                if (h == -2 || (h >= 0 && last_reader[static_cast<size_t>(h)] <= k) || (h == -1 && input_last_reader <= k)) pick = t;
             }
-            holder[st.dst_tile] = k;
+            if (pick < 0) BAND_GIVE_UP;   // more tensors alive than tiles
+            st.dst_tile = pick;
+            holder[pick] = k;
+            ntiles = std::max(ntiles, pick + 1);
             tile_floats = std::max(tile_floats, bandnet_tile_floats(st.R, st.Wo, st.Co));
             if (st.pub_lo || st.pub_hi) {
                 st.dst_ll = ws;
@@ -869,14 +999,15 @@ void Model::build_bandnet() {
     dw_floats = static_cast<int>(align_up(dw_floats, 4));
     band_tile_floats_ = tile_floats;
     band_dw_floats_ = dw_floats;
-    band_lds_bytes_ = bandnet_lds_bytes(tile_floats, dw_floats, NS);
-    if (band_lds_bytes_ > 160 * 1024) return;
+    band_ntiles_ = ntiles;
+    band_lds_bytes_ = bandnet_lds_bytes(ntiles, tile_floats, dw_floats, NS);
+    if (band_lds_bytes_ > 160 * 1024) BAND_GIVE_UP;
     band_ws_frame_floats_ = std::max<long>(ws, 64);
     band_nstages_ = NS;
     consts.resize(consts.size() + 64, 0.f);
     std::vector<BandPacked> packed(prog.size());
     for (size_t k = 0; k < prog.size(); k++)
-        if (!bandnet_pack(prog[k], &packed[k])) return;
+        if (!bandnet_pack(prog[k], &packed[k])) BAND_GIVE_UP;
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_prog_), packed.size() * sizeof(BandPacked)), "hipMalloc band program");
     hip_check(hipMemcpy(d_band_prog_, packed.data(), packed.size() * sizeof(BandPacked), hipMemcpyHostToDevice), "upload band program");
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_consts_), consts.size() * sizeof(float)), "hipMalloc band constants");
@@ -891,6 +1022,8 @@ void Model::build_bandnet() {
     hip_check(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_band_fail_), h_band_fail_, 0), "hipHostGetDevicePointer");
     band_ready_ = true;
 }
+
+#undef BAND_GIVE_UP
 
 void Model::ensure_capacity(int batch) {
     int chunk = chunk_ > 0 ? std::min(chunk_, batch) : batch;
@@ -1063,7 +1196,15 @@ std::vector<Model::LaunchStat> Model::profile(const float* in, int batch, int re
     (void)saved_chunk;
     // plan nodes that ran inside the launch before them (a run of blocks on mstrip_chain_kernel): their work belongs to that launch
     for (size_t i = 1; i < stats.size();) {
-        if (stats[i].kernel == "(fused into previous launch)") {
+        if (stats[i].kernel == "(inside the band launch)") {   // its work belongs to the band launch, which need not be the entry in front of it
+            for (size_t j = 0; j < i; j++)
+                if (stats[j].kernel == "bandnet_kernel") {
+                    stats[j].ms += stats[i].ms; stats[j].bytes += stats[i].bytes; stats[j].macs += stats[i].macs;
+                    const size_t arrow = stats[i].detail.find("->"), parrow = stats[j].detail.find("->");
+                    if (arrow != std::string::npos && parrow != std::string::npos) stats[j].detail = stats[j].detail.substr(0, parrow) + stats[i].detail.substr(arrow);
+                }
+            stats.erase(stats.begin() + static_cast<long>(i));
+        } else if (stats[i].kernel == "(fused into previous launch)") {
             stats[i - 1].ms += stats[i].ms; stats[i - 1].bytes += stats[i].bytes; stats[i - 1].macs += stats[i].macs;
             const size_t arrow = stats[i].detail.find("->");
             const size_t parrow = stats[i - 1].detail.find("->");
@@ -1103,10 +1244,11 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
     for (size_t i = 0; i < plan_.nodes.size(); i++) {
         const Node& n = plan_.nodes[i];
         if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;  // views
-        if (band && static_cast<int>(i) >= band_first_) {
-            // the single-launch plan: everything behind the first convolution is this one launch (bandnet_kernels.hip)
+        if (band && static_cast<int>(i) >= band_first_ && !band_node_runs_[i]) {
+            // the single-launch plan: everything behind the first convolution is this one launch (bandnet_kernels.hip), but for the nodes behind
+            // the program's end (band_node_runs_), which keep their launches
             if (static_cast<int>(i) > band_first_) {
-                if (labels) labels->push_back("(fused into previous launch)");
+                if (labels) labels->push_back("(inside the band launch)");
                 mark();
                 continue;
             }
@@ -1117,7 +1259,11 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             long fs = 0;
             a.base[0] = d_band_ws_;
             a.base[1] = const_cast<float*>(tensor_ptr(band_stem_out_, in, chunk_start, &fs));
-            for (size_t k = 0; k < band_out_base_.size(); k++) a.base[band_out_base_[k]] = d_out_[k];
+            a.ntiles = band_ntiles_;
+            for (size_t k = 0; k < band_ext_.size(); k++) {
+                long efs = 0;
+                a.base[2 + k] = band_ext_[k].out_k >= 0 ? d_out_[static_cast<size_t>(band_ext_[k].out_k)] : tensor_ptr_mut(band_ext_[k].tensor, chunk_start, &efs);
+            }
             a.consts = d_band_consts_; a.sync = d_band_sync_; a.fail = d_band_fail_;
             int rc = 0;
             for (int rep_ = 0; rep_ < (marks ? profile_inner_ : 1) && rc == 0; rep_++) rc = launch_bandnet(a, trunk);

@@ -130,11 +130,14 @@ class Model {
     bool band_use_ = false;         // the run being enqueued takes it
     bool band_ran_ = false;         // the last run_device took it
     bool band_test_fail_ = false;   // option "band_test_fail"
-    int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it)
+    int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it that band_node_runs_ does not name)
     int band_stem_out_ = -1;        // tensor the first convolution writes = the band program's input
     int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_tile_floats_ = 0, band_dw_floats_ = 0;
     long band_ws_frame_floats_ = 0;
-    std::vector<int> band_out_base_;  // graph output k -> BandLaunch::base index
+    struct BandExt { int out_k = -1, tensor = -1; };   // BandLaunch::base[2 + j]: graph output out_k, or the arena storage of `tensor` (read by a launch behind the band program)
+    std::vector<BandExt> band_ext_;
+    std::vector<char> band_node_runs_;   // per plan_ node from band_first_ on: 1 = it runs as its own launch behind the band launch (the program stops in front of it)
+    int band_ntiles_ = 2;
     BandPacked* d_band_prog_ = nullptr;
     float* d_band_consts_ = nullptr;
     float* d_band_ws_ = nullptr;

@@ -438,7 +438,8 @@ int launch_project(const ProjArgs& a, void* stream);
 // workgroups of a frame sit on all eight XCDs, whose L2s are not coherent with each other) that the reader polls until both tags are
 // the producer stage's — no flag round trip, no wait for the stores, no launch boundary and no grid-wide barrier between blocks.
 enum BandKind : int { BAND_BLOCK = 0, BAND_PW = 1 };
-constexpr int kBandBases = 6;
+constexpr int kBandBases = 8;
+constexpr int kBandTiles = 4;
 struct alignas(16) BandStage {
     int kind = BAND_BLOCK;
     int S = 1;                   // BLOCK: DW3x3 stride (1: pad 1; 2: TF SAME on an even size, taps at 2o .. 2o+2)
@@ -450,11 +451,15 @@ struct alignas(16) BandStage {
     int nbands = 0;
     int dep = -1;                // stage that produces the input (-1: in global memory, complete before the launch)
     int Rin = 0;                 // input rows of this band that the workgroup owns (dep >= 0: the producer's R), from row S r0 on
-    int src_tile = 0;            // LDS tile (0 / 1) that holds the input band: rows [S r0 - 1, S r0 + Rin + 2) at tile rows 0 .., one zero pixel left and right
+    int src_tile = 0;            // LDS tile (0 .. kBandTiles - 1) that holds the input band: rows [S r0 - 1, S r0 + Rin + 2) at tile rows 0 .., one zero pixel left and right
     int dst_tile = -1;           // LDS tile the output band is left in for the stages that read it (-1: nobody does)
     int pub_lo = 0, pub_hi = 0;  // the first pub_lo and last pub_hi rows of the band also go to the packet buffer (other workgroups read them)
-    int src_base = 0, dst_base = -1;  // BandLaunch::base index of the input (dep < 0) / of a plain copy of the output (-1: none; graph outputs)
+    int src_base = 0, dst_base = -1;  // BandLaunch::base index of the input (dep < 0) / of a plain copy of the output (-1: none; graph outputs, and tensors
+                                 // the launches behind the band program read)
     int res_mode = RES_NONE;     // RES_DIRECT: the input itself (S == 1), RES_MAXPOOL: 2x2 max of the input (S == 2); channels >= C: zero (Co >= C)
+    int res_dep = -2;            // (host only) stage whose output the skip is when it is not the stage's input (-1: the program's input, -2: none)
+    int res_tile = -1;           // -1: the skip is the stage's own input; else RES_DIRECT from the tensor in this LDS tile (same rows, Co channels:
+                                 // the iris network's bottlenecks add the tensor in front of their 1x1 reduction)
     int act = ACT_NONE;
     long src_off = 0, dst_off = 0;   // floats from the base to frame 0 of the tensor
     long src_fs = 0, dst_fs = 0;     // floats between frames
@@ -478,10 +483,11 @@ bool bandnet_pack(const BandStage& st, BandPacked* out);
 struct BandLaunch {
     const BandPacked* prog = nullptr;
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
-    int tile_floats = 0;            // LDS: [tile 0][tile 1][depthwise result][small constants]
+    int ntiles = 2;                 // LDS tiles (2 .. kBandTiles)
+    int tile_floats = 0;            // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]
     int dw_floats = 0;
     long ws_frame_floats = 0;       // base[0]: floats between the frames' workspaces
-    float* base[kBandBases] = {};   // 0: the launch's own workspace (packet buffers), 1: the first stage's input, 2..: graph outputs
+    float* base[kBandBases] = {};   // 0: the launch's own workspace (packet buffers), 1: the first stage's input, 2..: graph outputs / tensors later launches read
     const float* consts = nullptr;
     unsigned* sync = nullptr;       // [0] generation (tags are 64 x generation + stage + 1), [1] workgroups finished
     int* fail = nullptr;            // set to 1 when a wait ran out of iterations (host-visible): the results of that launch are void
@@ -492,7 +498,7 @@ int launch_bandnet(const BandLaunch& a, void* stream);
 int bandnet_tile_floats(int R, int W, int C);
 int bandnet_dw_floats(const BandStage& st);
 int bandnet_const_floats(const BandStage& st);
-int bandnet_lds_bytes(int tile_floats, int dw_floats, int nstages);
+int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages);
 
 // Pointwise weight packing for the fused block kernel: [Co][C] (TFLite [O,1,1,I]) -> [Cop][Cp] zero padded.
 void block_weight_dims(int C, int Co, int* Cp, int* Cop);
