@@ -116,9 +116,11 @@ std::atomic<int> g_band_cus[64];
 struct BandClaim {
     int dev = 0, n = 0;
     bool ok = false;
-    BandClaim(mi::Model& m, int batch) {
-        dev = m.device();
-        n = m.band_workgroups(batch);
+    BandClaim(mi::Model& m, int batch) : BandClaim(m.device(), m.band_workgroups(batch)) {}
+    // (launches that follow one another on one stream share a claim of the largest of them)
+    BandClaim(int device, int workgroups) {
+        dev = device;
+        n = workgroups;
         if (n <= 0 || dev < 0 || dev >= 64) return;
         if (g_band_cus[dev].fetch_add(n) + n <= mi::device_cu_count()) ok = true;
         else g_band_cus[dev].fetch_sub(n);
@@ -1356,10 +1358,10 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
             p->sizes_B = B; p->sizes_w = width; p->sizes_h = height;
         }
-        // A picture or two from host memory (lib.rs:24-40 on one image): the detector may take its single-launch plan — this call holds
-        // the CUs until its synchronisation below, and repeats itself on the batched plan should that launch have given up.
+        // A picture or two from host memory (lib.rs:24-40 on one image): the detector and the face mesh may take their single-launch plans —
+        // this call holds the CUs until its synchronisation below, and repeats itself on the batched plan should such a launch have given up.
         std::unique_ptr<BandClaim> claim;
-        if (mem == MI_MEM_HOST) claim = std::make_unique<BandClaim>(fdm, B);
+        if (mem == MI_MEM_HOST) claim = std::make_unique<BandClaim>(fdm.device(), std::max(std::max(fdm.band_workgroups(B), flm.band_workgroups(B)), irm.band_workgroups(2 * B)));
         for (int attempt = 0; attempt < 2; attempt++) {
         const bool one_shot = claim && claim->ok && attempt == 0;
         // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
@@ -1386,7 +1388,7 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         float* d_in_lm = static_cast<float*>(p->in_lm.get(flm.input_elems() * sizeof(float) * B));
         mi::launch_pre_geom(it, d_geom, nullptr, s);
         mi::launch_pre_tensor(it, d_geom, d_in_lm, s);
-        flm.run_device(d_in_lm, B, s);
+        flm.run_device(d_in_lm, B, s, one_shot);
         float* d_lm = mem == MI_MEM_DEVICE ? landmarks : static_cast<float*>(p->lm.get(sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B));
         int* d_present = mem == MI_MEM_DEVICE ? present : static_cast<int*>(p->present.get(sizeof(int) * B));
         {
@@ -1410,7 +1412,7 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         float* d_in_eye = static_cast<float*>(p->in_eye.get(irm.input_elems() * sizeof(float) * 2 * B));
         mi::launch_pre_geom(it, d_geom, d_pad_eye, s);
         mi::launch_pre_tensor(it, d_geom, d_in_eye, s);
-        irm.run_device(d_in_eye, 2 * B, s);
+        irm.run_device(d_in_eye, 2 * B, s, one_shot);
         const long eye_fs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
         float* d_eyes = mem == MI_MEM_DEVICE ? eyes : static_cast<float*>(p->eyes.get(sizeof(float) * eye_fs * 2 * B));
         for (int k = 0; k < 2; k++) {
@@ -1433,7 +1435,7 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
             mi::hip_check(hipMemcpyAsync(present, d_present, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H present");
             mi::hip_check(hipMemcpyAsync(eyes, d_eyes, sizeof(float) * eye_fs * 2 * B, hipMemcpyDeviceToHost, s), "D2H eyes");
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
-            if (one_shot && fdm.band_failed()) continue;
+            if (one_shot && (static_cast<int>(fdm.band_failed()) | static_cast<int>(flm.band_failed()) | static_cast<int>(irm.band_failed()))) continue;
             for (int b = 0; b < B; b++) {
                 if (face_counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
                 if (face_counts[b] == 0) std::memset(&faces[b], 0, sizeof(mi_detection));

@@ -842,6 +842,7 @@ void Model::build_bandnet() {
                 if (is_out) { if (prog[static_cast<size_t>(d)].dst_base < 0) BAND_GIVE_UP; continue; }   // (already written where the launch reads it)
                 if (plan_.root_offset[static_cast<size_t>(sp.root)] < 0 || (plan_.root_offset[static_cast<size_t>(sp.root)] & 3)) BAND_GIVE_UP;
                 BandStage& pd = prog[static_cast<size_t>(d)];
+                if (pd.dst_base >= 2 && band_ext_[static_cast<size_t>(pd.dst_base - 2)].tensor == t) continue;   // (a second reader of the same tensor)
                 if (pd.dst_base >= 0 || (pd.Co & 3)) BAND_GIVE_UP;
                 pd.dst_base = ext_slot(-1, t); pd.dst_off = 0; pd.dst_fs = sp.frame_stride;
                 if (pd.dst_base < 0) BAND_GIVE_UP;
@@ -1231,7 +1232,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
     // heads beside the trunk (not while profiling: the per-launch events there assume one stream)
     // (with several lanes the chunks already overlap; the head streams and node events are one set per model, and sharing
     // them between concurrently captured lanes crashes hipGraph capture)
-    const bool fork = fork_ && !marks && lanes_ == 1 && !band_use_;
+    const bool fork = fork_ && !marks && lanes_ == 1;
     hipStream_t const trunk = s;
     unsigned used_heads = 0;
     auto node_event = [&](size_t k) {
@@ -1268,6 +1269,10 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             int rc = 0;
             for (int rep_ = 0; rep_ < (marks ? profile_inner_ : 1) && rc == 0; rep_++) rc = launch_bandnet(a, trunk);
             if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+            // launches behind the program that run beside the trunk wait for the node that made their input: every such node inside the
+            // program is this launch
+            for (size_t j = i; fork && j < plan_.nodes.size(); j++)
+                if (!band_node_runs_[j] && event_after_[j]) hip_check(record_event(node_event(j), trunk), "hipEventRecord");
             mark();
             continue;
         }
@@ -1279,7 +1284,10 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             continue;
         }
         s = trunk;
-        if (fork && head_slot_[i] >= 0) {
+        // (a whole-frame convolution right behind the band launch stays on the trunk: the face mesh's two heads are 9 + 11 us, a side stream's
+        // events cost more than they hide — FaceLandmark::infer 208 us forked, 190 us in line)
+        const bool in_line = band && n.gemm_head && head_wait_[i] >= 0 && !band_node_runs_[static_cast<size_t>(head_wait_[i])];
+        if (fork && head_slot_[i] >= 0 && !in_line) {
             while (static_cast<int>(head_streams_.size()) <= head_slot_[i]) {
                 hipStream_t st;
                 hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");

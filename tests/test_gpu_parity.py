@@ -371,14 +371,15 @@ def test_tail_programs_on_other_shapes(gpu, oracle, synth_models, case):
     m.close()
 
 
-@pytest.mark.parametrize("name,frames", [("back", 2), ("front", 4), ("short", 4), ("landmark", 2)])
+@pytest.mark.parametrize("name,frames", [("back", 2), ("front", 4), ("short", 4), ("landmark", 2), ("iris", 8)])
 def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames):
     """Round 5: the single-image plan (bandnet_kernels.hip) — everything behind the first convolution ONE launch, a row band per workgroup
     kept in LDS, halo rows handed over as tagged packets.  Option "band" = 2 runs it for every call of few enough frames: against the
     oracle frame by frame, against the batched plan (band = 0), run-to-run bit-identical (the arithmetic does not depend on who arrives
     first), eager and as a replayed graph, with one and with several rows per band, and one frame beyond what a launch takes.  The face
     mesh's program stops in front of its two whole-frame convolutions, which keep their launches behind it (three LDS tiles: the 6x6
-    tensor has two readers)."""
+    tensor has two readers); the iris network's stops in front of its first 2x2 convolution (eight stages, the bottlenecks' skips read
+    from a third tile)."""
     torch = pytest.importorskip("torch")
     m = gpu.Model(model_path(name))
     assert m.single_launch_workgroups(1) > 0 and m.single_launch_workgroups(frames) == frames * m.single_launch_workgroups(1)
@@ -403,12 +404,14 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
                     np.testing.assert_array_equal(o, o2)
     m.set_option("graph", 1)
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
-    assert labels[1:] == ["bandnet_kernel"] + (["head_gemm_kernel"] * 2 if name == "landmark" else []), labels
+    behind = {"landmark": ["head_gemm_kernel"] * 2,
+              "iris": ["resident_kernel", "bneck_kernel", "resident_kernel", "tail_kernel", "head_gemm_kernel", "tail_kernel", "head_gemm_kernel"]}.get(name, [])
+    assert labels[1:] == ["bandnet_kernel"] + behind, labels
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
     assert "bandnet_kernel" not in labels, labels
     # fewer workgroups per frame: several rows per band (both edge rows of a band travel), more frames per launch
     one = [o.copy() for o in m.run(x[:1])]
-    for nw in {"back": (128,), "landmark": (48,)}.get(name, (32,)):
+    for nw in {"back": (128,), "landmark": (48,), "iris": (16,)}.get(name, (32,)):
         m.set_option("band_nw", nw)
         assert m.single_launch_workgroups(1) == nw
         for nb in (1, 3):
@@ -423,7 +426,7 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
 
 
 def test_single_launch_plan_only_where_the_graph_has_one(gpu):
-    for name in ("full", "iris"):
+    for name in ("full", "sparse"):
         m = gpu.Model(model_path(name))
         assert m.single_launch_workgroups(1) == 0, name
         m.close()
