@@ -1835,7 +1835,20 @@ bool Model::band_failed() {
 }
 
 void Model::run_graph_or_eager(const float* in, int batch, hipStream_t s, const GraphKey& key) {
-    if (!use_graph_) {
+    // A single-launch run that is two launches in all (first convolution + band program) goes out eagerly: replaying a two-node graph costs
+    // more than it saves (tools/probes/graph_probe.py: FaceDetection::infer BackCamera 252 -> 242 us, Short 170 -> 160; with the face mesh's
+    // two more launches behind the program the graph wins again, 191 against 200 us)
+    bool eager = !use_graph_;
+    if (band_use_ && !eager) {
+        int launches = 1;
+        for (size_t i = 0; i < plan_.nodes.size(); i++) {
+            const Node& n = plan_.nodes[i];
+            if (n.kind == Node::Reshape || n.kind == Node::Concat) continue;
+            if (static_cast<int>(i) < band_first_ || band_node_runs_[i]) launches++;
+        }
+        eager = launches <= 2;
+    }
+    if (eager) {
         enqueue_all(in, batch, s);
         return;
     }
