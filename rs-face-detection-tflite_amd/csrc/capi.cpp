@@ -1362,6 +1362,9 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         // this call holds the CUs until its synchronisation below, and repeats itself on the batched plan should such a launch have given up.
         std::unique_ptr<BandClaim> claim;
         if (mem == MI_MEM_HOST) claim = std::make_unique<BandClaim>(fdm.device(), std::max(std::max(fdm.band_workgroups(B), flm.band_workgroups(B)), irm.band_workgroups(2 * B)));
+        static const bool ptrace = getenv("MI_PIPE_TRACE") != nullptr;
+        auto t_start = std::chrono::steady_clock::now();
+        auto tr = [&](const char* what) { if (ptrace) std::fprintf(stderr, "  %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count()); };
         for (int attempt = 0; attempt < 2; attempt++) {
         const bool one_shot = claim && claim->ok && attempt == 0;
         // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
@@ -1373,7 +1376,9 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         float* d_in_det = static_cast<float*>(p->in_det.get(fdm.input_elems() * sizeof(float) * B));
         mi::launch_pre_geom(it, d_geom, d_pad_det, s);
         mi::launch_pre_tensor(it, d_geom, d_in_det, s);
+        tr("pre det");
         fdm.run_device(d_in_det, B, s, one_shot);
+        tr("det run_device");
         float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
         mi::hip_check(hipMemsetAsync(d_dets, 0, sizeof(mi_detection) * cap * B, s), "hipMemsetAsync");  // frames without a face report zeros
         int* d_counts = mem == MI_MEM_DEVICE ? face_counts : static_cast<int*>(p->counts.get(sizeof(int) * B));
@@ -1382,13 +1387,16 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         // ---- 2. faces[0] -> face_detection_to_roi -> image_to_tensor(frame, roi, (192,192), false, (0,1)) -> mesh net
         auto* d_roi_face = static_cast<mi::RectD*>(p->roi_face.get(sizeof(mi::RectD) * B));
         int* d_valid_face = static_cast<int*>(p->valid_face.get(sizeof(int) * B));
+        tr("fd_post");
         mi::launch_face_rois(d_dets, d_counts, B, cap, width, height, d_roi_face, d_valid_face, s);
         it.rois = d_roi_face; it.roi_valid = d_valid_face; it.out_w = p->fl->in_w; it.out_h = p->fl->in_h; it.keep_aspect = 0;
         it.range_min = 0.0; it.range_max = 1.0;
         float* d_in_lm = static_cast<float*>(p->in_lm.get(flm.input_elems() * sizeof(float) * B));
         mi::launch_pre_geom(it, d_geom, nullptr, s);
         mi::launch_pre_tensor(it, d_geom, d_in_lm, s);
+        tr("pre mesh");
         flm.run_device(d_in_lm, B, s, one_shot);
+        tr("mesh run_device");
         float* d_lm = mem == MI_MEM_DEVICE ? landmarks : static_cast<float*>(p->lm.get(sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B));
         int* d_present = mem == MI_MEM_DEVICE ? present : static_cast<int*>(p->present.get(sizeof(int) * B));
         {
@@ -1412,7 +1420,9 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         float* d_in_eye = static_cast<float*>(p->in_eye.get(irm.input_elems() * sizeof(float) * 2 * B));
         mi::launch_pre_geom(it, d_geom, d_pad_eye, s);
         mi::launch_pre_tensor(it, d_geom, d_in_eye, s);
+        tr("pre iris");
         irm.run_device(d_in_eye, 2 * B, s, one_shot);
+        tr("iris run_device");
         const long eye_fs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
         float* d_eyes = mem == MI_MEM_DEVICE ? eyes : static_cast<float*>(p->eyes.get(sizeof(float) * eye_fs * 2 * B));
         for (int k = 0; k < 2; k++) {
@@ -1425,9 +1435,11 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
             if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
         }
         // ---- top-1 faces out (strided gather [B][cap][17] -> [B][17]) and host copies
+        tr("projections");
         mi_detection* d_faces = mem == MI_MEM_DEVICE ? faces : static_cast<mi_detection*>(p->faces.get(sizeof(mi_detection) * B));
         mi::hip_check(hipMemcpy2DAsync(d_faces, sizeof(mi_detection), d_dets, sizeof(mi_detection) * cap, sizeof(mi_detection), B,
                                        hipMemcpyDeviceToDevice, s), "gather faces");
+        tr("gather");
         if (mem == MI_MEM_HOST) {
             mi::hip_check(hipMemcpyAsync(faces, d_faces, sizeof(mi_detection) * B, hipMemcpyDeviceToHost, s), "D2H faces");
             mi::hip_check(hipMemcpyAsync(face_counts, d_counts, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H counts");

@@ -15,13 +15,13 @@ python3 tools/bench_configs.py > "$OUT/configs.log" 2>&1; echo configs done
 for m in "back 256" "front 256" "full 128" "landmark 512" "iris 1024"; do set -- $m; python3 tools/profile_model.py $1 $2 2>/dev/null | grep -v amdgpu > "$OUT/launches_$1.txt"; done; echo launches done
 CONFIGS=${CONFIGS:-"2 1 3 5"}   # (CONFIGS="3" for a quick partial collection)
 for c in $CONFIGS; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --warmup 10 --steps 100 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --no-event-profile --single-window > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window > "$OUT/fetch_c$c.log" 2>&1; echo fetch $c done
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window > "$OUT/write_c$c.log" 2>&1; echo write $c done
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --warmup 10 --steps 100 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --no-event-profile --single-window --in-flight 1 > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window --in-flight 1 > "$OUT/fetch_c$c.log" 2>&1; echo fetch $c done
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window --in-flight 1 > "$OUT/write_c$c.log" 2>&1; echo write $c done
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
     i=$((i+1))
-    rocprofv3 --pmc $set --output-format csv -d "$OUT/sq${i}_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window > "$OUT/sq${i}_c$c.log" 2>&1; echo sq pass $i config $c done
+    rocprofv3 --pmc $set --output-format csv -d "$OUT/sq${i}_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window --in-flight 1 > "$OUT/sq${i}_c$c.log" 2>&1; echo sq pass $i config $c done
   done
 done
 python3 tools/summarize_profiles.py "$TAG" "$OUT/summary" > "$OUT/summarize.log" 2>&1 || { tail -5 "$OUT/summarize.log"; exit 1; }
