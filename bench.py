@@ -485,7 +485,7 @@ def run_rank(args):
     B = args.batch or DEFAULT_BATCH[args.config]
     L = mi.lib()
     x_host = None
-    NW = max(1, min(int(args.in_flight), 2))   # batches in flight: consecutive steps alternate between NW handles on NW streams
+    NW = max(1, min(int(args.in_flight), 4))   # batches in flight: consecutive steps alternate between NW handles on NW streams
 
     def check(rc):
         if rc != 0:
@@ -572,8 +572,8 @@ def run_rank(args):
     # handles own side streams of their own: two streams that land on ONE hardware queue run strictly one after the other (what round 4's
     # two-stream probe measured without knowing it).  So the pair of streams is CHOSEN: a few steps are timed on (stream 0, stream j) for a
     # handful of candidates, outside the timed region, and the fastest pair is kept (`timing.stream_pair_probe_ms`).
-    cand = [torch.cuda.Stream(device=device) for _ in range(6 if NW > 1 else 1)]
-    spp = [C.c_void_p(cand[0].cuda_stream), C.c_void_p(cand[0].cuda_stream)]
+    cand = [torch.cuda.Stream(device=device) for _ in range(4 + NW if NW > 1 else 1)]
+    spp = [C.c_void_p(cand[0].cuda_stream) for _ in range(NW)]
     state = {"i": 0}
 
     def step():
@@ -591,14 +591,21 @@ def run_rank(args):
 
     pair_probe = {}
     if NW > 1:
-        for _ in range(4):
+        for _ in range(2 * NW):
             step()
-        for j in range(1, len(cand)):
-            spp[1] = C.c_void_p(cand[j].cuda_stream)
-            time_steps(4)
-            pair_probe[j] = round(time_steps(12), 4)
-        best = min(pair_probe, key=pair_probe.get)
-        spp[1] = C.c_void_p(cand[best].cuda_stream)
+        used = {0}
+        for k in range(1, NW):   # worker k's stream: the candidate that gives the shortest step beside the streams chosen so far
+            probe = {}
+            for j in range(1, len(cand)):
+                if j in used:
+                    continue
+                spp[k] = C.c_void_p(cand[j].cuda_stream)
+                time_steps(2 * NW)
+                probe[j] = round(time_steps(6 * NW), 4)
+            best = min(probe, key=probe.get)
+            spp[k] = C.c_void_p(cand[best].cuda_stream)
+            used.add(best)
+            pair_probe["worker %d" % k] = probe
         state["i"] = 0
 
     # ---- per-launch HIP-event pass for the roofline object (eager replays of the same plans on resident inputs of the same shapes, grouped
@@ -802,7 +809,7 @@ def main():
     ap.add_argument("--latency-calls", type=int, default=200)
     ap.add_argument("--gather", action="store_true", help="N > 1: collect every rank's per-frame detection counts on rank 0 (dist.gather_counts), outside the timed window")
     ap.add_argument("--rehearse", action="store_true", help="CPU rehearsal of the multi-rank plumbing over gloo (no kernels)")
-    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="batches in flight: 2 = consecutive steps alternate between two handles on two streams (default), 1 = one handle")
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2, 3, 4], help="batches in flight: 2 = consecutive steps alternate between two handles on two streams (default), 1 = one handle")
     ap.add_argument("--fuse", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--lanes", type=int, default=None)
