@@ -1364,3 +1364,49 @@ def test_dist_broadcast_bytes_world1(gpu, tmp_path):
         gpu.dist_broadcast_bytes(idf, 1, 1, 0, blob)          # rank outside the world
     with pytest.raises(gpu.MiError):
         gpu.dist_broadcast_bytes(str(tmp_path / "never_written"), 1, 2, 0, None, nbytes=16, timeout_ms=50)   # no root: times out, no hang
+
+
+def test_two_batches_in_flight_equal_one_at_a_time(gpu, man_image):
+    """bench.py keeps two batches in flight: consecutive steps alternate between two handles on two streams ("Two batches
+    in flight").  Whatever pair of streams is taken — on one hardware queue the batches simply follow each other, on two they overlap — every
+    batch's results must be bit-equal to the same batch run alone: the handles share no device state (arena, replay graphs, packet buffers,
+    the CU count of the single-launch plan is per call).  Detector (64 frames, two different inputs) and the device pipeline (16 frames)."""
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(3)
+    xs = [torch.from_numpy(rs.uniform(-1, 1, (64, 256, 256, 3)).astype(np.float32)).cuda() for _ in range(2)]
+    fds = [gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera) for _ in range(2)]
+    alone = []
+    for k in range(2):
+        o, c = fds[k].infer_tensor(xs[k], cap=8)
+        torch.cuda.synchronize()
+        alone.append((o.clone(), c.clone()))
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    for j in range(1, 5):
+        ss = (streams[0], streams[j])
+        outs = [(torch.zeros((64, 8, 17), device="cuda"), torch.zeros((64,), dtype=torch.int32, device="cuda")) for _ in range(2)]
+        torch.cuda.synchronize()
+        for i in range(12):
+            k = i & 1
+            fds[k].infer_tensor(xs[k], cap=8, out=outs[k][0], counts=outs[k][1], stream=ss[k].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(outs[k][0], alone[k][0]) and torch.equal(outs[k][1], alone[k][1]), (j, k)
+    for fd in fds:
+        fd.close()
+    frames = np.stack([np.roll(man_image[:192, 100:292], (3 * i, -2 * i), axis=(0, 1)) for i in range(16)]).astype(np.uint8)
+    ft = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    pipes = [gpu.Pipeline(gpu.FaceDetectionModel.Full) for _ in range(2)]
+    want = pipes[0].run(ft)
+    torch.cuda.synchronize()
+    want = {k: v.clone() for k, v in want.items()}
+    for j in (1, 2, 3, 4):
+        ss = (streams[0], streams[j])
+        got = [None, None]
+        for i in range(6):
+            got[i & 1] = pipes[i & 1].run(ft, stream=ss[i & 1].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2):
+            for name in want:
+                assert torch.equal(got[k][name], want[name]), (j, k, name)
+    for p in pipes:
+        p.close()
