@@ -107,6 +107,10 @@ extern "C" {
     pub fn mi_dist_broadcast_bytes(id_path: *const c_char, rank: c_int, world: c_int, root: c_int, device: c_int, buf: *mut u8, nbytes: usize,
                                    timeout_ms: c_int) -> c_int;
 
+    // two batches in flight: n hipStream_t's tested to sit on distinct hardware queues
+    pub fn mi_streams_create_distinct(device: c_int, n: c_int, streams: *mut *mut c_void) -> c_int;
+    pub fn mi_streams_destroy(device: c_int, n: c_int, streams: *mut *mut c_void) -> c_int;
+
     // batched detector -> mesh -> iris flow on the device (no counterpart in the reference: lib.rs:24-40 per frame)
     pub fn mi_pipeline_create(fd_kind: c_int, model_dir: *const c_char, device: c_int, out: *mut *mut mi_pipeline) -> c_int;
     pub fn mi_pipeline_free(p: *mut mi_pipeline);

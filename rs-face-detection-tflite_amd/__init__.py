@@ -8,5 +8,5 @@ import it as `rs_face_detection_tflite_amd` (shim module at the repo root).
 from .api import (  # noqa: F401
     DEFAULT_MODEL_DIR, EXPORTS, LIB_PATH, MI_MEM_DEVICE, MI_MEM_HOST, Detection, FaceDetection, FaceDetectionModel,
     FaceLandmark, IrisLandmark, IrisResults, Landmark, MiError, Model, PinnedBuffer, Pipeline, Rect, device_count, face_detection_to_roi,
-    bbox_from_landmarks, bbox_to_roi, convert_image_to_mat, image_to_tensor, iris_roi_from_face_landmarks, jpeg_info, lib, plan_describe, dist_broadcast_bytes, update_face_landmarks_with_iris_results,
+    bbox_from_landmarks, bbox_to_roi, convert_image_to_mat, image_to_tensor, iris_roi_from_face_landmarks, jpeg_info, lib, plan_describe, dist_broadcast_bytes, streams_create_distinct, streams_destroy, update_face_landmarks_with_iris_results,
 )

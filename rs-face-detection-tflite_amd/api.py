@@ -31,7 +31,7 @@ EXPORTS = [
     "mi_last_error", "mi_device_count", "mi_version",
     "mi_model_load_file", "mi_model_load_bytes", "mi_model_free", "mi_model_input_dims", "mi_model_num_outputs",
     "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
-    "mi_dist_broadcast_bytes", "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
+    "mi_dist_broadcast_bytes", "mi_streams_create_distinct", "mi_streams_destroy", "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
     "mi_fd_collect", "mi_host_alloc", "mi_host_free",
@@ -266,6 +266,24 @@ def dist_broadcast_bytes(id_path, rank, world, root, data, nbytes=None, device=0
     L.mi_dist_broadcast_bytes.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
     _check(L.mi_dist_broadcast_bytes(os.fsencode(id_path), rank, world, root, device, buf, n, timeout_ms))
     return bytes(buf)
+
+
+def streams_create_distinct(n=2, device=0):
+    """mi_streams_create_distinct: n hipStream_t handles (ints) that were tested to sit on distinct hardware queues — pass them as the
+    `stream` argument of the batched entries of n handles to keep n batches in flight.  Free with streams_destroy."""
+    L = lib()
+    arr = (C.c_void_p * n)()
+    L.mi_streams_create_distinct.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    _check(L.mi_streams_create_distinct(int(device), int(n), arr))
+    return [int(v) for v in arr]
+
+
+def streams_destroy(streams, device=0):
+    L = lib()
+    n = len(streams)
+    arr = (C.c_void_p * n)(*[C.c_void_p(s) for s in streams])
+    L.mi_streams_destroy.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    _check(L.mi_streams_destroy(int(device), n, arr))
 
 
 def plan_describe(tflite_bytes: bytes, fuse_level=4) -> str:

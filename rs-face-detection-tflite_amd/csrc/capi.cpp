@@ -1477,6 +1477,81 @@ struct Rccl {
 };
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ streams on distinct hardware queues
+// HIP streams share the device's hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in the order they are first used; work on two streams of
+// one queue runs strictly in order.  A host that keeps two batches in flight on two handles needs two streams that do NOT share a queue, and
+// HIP has no call that tells: so the streams are created one by one and each candidate is TESTED — an idle wave of 40 us goes to every stream
+// accepted so far and to the candidate at once; side by side the set takes 40 us, one after the other a multiple.
+int mi_streams_create_distinct(int device, int n, void** streams) {
+    return guarded([&] {
+        require(streams != nullptr, "null argument");
+        require(n >= 1 && n <= 4, "n must be 1 .. 4");
+        mi::hip_check(hipSetDevice(device), "hipSetDevice");
+        for (int k = 0; k < n; k++) streams[k] = nullptr;
+        int* sink = nullptr;
+        mi::hip_check(hipMalloc(reinterpret_cast<void**>(&sink), sizeof(int)), "hipMalloc");
+        std::vector<hipStream_t> accepted, rejected;
+        auto cleanup = [&](bool all) {
+            for (hipStream_t s : rejected) hipStreamDestroy(s);
+            if (all) for (hipStream_t s : accepted) hipStreamDestroy(s);
+            hipFree(sink);
+        };
+        const long long ticks = 40 * 100;   // 40 us of the 100 MHz wall clock
+        auto timed_together = [&](hipStream_t cand) {
+            double best = 1e30;
+            for (int rep = 0; rep < 3; rep++) {
+                for (hipStream_t s : accepted) mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+                mi::hip_check(hipStreamSynchronize(cand), "hipStreamSynchronize");
+                const auto t0 = std::chrono::steady_clock::now();
+                for (hipStream_t s : accepted)
+                    if (mi::launch_spin(ticks, 1 << 20, sink, s) != 0) throw std::runtime_error("spin kernel launch failed");
+                if (mi::launch_spin(ticks, 1 << 20, sink, cand) != 0) throw std::runtime_error("spin kernel launch failed");
+                for (hipStream_t s : accepted) mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+                mi::hip_check(hipStreamSynchronize(cand), "hipStreamSynchronize");
+                best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+            }
+            return best;
+        };
+        try {
+            for (int tries = 0; tries < 16 && static_cast<int>(accepted.size()) < n; tries++) {
+                hipStream_t c = nullptr;
+                mi::hip_check(hipStreamCreateWithFlags(&c, hipStreamNonBlocking), "hipStreamCreate");
+                if (accepted.empty()) {
+                    if (mi::launch_spin(ticks, 1 << 20, sink, c) != 0) throw std::runtime_error("spin kernel launch failed");   // (first use: the stream gets its queue)
+                    mi::hip_check(hipStreamSynchronize(c), "hipStreamSynchronize");
+                    accepted.push_back(c);
+                    continue;
+                }
+                // side by side: about one idle wave (40 us + launch and synchronisation cost); sharing a queue with any accepted stream: two or more
+                if (timed_together(c) < 1.6 * 40.0 + 30.0 * static_cast<double>(accepted.size())) accepted.push_back(c);
+                else rejected.push_back(c);
+            }
+        } catch (...) {
+            cleanup(true);
+            throw;
+        }
+        if (static_cast<int>(accepted.size()) < n) {
+            cleanup(true);
+            throw ApiError(MI_EDEVICE, "could not find that many streams on distinct hardware queues (GPU_MAX_HW_QUEUES?)");
+        }
+        for (int k = 0; k < n; k++) streams[k] = accepted[static_cast<size_t>(k)];
+        cleanup(false);
+    });
+}
+
+int mi_streams_destroy(int device, int n, void** streams) {
+    return guarded([&] {
+        require(streams != nullptr && n >= 0, "bad argument");
+        mi::hip_check(hipSetDevice(device), "hipSetDevice");
+        for (int k = 0; k < n; k++)
+            if (streams[k]) {
+                mi::hip_check(hipStreamSynchronize(static_cast<hipStream_t>(streams[k])), "hipStreamSynchronize");
+                mi::hip_check(hipStreamDestroy(static_cast<hipStream_t>(streams[k])), "hipStreamDestroy");
+                streams[k] = nullptr;
+            }
+    });
+}
+
 int mi_dist_broadcast_bytes(const char* id_path, int rank, int world, int root, int device, uint8_t* buf, size_t nbytes, int timeout_ms) {
     return guarded([&] {
         require(id_path && buf, "null argument");

@@ -783,4 +783,19 @@ int launch_project(const ProjArgs& a, void* stream) {
     return (int)hipGetLastError();
 }
 
+// One wave that does nothing for `ticks` of the 100 MHz wall clock (bounded: it leaves after `max_iters` looks at the clock whatever the
+// clock says).  mi_streams_create_distinct launches it on several streams at once: streams that share a hardware queue run it one after
+// the other, streams on different queues side by side.
+__global__ void spin_kernel(long long ticks, int max_iters, int* sink) {
+    const long long t0 = wall_clock64();
+    int it = 0;
+    while (wall_clock64() - t0 < ticks && ++it < max_iters) __builtin_amdgcn_s_sleep(8);
+    if (ticks < 0) *sink = it;
+}
+
+int launch_spin(long long ticks, int max_iters, int* sink, void* stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks, max_iters, sink);
+    return (int)hipGetLastError();
+}
+
 }  // namespace mi

@@ -430,6 +430,7 @@ int launch_depth_to_space(const EltArgs& a, void* stream);
 int launch_copy_strided(const EltArgs& a, void* stream);
 int launch_postprocess(const PostArgs& a, void* stream);
 int launch_project(const ProjArgs& a, void* stream);
+int launch_spin(long long ticks, int max_iters, int* sink, void* stream);   // one idle wave for `ticks` of the 100 MHz wall clock (bounded)
 
 // ---- bandnet_kernels.hip: a whole BlazeBlock network behind its first convolution as ONE launch, for the handful of frames of a
 // single-image call (face_detection.rs:205: one Mat per call).  NW workgroups per frame; every stage (one BlazeBlock or one 1x1

@@ -1410,3 +1410,30 @@ def test_two_batches_in_flight_equal_one_at_a_time(gpu, man_image):
                 assert torch.equal(got[k][name], want[name]), (j, k, name)
     for p in pipes:
         p.close()
+
+
+def test_streams_on_distinct_hardware_queues(gpu):
+    """mi_streams_create_distinct: the streams it returns were tested to run side by side; two detector handles alternating on them give
+    the results of one handle, and destroying clears the slots.  (A request for more queues than the device has must fail cleanly.)"""
+    torch = pytest.importorskip("torch")
+    ss = gpu.streams_create_distinct(2)
+    assert len(ss) == 2 and ss[0] and ss[1] and ss[0] != ss[1]
+    rs = np.random.RandomState(4)
+    x = torch.from_numpy(rs.uniform(-1, 1, (32, 128, 128, 3)).astype(np.float32)).cuda()
+    fds = [gpu.FaceDetection(gpu.FaceDetectionModel.Short) for _ in range(2)]
+    want, wc = fds[0].infer_tensor(x, cap=8)
+    torch.cuda.synchronize()
+    outs = [(torch.zeros((32, 8, 17), device="cuda"), torch.zeros((32,), dtype=torch.int32, device="cuda")) for _ in range(2)]
+    for i in range(10):
+        fds[i & 1].infer_tensor(x, cap=8, out=outs[i & 1][0], counts=outs[i & 1][1], stream=ss[i & 1])
+    torch.cuda.synchronize()
+    for o, c in outs:
+        assert torch.equal(o, want) and torch.equal(c, wc)
+    for fd in fds:
+        fd.close()
+    gpu.streams_destroy(ss)
+    three = gpu.streams_create_distinct(3)
+    assert len(set(three)) == 3
+    gpu.streams_destroy(three)
+    with pytest.raises(gpu.MiError):
+        gpu.streams_create_distinct(5)
