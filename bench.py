@@ -507,6 +507,10 @@ def run_rank(args):
             for key in ("fuse", "chunk", "lanes", "heads"):
                 if getattr(args, key) is not None:
                     fd.model.set_option(key, getattr(args, key))
+            if NW > 1:
+                # with another batch in flight the row pipelines take whole frames as bands: fewer fill steps, and the CUs a short grid leaves idle
+                # are the other batch's (profiles/r05_in_flight.txt: 1.221 -> 1.194 ms; with ONE batch in flight the automatic choice is better)
+                fd.model.set_option("pipe_band", 4096)
             for kv in args.opt:
                 kk, v = kv.split("=")
                 fd.model.set_option(kk, int(v))
@@ -654,6 +658,12 @@ def run_rank(args):
     # the same K steps with ONE batch in flight (one handle, one stream), for comparison (extra key, never `value`)
     one_in_flight_ms = None
     if NW > 1:
+        if args.config in (1, 2):
+            # ... with the band sizes that are best for one batch in flight (the automatic ones); the recorded per-launch pass for `roofline`
+            # below runs on this handle too: it describes every kernel running alone, like the rocprofv3 passes (--in-flight 1)
+            workers[0]["keep"][0].model.set_option("pipe_band", 0)
+            for _ in range(3):
+                workers[0]["step"](spp[0])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -684,7 +694,9 @@ def run_rank(args):
                        "in_flight_note": ("consecutive steps alternate between %d handles (each with its own arena, replay graphs and result buffers) on %d streams, so the "
                                           "tail of batch n runs beside the head of batch n + 1; every step is still one full pass over one batch and the K steps are "
                                           "bracketed by synchronisation as before.  The second stream is chosen from %d candidates by timing a few steps (streams "
-                                          "that share a hardware queue run one after the other); --in-flight 1 gives the one-handle figure" % (NW, NW, len(cand) - 1)) if NW > 1 else None,
+                                          "that share a hardware queue run one after the other); with two in flight the row pipelines take whole frames as bands "
+                                          "(option pipe_band); ms_per_step_one_batch_in_flight and `roofline` are taken afterwards on one handle with the automatic "
+                                          "band sizes (every kernel running alone); --in-flight 1 gives the one-handle figure" % (NW, NW, len(cand) - 1)) if NW > 1 else None,
                        "note": "ms_per_step / value = the first window (the driver's K steps, directly behind the W warm-up steps); the others repeat it. "
                                "Before the warm-up steps a per-launch HIP-event pass over the plan runs once (figures discarded; the recorded pass "
                                "for `roofline` runs behind the windows)"},

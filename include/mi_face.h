@@ -110,6 +110,9 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * blocks, 4 = + row-pipelined chains of narrow blocks, 5 = + stage programs, operand-layout kernels, fused edges; default 5),
  * "pipe" (blocks per row-pipelined chain, 2..4, 0 = none), "pipe_rows" (0 = automatic: two rows per pipeline step with the 1x1 convs on
  * the 4x4x1 MFMA, one row for odd heights; 1 / 2 = one / two rows per step with packed-FMA 1x1 convs; 4 = one row per step, MFMA),
+ * "pipe_band" (rows per band of those chains; 0 = automatic: about one resident set of workgroups over the chip, the best choice for ONE batch in
+ * flight; a host that keeps two batches in flight — mi_streams_create_distinct — sets the frame height: fewer pipeline fill steps, and the
+ * CUs a short grid leaves idle are the other batch's; BackCamera 256 frames 1.22 -> 1.19 ms per batch),
  * "small_chain" (frames up to which a row-pipelined chain runs one launch per block instead — what keeps a batch of one short;
  * default 16, 0 = never; the stand-alone stride-2 block of that form folds its depthwise bias differently, so one frame's raw
  * outputs differ between a batch <= small_chain and a larger one within the stated 1e-4 tolerance, not bit for bit), "strip" (0 = LDS-ring block kernel for every block),

@@ -75,6 +75,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "pipe") { pipe_max_ = std::min(4, std::max(0, value)); dirty_ = true; }   // blocks per row-pipelined chain (level 4)
     else if (key == "small_chain") { small_chain_ = std::max(0, std::min(value, 64)); if (d_small_) { hipFree(d_small_); d_small_ = nullptr; small_floats_ = 0; } invalidate_graphs(); }  // frames up to which a row-pipelined chain runs one launch per block (0: never)
     else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2 || value == 4) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel), 4: one row, MFMA pointwise convs (strip_pipe1m_kernel)
+    else if (key == "pipe_band") { pipe_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the row pipelines (0: automatic)
     else if (key == "strip") { strip_ = value != 0; }
     else if (key == "mchain") { mchain_ = value != 0; }   // 0: the 32x32x48 blocks run one launch each (mstrip_kernel) instead of one launch per run
     else if (key == "tail") { tail_ = value != 0; dirty_ = true; }   // 0: no stage program runs on tail_kernels.hip (the round-4 plan)
@@ -1557,6 +1558,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     b.in = ip; b.out = op; b.in_fs = in_fs; b.out_fs = out_fs;
                     b.has_dw = 1;
                     b.pipe_rows = pipe_rows_;
+                    b.pipe_band = pipe_band_;
                     b.w_dw = d_weights_ + mo.w;
                     b.b_dw = mo.b >= 0 ? d_weights_ + mo.b : nullptr;
                     b.w_pw = d_weights_ + mo.w2;

@@ -83,6 +83,7 @@ struct BlockArgs {
     int sh = 1, sw = 1, pt = 0, pl = 0;
     int has_dw = 1;               // 0: plain pointwise conv (no depthwise stage)
     int pipe_rows = 0;            // row pipelines: rows per step (0 = automatic: 2 when the height is even; 1 forces strip_pipe_kernel)
+    int pipe_band = 0;            // row pipelines: rows per band (0 = automatic: about one resident set of workgroups over the chip)
     Epilogue ep;
 };
 

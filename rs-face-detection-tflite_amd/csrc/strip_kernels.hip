@@ -2250,6 +2250,7 @@ int launch_strip_pipe(const BlockArgs* blocks, int n, void* stream) {
     long bands = std::max<long>(1, (256L * per_cu * wg_units + a.B / 2) / std::max(1, a.B));
     int rows = (int)((a.H + bands - 1) / bands);
     rows = std::max(rows, std::min(a.H, 8 * n));
+    if (a.pipe_band > 0) rows = std::min(a.pipe_band, a.H);   // option "pipe_band": with another batch in flight long bands win (fewer fill steps; the idle CUs are the other batch's)
     if (forced > 0) rows = std::min(forced, a.H);
     pa.rows_per_step = strip_pipe_rows_per_step(a.H, a.pipe_rows);
     if (nh2 || pa.rows_per_step == 2 || pa.rows_per_step == 3) rows = std::min(a.H, (rows + 1) & ~1);  // bands that start on even rows
