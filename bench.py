@@ -536,6 +536,9 @@ def run_rank(args):
         xp = C.c_void_p(x.data_ptr())
         for k in range(NW):
             fl = mi.FaceLandmark(device=local_rank, model_bytes=blobs[0])
+            for kv in args.opt:
+                kk, v = kv.split("=")
+                fl.model.set_option(kk, int(v))
             lm = torch.zeros((B, 468, 3), dtype=torch.float32, device=device)
             present = torch.zeros((B,), dtype=torch.int32, device=device)
             flags = torch.zeros((B,), dtype=torch.float32, device=device)
@@ -551,6 +554,10 @@ def run_rank(args):
         fp = C.c_void_p(frames.data_ptr())
         for k in range(NW):
             pipe = mi.Pipeline(mi.FaceDetectionModel.Full, device=local_rank, model_bytes=blobs)
+            for kv in args.opt:
+                kk, v = kv.split("=")
+                for m in pipe.models:
+                    m.set_option(kk, int(v))
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
             o = dict(faces=z((B, 17), torch.float32), face_counts=z((B,), torch.int32), landmarks=z((B, 468, 3), torch.float32),
                      present=z((B,), torch.int32), eyes=z((B, 2, 76, 3), torch.float32))
@@ -826,7 +833,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=None)
     ap.add_argument("--lanes", type=int, default=None)
     ap.add_argument("--heads", type=int, default=None)
-    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development), config 2 only")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (development), every model of the configuration")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

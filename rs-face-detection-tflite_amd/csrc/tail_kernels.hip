@@ -463,8 +463,14 @@ int launch_tail(const TailLaunch& a, void* stream) {
         if (atoi(only) != a.nstages) stamps = nullptr;
 #endif
     const unsigned nwg = (unsigned)((a.B + a.G - 1) / a.G);
-    // constants a stage ahead (one workgroup per CU) where a second workgroup would not fit or would have nothing to do
-    const bool pre = a.variant == 1 || (a.variant == 0 && (lds_bytes > 80 * 1024 || nwg <= (unsigned)device_cu_count()));
+    // constants a stage ahead (one workgroup per CU) where a second workgroup would not fit
+    // (round 5, second collection: the 256-register form only where a second workgroup would not fit into the CU's LDS anyway.  It used to be
+    // chosen for every launch of at most one workgroup per CU as well; measured with the whole pipeline around it the 128-register form is the faster
+    // one there — config 5 2.113 -> 2.061 ms with two batches in flight, 2.698 -> 2.638 with one, config 3 0.837 -> 0.828 — MI_TAIL_RULE=0 brings
+    // the old rule back)
+    static const int rule = getenv("MI_TAIL_RULE") ? atoi(getenv("MI_TAIL_RULE")) : 1;   // tuning aid
+    bool pre = a.variant == 1 || (a.variant == 0 && lds_bytes > 80 * 1024);
+    if (a.variant == 0 && rule == 0) pre = lds_bytes > 80 * 1024 || nwg <= (unsigned)device_cu_count();
     auto kern = pre ? tail_kernel<true> : tail_kernel<false>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
     return (int)launch_kernel(kern, dim3(nwg), dim3(512), (size_t)lds_bytes, (hipStream_t)stream, a.prog, a.nstages, a.G, a.B, (int)zero_off, a.bases, stamps);

@@ -4,9 +4,11 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 config = os.environ.get("SWEEP_CONFIG", "2")
 def run(env_extra):
-    env = dict(os.environ, **env_extra)
+    # KEY=value in capitals: an environment variable; opt:key=value: an engine option (bench.py --opt)
+    opts = [k[4:] + "=" + v for k, v in env_extra.items() if k.startswith("opt:")]
+    env = dict(os.environ, **{k: v for k, v in env_extra.items() if not k.startswith("opt:")})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--no-secondary", "--no-cpu-baseline", "--no-latency", "--no-host-feed",
-                        "--no-event-profile"], capture_output=True, text=True, env=env, timeout=600)
+                        "--no-event-profile"] + [x for o in opts for x in ("--opt", o)], capture_output=True, text=True, env=env, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not lines:
         return "FAILED " + r.stderr[-200:].replace("\n", " | ")
