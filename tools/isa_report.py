@@ -35,6 +35,10 @@ def kernels(asm_path):
                         lds=int(g("group_segment_fixed_size").group(1))))
     for k, d in zip(out, demangle([k["name"] for k in out])):
         k["pretty"] = re.sub(r"mi::\(anonymous namespace\)::|void |\(.*\)$", "", d)
+        # instructions that touch the private segment inside this kernel's text (a reserved segment nobody accesses costs nothing at run time)
+        m = re.search(r"^%s:\n(.*?)^\s*s_endpgm" % re.escape(k["name"]), txt, flags=re.S | re.M)
+        body = m.group(1) if m else ""
+        k["scratch_ops"] = len(re.findall(r"^\s*(?:scratch_(?:load|store)\w*|buffer_(?:load|store)\w* [^\n]*\bs\[0:3\])", body, flags=re.M))
     return out
 
 
