@@ -5,10 +5,15 @@
 // of a launch that holds a few thousand MACs per lane, and the 16x16x96 chain keeps one CU of 256 busy for 150 us.  Here the
 // network behind the first convolution is ONE launch of NW workgroups per frame:
 //
-//   * a stage is one BlazeBlock (DW3x3 -> PW1x1 -> [+ skip] -> activation) or one 1x1 convolution (the SSD heads);
+//   * a stage is one BlazeBlock (DW3x3 -> PW1x1 -> [+ skip] -> activation), one 1x1 convolution (the SSD heads) or one 2x2 stride-2
+//     convolution (the iris network's down-sampling steps, iris_landmark.rs:203: a 1x1 stage whose contraction runs over the four taps,
+//     A operands streamed from L2 in rounds of 128 input values);
 //   * every stage cuts its output rows into bands; workgroup w owns band w >> wshift of the stages it is active in (the bands get
 //     thinner towards the 16x16 and 8x8 stages, where only every 8th / 16th workgroup still has a row), and the owner of output
 //     row r owns input row S r: a workgroup's own part of every tensor stays in LDS (two tiles, used in turn);
+//   * behind a fork the second branch's stages belong to the workgroups at an offset (woff) inside each group of 1 << wshift, which
+//     have had nothing to do since the bands got thinner: both branches run at the same time; the second one's first stage takes all
+//     of its input rows from the packets (Rin = 0);
 //   * only the rows another workgroup needs — the halo of the 3x3 window — go through global memory, as 16-byte packets
 //     {value, tag, value, tag} stored with sc0 sc1 (write-through; the workgroups of a frame sit on all eight XCDs, whose L2s are
 //     not coherent with each other).  The reader polls the packets themselves (sc0 sc1 loads) until both tags are the producer
@@ -72,13 +77,13 @@ unsigned long long* g_band_stamps = nullptr;
 // global memory at the top of a stage is a dependent round trip in front of everything else — and a descriptor is then ONE LDS read
 // per lane (dword `lane` of it), a v_readlane per dword and scalar bit-field extracts.
 struct StageRegs {
-    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, res_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats;
+    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, res_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats, res_co;
     int wpc_shift, per_ct;
     unsigned mC4, mWo, mrowq;
     int src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
 };
-// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3
-// word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:16 per_ct:16
+// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3 res_co:1
+// word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:12 woff:4 per_ct:16
 // words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)
 __host__ __device__ inline unsigned bf(unsigned v, int lo, int n) { return (v >> lo) & ((1u << n) - 1u); }
 __device__ __forceinline__ StageRegs stage_regs(const BandPacked* p, int lane) {
@@ -89,10 +94,10 @@ __device__ __forceinline__ StageRegs stage_regs(const BandPacked* p, int lane) {
     StageRegs r;
     r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
     r.src_tile = bf(w[0], 12, 2); r.dst_tile = (int)bf(w[0], 14, 3) - 1; r.pub_lo = bf(w[0], 17, 1); r.pub_hi = bf(w[0], 18, 1);
-    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1;
+    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1; r.res_co = bf(w[0], 31, 1);
     r.R = bf(w[1], 0, 8); r.Rin = bf(w[1], 8, 8); r.dep = (int)bf(w[1], 16, 8) - 1; r.nbands = bf(w[1], 24, 8);
     r.H = bf(w[2], 0, 16); r.W = bf(w[2], 16, 16); r.Ho = bf(w[3], 0, 16); r.Wo = bf(w[3], 16, 16); r.C = bf(w[4], 0, 16); r.Co = bf(w[4], 16, 16);
-    r.c_floats = bf(w[5], 0, 16); r.per_ct = bf(w[5], 16, 16);
+    r.c_floats = bf(w[5], 0, 12); r.per_ct = bf(w[5], 16, 16);
     r.mC4 = w[6]; r.mWo = w[7]; r.mrowq = w[8];
     r.src_off = (int)w[9]; r.dst_off = (int)w[10]; r.src_fs = (int)w[11]; r.dst_fs = (int)w[12];
     r.src_ll = (int)w[13]; r.dst_ll = (int)w[14]; r.w_a = (int)w[15]; r.w_c = (int)w[16];
@@ -116,13 +121,13 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         for (int i = tid; i < a.nstages * (int)(sizeof(BandPacked) / 16); i += kThreads) lp[i] = gp[i];
     }
     __syncthreads();
-    // the stages this workgroup takes part in (workgroup w owns band w >> wshift of a stage where its low wshift bits are 0), as a bit mask:
+    // the stages this workgroup takes part in (workgroup w owns band w >> wshift of a stage where its low wshift bits are the stage's woff), as a bit mask:
     // lane k looks at stage k
     unsigned long long amask;
     {
         const int k = lane < a.nstages ? lane : 0;
-        const int sh = (int)bf(lprog[k].w[0], 3, 4), nb = (int)bf(lprog[k].w[1], 24, 8);
-        amask = __ballot(lane < a.nstages && (w & ((1 << sh) - 1)) == 0 && (w >> sh) < nb);
+        const int sh = (int)bf(lprog[k].w[0], 3, 4), nb = (int)bf(lprog[k].w[1], 24, 8), off = (int)bf(lprog[k].w[5], 12, 4);
+        amask = __ballot(lane < a.nstages && (w & ((1 << sh) - 1)) == off && (w >> sh) < nb);
     }
     auto next_active = [&](int from) {   // the next such stage after `from` (nstages: none)
         const unsigned long long rest = from + 1 < 64 ? amask >> (from + 1) : 0ull;
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     };
     // a stage's A operands for this wave (it keeps one 16-channel output tile for the whole stage) and its small constants
     auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, float& A4, f32x4& creg) {
-        const int nct = (st.Co + 15) >> 4, n16 = st.C >> 4, has8 = (st.C >> 3) & 1, has4 = (st.C >> 2) & 1;
+        const bool cv2 = st.kind != BAND_BLOCK && st.S == 2;   // (its first round of eight 16-value chunks; C % 32 == 0)
+        const int nct = (st.Co + 15) >> 4, n16 = cv2 ? kMaxN16 : st.C >> 4, has8 = cv2 ? 0 : (st.C >> 3) & 1, has4 = cv2 ? 0 : (st.C >> 2) & 1;
         const int myct = wave >> st.wpc_shift;
         const float* ga = a.consts + st.w_a + (myct < nct ? myct : 0) * st.per_ct;
 #pragma unroll
@@ -152,13 +158,14 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     while (s < a.nstages) {
         MI_BAND_STAMP(0)
         const bool blk = st.kind == BAND_BLOCK;
+        const bool cv2 = !blk && st.S == 2;        // 2x2 stride-2 convolution: output row r reads input rows 2r, 2r + 1 (no row above, none below them)
         const int S = st.S, C = st.C, Cs = C + 4, C4 = C >> 2, Co = st.Co, Wo = st.Wo, W = st.W, TW = W + 2;
         const int bi = w >> st.wshift;
         const int r0 = bi * st.R, nro = min(st.Ho, r0 + st.R) - r0, npx = nro * Wo;
         const int p0 = S * r0;                     // first input row of the band; tile row of input row y: y - p0 + 1
         const int Rin = st.dep >= 0 ? min(st.Rin, st.H - p0) : 0;
         const int ya = blk && S == 1 ? p0 - 1 : p0;
-        const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : p0 + nro;
+        const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : (cv2 ? p0 + 2 * nro : p0 + nro);
         float* const tile = lds + st.src_tile * a.tile_floats;
         const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C >> 3) & 1, has4 = (C >> 2) & 1;
         const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             const float hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
             __amdgpu_buffer_rsrc_t osrc = packet_buffer(ws + (llo ? st.dst_ll : 0), llo ? 2L * st.Ho * Wo * Co : 0);
             if (dtile)   // the output band's border pixels
-                for (int i = tid; i < (st.R + 3) * 2 * (Co >> 2); i += kThreads) {
+                for (int i = tid; i < (st.R + a.halo) * 2 * (Co >> 2); i += kThreads) {
                     const int rr = i / (2 * (Co >> 2)), e = i - rr * 2 * (Co >> 2), side = e / (Co >> 2), q = e - side * (Co >> 2);
                     *reinterpret_cast<f32x4*>(dtile + (rr * TWo + (side ? Wo + 1 : 0)) * Cso + 4 * q) = zero4;
                 }
@@ -278,6 +285,29 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     const float* bp = blk ? dwb + pxc * Cs : tile + ((1 + oy) * TW + ox + 1) * Cs;
                     // four accumulators, one per k-step of a 16-channel chunk: a chain of dependent MFMAs runs at a quarter of the issue rate
                     f32x4 D = zero4, D1 = zero4, D2 = zero4, D3 = zero4;
+                    if (cv2) {
+                        // contraction over (tap, channel): 4 C / 128 rounds of eight chunks; round 0's A operands came with the stage's
+                        // descriptor, the others (and round 0 again for a wave's second pixel tile) are read here
+                        const float* ga = a.consts + st.w_a + myct * st.per_ct;
+                        const float* t00 = tile + ((1 + 2 * oy) * TW + 2 * ox + 1) * Cs + 4 * kq;
+                        const int nr = C >> 5;
+                        for (int r = 0; r < nr; r++) {
+                            if (r > 0 || (nr > 1 && pt >= wpc)) {   // (the registers hold round 0 only in front of the wave's first pixel tile)
+#pragma unroll
+                                for (int j = 0; j < kMaxN16; j++) A[j] = *reinterpret_cast<const f32x4*>(ga + ((r * kMaxN16 + j) * 64 + lane) * 4);
+                            }
+#pragma unroll
+                            for (int j = 0; j < kMaxN16; j++) {
+                                const int k0 = (r * kMaxN16 + j) * 16;
+                                const int tap = (k0 >= C) + (k0 >= 2 * C) + (k0 >= 3 * C);
+                                const f32x4 bv = *reinterpret_cast<const f32x4*>(t00 + ((tap >> 1) * TW + (tap & 1)) * Cs + (k0 - tap * C));
+                                D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].x, bv.x, D, 0, 0, 0);
+                                D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].y, bv.y, D1, 0, 0, 0);
+                                D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].z, bv.z, D2, 0, 0, 0);
+                                D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].w, bv.w, D3, 0, 0, 0);
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int j = 0; j < kMaxN16; j++)
                         if (j < n16) {
@@ -293,6 +323,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                         D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A8.y, bv.y, D1, 0, 0, 0);
                     }
                     if (has4) D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A4, bp[16 * n16 + 8 * has8 + kq], D2, 0, 0, 0);
+                    }
                     D = (D + D1) + (D2 + D3);
                     // D[i] = output channel 16 ct + 4 kq + i of pixel px
                     const int c0 = 16 * myct + 4 * kq;
@@ -302,10 +333,14 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                         sk = *reinterpret_cast<const f32x4*>(lds + st.res_tile * a.tile_floats + ((1 + oy) * TW + ox + 1) * Cso + c0);
                     } else if (st.res_mode == RES_DIRECT) {
                         if (c0 < C) sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // channels >= C: the zero pad of a widening block
-                    } else if (st.res_mode == RES_MAXPOOL && c0 < C) {
-                        const float* t0 = tile + ((1 + 2 * oy) * TW + 2 * ox + 1) * Cs + c0;
-                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(t0), s1 = *reinterpret_cast<const f32x4*>(t0 + Cs);
-                        const f32x4 s2 = *reinterpret_cast<const f32x4*>(t0 + TW * Cs), s3 = *reinterpret_cast<const f32x4*>(t0 + TW * Cs + Cs);
+                    } else if (st.res_mode == RES_MAXPOOL && c0 < (st.res_co ? Co : C)) {
+                        // 2x2 max of a tensor of twice the output's size: the stride-2 block's own input (C channels), or (res_tile) the tensor the
+                        // 2x2 convolution in front of this block read (C, or with res_co Co channels) — its rows 2r, 2r + 1 are still in that tile
+                        const float* rt = st.res_tile >= 0 ? lds + st.res_tile * a.tile_floats : tile;
+                        const int TWr = 2 * Wo + 2, Csr = st.res_co ? Cso : Cs;
+                        const float* t0 = rt + ((1 + 2 * oy) * TWr + 2 * ox + 1) * Csr + c0;
+                        const f32x4 s0 = *reinterpret_cast<const f32x4*>(t0), s1 = *reinterpret_cast<const f32x4*>(t0 + Csr);
+                        const f32x4 s2 = *reinterpret_cast<const f32x4*>(t0 + TWr * Csr), s3 = *reinterpret_cast<const f32x4*>(t0 + TWr * Csr + Csr);
                         sk.x = fmaxf(fmaxf(s0.x, s1.x), fmaxf(s2.x, s3.x));
                         sk.y = fmaxf(fmaxf(s0.y, s1.y), fmaxf(s2.y, s3.y));
                         sk.z = fmaxf(fmaxf(s0.z, s1.z), fmaxf(s2.z, s3.z));
@@ -368,7 +403,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 
 }  // namespace
 
-int bandnet_tile_floats(int R, int W, int C) { return (R + 3) * (W + 2) * (C + 4); }
+int bandnet_tile_floats(int R, int W, int C, int halo) { return (R + halo) * (W + 2) * (C + 4); }
 int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
 int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
 int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages) { return (ntiles * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked); }
@@ -379,20 +414,20 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
     for (long v : offs)
         if (v < -1 || v > 0x7fffffffL) return false;
     if (!fits(st.kind, 1) || !fits(st.S, 2) || !fits(st.wshift, 4) || !fits(st.res_mode, 2) || !fits(st.act, 3) || !fits(st.src_tile, 2) || !fits(st.dst_tile + 1, 3) ||
-        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 4) || !fits(st.wpc_shift, 2) || !fits(st.res_tile + 1, 3) ||
+        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 4) || !fits(st.wpc_shift, 2) || !fits(st.res_tile + 1, 3) || !fits(st.res_co, 1) ||
         st.src_tile >= kBandTiles || st.dst_tile >= kBandTiles || st.res_tile >= kBandTiles || st.dst_base >= kBandBases || !fits(st.R, 8) || !fits(st.Rin, 8) ||
         !fits(st.dep + 1, 8) || !fits(st.nbands, 8) || !fits(st.H, 16) || !fits(st.W, 16) || !fits(st.Ho, 16) || !fits(st.Wo, 16) || !fits(st.C, 16) || !fits(st.Co, 16) ||
-        !fits(st.c_floats, 16) || !fits(st.per_ct, 16))
+        !fits(st.c_floats, 12) || !fits(st.woff, 4) || st.woff >= (1 << st.wshift) || !fits(st.per_ct, 16))
         return false;
     BandPacked p{};
     p.w[0] = (unsigned)st.kind | (unsigned)st.S << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
              (unsigned)(st.dst_tile + 1) << 14 | (unsigned)st.pub_lo << 17 | (unsigned)st.pub_hi << 18 | (unsigned)st.src_base << 19 | (unsigned)(st.dst_base + 1) << 22 |
-             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28;
+             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28 | (unsigned)st.res_co << 31;
     p.w[1] = (unsigned)st.R | (unsigned)st.Rin << 8 | (unsigned)(st.dep + 1) << 16 | (unsigned)st.nbands << 24;
     p.w[2] = (unsigned)st.H | (unsigned)st.W << 16;
     p.w[3] = (unsigned)st.Ho | (unsigned)st.Wo << 16;
     p.w[4] = (unsigned)st.C | (unsigned)st.Co << 16;
-    p.w[5] = (unsigned)st.c_floats | (unsigned)st.per_ct << 16;
+    p.w[5] = (unsigned)st.c_floats | (unsigned)st.woff << 12 | (unsigned)st.per_ct << 16;
     p.w[6] = st.mC4; p.w[7] = st.mWo; p.w[8] = st.mrowq;
     for (int k = 0; k < 8; k++) p.w[9 + k] = (unsigned)(int)offs[k];
     *out = p;
@@ -400,7 +435,7 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
 }
 
 int launch_bandnet(const BandLaunch& a, void* stream) {
-    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles) return (int)hipErrorInvalidValue;
+    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles || a.halo < 2 || a.halo > 3) return (int)hipErrorInvalidValue;
     if (bandnet_lds_bytes(a.ntiles, a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
     auto kern = bandnet_kernel;

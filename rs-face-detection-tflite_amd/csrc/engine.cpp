@@ -83,6 +83,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "tail_g") { tail_g_ = std::max(0, std::min(value, 64)); }   // frames per workgroup of the tail stage programs (0: chosen per launch)
     else if (key == "band") { band_ = std::max(0, std::min(value, 2)); dirty_ = true; }   // single-launch plan: 0 never, 1 one_shot runs (the single-image entries), 2 every run of few enough frames
     else if (key == "band_test_fail") { band_test_fail_ = value != 0; }   // test hook: the next single-launch run reports that it gave up
+    else if (key == "band_fork") { band_fork_ = value != 0; dirty_ = true; }   // single-launch plan: the second branch behind a fork on the idle workgroups
     else if (key == "band_nw") { band_nw_ = std::max(8, std::min(value, 256)); dirty_ = true; }   // its workgroups per frame
     else if (key == "fork") { fork_ = value != 0; }
     else if (key == "heads") { head_streams_opt_ = std::min(kHeadStreams, std::max(1, value)); dirty_ = true; }  // side streams the output heads are spread over                                             // 0: output heads stay on the trunk's stream                                          // 0: LDS-ring block kernel for every block
@@ -624,7 +625,15 @@ void Model::free_bandnet() {
 // double blocks) leave band_ready_ false and the handle on the batched plan.
 // MI_BAND_DEBUG=1 names the line at which a graph was found to have no single-launch form
 #define BAND_GIVE_UP do { if (std::getenv("MI_BAND_DEBUG")) std::fprintf(stderr, "bandnet: no single-launch plan (engine.cpp:%d)\n", __LINE__); return; } while (0)
+// (round 5) 2x2 stride-2 convolutions and the blocks behind them, whose skip is the 2x2 max of the convolution's input,
+// are stages too: the whole iris network but its two whole-frame heads is one program (iris_landmark.rs:203).  Should a graph with such
+// nodes have no program with them, it is lowered once more with the program ending in front of the first of them (the earlier form).
 void Model::build_bandnet() {
+    build_bandnet_try(true);
+    if (!band_ready_) build_bandnet_try(false);
+}
+
+void Model::build_bandnet_try(bool conv2_ok) {
     free_bandnet();
     if (!band_ || fuse_level_ < 2) BAND_GIVE_UP;
     const Plan p2 = build_plan(parse_tflite(blob_.data(), blob_.size()), 2);
@@ -683,7 +692,10 @@ void Model::build_bandnet() {
         const bool pw_block = n.kind == Node::Block && n.w < 0;
         const bool dw_block = n.kind == Node::Block && n.w >= 0;
         const bool conv1 = n.kind == Node::Conv && n.KH == 1 && n.KW == 1 && n.sh == 1 && n.sw == 1 && !n.gemm_head;
-        if (!pw_block && !dw_block && !conv1) { cut = i; break; }
+        const bool conv2 = conv2_ok && n.kind == Node::Conv && n.KH == 2 && n.KW == 2 && n.sh == 2 && n.sw == 2 && !n.gemm_head && n.in.size() == 1 &&
+                           g.tensors[n.in[0]].shape.size() == 4 && g.tensors[n.in[0]].shape[1] % 2 == 0 && g.tensors[n.in[0]].shape[2] % 2 == 0 &&
+                           g.tensors[n.in[0]].shape[3] % 32 == 0 && n.in[0] != band_stem_out_;
+        if (!pw_block && !dw_block && !conv1 && !conv2) { cut = i; break; }
         if (n.in.size() != 1 || n.ept >= 0 || n.res_after) BAND_GIVE_UP;
         const auto& si = g.tensors[n.in[0]].shape;
         const auto& so = g.tensors[n.out].shape;
@@ -698,6 +710,9 @@ void Model::build_bandnet() {
             st.S = n.sh;
             if (st.S == 2 && ((st.H & 1) || (st.W & 1))) BAND_GIVE_UP;
             if (st.Ho != st.H / st.S || st.Wo != st.W / st.S) BAND_GIVE_UP;
+        } else if (conv2) {
+            st.S = 2;   // (even sizes: SAME and VALID are the same window)
+            if (st.Ho != st.H / 2 || st.Wo != st.W / 2 || n.res >= 0) BAND_GIVE_UP;
         } else if (st.Ho != st.H || st.Wo != st.W) {
             BAND_GIVE_UP;
         }
@@ -706,7 +721,19 @@ void Model::build_bandnet() {
         st.res_mode = RES_NONE;
         if (n.res >= 0) {
             if (!dw_block) BAND_GIVE_UP;
-            if (n.res != n.in[0]) {
+            if (n.res != n.in[0] && n.res_mode == RES_MAXPOOL) {
+                // the skip is the 2x2 max of the tensor the 2x2 convolution in front of this block read: the rows 2r, 2r + 1 of it that the
+                // owner of output row r needs are in the LDS tile that convolution read them from
+                const auto& sr = g.tensors[n.res].shape;
+                const int d = producer[static_cast<size_t>(n.in[0])];
+                if (st.S != 1 || sr.size() != 4 || sr[1] != 2 * st.Ho || sr[2] != 2 * st.Wo || (sr[3] != st.C && sr[3] != st.Co) || st.Co < st.C || d < 0) BAND_GIVE_UP;
+                const BandStage& cv = prog[static_cast<size_t>(d)];
+                if (cv.kind != BAND_PW || cv.S != 2 || cv.dep < 0 || cv.dep != producer[static_cast<size_t>(n.res)]) BAND_GIVE_UP;
+                st.res_dep = cv.dep;
+                st.res_mode = RES_MAXPOOL;
+                st.res_co = sr[3] != st.C ? 1 : 0;
+            }
+            else if (n.res != n.in[0]) {
                 // the skip is another tensor of the program, with the output's shape (its rows then have the output's owners)
                 const auto& sr = g.tensors[n.res].shape;
                 if (n.res_mode != RES_DIRECT || st.S != 1 || sr.size() != 4 || sr[1] != st.Ho || sr[2] != st.Wo || sr[3] != st.Co) BAND_GIVE_UP;
@@ -743,7 +770,7 @@ void Model::build_bandnet() {
                 const int r0 = b * st.R, nro = std::min(st.Ho, r0 + st.R) - r0, p0 = st.S * r0;
                 if (((p0 / pd.R) << pd.wshift) != (b << st.wshift) || p0 % pd.R) BAND_GIVE_UP;
                 const int rin = std::min(pd.R, st.H - p0);
-                const int yb = dw_block ? (st.S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : p0 + nro;
+                const int yb = dw_block ? (st.S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : (conv2 ? p0 + 2 * nro : p0 + nro);
                 const int below = yb - (p0 + rin);
                 if (below < 0 || below > 2) BAND_GIVE_UP;
                 if (((dw_block && st.S == 1 ? 1 : 0) + below) * st.W * (st.C / 4) > 4 * 512) BAND_GIVE_UP;   // the halo rows: four 16-byte elements per lane
@@ -764,7 +791,8 @@ void Model::build_bandnet() {
         // constants
         const int wt = n.kind == Node::Conv ? n.w : n.w2, bt = n.kind == Node::Conv ? n.b : n.b2;
         const auto& wsrc = g.tensors[wt].f32;
-        const int C = st.C, Co = st.Co, nct = (Co + 15) / 16, n16 = C / 16, has8 = (C / 8) & 1, has4 = (C / 4) & 1, per_ct = n16 * 256 + has8 * 128 + has4 * 64;
+        const int C = conv2 ? 4 * st.C : st.C;   // (the contraction length: [Co][2][2][C] read as [Co][4 C])
+        const int Co = st.Co, nct = (Co + 15) / 16, n16 = C / 16, has8 = (C / 8) & 1, has4 = (C / 4) & 1, per_ct = n16 * 256 + has8 * 128 + has4 * 64;
         if (wsrc.size() != static_cast<size_t>(Co) * C) BAND_GIVE_UP;
         std::vector<float> A(static_cast<size_t>(nct) * per_ct, 0.f);
         for (int ct = 0; ct < nct; ct++)
@@ -880,6 +908,74 @@ void Model::build_bandnet() {
             if (band_node_runs_[i] && plan_.storage[static_cast<size_t>(plan_.nodes[i].out)].root == out_root[k]) later = true;
         if (!later && written != g.tensors[g.outputs[k]].elems()) BAND_GIVE_UP;
     }
+    // ---- a program with 2x2 convolutions (the iris network: two branches of 21 stages behind its 8x8 fork) runs branch by branch, not in the
+    // graph's interleaved order: a stage goes behind the newest tensor it can read, so that one branch's skip / middle / output tensors and the
+    // fork tensor the other branch still waits for are all that is alive — four LDS tiles
+    {
+        const int N0 = static_cast<int>(prog.size());
+        bool any_cv2 = false;
+        for (const BandStage& st : prog) any_cv2 = any_cv2 || (st.kind == BAND_PW && st.S == 2);
+        if (any_cv2) {
+            std::vector<int> pos(static_cast<size_t>(N0), -1), order;
+            for (int step = 0; step < N0; step++) {
+                int best = -1, best_pos = -2;
+                for (int k = 0; k < N0; k++) {
+                    const BandStage& st = prog[static_cast<size_t>(k)];
+                    if (pos[static_cast<size_t>(k)] >= 0) continue;
+                    if (st.dep >= 0 && pos[static_cast<size_t>(st.dep)] < 0) continue;
+                    if (st.res_dep >= 0 && pos[static_cast<size_t>(st.res_dep)] < 0) continue;
+                    const int dp = st.dep >= 0 ? pos[static_cast<size_t>(st.dep)] : -1;
+                    if (dp > best_pos) { best = k; best_pos = dp; }
+                }
+                if (best < 0) BAND_GIVE_UP;
+                pos[static_cast<size_t>(best)] = step;
+                order.push_back(best);
+            }
+            std::vector<BandStage> re;
+            for (int k = 0; k < N0; k++) {
+                BandStage st = prog[static_cast<size_t>(order[static_cast<size_t>(k)])];
+                if (st.dep >= 0) st.dep = pos[static_cast<size_t>(st.dep)];
+                if (st.res_dep >= 0) st.res_dep = pos[static_cast<size_t>(st.res_dep)];
+                re.push_back(st);
+            }
+            prog.swap(re);
+            for (int& pr : producer)
+                if (pr >= 0) pr = pos[static_cast<size_t>(pr)];
+            // ... and the second branch behind a fork goes to the workgroups the first one leaves idle (BandStage::woff): where a tensor of one-row
+            // bands on every 2nd / 4th ... workgroup is the input of two stages, the later one and everything behind it are run by the workgroups
+            // half a group further on, at the same time as the first branch; its first stage takes its whole input from the packet buffer
+            if (band_fork_) {
+                for (int k = 0; k < N0; k++) {
+                    const BandStage& fk = prog[static_cast<size_t>(k)];
+                    std::vector<int> readers;
+                    for (int j = 0; j < N0; j++)
+                        if (prog[static_cast<size_t>(j)].dep == k) readers.push_back(j);
+                    if (readers.size() != 2 || fk.R != 1 || fk.wshift < 1 || fk.woff != 0) continue;
+                    const int woff = 1 << (fk.wshift - 1);
+                    std::vector<char> inB(static_cast<size_t>(N0), 0);
+                    inB[static_cast<size_t>(readers[1])] = 1;
+                    for (int j = readers[1] + 1; j < N0; j++)
+                        if (prog[static_cast<size_t>(j)].dep >= 0 && inB[static_cast<size_t>(prog[static_cast<size_t>(j)].dep)]) inB[static_cast<size_t>(j)] = 1;
+                    bool ok = true;
+                    for (int j = 0; j < N0 && ok; j++) {
+                        const BandStage& st = prog[static_cast<size_t>(j)];
+                        if (inB[static_cast<size_t>(j)]) {
+                            ok = st.wshift >= fk.wshift && st.woff == 0 && (st.res_dep < 0 || st.res_dep == k || inB[static_cast<size_t>(st.res_dep)]);
+                        } else if (st.res_dep >= 0 && inB[static_cast<size_t>(st.res_dep)]) {
+                            ok = false;
+                        }
+                    }
+                    const BandStage& root = prog[static_cast<size_t>(readers[1])];
+                    const int rows = root.kind == BAND_BLOCK ? (root.S == 1 ? root.R + 2 : 2 * root.R + 1) : (root.S == 2 ? 2 * root.R : root.R);
+                    if (!ok || rows * root.W * (root.C / 4) > 4 * 512) continue;
+                    for (int j = 0; j < N0; j++)
+                        if (inB[static_cast<size_t>(j)]) prog[static_cast<size_t>(j)].woff = woff;
+                    prog[static_cast<size_t>(readers[1])].Rin = 0;
+                    prog[static_cast<size_t>(readers[1])].cross = 1;
+                }
+            }
+        }
+    }
     // ---- the output heads (stages nobody reads) move up behind the first other reader of their input: the two LDS tiles hold a tensor
     // only until the trunk has moved on twice, and a head costs its workgroups two microseconds wherever it stands
     {
@@ -932,9 +1028,11 @@ void Model::build_bandnet() {
         if (st.dep >= 0) {
             BandStage& pd = prog[static_cast<size_t>(st.dep)];
             last_reader[static_cast<size_t>(st.dep)] = k;
-            if (st.kind == BAND_BLOCK && pd.nbands > 1) {
+            const bool cv2_halo = st.kind == BAND_PW && st.S == 2 && pd.R < 2 * st.R;   // its row 2r + 1 is the next workgroup's
+            if (st.cross) pd.pub_lo = 1;   // (one-row bands: all of the tensor)
+            if ((st.kind == BAND_BLOCK || cv2_halo) && pd.nbands > 1) {
                 pd.pub_lo = 1;
-                if (st.S == 1 && pd.R > 1) pd.pub_hi = 1;
+                if (st.kind == BAND_BLOCK && st.S == 1 && pd.R > 1) pd.pub_hi = 1;
             }
         } else {
             input_last_reader = k;
@@ -944,6 +1042,9 @@ void Model::build_bandnet() {
     }
     long ws = 0;
     int tile_floats = 0, dw_floats = 0, ntiles = 2;
+    int halo = 2;   // tile rows beside a band's own: one above and one below, two below where a stride-2 block reads the tensor
+    for (const BandStage& st : prog)
+        if (st.kind == BAND_BLOCK && st.S == 2) halo = 3;
     int holder[kBandTiles];   // stage whose output a tile holds (-1: the program's input, -2: nothing)
     for (int& h : holder) h = -2;
     auto tile_of = [&](int stage) {
@@ -964,13 +1065,24 @@ void Model::build_bandnet() {
             st.src_tile = tile_of(st.dep);
             if (st.src_tile < 0) BAND_GIVE_UP;   // its input is no longer in LDS
             st.src_ll = prog[static_cast<size_t>(st.dep)].dst_ll;
-            if (st.kind == BAND_BLOCK && st.nbands > 1 && st.src_ll < 0) BAND_GIVE_UP;
+            const BandStage& pd = prog[static_cast<size_t>(st.dep)];
+            const bool cv2_halo = st.kind == BAND_PW && st.S == 2 && pd.R < 2 * st.R;
+            if (((st.kind == BAND_BLOCK || cv2_halo) && st.nbands > 1 && st.src_ll < 0) || (st.cross && st.src_ll < 0)) BAND_GIVE_UP;
         }
         if (st.res_dep >= -1) {
             st.res_tile = tile_of(st.res_dep);
             if (st.res_tile < 0) BAND_GIVE_UP;
             // the skip is read at the output's pixel positions: its band must have the output's rows (same shape, same owners)
-            if (st.res_dep >= 0) {
+            if (st.res_mode == RES_MAXPOOL) {
+                // ... or, the 2x2 max of the input of the 2x2 convolution in front: that stage, run by the same workgroups on the same bands,
+                // left rows 2 r0 .. 2 r0 + 2 R - 1 of the tensor in the tile it read them from
+                if (st.dep < 0 || st.res_dep < 0) BAND_GIVE_UP;
+                const BandStage& cv = prog[static_cast<size_t>(st.dep)];
+                const BandStage& rd = prog[static_cast<size_t>(st.res_dep)];
+                if (cv.kind != BAND_PW || cv.S != 2 || cv.dep != st.res_dep || cv.src_tile != st.res_tile || cv.R != st.R || cv.wshift != st.wshift || cv.nbands != st.nbands)
+                    BAND_GIVE_UP;
+                if (rd.Ho != 2 * st.Ho || rd.Wo != 2 * st.Wo || rd.Co != (st.res_co ? st.Co : st.C)) BAND_GIVE_UP;
+            } else if (st.res_dep >= 0) {
                 const BandStage& rd = prog[static_cast<size_t>(st.res_dep)];
                 if (rd.Ho != st.Ho || rd.Wo != st.Wo || rd.Co != st.Co || rd.R != st.R || rd.wshift != st.wshift) BAND_GIVE_UP;
             } else {
@@ -989,7 +1101,7 @@ void Model::build_bandnet() {
             st.dst_tile = pick;
             holder[pick] = k;
             ntiles = std::max(ntiles, pick + 1);
-            tile_floats = std::max(tile_floats, bandnet_tile_floats(st.R, st.Wo, st.Co));
+            tile_floats = std::max(tile_floats, bandnet_tile_floats(st.R, st.Wo, st.Co, halo));
             if (st.pub_lo || st.pub_hi) {
                 st.dst_ll = ws;
                 ws += align_up(2 * static_cast<long>(st.Ho) * st.Wo * st.Co, 64);
@@ -1002,6 +1114,7 @@ void Model::build_bandnet() {
     band_tile_floats_ = tile_floats;
     band_dw_floats_ = dw_floats;
     band_ntiles_ = ntiles;
+    band_halo_ = halo;
     band_lds_bytes_ = bandnet_lds_bytes(ntiles, tile_floats, dw_floats, NS);
     if (band_lds_bytes_ > 160 * 1024) BAND_GIVE_UP;
     band_ws_frame_floats_ = std::max<long>(ws, 64);
@@ -1262,6 +1375,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             a.base[0] = d_band_ws_;
             a.base[1] = const_cast<float*>(tensor_ptr(band_stem_out_, in, chunk_start, &fs));
             a.ntiles = band_ntiles_;
+            a.halo = band_halo_;
             for (size_t k = 0; k < band_ext_.size(); k++) {
                 long efs = 0;
                 a.base[2 + k] = band_ext_[k].out_k >= 0 ? d_out_[static_cast<size_t>(band_ext_[k].out_k)] : tensor_ptr_mut(band_ext_[k].tensor, chunk_start, &efs);

@@ -68,6 +68,7 @@ class Model {
    private:
     void rebuild();                       // (re)lower + upload weights for the current options
     void build_bandnet();                 // the single-launch plan of the same graph, when its operators have band stages
+    void build_bandnet_try(bool conv2_ok);
     void free_bandnet();
     bool band_usable(int batch) const;
     void ensure_capacity(int batch);
@@ -137,7 +138,8 @@ class Model {
     struct BandExt { int out_k = -1, tensor = -1; };   // BandLaunch::base[2 + j]: graph output out_k, or the arena storage of `tensor` (read by a launch behind the band program)
     std::vector<BandExt> band_ext_;
     std::vector<char> band_node_runs_;   // per plan_ node from band_first_ on: 1 = it runs as its own launch behind the band launch (the program stops in front of it)
-    int band_ntiles_ = 2;
+    int band_ntiles_ = 2, band_halo_ = 3;
+    bool band_fork_ = true;
     BandPacked* d_band_prog_ = nullptr;
     float* d_band_consts_ = nullptr;
     float* d_band_ws_ = nullptr;

@@ -444,12 +444,14 @@ constexpr int kBandBases = 8;
 constexpr int kBandTiles = 4;
 struct alignas(16) BandStage {
     int kind = BAND_BLOCK;
-    int S = 1;                   // BLOCK: DW3x3 stride (1: pad 1; 2: TF SAME on an even size, taps at 2o .. 2o+2)
+    int S = 1;                   // BLOCK: DW3x3 stride (1: pad 1; 2: TF SAME on an even size, taps at 2o .. 2o+2); PW with S == 2: a 2x2 stride-2
+                                 // convolution (C % 32 == 0; contraction over (ky, kx, c), weights [Co][2][2][C] as TFLite stores them)
     int H = 0, W = 0, C = 0;     // input  (C % 4 == 0, C <= 128)
     int Ho = 0, Wo = 0, Co = 0;  // output (Co <= 128)
     int R = 1;                   // output rows per band
     int wshift = 0;              // workgroup w runs the stage when its low wshift bits are 0; it owns band w >> wshift (the owner of output row r
                                  // also owns input row S r: its part of the input is still in LDS)
+    int woff = 0;                // ... or, for the second branch behind a fork, when they are woff (< 1 << wshift): workgroups the first branch leaves idle
     int nbands = 0;
     int dep = -1;                // stage that produces the input (-1: in global memory, complete before the launch)
     int Rin = 0;                 // input rows of this band that the workgroup owns (dep >= 0: the producer's R), from row S r0 on
@@ -461,7 +463,10 @@ struct alignas(16) BandStage {
     int res_mode = RES_NONE;     // RES_DIRECT: the input itself (S == 1), RES_MAXPOOL: 2x2 max of the input (S == 2); channels >= C: zero (Co >= C)
     int res_dep = -2;            // (host only) stage whose output the skip is when it is not the stage's input (-1: the program's input, -2: none)
     int res_tile = -1;           // -1: the skip is the stage's own input; else RES_DIRECT from the tensor in this LDS tile (same rows, Co channels:
-                                 // the iris network's bottlenecks add the tensor in front of their 1x1 reduction)
+                                 // the iris network's bottlenecks add the tensor in front of their 1x1 reduction), or RES_MAXPOOL of the C-channel
+                                 // tensor of twice the size in this tile (the input of the 2x2 convolution in front of this block)
+    int cross = 0;               // (host only) the stage reads a tensor of the other branch's workgroups: Rin = 0, every row from the packets
+    int res_co = 0;              // RES_MAXPOOL from res_tile: that tensor has Co channels (no zero pad), not C
     int act = ACT_NONE;
     long src_off = 0, dst_off = 0;   // floats from the base to frame 0 of the tensor
     long src_fs = 0, dst_fs = 0;     // floats between frames
@@ -486,6 +491,7 @@ struct BandLaunch {
     const BandPacked* prog = nullptr;
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
     int ntiles = 2;                 // LDS tiles (2 .. kBandTiles)
+    int halo = 3;                   // tile rows beside the band's own: 3 when a stride-2 block reads two rows below its band, else 2
     int tile_floats = 0;            // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]
     int dw_floats = 0;
     long ws_frame_floats = 0;       // base[0]: floats between the frames' workspaces
@@ -497,7 +503,7 @@ struct BandLaunch {
 };
 int launch_bandnet(const BandLaunch& a, void* stream);
 // LDS floats of a band of R rows of a W x C tensor (with its halo rows and border pixels) / of a stage's depthwise result / small constants
-int bandnet_tile_floats(int R, int W, int C);
+int bandnet_tile_floats(int R, int W, int C, int halo);
 int bandnet_dw_floats(const BandStage& st);
 int bandnet_const_floats(const BandStage& st);
 int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages);

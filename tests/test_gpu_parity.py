@@ -378,8 +378,10 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
     oracle frame by frame, against the batched plan (band = 0), run-to-run bit-identical (the arithmetic does not depend on who arrives
     first), eager and as a replayed graph, with one and with several rows per band, and one frame beyond what a launch takes.  The face
     mesh's program stops in front of its two whole-frame convolutions, which keep their launches behind it (three LDS tiles: the 6x6
-    tensor has two readers); the iris network's stops in front of its first 2x2 convolution (eight stages, the bottlenecks' skips read
-    from a third tile)."""
+    tensor has two readers); the iris network's (iris_landmark.rs:203) is all 54 nodes between its first convolution and its two whole-frame
+    heads: the bottlenecks' skips read from a third tile, the 2x2 stride-2 convolutions as stages whose contraction runs over the four taps,
+    the 2x2-max skips of the blocks behind them read from the tile the convolution read, the two branches behind the 8x8 fork one after
+    the other (four tiles)."""
     torch = pytest.importorskip("torch")
     m = gpu.Model(model_path(name))
     assert m.single_launch_workgroups(1) > 0 and m.single_launch_workgroups(frames) == frames * m.single_launch_workgroups(1)
@@ -405,7 +407,7 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
     m.set_option("graph", 1)
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
     behind = {"landmark": ["head_gemm_kernel"] * 2,
-              "iris": ["resident_kernel", "bneck_kernel", "resident_kernel", "tail_kernel", "head_gemm_kernel", "tail_kernel", "head_gemm_kernel"]}.get(name, [])
+              "iris": ["head_gemm_kernel"] * 2}.get(name, [])
     assert labels[1:] == ["bandnet_kernel"] + behind, labels
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
     assert "bandnet_kernel" not in labels, labels
@@ -417,6 +419,8 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
         for nb in (1, 3):
             for o, r in zip(m.run(x[:nb]), refs):
                 _raw_close(o, r[:nb])
+        if name == "iris":
+            continue   # (16 workgroups: four two-row tiles of 32x32x64 do not fit the LDS, the program ends in front of the first 2x2 convolution again)
         for o, o1 in zip(m.run(x[:1]), one):   # the band height does not enter a pixel's arithmetic
             np.testing.assert_array_equal(o, o1)
     m.set_option("band", 1)   # the default: only the single-image entries take it
