@@ -73,6 +73,13 @@ unsigned long long* g_band_stamps = nullptr;
 #define MI_BAND_STAMP(k)
 #endif
 
+#ifdef MI_BAND_OLDMAP
+#define MI_BAND_MYCT(wave, sh) ((wave) >> (sh))
+#define MI_BAND_MYPT(wave, sh) ((wave) & ((1 << (sh)) - 1))
+#else
+#define MI_BAND_MYCT(wave, sh) ((wave) & ((8 >> (sh)) - 1))
+#define MI_BAND_MYPT(wave, sh) ((wave) >> (3 - (sh)))
+#endif
 // A stage descriptor in scalar registers.  The program (BandPacked, 20 dwords a stage) is copied to LDS once — a descriptor read from
 // global memory at the top of a stage is a dependent round trip in front of everything else — and a descriptor is then ONE LDS read
 // per lane (dword `lane` of it), a v_readlane per dword and scalar bit-field extracts.
@@ -86,8 +93,8 @@ struct StageRegs {
 // word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:12 woff:4 per_ct:16
 // words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)
 __host__ __device__ inline unsigned bf(unsigned v, int lo, int n) { return (v >> lo) & ((1u << n) - 1u); }
-__device__ __forceinline__ StageRegs stage_regs(const BandPacked* p, int lane) {
-    const int word = reinterpret_cast<const int*>(p)[lane < kBandPackedWords ? lane : 0];
+__device__ __forceinline__ int stage_word(const BandPacked* p, int lane) { return reinterpret_cast<const int*>(p)[lane < kBandPackedWords ? lane : 0]; }
+__device__ __forceinline__ StageRegs stage_regs(int word) {
     unsigned w[17];
 #pragma unroll
     for (int k = 0; k < 17; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
@@ -104,6 +111,11 @@ __device__ __forceinline__ StageRegs stage_regs(const BandPacked* p, int lane) {
     return r;
 }
 
+// CV2: the program has 2x2 stride-2 convolution stages (the iris network).  Their code lives in an instantiation of its own: beside it the other
+// stage kinds' code comes out with 37 instead of 9 scalar registers kept in vector lanes and waits on the A registers it reloads, 0.5 us per
+// stage on every network (BackCamera 178 -> 204 us; as a second compile-time copy of the stage body inside one kernel the packet loop was
+// unswitched into 250 KB of code: the same 0.5 us, from the instruction cache).
+template <bool CV2>
 __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,9 +147,9 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     };
     // a stage's A operands for this wave (it keeps one 16-channel output tile for the whole stage) and its small constants
     auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, float& A4, f32x4& creg) {
-        const bool cv2 = st.kind != BAND_BLOCK && st.S == 2;   // (its first round of eight 16-value chunks; C % 32 == 0)
+        const bool cv2 = CV2 && st.kind != BAND_BLOCK && st.S == 2;   // (its first round of eight 16-value chunks; C % 32 == 0)
         const int nct = (st.Co + 15) >> 4, n16 = cv2 ? kMaxN16 : st.C >> 4, has8 = cv2 ? 0 : (st.C >> 3) & 1, has4 = cv2 ? 0 : (st.C >> 2) & 1;
-        const int myct = wave >> st.wpc_shift;
+        const int myct = MI_BAND_MYCT(wave, st.wpc_shift);
         const float* ga = a.consts + st.w_a + (myct < nct ? myct : 0) * st.per_ct;
 #pragma unroll
         for (int j = 0; j < kMaxN16; j++) A[j] = j < n16 ? *reinterpret_cast<const f32x4*>(ga + (j * 64 + lane) * 4) : zero4;
@@ -152,13 +164,13 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     f32x2 A8 = {0.f, 0.f};
     float A4 = 0.f;
     if (s < a.nstages) {
-        st = stage_regs(lprog + s, lane);
+        st = stage_regs(stage_word(lprog + s, lane));
         fetch(st, A, A8, A4, creg);
     }
     while (s < a.nstages) {
         MI_BAND_STAMP(0)
         const bool blk = st.kind == BAND_BLOCK;
-        const bool cv2 = !blk && st.S == 2;        // 2x2 stride-2 convolution: output row r reads input rows 2r, 2r + 1 (no row above, none below them)
+        const bool cv2 = CV2 && !blk && st.S == 2;   // 2x2 stride-2 convolution: output row r reads input rows 2r, 2r + 1 (no row above, none below them)
         const int S = st.S, C = st.C, Cs = C + 4, C4 = C >> 2, Co = st.Co, Wo = st.Wo, W = st.W, TW = W + 2;
         const int bi = w >> st.wshift;
         const int r0 = bi * st.R, nro = min(st.Ho, r0 + st.R) - r0, npx = nro * Wo;
@@ -169,7 +181,9 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         float* const tile = lds + st.src_tile * a.tile_floats;
         const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C >> 3) & 1, has4 = (C >> 2) & 1;
         const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
-        const int wpc = 1 << st.wpc_shift, myct = wave >> st.wpc_shift;    // wpc = 8 / nct rounded down to a power of two (nct <= 8)
+        // wpc = 8 / nct rounded down to a power of two (nct <= 8) waves share an output-channel tile and take its pixel tiles in turn.  The channel
+        // tile is the wave's LOW bits — waves w and w + 4 sit on one SIMD, and of a tile's waves only the first has work where a band is one pixel tile
+        const int wpc = 1 << st.wpc_shift, myct = MI_BAND_MYCT(wave, st.wpc_shift), mypt = MI_BAND_MYPT(wave, st.wpc_shift);
         const bool wave_on = myct < nct;
 
         // ---- the rows of the input that this workgroup does not own: above [ya, p0) and below [p0 + Rin, yb)
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     *reinterpret_cast<f32x4*>(dtile + (rr * TWo + (side ? Wo + 1 : 0)) * Cso + 4 * q) = zero4;
                 }
             if (wave_on)
-                for (int pt = wave & (wpc - 1); pt < npt; pt += wpc) {
+                for (int pt = mypt; pt < npt; pt += wpc) {
                     const int px = 16 * pt + n, pxc = min(px, npx - 1);
                     const int oy = mdiv(pxc, st.mWo), ox = pxc - oy * Wo;
                     const float* bp = blk ? dwb + pxc * Cs : tile + ((1 + oy) * TW + ox + 1) * Cs;
@@ -287,24 +301,30 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     f32x4 D = zero4, D1 = zero4, D2 = zero4, D3 = zero4;
                     if (cv2) {
                         // contraction over (tap, channel): 4 C / 128 rounds of eight chunks; round 0's A operands came with the stage's
-                        // descriptor, the others (and round 0 again for a wave's second pixel tile) are read here
+                        // descriptor (A keeps them for the wave's next pixel tile), the others are read here
                         const float* ga = a.consts + st.w_a + myct * st.per_ct;
                         const float* t00 = tile + ((1 + 2 * oy) * TW + 2 * ox + 1) * Cs + 4 * kq;
+                        // (a register set of its own for the later rounds: were they loaded into A, every use of A — the other stage kinds' too —
+                        // would stand behind a wait for ALL outstanding memory operations, the previous pixel tile's packet stores among them:
+                        // measured 0.6 us per stage on every network)
                         const int nr = C >> 5;
-                        for (int r = 0; r < nr; r++) {
-                            if (r > 0 || (nr > 1 && pt >= wpc)) {   // (the registers hold round 0 only in front of the wave's first pixel tile)
+                        f32x4 Ar[kMaxN16];
 #pragma unroll
-                                for (int j = 0; j < kMaxN16; j++) A[j] = *reinterpret_cast<const f32x4*>(ga + ((r * kMaxN16 + j) * 64 + lane) * 4);
+                        for (int j = 0; j < kMaxN16; j++) Ar[j] = A[j];
+                        for (int r = 0; r < nr; r++) {
+                            if (r > 0) {
+#pragma unroll
+                                for (int j = 0; j < kMaxN16; j++) Ar[j] = *reinterpret_cast<const f32x4*>(ga + ((r * kMaxN16 + j) * 64 + lane) * 4);
                             }
 #pragma unroll
                             for (int j = 0; j < kMaxN16; j++) {
                                 const int k0 = (r * kMaxN16 + j) * 16;
                                 const int tap = (k0 >= C) + (k0 >= 2 * C) + (k0 >= 3 * C);
                                 const f32x4 bv = *reinterpret_cast<const f32x4*>(t00 + ((tap >> 1) * TW + (tap & 1)) * Cs + (k0 - tap * C));
-                                D = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].x, bv.x, D, 0, 0, 0);
-                                D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].y, bv.y, D1, 0, 0, 0);
-                                D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].z, bv.z, D2, 0, 0, 0);
-                                D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j].w, bv.w, D3, 0, 0, 0);
+                                D = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].x, bv.x, D, 0, 0, 0);
+                                D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].y, bv.y, D1, 0, 0, 0);
+                                D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].z, bv.z, D2, 0, 0, 0);
+                                D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].w, bv.w, D3, 0, 0, 0);
                             }
                         }
                     } else {
@@ -375,12 +395,13 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                 }
         }
         MI_BAND_STAMP(4)
-        // ---- the next stage's A operands and constants: requested here, needed behind its halo rows
+        // ---- the next stage's A operands and constants: requested here, needed behind its halo rows.  (Requested in front of the depthwise phase
+        // instead, into a second register set: BackCamera 178 -> 226 us, iris 182 -> 200 — the closing barriers of the phases in between wait for them.)
         const int sn = next_active(s);
         MI_BAND_STAMP(6)
         StageRegs stn{};
         if (sn < a.nstages) {
-            stn = stage_regs(lprog + sn, lane);
+            stn = stage_regs(stage_word(lprog + sn, lane));
             MI_BAND_STAMP(7)
             fetch(stn, A, A8, A4, creg);
         }
@@ -438,7 +459,7 @@ int launch_bandnet(const BandLaunch& a, void* stream) {
     if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles || a.halo < 2 || a.halo > 3) return (int)hipErrorInvalidValue;
     if (bandnet_lds_bytes(a.ntiles, a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
-    auto kern = bandnet_kernel;
+    auto kern = a.cv2 ? bandnet_kernel<true> : bandnet_kernel<false>;
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
 #ifdef MI_BAND_STAMPS
     BandLaunch b = a;

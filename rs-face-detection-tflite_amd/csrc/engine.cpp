@@ -1115,6 +1115,8 @@ void Model::build_bandnet_try(bool conv2_ok) {
     band_dw_floats_ = dw_floats;
     band_ntiles_ = ntiles;
     band_halo_ = halo;
+    band_cv2_ = false;
+    for (const BandStage& st : prog) band_cv2_ = band_cv2_ || (st.kind == BAND_PW && st.S == 2);
     band_lds_bytes_ = bandnet_lds_bytes(ntiles, tile_floats, dw_floats, NS);
     if (band_lds_bytes_ > 160 * 1024) BAND_GIVE_UP;
     band_ws_frame_floats_ = std::max<long>(ws, 64);
@@ -1376,6 +1378,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             a.base[1] = const_cast<float*>(tensor_ptr(band_stem_out_, in, chunk_start, &fs));
             a.ntiles = band_ntiles_;
             a.halo = band_halo_;
+            a.cv2 = band_cv2_ ? 1 : 0;
             for (size_t k = 0; k < band_ext_.size(); k++) {
                 long efs = 0;
                 a.base[2 + k] = band_ext_[k].out_k >= 0 ? d_out_[static_cast<size_t>(band_ext_[k].out_k)] : tensor_ptr_mut(band_ext_[k].tensor, chunk_start, &efs);

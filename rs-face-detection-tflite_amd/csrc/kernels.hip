@@ -155,8 +155,13 @@ __global__ __launch_bounds__(256) void pw_few_kernel(ConvArgs a) {
 // through the scalar cache into SGPR operands of v_fmac and every VALU lane does useful work; the input patch comes
 // from an LDS tile (zero padded, TF SAME), staged with coalesced row-segment loads.  Output 16 B stores.
 // U8: the input is 8UC3 frames (rows of u8_row_bytes bytes); a byte is normalised through a 256-entry table while the tile is filled.
-template <int K, int CO, bool U8 = false>
+// CS: the output channels are split over CS workgroups per tile (a single-image call, face_detection.rs:205, has 2 - 32 tiles for 256 CUs and
+// a thread's K K 3 CO FMAs are one dependent chain of scalar-cache round trips: CO / CS channels per thread shorten it; the per-channel
+// arithmetic is the same, so the results are bit-identical).
+template <int K, int CO_ALL, bool U8 = false, int CS = 1>
 __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
+    constexpr int CO = CO_ALL / CS;
+    static_assert(CO * CS == CO_ALL && CO % 4 == 0, "channel split");
     // PP output pixels per thread (rows ly and ly + 8): every scalar-loaded weight pair then feeds PP packed FMAs, which
     // halves the scalar-cache round trips per FMA (they, not the VALU, set the pace at one pixel per thread)
     constexpr int PP = 2;
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     const int tid = threadIdx.x;
     const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
     int t = blockIdx.x;
+    const int cs0 = (t % CS) * CO; t /= CS;   // first output channel of this workgroup
     const int tx0 = (t % tiles_x) * TW; t /= tiles_x;
     const int ty0 = (t % tiles_y) * TH;
     const int b = t / tiles_y;
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     for (int p = 0; p < PP; p++)
 #pragma unroll
         for (int o = 0; o < CO / 2; o++) acc2[p][o] = v2f{0.f, 0.f};
-    const float* __restrict__ w = a.w;  // [K][K][3][Cop], uniform -> scalar loads
-    const int Cop = (CO + 3) & ~3;
+    const float* __restrict__ w = a.w + cs0;  // [K][K][3][Cop], uniform -> scalar loads
+    const int Cop = (CO_ALL + 3) & ~3;
     // Not unrolled beyond 3 taps: the weights of a tap are 24..64 SGPRs; letting the compiler hoist all K*K*3 taps'
     // scalar loads would spill SGPRs into VGPR lanes.  Occupancy (<= 64 VGPRs) hides the scalar-load latency instead.
 #pragma unroll 1
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     // which took longer than the 900 packed FMAs of the 5x5 stem.
     const bool prelu = a.ep.act == ACT_PRELU;
     const float base_slope = a.ep.act == ACT_NONE ? 1.f : 0.f, hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY;
-    const float* __restrict__ bias = a.ep.bias;
-    const float* __restrict__ al = prelu ? a.ep.alpha : a.ep.bias;  // always a readable array: no branch around the loads
+    const float* __restrict__ bias = a.ep.bias + cs0;
+    const float* __restrict__ al = (prelu ? a.ep.alpha : a.ep.bias) + cs0;  // always a readable array: no branch around the loads
     constexpr int C4 = CO / 4;
     const bool relu = a.ep.act == ACT_RELU;  // wave-uniform: the three detector stems; one packed add + one packed max per channel pair
 #pragma unroll
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
             int px = i / C4, c4 = i - px * C4;
             int y = ty0 + 8 * p + px / TW, x = tx0 + (px & (TW - 1));
             if (y < a.Ho && x < a.Wo)
-                *reinterpret_cast<float4*>(a.out + (long)b * a.out_fs + ((long)y * a.Wo + x) * CO + 4 * c4) =
+                *reinterpret_cast<float4*>(a.out + (long)b * a.out_fs + ((long)y * a.Wo + x) * CO_ALL + cs0 + 4 * c4) =
                     *reinterpret_cast<const float4*>(otile + px * OS + 4 * c4);
         }
     }
@@ -288,6 +294,9 @@ static int launch_stem(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 16;  // rows of a tile (two output pixels per thread)
     unsigned tiles = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + TH - 1) / TH));
     if (a.in_u8) return (int)launch_kernel(stem_conv_kernel<K, CO, true>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
+    // a handful of frames: 8 output channels per workgroup (16 of the iris network's 64), CS times the workgroups
+    constexpr int CS = CO == 64 ? 4 : CO / 8;
+    if (tiles * (unsigned)a.B * CS <= 256u) return (int)launch_kernel(stem_conv_kernel<K, CO, false, CS>, dim3(tiles * (unsigned)a.B * CS), dim3(256), 0, s, a);
     return (int)launch_kernel(stem_conv_kernel<K, CO, false>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
 }
 

@@ -491,6 +491,7 @@ struct BandLaunch {
     const BandPacked* prog = nullptr;
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
     int ntiles = 2;                 // LDS tiles (2 .. kBandTiles)
+    int cv2 = 0;                    // the program has 2x2 stride-2 convolution stages (the kernel instantiation with their code)
     int halo = 3;                   // tile rows beside the band's own: 3 when a stride-2 block reads two rows below its band, else 2
     int tile_floats = 0;            // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]
     int dw_floats = 0;
