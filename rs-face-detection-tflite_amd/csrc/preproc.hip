@@ -413,6 +413,27 @@ size_t image_to_tensor_scratch_bytes(int width, int height, int stride, const mi
     return align256(static_cast<size_t>(stride) * height) + align256(sizeof(PreGeom)) + 256;
 }
 
+// The source rows a single picture's pre-processing can read.  With a ROI only the rows the warp samples travel to the device (an eye's ROI
+// spans a tenth of the picture's rows: IrisLandmark::infer, iris_landmark.rs:188, copies 60 - 100 KB of man.jpg's 583): dst -> src is a
+// homography whose denominator is positive over the target rectangle, so the source row is extreme at one of its corners; the second
+// bilinear tap and OpenCV's 1/32-pixel rounding of the coordinates stay inside a margin of four rows.
+static void sampled_rows(const PreGeom& g, bool has_roi, int height, int* y_first, int* y_last) {
+    *y_first = 0;
+    *y_last = height - 1;
+    if (!has_roi || g.warp_w <= 0 || g.warp_h <= 0) return;
+    double lo = 1e300, hi = -1e300;
+    for (int c = 0; c < 4; c++) {
+        const double x = (c & 1) ? g.warp_w : -1.0, y = (c & 2) ? g.warp_h : -1.0;
+        const double w = g.Minv[6] * x + g.Minv[7] * y + g.Minv[8];
+        const double sy = (g.Minv[3] * x + g.Minv[4] * y + g.Minv[5]) / w;
+        if (!(w > 1e-9) || !(sy > -1e9 && sy < 1e9)) return;   // (not a map this argument covers: the whole picture)
+        lo = std::min(lo, sy);
+        hi = std::max(hi, sy);
+    }
+    *y_first = static_cast<int>(std::max(0.0, std::min(static_cast<double>(height - 1), std::floor(lo) - 4.0)));
+    *y_last = static_cast<int>(std::max(static_cast<double>(*y_first), std::min(static_cast<double>(height - 1), std::ceil(hi) + 4.0)));
+}
+
 void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
                             bool keep_aspect, double range_min, double range_max, bool flip, float* d_out, double padding[4],
                             void* d_scratch, hipStream_t s) {
@@ -424,7 +445,11 @@ void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int 
     uint8_t* d_img = static_cast<uint8_t*>(d_scratch);
     PreGeom* d_geom = reinterpret_cast<PreGeom*>(d_img + align256(static_cast<size_t>(stride) * height));
     // the caller's last row owns 3 * width bytes, not a whole stride (a cv::Mat ROI view ends there)
-    hip_check(hipMemcpyAsync(d_img, rgb_host, static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width, hipMemcpyHostToDevice, s), "H2D image");
+    int y_first = 0, y_last = height - 1;
+    sampled_rows(g, roi != nullptr, height, &y_first, &y_last);
+    const size_t off = static_cast<size_t>(stride) * y_first;
+    const size_t bytes = static_cast<size_t>(stride) * (y_last - y_first) + (y_last == height - 1 ? static_cast<size_t>(3) * width : static_cast<size_t>(stride));
+    hip_check(hipMemcpyAsync(d_img + off, rgb_host + off, bytes, hipMemcpyHostToDevice, s), "H2D image");
     hip_check(hipMemcpyAsync(d_geom, &g, sizeof g, hipMemcpyHostToDevice, s), "H2D geometry");
     PreItems it{};
     it.frames = d_img; it.frame_bytes = 0; it.width = width; it.height = height; it.stride = stride;
@@ -451,7 +476,11 @@ void image_to_tensor_enqueue(const uint8_t* rgb_host, int width, int height, int
     const PreGeom g = compute_geom(width, height, roi ? &r : nullptr, out_w, out_h, keep_aspect);  // same code as the device path
     if (!g.valid) throw std::runtime_error("ROI is empty or degenerate (singular perspective transform)");
     // the caller's last row owns 3 * width bytes, not a whole stride (a cv::Mat ROI view ends there)
-    hip_check(hipMemcpyAsync(d_img, rgb_host, static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width, hipMemcpyHostToDevice, s), "H2D image");
+    int y_first = 0, y_last = height - 1;
+    sampled_rows(g, roi != nullptr, height, &y_first, &y_last);
+    const size_t off = static_cast<size_t>(stride) * y_first;
+    const size_t bytes = static_cast<size_t>(stride) * (y_last - y_first) + (y_last == height - 1 ? static_cast<size_t>(3) * width : static_cast<size_t>(stride));
+    hip_check(hipMemcpyAsync(d_img + off, rgb_host + off, bytes, hipMemcpyHostToDevice, s), "H2D image");
     PreItems it{};
     it.frames = d_img; it.frame_bytes = 0; it.width = width; it.height = height; it.stride = stride;
     it.items_per_frame = 1; it.N = 1; it.out_w = out_w; it.out_h = out_h; it.keep_aspect = keep_aspect;

@@ -846,6 +846,37 @@ def test_image_to_tensor_vs_oracle(gpu, oracle, gold, man_image):
     np.testing.assert_array_equal(got, ref)
 
 
+def test_single_image_entries_copy_every_row_the_warp_samples(gpu, gold, man_image):
+    """FaceLandmark::infer / IrisLandmark::infer with a ROI (face_landmark.rs:250, iris_landmark.rs:188) send only the source rows the warp
+    can sample to the device.  A handle whose picture buffer holds the INVERTED picture in every row (a call without ROI uploads all rows)
+    must give, bit for bit, what a handle whose buffer holds the picture itself gives: a sampled row outside the copied range would be read
+    from the stale contents.  Upright, rotated, tiny and mostly-off-picture ROIs."""
+    poison = np.ascontiguousarray(255 - man_image)
+    rs = np.random.RandomState(5)
+    rois = [gold["man_face_roi"], gold["man_eye_left_roi"], gold["man_eye_right_roi"],
+            np.array([0.5, 0.02, 0.3, 0.2, 0.0, 1]), np.array([0.5, 0.98, 0.3, 0.2, 3.0, 1]),           # over the top / bottom edge
+            np.array([0.05, 0.1, 0.5, 0.45, 2.4, 1]), np.array([270.0, 180.0, 40.0, 30.0, 0.785, 0]),   # mostly outside; pixels, 45 degrees
+            np.array([0.5, 0.5, 0.01, 0.01, 0.3, 1])]                                                    # a few pixels
+    for k in range(10):
+        rois.append(np.array([rs.uniform(0.1, 0.9), rs.uniform(0.0, 1.0), rs.uniform(0.02, 0.9), rs.uniform(0.02, 0.9), rs.uniform(-3.1, 3.1), 1]))
+    fresh, stale = gpu.IrisLandmark(), gpu.IrisLandmark()
+    fresh_fl, stale_fl = gpu.FaceLandmark(), gpu.FaceLandmark()
+    for roi in rois:
+        r = gpu.Rect(*[float(v) for v in roi[:5]], int(roi[5]))
+        for right in (False, True):
+            fresh.infer(man_image, None, right)
+            stale.infer(poison, None, right)
+            a, b = fresh.infer(man_image, r, right), stale.infer(man_image, r, right)
+            np.testing.assert_array_equal(a.contour.array, b.contour.array, err_msg="iris roi %s" % roi)
+            np.testing.assert_array_equal(a.iris.array, b.iris.array, err_msg="iris roi %s" % roi)
+        fresh_fl.infer(man_image, None)
+        stale_fl.infer(poison, None)
+        a, b = fresh_fl.infer(man_image, r), stale_fl.infer(man_image, r)
+        np.testing.assert_array_equal(a.array, b.array, err_msg="mesh roi %s" % roi)
+    for h in (fresh, stale, fresh_fl, stale_fl):
+        h.close()
+
+
 def test_fl_and_iris_infer_images_vs_tensor_entries(gpu, oracle, gold, man_image):
     """Round 5: mi_fl_infer_images / mi_iris_infer_images take the frames as the reference's callers hold them (8UC3) plus one ROI (and
     is_right_eye) per item and warp on the device (face_landmark.rs:250, iris_landmark.rs:188-189).  On the 25-ROI set of
