@@ -134,8 +134,9 @@ size_t mi_model_profile(mi_model *m, const float *in_device, int batch, int reps
 int mi_model_plan_stats(const mi_model *m, double *bytes_per_frame, double *macs_per_frame, int *launches);
 /* The single-image entries (mi_fd_infer_image ...: one Mat per call, face_detection.rs:205) run a graph that is a first convolution
  * followed by BlazeBlocks / 1x1 convolutions as ONE launch behind that convolution (bandnet_kernels.hip) instead of the batched
- * plan's launches; a graph that continues with other operators (the face mesh's whole-frame convolutions, the iris network from its
- * first 2x2 convolution on) runs its leading part that way and the rest on the batched plan's launches.  Returns the workgroups (= CUs held for the launch) such a call of `batch` frames occupies, 0 when the graph has
+ * plan's launches (2x2 stride-2 convolutions and the blocks behind them, whose skip is the 2x2 max of the convolution's input, are stages
+ * too: the iris network); a graph that continues with other operators (the face mesh's and the iris network's whole-frame convolutions)
+ * runs its leading part that way and the rest on the batched plan's launches.  Returns the workgroups (= CUs held for the launch) such a call of `batch` frames occupies, 0 when the graph has
  * no such form or `batch` is too large for it, negative on error.  Engine option "band" = 0 turns the form off. */
 int mi_model_single_launch_workgroups(mi_model *m, int batch);
 

@@ -617,9 +617,9 @@ void Model::free_bandnet() {
 
 // The single-launch plan (bandnet_kernels.hip).  It is made from the level-2 lowering of the same graph — one node per BlazeBlock /
 // convolution — when that is: a first convolution (which keeps its launch of the batched plan), then nothing but 3x3 BlazeBlocks whose
-// skip is their own input (or, without a stride, another tensor of the program: the iris network's bottlenecks), pointwise blocks and
-// 1x1 convolutions, each reading the tensor of an earlier one.  The program stops in front of the first node that is none of these
-// (the face mesh's two whole-frame convolutions, the iris network's first 2x2 convolution): the plan nodes from there on keep their
+// skip is their own input (or, without a stride, another tensor of the program: the iris network's bottlenecks), pointwise blocks,
+// 1x1 convolutions and 2x2 stride-2 convolutions, each reading the tensor of an earlier one.  The program stops in front of the first node
+// that is none of these (the face mesh's and the iris network's two whole-frame convolutions): the plan nodes from there on keep their
 // launches of the batched plan, behind the band launch, and the tensors they read are written to their arena storage by the band
 // program — provided no launch of the batched plan straddles the cut.  Graphs whose FIRST block is already something else (full_range's
 // double blocks) leave band_ready_ false and the handle on the batched plan.
