@@ -629,8 +629,9 @@ void Model::free_bandnet() {
 // are stages too: the whole iris network but its two whole-frame heads is one program (iris_landmark.rs:203).  Should a graph with such
 // nodes have no program with them, it is lowered once more with the program ending in front of the first of them (the earlier form).
 void Model::build_bandnet() {
+    band_saw_conv2_ = false;
     build_bandnet_try(true);
-    if (!band_ready_) build_bandnet_try(false);
+    if (!band_ready_ && band_saw_conv2_) build_bandnet_try(false);
 }
 
 void Model::build_bandnet_try(bool conv2_ok) {
@@ -696,6 +697,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
                            g.tensors[n.in[0]].shape.size() == 4 && g.tensors[n.in[0]].shape[1] % 2 == 0 && g.tensors[n.in[0]].shape[2] % 2 == 0 &&
                            g.tensors[n.in[0]].shape[3] % 32 == 0 && n.in[0] != band_stem_out_;
         if (!pw_block && !dw_block && !conv1 && !conv2) { cut = i; break; }
+        if (conv2) band_saw_conv2_ = true;
         if (n.in.size() != 1 || n.ept >= 0 || n.res_after) BAND_GIVE_UP;
         const auto& si = g.tensors[n.in[0]].shape;
         const auto& so = g.tensors[n.out].shape;
@@ -1453,7 +1455,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     h.bias = ep.bias; h.alpha = ep.alpha; h.act = ep.act;
                     h.B = F; h.K = si[1] * si[2] * si[3]; h.N = so[3];
                     rc = launch_head_gemm(h, s);
-                    if (labels) labels->back() = "head_gemm_kernel";
+                    if (labels) labels->back() = F <= 4 ? "head_dot_kernel" : "head_gemm_kernel";   // (launch_head_gemm: a handful of frames take the dot-product form)
                     break;
                 }
                 ConvArgs a;

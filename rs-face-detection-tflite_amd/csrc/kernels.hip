@@ -422,11 +422,39 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(HeadGemmArgs a) {
     }
 }
 
+// The same product for the one to four frames of a single-image call (face_landmark.rs:265, iris_landmark.rs:203): a 32-frame MFMA tile with one live
+// frame is 256 dependent 64-cycle MFMAs for the iris network's K = 512 (17 us per head, two heads in line behind the band launch).  Here a wave owns
+// one (output, frame): its lanes read 16 bytes of x and of W[n] each per round (coalesced), four partial sums per lane, then a butterfly over the
+// wave — a fixed order, so run-to-run bit-identical (it is not the MFMA's order: within the raw tolerance of the batched form, like every small-batch form).
+__global__ __launch_bounds__(256) void head_dot_kernel(HeadGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave, b = blockIdx.y;
+    if (n >= a.N) return;  // whole wave
+    const float4* x = reinterpret_cast<const float4*>(a.in + (long)b * a.in_fs);
+    const float4* w = reinterpret_cast<const float4*>(a.w + (long)n * a.K);
+    const int K4 = a.K >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int j = lane; j < K4; j += 64) {
+        const float4 xv = x[j], wv = w[j];
+        s0 = fmaf(xv.x, wv.x, s0); s1 = fmaf(xv.y, wv.y, s1); s2 = fmaf(xv.z, wv.z, s2); s3 = fmaf(xv.w, wv.w, s3);
+    }
+    float sum = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) {
+        const float t = sum + (a.bias ? a.bias[n] : 0.f);
+        const float slope = a.act == ACT_PRELU ? a.alpha[n] : (a.act == ACT_NONE ? 1.f : 0.f);
+        const float hi = a.act == ACT_RELU6 ? 6.f : INFINITY;
+        a.out[(long)b * a.out_fs + n] = fminf(fmaxf(t, 0.f) + slope * fminf(t, 0.f), hi);
+    }
+}
+
 bool head_gemm_supports(int K, int N) { return K >= 16 && (K % 8) == 0 && N >= 1; }
 
 int launch_head_gemm(const HeadGemmArgs& a, void* stream) {
     if (!head_gemm_supports(a.K, a.N) || a.B < 1 || (a.in_fs & 3) || (reinterpret_cast<uintptr_t>(a.in) & 15) || (reinterpret_cast<uintptr_t>(a.w) & 15))
         return (int)hipErrorInvalidValue;
+    if (a.B <= 4) return (int)launch_kernel(head_dot_kernel, dim3((unsigned)((a.N + 3) / 4), (unsigned)a.B), dim3(256), 0, (hipStream_t)stream, a);
     const unsigned tiles_n = (unsigned)((a.N + 31) / 32);
     return (int)launch_kernel(head_gemm_kernel, dim3((tiles_n + 3) / 4, (unsigned)((a.B + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
 }

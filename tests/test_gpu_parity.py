@@ -406,8 +406,8 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
                     np.testing.assert_array_equal(o, o2)
     m.set_option("graph", 1)
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
-    behind = {"landmark": ["head_gemm_kernel"] * 2,
-              "iris": ["head_gemm_kernel"] * 2}.get(name, [])
+    behind = {"landmark": ["head_dot_kernel"] * 2,     # (the whole-frame convolutions of one to four frames: a wave per output, kernels.hip)
+              "iris": ["head_dot_kernel"] * 2}.get(name, [])
     assert labels[1:] == ["bandnet_kernel"] + behind, labels
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
     assert "bandnet_kernel" not in labels, labels
