@@ -303,8 +303,17 @@ bool make_dblock_geom(const DblockArgs& a, DblockGeom* out) {
     g.cfl = 10 * g.Cp + 64 * MTA + 10 * g.Cmp + 64 * MT;
     const int wfl = 32 * MTA * g.Cp + 32 * MT * g.Cmp;
     // rows per band: as many as LDS and the prefetch registers hold (fewer bands = less halo work)
+    // ... but a handful of frames (a single-image call, face_detection.rs:205) would then be a handful of workgroups on 256 CUs: there the
+    // bands get as short as it takes to have about a workgroup per CU (at least two rows; the halo rows of stage 1 are recomputed per band)
     int RB = 0;
-    for (int r = std::min(a.H, 32); r >= 1; r--) {
+    int cap = 32;
+    {
+        static const int env_cap = getenv("MI_DBLOCK_RBCAP") ? atoi(getenv("MI_DBLOCK_RBCAP")) : 0;   // tuning aid
+        const long cus = device_cu_count();
+        if ((long)a.B * ((a.H + 31) / 32) * 4 <= cus) cap = std::max(2, (int)(((long)a.H * a.B + cus - 1) / cus));
+        if (env_cap > 0) cap = env_cap;
+    }
+    for (int r = std::min(std::min(a.H, 32), cap); r >= 1; r--) {
         const long fl = (long)(r + 4) * g.RSx + (long)(r + 2) * g.RSa + g.cfl + wfl + 16;
         const long n4 = (long)(r + 4) * a.W * (a.C / 4);
         if (fl * 4 <= 160 * 1024 - 256 && n4 <= (long)kDbPrefetch * 512) { RB = r; break; }
