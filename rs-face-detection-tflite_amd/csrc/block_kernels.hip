@@ -498,7 +498,12 @@ bool make_geom_pg(const BlockArgs& a, int PG, BlockGeom* out) {
     const int fixed = (a.has_dw ? 10 * g.Cp * 4 : 0) + (g.a_lds ? (int)a_bytes : 0) + g.MT * 32 * 8 + 64;
     auto lds_for = [&](int R) { return ((R - 1) * S + KS) * g.RS * 4 + fixed; };
     auto pf_ok = [&](int R) { return (long)R * S * a.W * g.C4 <= (long)kPrefetch * 256; };
-    const int Rfull = std::max(1, std::min(a.Ho, (128 * PG) / a.Wo));  // rows that fill every lane of the 4 waves
+    // ... of a handful of frames (a single-image call of full_range, face_detection.rs:205: 1 - 2 such steps per frame on 256 CUs) only 32 pixels'
+    // worth: a step's MFMA time goes with its 32-pixel groups, and the shorter bands are more workgroups (full_range at one frame: its 19
+    // block_kernel launches 0.260 -> 0.226 ms; 16 pixels: 0.217, 64: 0.242).  The arithmetic of a pixel does not depend on the band it is in.
+    static const int rcap_px = getenv("MI_BLOCK_RCAP_PX") ? atoi(getenv("MI_BLOCK_RCAP_PX")) : 32;  // tuning aid (0: off)
+    int Rfull = std::max(1, std::min(a.Ho, (128 * PG) / a.Wo));  // rows that fill every lane of the 4 waves
+    if (rcap_px > 0 && (long)a.B * ((a.Ho + Rfull - 1) / Rfull) * 8 <= cu_count()) Rfull = std::max(1, std::min(Rfull, rcap_px / a.Wo));
     int R = Rfull;
     while (R > 1 && (lds_for(R) > lds_budget() || !pf_ok(R))) R--;
     if (R * a.Wo * 4 < 128 * PG * 3) {  // step under 75% full: small, channel-heavy layer -> spend the whole LDS of a CU on one workgroup
