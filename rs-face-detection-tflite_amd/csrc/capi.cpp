@@ -1111,22 +1111,25 @@ mi_model* mi_iris_model(mi_iris* h) { return h ? &h->model : nullptr; }
 static void iris_project(mi_iris* h, int batch, const mi::RectD* d_roi, const int* d_size, const double* d_pad, const int* d_flip,
                          float* d_contour, float* d_iris, hipStream_t s) {
     mi::Model& m = *h->model.m;
-    for (int k = 0; k < 2; k++) {
-        mi::ProjArgs a;
-        a.B = batch;
-        a.n = k == 0 ? MI_NUM_EYE_LANDMARKS : MI_NUM_IRIS_LANDMARKS;
-        a.tensor_w = h->in_w;
-        a.tensor_h = h->in_h;
-        a.roi = d_roi;
-        a.image_size = d_size;
-        a.padding = d_pad;
-        a.flip = d_flip;
-        a.raw = m.output_device(k);
-        a.raw_fs = static_cast<long>(m.output_elems(k));
-        a.out = k == 0 ? d_contour : d_iris;
-        int rc = mi::launch_project(a, s);
-        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-    }
+    // both outputs (71 contour + 5 iris landmarks per eye) in one launch
+    mi::ProjArgs a;
+    a.B = batch;
+    a.n = MI_NUM_EYE_LANDMARKS;
+    a.n2 = MI_NUM_IRIS_LANDMARKS;
+    a.tensor_w = h->in_w;
+    a.tensor_h = h->in_h;
+    a.roi = d_roi;
+    a.image_size = d_size;
+    a.padding = d_pad;
+    a.flip = d_flip;
+    a.raw = m.output_device(0);
+    a.raw_fs = static_cast<long>(m.output_elems(0));
+    a.out = d_contour;
+    a.raw2 = m.output_device(1);
+    a.raw2_fs = static_cast<long>(m.output_elems(1));
+    a.out2 = d_iris;
+    int rc = mi::launch_project(a, s);
+    if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
 }
 
 int mi_iris_infer_tensor(mi_iris* h, const float* in, int batch, const mi_rect* rois, const int* image_sizes, const double* padding,

@@ -764,16 +764,21 @@ int launch_postprocess(const PostArgs& a, void* stream) {
 // project_landmarks (transform.rs:351-432); one thread per landmark; f32/f64 mix kept as in the Rust source.
 __global__ void project_landmarks_kernel(ProjArgs a) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)a.B * a.n) return;
-    int b = (int)(idx / a.n), i = (int)(idx % a.n);
-    float* o = a.out + (long)b * (a.out_fs ? a.out_fs : 3L * a.n) + 3 * i;
+    const int nt = a.n + a.n2;
+    if (idx >= (long)a.B * nt) return;
+    const int b = (int)(idx / nt), k = (int)(idx % nt);
+    // (a second list of landmarks of the same items — the iris network's two outputs, iris_landmark.rs:213-245, in one launch)
+    const bool second = k >= a.n;
+    const int li = second ? k - a.n : k;            // index within its list
+    const int i = second ? -1 : li;                 // i == 0: the item's first landmark (the flag and the gate bookkeeping belong to it)
+    float* o = (second ? a.out2 + (long)b * 3L * a.n2 : a.out + (long)b * (a.out_fs ? a.out_fs : 3L * a.n)) + 3 * li;
     if (a.gate && !a.gate[b]) {
         o[0] = o[1] = o[2] = 0.f;
         if (i == 0 && a.present) a.present[b] = 0;
         if (i == 0 && a.raw_flag_out && a.flag) a.raw_flag_out[b] = a.flag[(long)b * a.flag_fs];
         return;
     }
-    const float* r = a.raw + (long)b * a.raw_fs + 3 * i;
+    const float* r = (second ? a.raw2 + (long)b * a.raw2_fs : a.raw + (long)b * a.raw_fs) + 3 * li;
     float wf = (float)a.tensor_w, hf = (float)a.tensor_h;
     float x = __fdiv_rn(r[0], wf), y = __fdiv_rn(r[1], hf), z = __fdiv_rn(r[2], wf);
     if (a.flip && a.flip[b]) x = __fadd_rn(__fmul_rn(x, -1.0f), 1.0f);
@@ -815,7 +820,7 @@ __global__ void project_landmarks_kernel(ProjArgs a) {
 }
 
 int launch_project(const ProjArgs& a, void* stream) {
-    long n = (long)a.B * a.n;
+    long n = (long)a.B * (a.n + a.n2);
     if (n > 0) hipLaunchKernelGGL(project_landmarks_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
