@@ -251,8 +251,12 @@ struct mi_pipeline {
     std::unique_ptr<mi_fd> fd;
     std::unique_ptr<mi_fl> fl;
     std::unique_ptr<mi_iris> iris;
-    DeviceBuf frames, geom, pad_det, pad_eye, in_det, dets, counts, roi_face, valid_face, in_lm, lm, present, roi_eye, valid_eye,
-        flip_eye, in_eye, eyes, sizes, faces;
+    DeviceBuf frames, geom, pad_det, pad_eye, in_det, dets, roi_face, valid_face, in_lm, roi_eye, valid_eye, flip_eye, in_eye, sizes;
+    // results of a call from host memory: ONE device block (faces | counts | landmarks | present | eyes) and its pinned host image — one
+    // asynchronous copy and one synchronisation per call (five copies into the caller's pageable arrays were five synchronous round trips:
+    // 115 us of the 0.66 ms of a one-picture call)
+    DeviceBuf results;
+    OneShot out;
     int sizes_B = 0, sizes_w = 0, sizes_h = 0;  // what `sizes` holds (uploaded once per batch geometry, not per call)
 };
 
@@ -1342,6 +1346,16 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fdm.stream();
         Use use_fd(p->fd->model, s), use_fl(p->fl->model, s), use_ir(p->iris->model, s);  // the pipeline's own three handles, fixed order
         const int B = batch, cap = 4;
+        const long eye_fs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
+        auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+        const size_t off_faces = 0, off_counts = up16(off_faces + sizeof(mi_detection) * B), off_lm = up16(off_counts + sizeof(int) * B),
+                     off_present = up16(off_lm + sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B), off_eyes = up16(off_present + sizeof(int) * B),
+                     results_bytes = up16(off_eyes + sizeof(float) * eye_fs * 2 * B);
+        char* d_results = nullptr;
+        if (mem == MI_MEM_HOST) {
+            d_results = static_cast<char*>(p->results.get(results_bytes));
+            p->out.reserve(results_bytes);
+        }
         const size_t frame_bytes = static_cast<size_t>(stride) * height;
         const uint8_t* d_frames = frames;
         if (mem == MI_MEM_HOST) {
@@ -1384,7 +1398,7 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         tr("det run_device");
         float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
         mi::hip_check(hipMemsetAsync(d_dets, 0, sizeof(mi_detection) * cap * B, s), "hipMemsetAsync");  // frames without a face report zeros
-        int* d_counts = mem == MI_MEM_DEVICE ? face_counts : static_cast<int*>(p->counts.get(sizeof(int) * B));
+        int* d_counts = mem == MI_MEM_DEVICE ? face_counts : reinterpret_cast<int*>(d_results + off_counts);
         fd_post(p->fd.get(), fdm.output_device(0), fdm.output_device(1), B, d_pad_det, reinterpret_cast<mi_detection*>(d_dets), cap, d_counts,
                 MI_MEM_DEVICE, s);
         // ---- 2. faces[0] -> face_detection_to_roi -> image_to_tensor(frame, roi, (192,192), false, (0,1)) -> mesh net
@@ -1400,8 +1414,8 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         tr("pre mesh");
         flm.run_device(d_in_lm, B, s, one_shot);
         tr("mesh run_device");
-        float* d_lm = mem == MI_MEM_DEVICE ? landmarks : static_cast<float*>(p->lm.get(sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B));
-        int* d_present = mem == MI_MEM_DEVICE ? present : static_cast<int*>(p->present.get(sizeof(int) * B));
+        float* d_lm = mem == MI_MEM_DEVICE ? landmarks : reinterpret_cast<float*>(d_results + off_lm);
+        int* d_present = mem == MI_MEM_DEVICE ? present : reinterpret_cast<int*>(d_results + off_present);
         {
             mi::ProjArgs a;
             a.B = B; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = p->fl->in_w; a.tensor_h = p->fl->in_h;
@@ -1426,31 +1440,33 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         tr("pre iris");
         irm.run_device(d_in_eye, 2 * B, s, one_shot);
         tr("iris run_device");
-        const long eye_fs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
-        float* d_eyes = mem == MI_MEM_DEVICE ? eyes : static_cast<float*>(p->eyes.get(sizeof(float) * eye_fs * 2 * B));
-        for (int k = 0; k < 2; k++) {
+        float* d_eyes = mem == MI_MEM_DEVICE ? eyes : reinterpret_cast<float*>(d_results + off_eyes);
+        {   // contour and iris landmarks of both eyes in one launch
             mi::ProjArgs a;
-            a.B = 2 * B; a.n = k == 0 ? MI_NUM_EYE_LANDMARKS : MI_NUM_IRIS_LANDMARKS; a.tensor_w = p->iris->in_w; a.tensor_h = p->iris->in_h;
+            a.B = 2 * B; a.n = MI_NUM_EYE_LANDMARKS; a.n2 = MI_NUM_IRIS_LANDMARKS; a.tensor_w = p->iris->in_w; a.tensor_h = p->iris->in_h;
             a.roi = d_roi_eye; a.image_size = d_sizes; a.padding = d_pad_eye; a.flip = d_flip_eye; a.gate = d_valid_eye;
-            a.raw = irm.output_device(k); a.raw_fs = static_cast<long>(irm.output_elems(k));
-            a.out = d_eyes + (k == 0 ? 0 : 3 * MI_NUM_EYE_LANDMARKS); a.out_fs = eye_fs;
+            a.raw = irm.output_device(0); a.raw_fs = static_cast<long>(irm.output_elems(0));
+            a.raw2 = irm.output_device(1); a.raw2_fs = static_cast<long>(irm.output_elems(1));
+            a.out = d_eyes; a.out_fs = eye_fs;
+            a.out2 = d_eyes + 3 * MI_NUM_EYE_LANDMARKS; a.out2_fs = eye_fs;
             int rc = mi::launch_project(a, s);
             if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
         }
         // ---- top-1 faces out (strided gather [B][cap][17] -> [B][17]) and host copies
         tr("projections");
-        mi_detection* d_faces = mem == MI_MEM_DEVICE ? faces : static_cast<mi_detection*>(p->faces.get(sizeof(mi_detection) * B));
+        mi_detection* d_faces = mem == MI_MEM_DEVICE ? faces : reinterpret_cast<mi_detection*>(d_results + off_faces);
         mi::hip_check(hipMemcpy2DAsync(d_faces, sizeof(mi_detection), d_dets, sizeof(mi_detection) * cap, sizeof(mi_detection), B,
                                        hipMemcpyDeviceToDevice, s), "gather faces");
         tr("gather");
         if (mem == MI_MEM_HOST) {
-            mi::hip_check(hipMemcpyAsync(faces, d_faces, sizeof(mi_detection) * B, hipMemcpyDeviceToHost, s), "D2H faces");
-            mi::hip_check(hipMemcpyAsync(face_counts, d_counts, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H counts");
-            mi::hip_check(hipMemcpyAsync(landmarks, d_lm, sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B, hipMemcpyDeviceToHost, s), "D2H landmarks");
-            mi::hip_check(hipMemcpyAsync(present, d_present, sizeof(int) * B, hipMemcpyDeviceToHost, s), "D2H present");
-            mi::hip_check(hipMemcpyAsync(eyes, d_eyes, sizeof(float) * eye_fs * 2 * B, hipMemcpyDeviceToHost, s), "D2H eyes");
+            mi::hip_check(hipMemcpyAsync(p->out.host, d_results, results_bytes, hipMemcpyDeviceToHost, s), "D2H results");
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
             if (one_shot && (static_cast<int>(fdm.band_failed()) | static_cast<int>(flm.band_failed()) | static_cast<int>(irm.band_failed()))) continue;
+            std::memcpy(faces, p->out.h<char>(off_faces), sizeof(mi_detection) * B);
+            std::memcpy(face_counts, p->out.h<char>(off_counts), sizeof(int) * B);
+            std::memcpy(landmarks, p->out.h<char>(off_lm), sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B);
+            std::memcpy(present, p->out.h<char>(off_present), sizeof(int) * B);
+            std::memcpy(eyes, p->out.h<char>(off_eyes), sizeof(float) * eye_fs * 2 * B);
             for (int b = 0; b < B; b++) {
                 if (face_counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
                 if (face_counts[b] == 0) std::memset(&faces[b], 0, sizeof(mi_detection));

@@ -771,7 +771,7 @@ __global__ void project_landmarks_kernel(ProjArgs a) {
     const bool second = k >= a.n;
     const int li = second ? k - a.n : k;            // index within its list
     const int i = second ? -1 : li;                 // i == 0: the item's first landmark (the flag and the gate bookkeeping belong to it)
-    float* o = (second ? a.out2 + (long)b * 3L * a.n2 : a.out + (long)b * (a.out_fs ? a.out_fs : 3L * a.n)) + 3 * li;
+    float* o = (second ? a.out2 + (long)b * (a.out2_fs ? a.out2_fs : 3L * a.n2) : a.out + (long)b * (a.out_fs ? a.out_fs : 3L * a.n)) + 3 * li;
     if (a.gate && !a.gate[b]) {
         o[0] = o[1] = o[2] = 0.f;
         if (i == 0 && a.present) a.present[b] = 0;

@@ -180,10 +180,11 @@ struct ProjArgs {  // project_landmarks, one thread per landmark
     float* out = nullptr;             // [B][out_fs] (first n*3 floats written)
     long out_fs = 0;                  // floats between items (0 = n*3)
     int B = 0, n = 0, tensor_w = 1, tensor_h = 1;
-    // optional second list of landmarks of the same items (same ROI / padding / flip; no flag): raw2 [B][raw2_fs] -> out2 [B][3 n2]
+    // optional second list of landmarks of the same items (same ROI / padding / flip; no flag): raw2 [B][raw2_fs] -> out2 [B][out2_fs]
     const float* raw2 = nullptr;
     long raw2_fs = 0;
     float* out2 = nullptr;
+    long out2_fs = 0;   // floats between items (0 = n2*3)
     int n2 = 0;
 };
 

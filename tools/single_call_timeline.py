@@ -22,6 +22,10 @@ def run(kind):
         h = mi.IrisLandmark()
         roi = mi.Rect(*[float(v) for v in gold["man_eye_left_roi"][:5]], int(gold["man_eye_left_roi"][5]))
         fn = lambda: h.infer(img, roi, False)
+    elif kind == "pipe":   # the whole flow of lib.rs:24-40 on one picture (detector -> mesh -> both eyes), one call
+        h = mi.Pipeline(mi.FaceDetectionModel.BackCamera)
+        one = np.ascontiguousarray(img[None])
+        fn = lambda: h.run(one)
     else:
         h = mi.FaceDetection({"back": mi.FaceDetectionModel.BackCamera, "short": mi.FaceDetectionModel.Short, "full": mi.FaceDetectionModel.Full}[kind])
         fn = lambda: h.infer(img, None)
