@@ -423,6 +423,15 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
             continue   # (16 workgroups: four two-row tiles of 32x32x64 do not fit the LDS, the program ends in front of the first 2x2 convolution again)
         for o, o1 in zip(m.run(x[:1]), one):   # the band height does not enter a pixel's arithmetic
             np.testing.assert_array_equal(o, o1)
+    if name == "iris":
+        # the second branch behind the 8x8 fork on the workgroups the first one leaves idle (the default), or both branches one after the
+        # other on the same workgroups: who computes a pixel does not enter its arithmetic
+        m.set_option("band_nw", 32)
+        forked = [o.copy() for o in m.run(x[:3])]
+        m.set_option("band_fork", 0)
+        for o, o1 in zip(m.run(x[:3]), forked):
+            np.testing.assert_array_equal(o, o1)
+        m.set_option("band_fork", 1)
     m.set_option("band", 1)   # the default: only the single-image entries take it
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
     assert "bandnet_kernel" not in labels, labels
