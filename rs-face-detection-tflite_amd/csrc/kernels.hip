@@ -158,13 +158,13 @@ __global__ __launch_bounds__(256) void pw_few_kernel(ConvArgs a) {
 // CS: the output channels are split over CS workgroups per tile (a single-image call, face_detection.rs:205, has 2 - 32 tiles for 256 CUs and
 // a thread's K K 3 CO FMAs are one dependent chain of scalar-cache round trips: CO / CS channels per thread shorten it; the per-channel
 // arithmetic is the same, so the results are bit-identical).
-template <int K, int CO_ALL, bool U8 = false, int CS = 1>
+template <int K, int CO_ALL, bool U8 = false, int CS = 1, int PP = 2>
 __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     constexpr int CO = CO_ALL / CS;
     static_assert(CO * CS == CO_ALL && CO % 4 == 0, "channel split");
     // PP output pixels per thread (rows ly and ly + 8): every scalar-loaded weight pair then feeds PP packed FMAs, which
-    // halves the scalar-cache round trips per FMA (they, not the VALU, set the pace at one pixel per thread)
-    constexpr int PP = 2;
+    // halves the scalar-cache round trips per FMA (they, not the VALU, set the pace at one pixel per thread).  The channel-split form of a
+    // single-image call takes PP = 1: twice the workgroups, half the chain.
     constexpr int TW = 32, TH = 8 * PP;                  // output tile
     constexpr int IW = 2 * TW + K - 2, IH = 2 * TH + K - 2;  // input tile (stride 2)
     constexpr int RS = (IW * 3 + 1) & ~1;                // row stride in floats (even: 8-byte aligned float2 reads)
@@ -296,6 +296,8 @@ static int launch_stem(const ConvArgs& a, hipStream_t s) {
     if (a.in_u8) return (int)launch_kernel(stem_conv_kernel<K, CO, true>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
     // a handful of frames: 8 output channels per workgroup (16 of the iris network's 64), CS times the workgroups
     constexpr int CS = CO == 64 ? 4 : CO / 8;
+    const unsigned tiles1 = (unsigned)(((a.Wo + 31) / 32) * ((a.Ho + 7) / 8));   // 8-row tiles: one output pixel per thread
+    if (tiles1 * (unsigned)a.B * CS <= 256u) return (int)launch_kernel(stem_conv_kernel<K, CO, false, CS, 1>, dim3(tiles1 * (unsigned)a.B * CS), dim3(256), 0, s, a);
     if (tiles * (unsigned)a.B * CS <= 256u) return (int)launch_kernel(stem_conv_kernel<K, CO, false, CS>, dim3(tiles * (unsigned)a.B * CS), dim3(256), 0, s, a);
     return (int)launch_kernel(stem_conv_kernel<K, CO, false>, dim3(tiles * (unsigned)a.B), dim3(256), 0, s, a);
 }
