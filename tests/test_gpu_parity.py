@@ -882,6 +882,18 @@ def test_single_image_entries_copy_every_row_the_warp_samples(gpu, gold, man_ima
         stale_fl.infer(poison, None)
         a, b = fresh_fl.infer(man_image, r), stale_fl.infer(man_image, r)
         np.testing.assert_array_equal(a.array, b.array, err_msg="mesh roi %s" % roi)
+    # a strided view (cv::Mat ROI: rows `stride` bytes apart, the last row owns only 3 * width bytes) — the copied range is cut out of it
+    view, pview = man_image[40:300, 100:420], poison[40:300, 100:420]
+    for roi in rois[:8]:
+        r = gpu.Rect(*[float(v) for v in roi[:5]], int(roi[5]))
+        if not r.normalized:
+            continue
+        fresh.infer(view, None, False)
+        stale.infer(pview, None, False)
+        a, b = fresh.infer(view, r, False), stale.infer(view, r, False)
+        np.testing.assert_array_equal(a.contour.array, b.contour.array, err_msg="view, iris roi %s" % roi)
+        c = fresh.infer(np.ascontiguousarray(view), r, False)
+        np.testing.assert_array_equal(a.contour.array, c.contour.array, err_msg="view against its contiguous copy, roi %s" % roi)
     for h in (fresh, stale, fresh_fl, stale_fl):
         h.close()
 
