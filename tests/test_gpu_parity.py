@@ -488,6 +488,53 @@ def test_single_image_entry_on_the_single_launch_plan(gpu, oracle, man_image):
     off.close()
 
 
+def test_mesh_and_iris_single_image_entries_on_threads(gpu, gold, man_image):
+    """FaceLandmark::infer / IrisLandmark::infer (face_landmark.rs:232, iris_landmark.rs:158) on the single-launch plan from eight threads, a
+    handle each: 96 / 32 workgroups per call on 256 CUs — calls that do not get their CUs run on the batched plan instead (never wait), a forced
+    give-up repeats itself there; every call returns the landmarks of a handle with the plan turned off, within the tolerance between the two plans."""
+    import threading
+    face = gpu.Rect(*[float(v) for v in gold["man_face_roi"][:5]], int(gold["man_face_roi"][5]))
+    eye = gpu.Rect(*[float(v) for v in gold["man_eye_left_roi"][:5]], int(gold["man_eye_left_roi"][5]))
+    fl_off, ir_off = gpu.FaceLandmark(), gpu.IrisLandmark()
+    fl_off.model.set_option("band", 0)
+    ir_off.model.set_option("band", 0)
+    want_lm = fl_off.infer(man_image, face).array
+    want_eye = ir_off.infer(man_image, eye, False)
+    assert len(want_lm) == 468
+
+    def same(lm, eyes):
+        np.testing.assert_allclose(lm.array, want_lm, atol=2e-3)          # (pixel coordinates of a 540 x 360 picture)
+        np.testing.assert_allclose(eyes.contour.array, want_eye.contour.array, atol=2e-3)
+        np.testing.assert_allclose(eyes.iris.array, want_eye.iris.array, atol=2e-3)
+
+    fl, ir = gpu.FaceLandmark(), gpu.IrisLandmark()
+    assert fl.model.single_launch_workgroups(1) == 96 and ir.model.single_launch_workgroups(1) == 32
+    same(fl.infer(man_image, face), ir.infer(man_image, eye, False))
+    fl.model.set_option("band_test_fail", 1)
+    ir.model.set_option("band_test_fail", 1)
+    same(fl.infer(man_image, face), ir.infer(man_image, eye, False))
+    errors = []
+
+    def worker():
+        try:
+            a, b = gpu.FaceLandmark(), gpu.IrisLandmark()
+            for _ in range(25):
+                same(a.infer(man_image, face), b.infer(man_image, eye, False))
+            a.close()
+            b.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+    for h in (fl, ir, fl_off, ir_off):
+        h.close()
+
+
 @pytest.mark.parametrize("name", ["back", "landmark", "iris", "full"])
 def test_network_matches_committed_golden(gpu, gold, name):
     m = gpu.Model(model_path(name))
