@@ -257,6 +257,8 @@ struct mi_pipeline {
     // 115 us of the 0.66 ms of a one-picture call)
     DeviceBuf results;
     OneShot out;
+    DeviceBuf geom_det;                              // the detector's letterbox geometry of `geom_B` pictures of geom_w x geom_h (no ROI: uploaded once)
+    int geom_B = 0, geom_w = 0, geom_h = 0;
     int sizes_B = 0, sizes_w = 0, sizes_h = 0;  // what `sizes` holds (uploaded once per batch geometry, not per call)
 };
 
@@ -1391,8 +1393,14 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         it.range_min = -1.0; it.range_max = 1.0;
         double* d_pad_det = static_cast<double*>(p->pad_det.get(sizeof(double) * 4 * B));
         float* d_in_det = static_cast<float*>(p->in_det.get(fdm.input_elems() * sizeof(float) * B));
-        mi::launch_pre_geom(it, d_geom, d_pad_det, s);
-        mi::launch_pre_tensor(it, d_geom, d_in_det, s);
+        // (no ROI: the geometry is the same for every call on pictures of this size — no pre_geom launch, 9 us of a one-picture call)
+        auto* d_geom_det = static_cast<mi::PreGeom*>(p->geom_det.get(sizeof(mi::PreGeom) * B));
+        if (p->geom_B != B || p->geom_w != width || p->geom_h != height) {
+            p->geom_B = 0;
+            mi::upload_whole_image_geom(width, height, it.out_w, it.out_h, true, B, d_geom_det, d_pad_det, s);
+            p->geom_B = B; p->geom_w = width; p->geom_h = height;
+        }
+        mi::launch_pre_tensor(it, d_geom_det, d_in_det, s);
         tr("pre det");
         fdm.run_device(d_in_det, B, s, one_shot);
         tr("det run_device");

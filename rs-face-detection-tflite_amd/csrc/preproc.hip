@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
+#include <vector>
 
 #include "engine.hpp"
 
@@ -388,6 +389,19 @@ void launch_pre_geom(const PreItems& it, PreGeom* d_geom, double* d_padding, hip
     if (it.N <= 0) return;
     hipLaunchKernelGGL(pre_geom_kernel, dim3((it.N + 7) / 8), dim3(64), 0, s, it, d_geom, d_padding);
     hip_check(hipGetLastError(), "pre_geom kernel launch");
+}
+
+// The geometry of N whole pictures of one size (no ROI: the detector's letterbox, face_detection.rs:226) does not depend on the call: computed
+// on the host by the same code and uploaded — the caller keeps it for as long as (width, height, N) stay what they are.  Synchronous.
+void upload_whole_image_geom(int width, int height, int out_w, int out_h, bool keep_aspect, int N, PreGeom* d_geom, double* d_padding, hipStream_t s) {
+    if (N <= 0) return;
+    const PreGeom g = compute_geom(width, height, nullptr, out_w, out_h, keep_aspect);
+    std::vector<PreGeom> hg(static_cast<size_t>(N), g);
+    std::vector<double> hp(4 * static_cast<size_t>(N));
+    for (int i = 0; i < N; i++) { hp[4 * i] = g.pad_x; hp[4 * i + 1] = g.pad_y; hp[4 * i + 2] = g.pad_x; hp[4 * i + 3] = g.pad_y; }
+    hip_check(hipMemcpyAsync(d_geom, hg.data(), hg.size() * sizeof(PreGeom), hipMemcpyHostToDevice, s), "H2D geometry");
+    if (d_padding) hip_check(hipMemcpyAsync(d_padding, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, s), "H2D padding");
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
 }
 
 void launch_pre_tensor(const PreItems& it, const PreGeom* d_geom, float* d_out, hipStream_t s) {

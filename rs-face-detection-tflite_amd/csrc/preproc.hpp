@@ -38,6 +38,8 @@ struct PreItems {               // batch description (device pointers unless sta
 
 // geometry for N items -> d_geom[N], d_padding[N][4] (may be null)
 void launch_pre_geom(const PreItems& it, PreGeom* d_geom, double* d_padding, hipStream_t s);
+// ... of N whole pictures of one size (no ROI), computed on the host and uploaded (synchronous: the caller caches it per (width, height, N))
+void upload_whole_image_geom(int width, int height, int out_w, int out_h, bool keep_aspect, int N, PreGeom* d_geom, double* d_padding, hipStream_t s);
 // warp -> (border, resize) -> resize -> flip -> normalise, fused per output pixel; out f32 [N][out_h][out_w][3]
 void launch_pre_tensor(const PreItems& it, const PreGeom* d_geom, float* d_out, hipStream_t s);
 
