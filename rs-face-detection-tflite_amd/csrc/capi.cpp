@@ -495,8 +495,13 @@ int mi_fd_anchors(const mi_fd* h, float* out_xy, int cap) {
 
 // shared tail: raw device outputs -> detections
 static void fd_post(mi_fd* h, const float* d_boxes, const float* d_scores, int batch, const double* padding, mi_detection* out,
-                    int cap, int* counts, int mem, hipStream_t s) {
+                    int cap, int* counts, int mem, hipStream_t s, mi::RectD* d_face_rois = nullptr, int* d_face_valid = nullptr, int image_w = 0,
+                    int image_h = 0) {
     mi::PostArgs a;
+    if (d_face_rois) {   // (device results only: the batched pipeline) zeros behind the last detection and faces[0]'s ROI from the same launch
+        a.zero_rest = 1;
+        a.face_rois = d_face_rois; a.face_valid = d_face_valid; a.image_w = image_w; a.image_h = image_h;
+    }
     a.raw_boxes = d_boxes;
     a.raw_scores = d_scores;
     a.anchors = h->d_anchors;
@@ -1405,15 +1410,14 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         fdm.run_device(d_in_det, B, s, one_shot);
         tr("det run_device");
         float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
-        mi::hip_check(hipMemsetAsync(d_dets, 0, sizeof(mi_detection) * cap * B, s), "hipMemsetAsync");  // frames without a face report zeros
         int* d_counts = mem == MI_MEM_DEVICE ? face_counts : reinterpret_cast<int*>(d_results + off_counts);
-        fd_post(p->fd.get(), fdm.output_device(0), fdm.output_device(1), B, d_pad_det, reinterpret_cast<mi_detection*>(d_dets), cap, d_counts,
-                MI_MEM_DEVICE, s);
         // ---- 2. faces[0] -> face_detection_to_roi -> image_to_tensor(frame, roi, (192,192), false, (0,1)) -> mesh net
+        // (the post-processing launch writes zeros behind a frame's last detection — frames without a face report zeros — and faces[0]'s ROI)
         auto* d_roi_face = static_cast<mi::RectD*>(p->roi_face.get(sizeof(mi::RectD) * B));
         int* d_valid_face = static_cast<int*>(p->valid_face.get(sizeof(int) * B));
+        fd_post(p->fd.get(), fdm.output_device(0), fdm.output_device(1), B, d_pad_det, reinterpret_cast<mi_detection*>(d_dets), cap, d_counts,
+                MI_MEM_DEVICE, s, d_roi_face, d_valid_face, width, height);
         tr("fd_post");
-        mi::launch_face_rois(d_dets, d_counts, B, cap, width, height, d_roi_face, d_valid_face, s);
         it.rois = d_roi_face; it.roi_valid = d_valid_face; it.out_w = p->fl->in_w; it.out_h = p->fl->in_h; it.keep_aspect = 0;
         it.range_min = 0.0; it.range_max = 1.0;
         float* d_in_lm = static_cast<float*>(p->in_lm.get(flm.input_elems() * sizeof(float) * B));

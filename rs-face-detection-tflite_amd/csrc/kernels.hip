@@ -15,6 +15,7 @@
 
 #include "kernels.hpp"
 #include "launch.hpp"
+#include "roi_dev.hpp"
 
 namespace mi {
 
@@ -750,6 +751,13 @@ __global__ __launch_bounds__(256) void ssd_postprocess_kernel(PostArgs a) {
         if (nrem == 0) break;  // "number of indexed scores didn't change" (nms.rs:117-119)
     }
     if (tid == 0) a.counts[b] = lb_bad ? -1 : nout;  // -1: the reference's letterbox assert! would have fired
+    if (a.zero_rest)
+        for (int i = min(nout, a.cap) * 17 + tid; i < a.cap * 17; i += 256) outp[i] = 0.f;
+    if (a.face_rois && tid == 0) {   // (slot 0 was written by this workgroup, barriers since)
+        RectD r;
+        a.face_valid[b] = face_roi_dev(outp, lb_bad ? -1 : nout, a.image_w, a.image_h, &r);
+        a.face_rois[b] = r;
+    }
 }
 
 int launch_postprocess(const PostArgs& a, void* stream) {

@@ -148,6 +148,12 @@ struct EltArgs {  // ADD / activation / MAX_POOL / channel PAD / RESIZE / DEPTH_
     int p0 = 0, p1 = 0, p2 = 0, p3 = 0;  // op-specific ints (pool filter/stride, pad offsets, block size, flags)
 };
 
+struct RectD {  // layout-compatible with mi_rect (include/mi_face.h) / Rect (types.rs:24-36)
+    double x_center, y_center, width, height, rotation;
+    int normalized;
+    int pad_;
+};
+
 struct PostArgs {  // fused SSD decode + sigmoid + threshold + weighted NMS + letterbox removal, one workgroup/frame
     const float* raw_boxes = nullptr;   // [B][N][16]
     const float* raw_scores = nullptr;  // [B][N]
@@ -157,12 +163,12 @@ struct PostArgs {  // fused SSD decode + sigmoid + threshold + weighted NMS + le
     int* counts = nullptr;              // [B]; -1 where the reference's letterbox-scale assert would fire
     int B = 0, N = 0, cap = 0;
     float scale = 1.f;
-};
-
-struct RectD {  // layout-compatible with mi_rect (include/mi_face.h) / Rect (types.rs:24-36)
-    double x_center, y_center, width, height, rotation;
-    int normalized;
-    int pad_;
+    // the batched pipeline (lib.rs:24-40 per frame): slots behind the frame's last detection are written as zeros (no memset in front of the
+    // launch), and the ROI of faces[0] (face_detection_to_roi on a picture of image_w x image_h) comes out of the same launch
+    int zero_rest = 0;
+    RectD* face_rois = nullptr;         // [B] or null
+    int* face_valid = nullptr;          // [B]
+    int image_w = 0, image_h = 0;
 };
 
 struct ProjArgs {  // project_landmarks, one thread per landmark

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "engine.hpp"
+#include "roi_dev.hpp"
 
 namespace mi {
 namespace {
@@ -326,40 +327,12 @@ __global__ __launch_bounds__(256) void pre_tensor_one_kernel(PreItems it, PreGeo
 }
 
 // ---------------------------------------------------------------------------------------------- ROI maths (device)
-// bbox_to_roi + select_roi_size(SquareLong) (transform.rs:44-109), f64 like the reference
-__device__ inline bool bbox_to_roi_dev(const double bbox[4], int image_w, int image_h, const double kp[4], double scale, RectD* out) {
-    const double xmin = bbox[0], ymin = bbox[1], xmax = bbox[2], ymax = bbox[3];
-    if (!(xmin >= -1.0 && xmax < 2.0 && ymin >= -1.0)) return false;  // BBox::normalized (types.rs:133-135)
-    const double iw = image_w, ih = image_h;
-    const double aw = xmax * iw - xmin * iw, ah = ymax * ih - ymin * ih;
-    const double side = fmax(aw, ah);
-    const double width = side / iw * scale, height = side / ih * scale;
-    const double pi = 3.14159265358979323846;
-    const double angle = -atan2(kp[1] - kp[3], kp[2] - kp[0]);
-    out->x_center = xmin + (xmax - xmin) / 2.0;
-    out->y_center = ymin + (ymax - ymin) / 2.0;
-    out->width = width;
-    out->height = height;
-    out->rotation = angle - 2.0 * pi * floor((angle + pi) / (2.0 * pi));
-    out->normalized = 1;
-    out->pad_ = 0;
-    return true;
-}
-
 __global__ void face_roi_kernel(const float* dets, const int* counts, int B, int cap, int image_w, int image_h, RectD* rois, int* valid) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    RectD r = {0.5, 0.5, 1.0, 1.0, 0.0, 1, 0};
-    int ok = 0;
-    if (counts[b] > 0) {  // faces[0] (lib.rs:29); Detection::scaled_by_image_size multiplies in f32 (types.rs:237-245)
-        const float* d = dets + (long)b * cap * 17;
-        const float w = (float)image_w, h = (float)image_h;
-        const double kp[4] = {(double)__fmul_rn(d[4], w), (double)__fmul_rn(d[5], h), (double)__fmul_rn(d[6], w), (double)__fmul_rn(d[7], h)};
-        const double bbox[4] = {(double)d[0], (double)d[1], (double)d[2], (double)d[3]};
-        ok = bbox_to_roi_dev(bbox, image_w, image_h, kp, 1.5, &r) ? 1 : 0;  // ROI_SCALE, SquareLong (face_landmark.rs:30,189)
-    }
+    RectD r;
+    valid[b] = face_roi_dev(dets + (long)b * cap * 17, counts[b], image_w, image_h, &r);   // roi_dev.hpp
     rois[b] = r;
-    valid[b] = ok;
 }
 
 __global__ void iris_roi_kernel(const float* lm, const int* present, int B, int image_w, int image_h, RectD* rois, int* valid, int* flip) {
