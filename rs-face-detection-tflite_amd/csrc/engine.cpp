@@ -978,6 +978,31 @@ void Model::build_bandnet_try(bool conv2_ok) {
             }
         }
     }
+    // ---- the output heads (1x1 stages nobody reads: the SSD heads of the detectors) of a tensor of one-row bands go to workgroups the trunk
+    // leaves idle there (BandStage::woff, as the iris network's second branch): they take their input rows from the packet buffer and run beside
+    // the trunk's next stages instead of in front of them; the two heads of one tensor on two different sets of idle workgroups where there are two
+    if (band_fork_) {
+        const int N0 = static_cast<int>(prog.size());
+        std::vector<char> read(static_cast<size_t>(N0), 0);
+        for (const BandStage& st : prog) {
+            if (st.dep >= 0) read[static_cast<size_t>(st.dep)] = 1;
+            if (st.res_dep >= 0) read[static_cast<size_t>(st.res_dep)] = 1;
+        }
+        std::vector<int> moved(static_cast<size_t>(N0), 0);   // heads of a tensor already moved
+        for (int k = 0; k < N0; k++) {
+            BandStage& st = prog[static_cast<size_t>(k)];
+            if (read[static_cast<size_t>(k)] || st.kind != BAND_PW || st.S != 1 || st.dep < 0 || st.woff != 0 || st.cross || st.res_mode != RES_NONE) continue;
+            const BandStage& pd = prog[static_cast<size_t>(st.dep)];
+            if (pd.R != 1 || pd.wshift < 1 || pd.woff != 0 || st.R != 1 || st.wshift != pd.wshift || st.nbands != pd.nbands) continue;
+            if (st.W * (st.C / 4) > 4 * 512) continue;   // its one input row: four 16-byte elements per lane
+            const int j = moved[static_cast<size_t>(st.dep)]++;
+            int woff = 1 << (pd.wshift - 1);
+            if ((j & 1) && pd.wshift >= 2) woff += 1 << (pd.wshift - 2);
+            st.woff = woff;
+            st.Rin = 0;
+            st.cross = 1;
+        }
+    }
     // ---- the output heads (stages nobody reads) move up behind the first other reader of their input: the two LDS tiles hold a tensor
     // only until the trunk has moved on twice, and a head costs its workgroups two microseconds wherever it stands
     {
