@@ -115,7 +115,10 @@ __device__ __forceinline__ StageRegs stage_regs(int word) {
 // stage kinds' code comes out with 37 instead of 9 scalar registers kept in vector lanes and waits on the A registers it reloads, 0.5 us per
 // stage on every network (BackCamera 178 -> 204 us; as a second compile-time copy of the stage body inside one kernel the packet loop was
 // unswitched into 250 KB of code: the same 0.5 us, from the instruction cache).
-template <bool CV2>
+// XB: a BLOCK stage of the program takes ALL of its input rows from the packets (the first block of a branch that runs on the workgroups its
+// sibling leaves idle: the face mesh) and has to zero its tile's border pixels itself — an instantiation of its own for the same reason (the
+// three lines cost every stage of BackCamera 0.04 us).
+template <bool CV2, bool XB>
 __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -232,6 +235,11 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                 if (dsto[u] >= 0) {
                     const f32x4 v = {__uint_as_float(pa[u].x), __uint_as_float(pa[u].z), __uint_as_float(pb[u].x), __uint_as_float(pb[u].z)};
                     *reinterpret_cast<f32x4*>(tile + dsto[u]) = real[u] ? v : zero4;
+                }
+            if (XB && st.Rin == 0 && blk)   // the first block of a branch that runs on the workgroups its sibling leaves idle: nobody here wrote the tile's border pixels
+                for (int i = tid; i < (yb - ya) * 2 * C4; i += kThreads) {
+                    const int rr = i / (2 * C4), e = i - rr * 2 * C4, side = e / C4, q = e - side * C4;
+                    *reinterpret_cast<f32x4*>(tile + ((ya + rr - p0 + 1) * TW + (side ? W + 1 : 0)) * Cs + 4 * q) = zero4;
                 }
         } else if (st.dep < 0) {
             // the program's input: plain memory, complete before the launch
@@ -459,7 +467,8 @@ int launch_bandnet(const BandLaunch& a, void* stream) {
     if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles || a.halo < 2 || a.halo > 3) return (int)hipErrorInvalidValue;
     if (bandnet_lds_bytes(a.ntiles, a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
-    auto kern = a.cv2 ? bandnet_kernel<true> : bandnet_kernel<false>;
+    auto kern = a.cv2 ? bandnet_kernel<true, false> : (a.xb ? bandnet_kernel<false, true> : bandnet_kernel<false, false>);
+    if (a.cv2 && a.xb) return (int)hipErrorInvalidValue;   // (no such program: the planner does not build one)
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
 #ifdef MI_BAND_STAMPS
     BandLaunch b = a;

@@ -943,9 +943,12 @@ void Model::build_bandnet_try(bool conv2_ok) {
             prog.swap(re);
             for (int& pr : producer)
                 if (pr >= 0) pr = pos[static_cast<size_t>(pr)];
-            // ... and the second branch behind a fork goes to the workgroups the first one leaves idle (BandStage::woff): where a tensor of one-row
-            // bands on every 2nd / 4th ... workgroup is the input of two stages, the later one and everything behind it are run by the workgroups
-            // half a group further on, at the same time as the first branch; its first stage takes its whole input from the packet buffer
+        }
+        // ... and (any program: the face mesh's two branches behind its 6x6 tensor as well) the second branch behind a fork goes to the workgroups
+        // the first one leaves idle (BandStage::woff): where a tensor of one-row bands on every 2nd / 4th ... workgroup is the input of two stages, the
+        // later one and everything behind it are run by the workgroups half a group further on, at the same time as the first branch; its first
+        // stage takes its whole input from the packet buffer
+        {
             if (band_fork_) {
                 for (int k = 0; k < N0; k++) {
                     const BandStage& fk = prog[static_cast<size_t>(k)];
@@ -953,6 +956,13 @@ void Model::build_bandnet_try(bool conv2_ok) {
                     for (int j = 0; j < N0; j++)
                         if (prog[static_cast<size_t>(j)].dep == k) readers.push_back(j);
                     if (readers.size() != 2 || fk.R != 1 || fk.wshift < 1 || fk.woff != 0) continue;
+                    bool leaf = false;   // (a reader nobody reads is an output head: those have their own rule below)
+                    for (int r : readers) {
+                        bool is_read = false;
+                        for (int j = 0; j < N0; j++) is_read = is_read || prog[static_cast<size_t>(j)].dep == r || prog[static_cast<size_t>(j)].res_dep == r;
+                        leaf = leaf || !is_read;
+                    }
+                    if (leaf) continue;
                     const int woff = 1 << (fk.wshift - 1);
                     std::vector<char> inB(static_cast<size_t>(N0), 0);
                     inB[static_cast<size_t>(readers[1])] = 1;
@@ -1144,6 +1154,9 @@ void Model::build_bandnet_try(bool conv2_ok) {
     band_halo_ = halo;
     band_cv2_ = false;
     for (const BandStage& st : prog) band_cv2_ = band_cv2_ || (st.kind == BAND_PW && st.S == 2);
+    band_xb_ = false;
+    for (const BandStage& st : prog) band_xb_ = band_xb_ || (st.kind == BAND_BLOCK && st.cross);
+    if (band_cv2_ && band_xb_) BAND_GIVE_UP;   // (no kernel instantiation for both: the iris network's second branch starts with a 1x1 stage)
     band_lds_bytes_ = bandnet_lds_bytes(ntiles, tile_floats, dw_floats, NS);
     if (band_lds_bytes_ > 160 * 1024) BAND_GIVE_UP;
     band_ws_frame_floats_ = std::max<long>(ws, 64);
@@ -1406,6 +1419,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             a.ntiles = band_ntiles_;
             a.halo = band_halo_;
             a.cv2 = band_cv2_ ? 1 : 0;
+            a.xb = band_xb_ ? 1 : 0;
             for (size_t k = 0; k < band_ext_.size(); k++) {
                 long efs = 0;
                 a.base[2 + k] = band_ext_[k].out_k >= 0 ? d_out_[static_cast<size_t>(band_ext_[k].out_k)] : tensor_ptr_mut(band_ext_[k].tensor, chunk_start, &efs);

@@ -504,6 +504,7 @@ struct BandLaunch {
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
     int ntiles = 2;                 // LDS tiles (2 .. kBandTiles)
     int cv2 = 0;                    // the program has 2x2 stride-2 convolution stages (the kernel instantiation with their code)
+    int xb = 0;                     // ... a BLOCK stage that takes all of its input rows from the packets (Rin = 0: zeroes its tile's border pixels)
     int halo = 3;                   // tile rows beside the band's own: 3 when a stride-2 block reads two rows below its band, else 2
     int tile_floats = 0;            // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]
     int dw_floats = 0;
