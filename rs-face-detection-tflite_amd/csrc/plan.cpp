@@ -1789,9 +1789,12 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
         } else if (n.kind == Node::Concat) {
             const auto& so = g.tensors[n.out].shape;
             int axis = n.axis < 0 ? n.axis + static_cast<int>(so.size()) : n.axis;
+            // (a crafted graph's axis may lie outside the output's shape: so[d] below must not be read beyond it — found by the mutation test
+            // under AddressSanitizer, a read of four bytes behind the shape vector)
+            if (axis < 1 || axis >= static_cast<int>(so.size())) throw std::runtime_error("plan: CONCATENATION axis outside the output's shape");
             long outer = 1;
             for (int d = 1; d < axis; d++) outer *= so[d];
-            if (axis < 1 || outer != 1) throw std::runtime_error("plan: CONCATENATION must join the first non-batch axis");
+            if (outer != 1) throw std::runtime_error("plan: CONCATENATION must join the first non-batch axis");
             long off = 0;
             for (int t : n.in) {
                 if (plan.storage[t].root != t) throw std::runtime_error("plan: tensor feeds two concatenations/views");
