@@ -1430,6 +1430,19 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
     Plan plan;
     plan.graph = std::move(graph);
     plan.fuse_level = fuse_level;
+    // (untrusted bytes, mi_*_create_from_bytes: the reader has checked every tensor index; the lowering below reads shape.back() of the tensors an
+    // operator touches — a crafted tensor of rank 0 made that a read in front of an empty vector, found under AddressSanitizer)
+    for (const OpInfo& op : plan.graph.ops) {
+        if (op.outputs.empty()) throw std::runtime_error("plan: operator without an output");
+        for (int t : op.outputs)
+            if (t < 0 || plan.graph.tensors[static_cast<size_t>(t)].shape.empty()) throw std::runtime_error("plan: operator output without a shape");
+        for (int t : op.inputs)
+            if (t >= 0 && plan.graph.tensors[static_cast<size_t>(t)].shape.empty()) throw std::runtime_error("plan: operator input without a shape");
+    }
+    for (int t : plan.graph.inputs)
+        if (t < 0 || plan.graph.tensors[static_cast<size_t>(t)].shape.empty()) throw std::runtime_error("plan: graph input without a shape");
+    for (int t : plan.graph.outputs)
+        if (t < 0 || plan.graph.tensors[static_cast<size_t>(t)].shape.empty()) throw std::runtime_error("plan: graph output without a shape");
     // algorithmic sizes (traffic / MAC figures of the plan) are those of the graph as stored, whatever padding the lowering adds
     std::vector<double> logical_elems;
     std::vector<int> logical_C;

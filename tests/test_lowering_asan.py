@@ -14,7 +14,8 @@ CSRC = os.path.join(ROOT, "rs-face-detection-tflite_amd", "csrc")
 def test_lowering_of_mutated_models_under_address_sanitizer(tmp_path):
     """The lowering (plan.cpp) reads shapes, axes and option fields of an untrusted graph: built with AddressSanitizer (host side of hipcc,
     linked against the product's other objects) and run over mutated blobs of three graphs.  Round 5 found a CONCATENATION whose axis lay behind
-    its output's shape that way — a four-byte read behind a vector, which crashed the plain build once in twenty runs."""
+    its output's shape that way — a four-byte read behind a vector, which crashed the plain build once in twenty runs — and a PRELU on a
+    tensor of rank 0."""
     build = os.path.join(ROOT, "rs-face-detection-tflite_amd", "build")
     objs = sorted(f for f in (os.path.join(build, n) for n in os.listdir(build)) if f.endswith(".o") and os.path.basename(f) not in ("plan.o", "tflite_graph.o"))
     assert len(objs) >= 15, "build the product first (__graft_entry__.build())"
@@ -29,15 +30,17 @@ def test_lowering_of_mutated_models_under_address_sanitizer(tmp_path):
     exe = str(tmp_path / "asan_lowering")
     subprocess.check_call([hipcc, "-fsanitize=address", "--offload-arch=gfx950", "-o", exe] + mine + objs, stderr=subprocess.DEVNULL)
     blobs = []
-    for name in ("face_detection_back.tflite", "face_detection_full_range_sparse.tflite", "iris_landmark.tflite"):
-        rs = np.random.RandomState(7)   # (the mutations of test_mutated_models_never_crash_the_lowering: blob 81 of the BackCamera graph is the one)
+    # (seed 7 = the mutations of test_mutated_models_never_crash_the_lowering: blob 81 of the BackCamera graph has the CONCATENATION axis; the iris
+    # graph with seed 5 holds a PRELU on a tensor of rank 0 — shape.back() of an empty vector)
+    for name, seed in (("face_detection_back.tflite", 7), ("face_detection_full_range_sparse.tflite", 7), ("iris_landmark.tflite", 7), ("iris_landmark.tflite", 5)):
+        rs = np.random.RandomState(seed)
         orig = np.frombuffer(open(os.path.join(MODELS, name), "rb").read(), np.uint8)
         for r in range(150):
             b = orig.copy()
             lo = 0 if r % 3 == 0 else max(0, len(b) - 60000)
             for _ in range(rs.randint(1, 6)):
                 b[rs.randint(lo, len(b))] = rs.randint(0, 256)
-            f = str(tmp_path / ("%s_%03d.bin" % (name, r)))
+            f = str(tmp_path / ("%s_%d_%03d.bin" % (name, seed, r)))
             open(f, "wb").write(b.tobytes())
             blobs.append(f)
     r = subprocess.run([exe] + blobs, capture_output=True, text=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
