@@ -119,8 +119,14 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * "fork" (0 = output heads run on the trunk's stream instead of beside it), "heads" (side streams the output heads are spread
  * over, 1..4), "mchain" (0 = the 32x32x48 blocks run one launch each instead of one launch per run), "tail" (0 = no stage program takes the several-frames-per-workgroup form of round 5: the round-4 plan),
  * "tail_g" (frames per workgroup of those programs; 0 = chosen per launch from the batch and the LDS a frame needs), "reuse",
- * "lanes". Takes effect on the next run. */
+ * "lanes"; "band" (the single-launch plan of the single-image entries, below: 0 = never, 1 = the single-image entries only (default), 2 = every run of few
+ * enough frames — a tuning / test setting: such a run is synchronised and checked inside the call, and repeated on the batched plan when its launch
+ * gave up waiting for its CUs), "band_nw" (workgroups per frame of that plan, 8..256). Takes effect on the next run. */
 int mi_model_set_option(mi_model *m, const char *key, int value);
+/* Reads an option back (same keys), plus the state the engine keeps about the single-launch plan: "band" reads 0 once three single launches in a
+ * row have given up (CUs held by other processes, a CU mask) and the handle has stopped using the plan; "band_fail_streak" = such launches in a
+ * row so far; "band_wraps" = times the packet workspace was cleared because the 32-bit packet tags were about to wrap (every 2^26 launches). */
+int mi_model_get_option(mi_model *m, const char *key, int *value);
 /* Host-only: parse + lower a .tflite blob WITHOUT touching a GPU and write the launch plan text (same format as
  * mi_model_describe). Returns bytes needed (incl. NUL), 0 on error (see mi_last_error). Used by CPU-side tests. */
 size_t mi_plan_describe(const uint8_t *tflite, size_t nbytes, int fuse_level, char *buf, size_t cap);
@@ -335,7 +341,10 @@ int mi_image_to_tensor(int device, const uint8_t *rgb, int width, int height, in
  * mi_*_create_from_bytes (the counterpart of FlatBufferModel::build_from_file, face_detection.rs:188, on ranks that have no
  * file).  One process per GPU; no PyTorch needed (librccl is loaded at call time).  Rendezvous: `root` writes the ncclUniqueId
  * to `id_path` (a file every rank of the node can read, e.g. under /dev/shm; a fresh name per broadcast), the other ranks wait
- * up to timeout_ms (< 0: for ever) for it.  buf: HOST memory of nbytes on every rank — the data on `root`, the receive
+ * up to timeout_ms (< 0: for ever) for it.  The root removes whatever an earlier run left under that name before it publishes, and the file
+ * carries the job's shape (world, root): a file of another shape is never accepted; a stale file of the same shape is caught by the bound on the
+ * communicator set-up — with timeout_ms >= 0 ncclCommInitRank runs under max(timeout_ms, 10 s) and the call fails with MI_EIO instead of
+ * hanging.  buf: HOST memory of nbytes on every rank — the data on `root`, the receive
  * buffer elsewhere.  device: this rank's GPU ordinal.  Collective: every rank of `world` must call it. */
 int mi_dist_broadcast_bytes(const char *id_path, int rank, int world, int root, int device, uint8_t *buf, size_t nbytes,
                             int timeout_ms);

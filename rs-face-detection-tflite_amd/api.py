@@ -31,7 +31,7 @@ EXPORTS = [
     "mi_last_error", "mi_device_count", "mi_version",
     "mi_model_load_file", "mi_model_load_bytes", "mi_model_free", "mi_model_input_dims", "mi_model_num_outputs",
     "mi_model_output_dims", "mi_model_output_elems", "mi_model_run", "mi_model_debug_tensor", "mi_model_describe",
-    "mi_dist_broadcast_bytes", "mi_streams_create_distinct", "mi_streams_destroy", "mi_model_set_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
+    "mi_dist_broadcast_bytes", "mi_streams_create_distinct", "mi_streams_destroy", "mi_model_set_option", "mi_model_get_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
     "mi_fd_collect", "mi_host_alloc", "mi_host_free",
@@ -180,6 +180,7 @@ def lib():
     L.mi_model_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.mi_model_describe.restype = C.c_size_t
     L.mi_model_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.mi_model_get_option.argtypes = [vp, C.c_char_p, ip]
     L.mi_plan_describe.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
     L.mi_plan_describe.restype = C.c_size_t
     L.mi_model_plan_stats.argtypes = [vp, dp, dp, ip]
@@ -362,6 +363,11 @@ class Model:
 
     def set_option(self, key, value):
         _check(self.L.mi_model_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int(0)
+        _check(self.L.mi_model_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def describe(self):
         n = self.L.mi_model_describe(self.h, None, 0)

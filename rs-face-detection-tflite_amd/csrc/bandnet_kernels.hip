@@ -24,7 +24,9 @@
 //     stage has a packet buffer of its own: nothing has to be cleared between launches and a stale packet never carries the tag a
 //     reader waits for;
 //   * every wait is bounded: a launch whose workgroups are not all resident (CUs taken by someone else) runs out of iterations,
-//     raises *fail and drains; the host repeats that call on the batched plan.
+//     raises *fail and drains; the host repeats that call on the batched plan.  The drain costs ONE limit in all: the workgroup that
+//     gives up raises sync[2] (every waiting workgroup looks at it each 64th poll) and a word in its own LDS — a workgroup that has
+//     failed, or has seen sync[2], never polls again (its later stages take whatever the first load returned: the results are void).
 //
 // Per stage and band: [A operands -> registers, small constants -> LDS] [halo rows: packets -> LDS] | DW3x3 on the VALU, one
 // thread per (pixel, channel quad) -> LDS | v_mfma_f32_16x16x4_f32 per (16 pixels x 16 output channels) tile, depthwise
@@ -47,7 +49,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512;
-constexpr int kSpinLimit = 1 << 18;   // polls of a packet before the launch gives up (a poll is a memory round trip, ~1 us: ~0.3 s)
+constexpr int kSpinLimit = 1 << 12;   // polls of a packet before the launch gives up (a poll is a memory round trip, 1 - 2 us: a few ms — the time the
+                                      // batched plan takes for the same call; round 5 waited 2^18 polls = 0.3 s, per stage)
+constexpr int kFailCheck = 64;        // ... and every 64th poll looks at sync[2], which the first workgroup to give up raises: the others stop waiting at once
 constexpr int kMaxN16 = 8;            // C <= 128
 constexpr int kConstFloats = 2048;    // LDS floats of a stage's small constants (32 nct + 10 C <= 1536)
 
@@ -130,12 +134,17 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     float* const dwb = lds + a.ntiles * a.tile_floats;
     float* const lC = dwb + a.dw_floats;
     const BandPacked* const lprog = reinterpret_cast<const BandPacked*>(lC + kConstFloats);
+    int* const lfail = reinterpret_cast<int*>(lC + kConstFloats) + a.nstages * (int)(sizeof(BandPacked) / 4);   // this workgroup has given up (16 bytes behind the program)
     {
         const f32x4* gp = reinterpret_cast<const f32x4*>(a.prog);
         f32x4* lp = reinterpret_cast<f32x4*>(lC + kConstFloats);
         for (int i = tid; i < a.nstages * (int)(sizeof(BandPacked) / 16); i += kThreads) lp[i] = gp[i];
+        if (tid == 0) *lfail = 0;
     }
     __syncthreads();
+    // test hook (engine option "band_test_absent" = k): every k-th workgroup leaves at once and publishes nothing — what its neighbours see when a
+    // workgroup of the launch is not resident.  It still counts as finished, so the generation moves on when the others have drained.
+    const bool absent = a.absent_mod > 0 && w % a.absent_mod == a.absent_mod - 1;
     // the stages this workgroup takes part in (workgroup w owns band w >> wshift of a stage where its low wshift bits are the stage's woff), as a bit mask:
     // lane k looks at stage k
     unsigned long long amask;
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         creg = tid < (st.c_floats >> 2) ? reinterpret_cast<const f32x4*>(a.consts + st.w_c)[tid] : zero4;   // c_floats <= 4 x 512
     };
 
-    int s = next_active(-1);
+    int s = absent ? a.nstages : next_active(-1);
     StageRegs st{};
     f32x4 A[kMaxN16], creg = zero4;
     f32x2 A8 = {0.f, 0.f};
@@ -216,13 +225,18 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             }
         }
         if (packets) {
-            int it = 0;
+            int it = *lfail ? kSpinLimit : 0;   // a workgroup that has given up once does not wait again (written before the previous stage's closing barrier)
             for (;;) {
                 bool ok = true;
 #pragma unroll
                 for (int u = 0; u < 4; u++) ok = ok && (!real[u] || (pa[u].y == tag_in && pa[u].w == tag_in && pb[u].y == tag_in && pb[u].w == tag_in));
                 if (ok) break;
-                if (++it > kSpinLimit) { *a.fail = 1; break; }
+                if (++it > kSpinLimit || (it % kFailCheck == 0 && poll(a.sync + 2) != 0u)) {
+                    *a.fail = 1;
+                    *lfail = 1;
+                    __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -425,6 +439,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         const unsigned done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == total - 1) {
             __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody polls any more: the next launch starts unflagged)
             __hip_atomic_store(a.sync, base / 64u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -435,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 int bandnet_tile_floats(int R, int W, int C, int halo) { return (R + halo) * (W + 2) * (C + 4); }
 int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
 int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
-int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages) { return (ntiles * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked); }
+int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages) { return (ntiles * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked) + 16; }
 
 bool bandnet_pack(const BandStage& st, BandPacked* out) {
     auto fits = [](long v, int bits) { return v >= 0 && v < (1L << bits); };

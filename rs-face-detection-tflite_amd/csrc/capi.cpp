@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <thread>
 
@@ -379,6 +380,14 @@ int mi_model_set_option(mi_model* m, const char* key, int value) {
         require(m && key, "null argument");
         std::lock_guard<std::mutex> lock(m->mu);
         m->m->set_option(key, value);
+    });
+}
+
+int mi_model_get_option(mi_model* m, const char* key, int* value) {
+    return guarded([&] {
+        require(m && key && value, "null argument");
+        std::lock_guard<std::mutex> lock(m->mu);
+        *value = m->m->get_option(key);
     });
 }
 
@@ -1615,20 +1624,29 @@ int mi_dist_broadcast_bytes(const char* id_path, int rank, int world, int root, 
         };
         UniqueId id{};
         const std::string path = id_path, tmp = path + ".tmp";
+        // rendezvous file: {"MIRV", world, root} + the 128-byte id.  A file of another job shape is never taken for this one's; a stale file of the
+        // SAME shape (a crashed earlier run under a reused name) cannot be told from a root that was simply early — for that case ncclCommInitRank
+        // runs under the caller's timeout below instead of blocking for ever.
+        const uint32_t head[3] = {0x5652494du, static_cast<uint32_t>(world), static_cast<uint32_t>(root)};
         if (rank == root) {
+            std::remove(path.c_str());   // whatever an earlier run left under this name
             nccl(R.GetUniqueId(&id), "ncclGetUniqueId");
             {
                 std::ofstream f(tmp, std::ios::binary | std::ios::trunc);
-                if (!f || !f.write(id.internal, sizeof id.internal)) throw ApiError(MI_EIO, "cannot write the rendezvous file '" + tmp + "'");
+                if (!f || !f.write(reinterpret_cast<const char*>(head), sizeof head) || !f.write(id.internal, sizeof id.internal))
+                    throw ApiError(MI_EIO, "cannot write the rendezvous file '" + tmp + "'");
             }
             if (std::rename(tmp.c_str(), path.c_str()) != 0) throw ApiError(MI_EIO, "cannot publish the rendezvous file '" + path + "'");
         } else {
             const auto t0 = std::chrono::steady_clock::now();
             for (;;) {
                 std::ifstream f(path, std::ios::binary);
-                if (f && f.read(id.internal, sizeof id.internal) && f.gcount() == static_cast<std::streamsize>(sizeof id.internal)) break;
+                uint32_t got[3] = {0, 0, 0};
+                if (f && f.read(reinterpret_cast<char*>(got), sizeof got) && got[0] == head[0] && got[1] == head[1] && got[2] == head[2] &&
+                    f.read(id.internal, sizeof id.internal) && f.gcount() == static_cast<std::streamsize>(sizeof id.internal))
+                    break;
                 if (timeout_ms >= 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms))
-                    throw ApiError(MI_EIO, "no rendezvous file '" + path + "' from the root rank within the timeout");
+                    throw ApiError(MI_EIO, "no rendezvous file '" + path + "' of this job (world " + std::to_string(world) + ", root " + std::to_string(root) + ") from the root rank within the timeout");
                 std::this_thread::sleep_for(std::chrono::milliseconds(2));
             }
         }
@@ -1636,7 +1654,29 @@ int mi_dist_broadcast_bytes(const char* id_path, int rank, int world, int root, 
         uint8_t* d = nullptr;
         hipStream_t s = nullptr;
         try {
-            nccl(R.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+            if (timeout_ms >= 0 && world > 1) {
+                // bounded: a communicator that does not form (a stale id, a rank that died) must not hang the caller.  The call cannot be cancelled; on
+                // a timeout its thread is left behind and the caller gets MI_EIO (and is expected to exit)
+                struct Init { std::mutex m; std::condition_variable cv; bool done = false; int rc = 0; void* comm = nullptr; };
+                auto st = std::make_shared<Init>();
+                auto fn = R.CommInitRank;
+                std::thread([st, fn, world, id, rank, device] {
+                    hipSetDevice(device);
+                    void* c = nullptr;
+                    const int rc = fn(&c, world, id, rank);
+                    std::lock_guard<std::mutex> g(st->m);
+                    st->rc = rc; st->comm = c; st->done = true;
+                    st->cv.notify_all();
+                }).detach();
+                std::unique_lock<std::mutex> lk(st->m);
+                // (the id exchange itself is quick; the bound is the caller's timeout, at least 10 s for the bootstrap of a whole node)
+                if (!st->cv.wait_for(lk, std::chrono::milliseconds(std::max(timeout_ms, 10000)), [&] { return st->done; }))
+                    throw ApiError(MI_EIO, "ncclCommInitRank did not complete within the timeout (a stale rendezvous file '" + path + "', or a rank that never arrived)");
+                comm = st->comm;
+                nccl(st->rc, "ncclCommInitRank");
+            } else {
+                nccl(R.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+            }
             if (rank == root) std::remove(path.c_str());   // every rank has read it: CommInitRank is collective
             mi::hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
             mi::hip_check(hipMalloc(reinterpret_cast<void**>(&d), nbytes), "hipMalloc");

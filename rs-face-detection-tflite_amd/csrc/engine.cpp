@@ -83,6 +83,8 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "tail_g") { tail_g_ = std::max(0, std::min(value, 64)); }   // frames per workgroup of the tail stage programs (0: chosen per launch)
     else if (key == "band") { band_ = std::max(0, std::min(value, 2)); dirty_ = true; }   // single-launch plan: 0 never, 1 one_shot runs (the single-image entries), 2 every run of few enough frames
     else if (key == "band_test_fail") { band_test_fail_ = value != 0; }   // test hook: the next single-launch run reports that it gave up
+    else if (key == "band_test_absent") { band_test_absent_ = std::max(0, std::min(value, 256)); }   // test hook: every k-th workgroup of a single-launch run leaves at once without publishing (a workgroup that is not resident; 0: off)
+    else if (key == "band_test_gen") { band_gen_ = static_cast<unsigned>(std::max(0, value)); band_gen_force_ = true; }   // test hook: the host's count of band launches (the packet tags wrap at 2^26: see run_device)
     else if (key == "band_fork") { band_fork_ = value != 0; dirty_ = true; }   // single-launch plan: the second branch behind a fork on the idle workgroups
     else if (key == "band_nw") { band_nw_ = std::max(8, std::min(value, 256)); dirty_ = true; }   // its workgroups per frame
     else if (key == "fork") { fork_ = value != 0; }
@@ -92,6 +94,32 @@ void Model::set_option(const std::string& key, int value) {
     else throw std::runtime_error("unknown option '" + key + "'");
     invalidate_graphs();
     chunk_cap_ = 0;  // arena is re-laid out on the next run
+}
+
+int Model::get_option(const std::string& key) const {
+    if (key == "chunk") return chunk_;
+    if (key == "graph") return use_graph_;
+    if (key == "fuse") return fuse_level_;
+    if (key == "res_budget") return res_budget_ / 1024;
+    if (key == "pipe") return pipe_max_;
+    if (key == "small_chain") return small_chain_;
+    if (key == "pipe_rows") return pipe_rows_;
+    if (key == "pipe_band") return pipe_band_;
+    if (key == "strip") return strip_;
+    if (key == "mchain") return mchain_;
+    if (key == "tail") return tail_;
+    if (key == "tail_pre") return tail_pre_;
+    if (key == "tail_g") return tail_g_;
+    if (key == "band") return band_;
+    if (key == "band_fork") return band_fork_;
+    if (key == "band_nw") return band_nw_;
+    if (key == "band_fail_streak") return band_fail_streak_;
+    if (key == "band_wraps") return band_wraps_;
+    if (key == "fork") return fork_;
+    if (key == "heads") return head_streams_opt_;
+    if (key == "reuse") return reuse_;
+    if (key == "lanes") return lanes_;
+    throw std::runtime_error("unknown option '" + key + "'");
 }
 
 void Model::rebuild() {
@@ -1170,6 +1198,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_consts_), consts.size() * sizeof(float)), "hipMalloc band constants");
     hip_check(hipMemcpy(d_band_consts_, consts.data(), consts.size() * sizeof(float), hipMemcpyHostToDevice), "upload band constants");
     const size_t ws_bytes = static_cast<size_t>(band_ws_frame_floats_) * band_max_frames_ * sizeof(float);
+    band_ws_bytes_ = ws_bytes;
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_ws_), ws_bytes), "hipMalloc band workspace");
     hip_check(hipMemset(d_band_ws_, 0, ws_bytes), "hipMemset");   // no packet carries a tag yet (tags start at 1)
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_sync_), 64 * sizeof(unsigned)), "hipMalloc band generation");
@@ -1425,6 +1454,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.base[2 + k] = band_ext_[k].out_k >= 0 ? d_out_[static_cast<size_t>(band_ext_[k].out_k)] : tensor_ptr_mut(band_ext_[k].tensor, chunk_start, &efs);
             }
             a.consts = d_band_consts_; a.sync = d_band_sync_; a.fail = d_band_fail_;
+            a.absent_mod = band_test_absent_;
             int rc = 0;
             for (int rep_ = 0; rep_ < (marks ? profile_inner_ : 1) && rc == 0; rep_++) rc = launch_bandnet(a, trunk);
             if (rc != 0) throw std::runtime_error(std::string("kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
@@ -1968,13 +1998,45 @@ void Model::run_device(const float* in, int batch, hipStream_t stream, bool one_
     band_ran_ = band_use_;
     GraphKey key{in, batch, 0, 0};
     key.band = band_use_;
+    hipStream_t s = stream ? stream : stream_;
+    if (band_use_) band_before_launch(s);
     try {
-        run_graph_or_eager(in, batch, stream ? stream : stream_, key);
+        run_graph_or_eager(in, batch, s, key);
     } catch (...) {
         band_use_ = false;
         throw;
     }
+    const bool checked_here = band_use_ && !one_shot;
     band_use_ = false;
+    if (checked_here) {
+        // option band = 2 (tests, profiling, bench --opt): nobody behind this call asks band_failed(), so the run is checked here — a launch that gave
+        // up leaves void results: wait for it and repeat the run on the batched plan
+        hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+        if (band_failed()) {
+            key.band = false;
+            run_graph_or_eager(in, batch, s, key);
+        }
+    }
+}
+
+// In front of every single-launch run: the packet tags are 64 x generation + stage + 1 in 32 bits, and the packet slots of frames a launch does not
+// have keep their old tags — after 2^26 launches of a handle (hours of single-image calls) a stale packet could carry the tag a reader waits for.
+// Well before that the workspace and the generation are cleared (behind everything the stream holds).
+void Model::band_before_launch(hipStream_t s) {
+    constexpr unsigned kWrap = (1u << 26) - 4096u;   // (Model::profile repeats a launch a few times per call)
+    band_gen_ += static_cast<unsigned>(std::max(1, profile_inner_));
+    if (band_gen_ < kWrap || !d_band_ws_) return;
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    hip_check(hipMemsetAsync(d_band_ws_, 0, band_ws_bytes_, s), "hipMemsetAsync band workspace");
+    if (!band_gen_force_) hip_check(hipMemsetAsync(d_band_sync_, 0, 64 * sizeof(unsigned), s), "hipMemsetAsync band generation");
+    else {   // test hook: the device's generation is moved to the same count, so that the real tags do wrap in the launches that follow
+        const unsigned g[4] = {kWrap + 4096u - 2u, 0u, 0u, 0u};
+        hip_check(hipMemcpyAsync(d_band_sync_, g, sizeof(g), hipMemcpyHostToDevice, s), "band generation");
+        band_gen_force_ = false;
+    }
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    band_gen_ = 0;
+    band_wraps_++;
 }
 
 bool Model::band_usable(int batch) const {
@@ -1988,9 +2050,20 @@ int Model::band_workgroups(int batch) {
 
 bool Model::band_failed() {
     if (band_test_fail_ && band_ran_) { band_test_fail_ = false; band_ran_ = false; return true; }
+    const bool ran = band_ran_;
     band_ran_ = false;
-    if (!h_band_fail_ || !*h_band_fail_) return false;
+    if (!h_band_fail_ || !*h_band_fail_) {
+        if (ran) band_fail_streak_ = 0;
+        return false;
+    }
     *h_band_fail_ = 0;
+    // a handle whose single launches keep giving up (other processes' kernels on the CUs, a CU mask) stops trying: every failed call costs the
+    // kernel's bounded wait on top of the batched plan it then runs anyway
+    if (++band_fail_streak_ >= 3 && band_ > 0) {
+        band_ = 0;
+        band_disabled_ = true;
+        invalidate_graphs();
+    }
     return true;
 }
 

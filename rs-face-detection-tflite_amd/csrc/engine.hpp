@@ -41,6 +41,7 @@ class Model {
     void run_device(const float* in, int batch, hipStream_t stream, bool one_shot = false);
     // true when the last single-launch run gave up waiting (its results are void; the flag is cleared): repeat the call with one_shot = false
     bool band_failed();
+    int get_option(const std::string& key) const;
     // workgroups a one_shot run of `batch` frames would occupy, one per CU for the whole launch (0: it would not use the single-launch plan)
     int band_workgroups(int batch);
     // Full boundary call (host or device user buffers).
@@ -71,6 +72,7 @@ class Model {
     void build_bandnet_try(bool conv2_ok);
     void free_bandnet();
     bool band_usable(int batch) const;
+    void band_before_launch(hipStream_t s);
     void ensure_capacity(int batch);
     void enqueue_chunk(const float* in, int chunk_start, int frames, hipStream_t s, std::vector<hipEvent_t>* marks = nullptr,
                        std::vector<std::string>* labels = nullptr);
@@ -131,6 +133,13 @@ class Model {
     bool band_use_ = false;         // the run being enqueued takes it
     bool band_ran_ = false;         // the last run_device took it
     bool band_test_fail_ = false;   // option "band_test_fail"
+    int band_test_absent_ = 0;      // option "band_test_absent"
+    int band_fail_streak_ = 0;      // single launches in a row that gave up; at 3 the handle stops using the plan (band_ = 0)
+    bool band_disabled_ = false;    // ... which it did
+    unsigned band_gen_ = 0;         // band launches since the workspace was last cleared (tags wrap at 2^26: band_before_launch)
+    bool band_gen_force_ = false;   // option "band_test_gen"
+    int band_wraps_ = 0;            // times the workspace was cleared for that reason
+    size_t band_ws_bytes_ = 0;
     int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it that band_node_runs_ does not name)
     int band_stem_out_ = -1;        // tensor the first convolution writes = the band program's input
     int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_tile_floats_ = 0, band_dw_floats_ = 0;

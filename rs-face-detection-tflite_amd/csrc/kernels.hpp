@@ -511,8 +511,9 @@ struct BandLaunch {
     long ws_frame_floats = 0;       // base[0]: floats between the frames' workspaces
     float* base[kBandBases] = {};   // 0: the launch's own workspace (packet buffers), 1: the first stage's input, 2..: graph outputs / tensors later launches read
     const float* consts = nullptr;
-    unsigned* sync = nullptr;       // [0] generation (tags are 64 x generation + stage + 1), [1] workgroups finished
+    unsigned* sync = nullptr;       // [0] generation (tags are 64 x generation + stage + 1), [1] workgroups finished, [2] somebody has given up (cleared by the last workgroup)
     int* fail = nullptr;            // set to 1 when a wait ran out of iterations (host-visible): the results of that launch are void
+    int absent_mod = 0;             // test hook: every absent_mod-th workgroup leaves at once without publishing (a workgroup that is not resident)
     unsigned long long* stamps = nullptr;  // diagnostic builds only (MI_BAND_STAMPS)
 };
 int launch_bandnet(const BandLaunch& a, void* stream);

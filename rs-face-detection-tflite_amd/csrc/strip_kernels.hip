@@ -1987,6 +1987,15 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
             if (tail) tail_step(t, tacc, tmx);
         }
         MI_PSTAMP(6)
+#ifdef MI_ABL_M_ONEBAR  // timing ablation (development harness only; racy, wrong values): what double-buffered rings would allow — the hand-over
+                        // writes right behind the wave's own compute phase and ONE barrier per step
+        if (hand_over) {
+            hand_row(c0 - 1, 0, o0);
+            hand_row(c0, 1, o1);
+        }
+        MI_PSTAMP(1)
+        MI_PSTAMP(2)
+#else
         wg_barrier();  // every reader of the previous pair is done
         MI_PSTAMP(1)
         if (hand_over) {
@@ -1994,6 +2003,7 @@ __global__ __launch_bounds__(NH2 ? 128 * (KB - 1) + 64 * NH2 : 128 * KB, 2) void
             hand_row(c0, 1, o1);
         }
         MI_PSTAMP(2)
+#endif
         prefetch_consts();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);

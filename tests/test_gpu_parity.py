@@ -488,6 +488,59 @@ def test_single_image_entry_on_the_single_launch_plan(gpu, oracle, man_image):
     off.close()
 
 
+def test_single_launch_plan_with_absent_workgroups_drains_fast_and_turns_itself_off(gpu, man_image):
+    """a single launch whose workgroups are not all resident.  Engine option "band_test_absent" = k makes every k-th
+    workgroup of the launch leave at once WITHOUT publishing its halo packets, so its neighbours really poll packets that never come (not the
+    host-side band_test_fail hook).  The call must (a) return the batched plan's detections, (b) drain in milliseconds — one bounded wait for
+    the whole launch, not one per stage (round 5: 2^18 polls per stage, ~0.3 s x 42 stages) — and (c) after three such calls in a row the
+    handle stops using the plan ("band" reads 0).  With option band = 2 (no caller asks band_failed()) the run is checked inside run_device and
+    repeated, so Model.run never returns the void results.  The packet tags' wrap at 2^26 launches is forced through "band_test_gen"."""
+    import time
+    off = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    off.model.set_option("band", 0)
+    want = off.infer(man_image)
+    assert len(want) >= 1
+    fd = gpu.FaceDetection(gpu.FaceDetectionModel.BackCamera)
+    got = fd.infer(man_image)                                # a good single launch first
+    assert fd.model.get_option("band") == 1 and fd.model.get_option("band_fail_streak") == 0
+    same = lambda a, b: len(a) == len(b) and all(np.allclose(x.data, y.data, atol=1e-4) and abs(x.score - y.score) < 1e-5 for x, y in zip(a, b))
+    assert same(got, want)
+    fd.model.set_option("band_test_absent", 4)
+    times = []
+    for k in range(3):
+        t0 = time.perf_counter()
+        got = fd.infer(man_image)
+        times.append(time.perf_counter() - t0)
+        assert same(got, want), k
+        assert fd.model.get_option("band_fail_streak") == k + 1 or k == 2
+    assert times[0] < 1.0 and max(times[1:]) < 0.06, times   # one bounded wait (a few ms) + the batched plan (built by the first of them); the old form: seconds
+    assert fd.model.get_option("band") == 0                  # three in a row: the handle has stopped trying
+    t0 = time.perf_counter()
+    assert same(fd.infer(man_image), want)
+    assert time.perf_counter() - t0 < 0.02
+    fd.close()
+    # band = 2: every small run takes the single launch; a launch that gave up is repeated inside the call
+    m = gpu.Model(model_path("back"))
+    x = seeded_input("back", 2, 77, m.input_dims[1:3])
+    m.set_option("band", 0)
+    ref = [o.copy() for o in m.run(x)]
+    m.set_option("band", 2)
+    for o, r in zip(m.run(x), ref):
+        _raw_close(o, r)
+    m.set_option("band_test_absent", 3)
+    for o, r in zip(m.run(x), ref):
+        _raw_close(o, r)
+    m.set_option("band_test_absent", 0)
+    # the tags wrap: host count forced to the clearing threshold, device generation moved two launches in front of 2^26
+    m.set_option("band_test_gen", (1 << 26) - 4096 - 1)
+    for _ in range(6):
+        for o, r in zip(m.run(x), ref):
+            _raw_close(o, r)
+    assert m.get_option("band_wraps") == 1
+    m.close()
+    off.close()
+
+
 def test_mesh_and_iris_single_image_entries_on_threads(gpu, gold, man_image):
     """FaceLandmark::infer / IrisLandmark::infer (face_landmark.rs:232, iris_landmark.rs:158) on the single-launch plan from eight threads, a
     handle each: 96 / 32 workgroups per call on 256 CUs — calls that do not get their CUs run on the batched plan instead (never wait), a forced
@@ -1181,6 +1234,56 @@ def test_config2_batch256_originals_vs_oracle(gpu, oracle, gold):
         fd.close()
 
 
+@pytest.mark.parametrize("kind,name,size,okind", [("BackCamera", "back", 256, "FD_BACK"), ("Short", "short", 128, "FD_SHORT")])
+def test_pipe_band_sizes_bit_equal_and_vs_oracle(gpu, oracle, gold, kind, name, size, okind):
+    """The band height of the row pipelines (engine option "pipe_band"; bench.py sets 4096 = whole frames while two batches are in flight, i.e.
+    inside its timed region — VERDICT r5 missing #3) must not change a bit: 256 frames (8 originals x 32 copies, shuffled) with
+    pipe_band 0 (automatic: 2 bands per 64-row frame at this batch), 2, 32 and 4096 (ONE band per frame: bands == 1 at 128^2 and 64^2) are
+    compared with each other bit for bit, and the originals of the whole-frame run with the oracle detection by detection."""
+    torch = pytest.importorskip("torch")
+    rs = np.random.RandomState(11)
+    u8 = gold["man_back_u8"].astype(np.float64)
+    if size == 128:
+        u8 = u8.reshape(128, 2, 128, 2, 3).mean(axis=(1, 3))
+    face = (u8 * 2.0 / 255.0 - 1.0).astype(np.float32)
+    base = np.stack([face, face[:, ::-1].copy(), np.roll(face, (size // 7, -size // 10), axis=(0, 1)), face * np.float32(0.9)] +
+                    [rs.uniform(-1, 1, face.shape).astype(np.float32) for _ in range(4)])
+    order = rs.permutation(256) % 8
+    xd = torch.from_numpy(base[order]).cuda()
+    results = {}
+    for band in (0, 2, 32, 4096):
+        fd = gpu.FaceDetection(getattr(gpu.FaceDetectionModel, kind))
+        fd.model.set_option("pipe_band", band)
+        out, counts = fd.infer_tensor(xd, cap=16)
+        torch.cuda.synchronize()
+        results[band] = (out.cpu().numpy(), counts.cpu().numpy())
+        # the raw network outputs too (post-processing could hide a difference below the score threshold)
+        raw = fd.model.run(base[order][:40])
+        results[band] += tuple(raw)
+        fd.close()
+    for band in (2, 32, 4096):
+        for a, b in zip(results[0], results[band]):
+            np.testing.assert_array_equal(a, b, err_msg="pipe_band %d differs from the automatic bands" % band)
+    out, counts = results[4096][:2]
+    om = oracle.Model(model_path(name))
+    rb, rsc = om.run(base, nthreads=8)
+    anchors = oracle.ssd_anchors(getattr(oracle, okind))
+    first = {int(k): int(np.where(order == k)[0][0]) for k in range(8)}
+    found = 0
+    for k in range(8):
+        want = oracle.fd_postprocess(rb[k], rsc[k], anchors, float(size))
+        j = first[k]
+        assert counts[j] == len(want), (name, k, counts[j], len(want))
+        if len(want):
+            np.testing.assert_allclose(out[j, : len(want)], want, atol=2e-5)
+            found += 1
+        j40 = np.where(order[:40] == k)[0]
+        for o, r in zip(results[4096][2:], (rb, rsc)):
+            if len(j40):
+                _raw_close(o[int(j40[0])], r[k])
+    assert found >= 4
+
+
 def test_config3_landmark_batch512_properties(gpu, oracle, gold):
     """BASELINE config 3 at full size (512 ROIs 192x192 through the face-mesh net + projection + face flag): the batch is 8
     distinct ROIs repeated 64 times in a shuffled order, so every copy must reproduce its original bit for bit (frames are
@@ -1494,6 +1597,19 @@ def test_two_batches_in_flight_equal_one_at_a_time(gpu, man_image):
         torch.cuda.synchronize()
         for k in range(2):
             assert torch.equal(outs[k][0], alone[k][0]) and torch.equal(outs[k][1], alone[k][1]), (j, k)
+    # the band height bench.py sets while two batches are in flight (whole frames as bands of the row pipelines): same bits
+    for fd in fds:
+        fd.model.set_option("pipe_band", 4096)
+    for j in (1, 2, 3):
+        ss = (streams[0], streams[j])
+        outs = [(torch.zeros((64, 8, 17), device="cuda"), torch.zeros((64,), dtype=torch.int32, device="cuda")) for _ in range(2)]
+        torch.cuda.synchronize()
+        for i in range(8):
+            k = i & 1
+            fds[k].infer_tensor(xs[k], cap=8, out=outs[k][0], counts=outs[k][1], stream=ss[k].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(outs[k][0], alone[k][0]) and torch.equal(outs[k][1], alone[k][1]), ("pipe_band 4096", j, k)
     for fd in fds:
         fd.close()
     frames = np.stack([np.roll(man_image[:192, 100:292], (3 * i, -2 * i), axis=(0, 1)) for i in range(16)]).astype(np.uint8)
