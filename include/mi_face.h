@@ -196,6 +196,15 @@ int mi_fd_infer_images(mi_fd *h, const uint8_t *frames, int batch, int width, in
 int mi_fd_submit_images(mi_fd *h, int slot, const uint8_t *frames, int batch, int width, int height, int stride,
                         int cap_per_frame);
 int mi_fd_collect(mi_fd *h, int slot, mi_detection *out, int *counts);
+/* convert_image_to_mat + FaceDetection::infer(&mat, None) for a STREAM of encoded pictures (utils.rs:8-21 then face_detection.rs:205-267, the
+ * first two lines of lib.rs:20-24), two slots.  submit does the serial part of the decoder (markers, Huffman decoding: baseline and progressive)
+ * on the calling thread — while the device is still busy with the picture in the other slot — and queues the rest: the coefficients' copy,
+ * dequantisation + IDCT + up-sampling + colour conversion (the RGB picture never visits the host), image_to_tensor, the network, the
+ * post-processing; collect waits for that slot and returns the detections (and the picture's size; width / height may be NULL).  A slot
+ * must be collected before it is submitted again; `bytes` may be released when submit returns.  Results are those of
+ * mi_jpeg_decode_rgb + mi_fd_infer_image.  Errors of the stream (MI_EINVAL: not a JPEG of the supported subset) are reported by submit. */
+int mi_fd_submit_jpeg(mi_fd *h, int slot, const uint8_t *bytes, size_t nbytes, int cap);
+int mi_fd_collect_jpeg(mi_fd *h, int slot, mi_detection *out, int cap, int *count, int *width, int *height);
 /* Page-locked host memory for frames handed to mi_fd_submit_images (hipHostMalloc / hipHostFree). */
 int mi_host_alloc(size_t bytes, void **out);
 void mi_host_free(void *p);

@@ -34,7 +34,7 @@ EXPORTS = [
     "mi_dist_broadcast_bytes", "mi_streams_create_distinct", "mi_streams_destroy", "mi_model_set_option", "mi_model_get_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
-    "mi_fd_collect", "mi_host_alloc", "mi_host_free",
+    "mi_fd_collect", "mi_fd_submit_jpeg", "mi_fd_collect_jpeg", "mi_host_alloc", "mi_host_free",
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_images", "mi_fl_submit_images", "mi_fl_collect", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor", "mi_iris_infer_images",
     "mi_iris_infer_image",
@@ -201,6 +201,8 @@ def lib():
     L.mi_fd_infer_images.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp]
     L.mi_fd_submit_images.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.mi_fd_collect.argtypes = [vp, C.c_int, vp, vp]
+    L.mi_fd_submit_jpeg.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int]
+    L.mi_fd_collect_jpeg.argtypes = [vp, C.c_int, vp, C.c_int, ip, ip, ip]
     L.mi_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.mi_host_free.argtypes = [vp]
     L.mi_host_free.restype = None
@@ -602,6 +604,22 @@ class FaceDetection:
         counts = np.zeros((B,), np.int32)
         _check(self.L.mi_fd_collect(self.h, slot, C.c_void_p(out.ctypes.data), C.c_void_p(counts.ctypes.data)))
         return out, counts
+
+    def submit_jpeg(self, slot, im_bytes, cap=64):
+        """convert_image_to_mat + infer for a stream of encoded pictures (utils.rs:8-21, face_detection.rs:205): Huffman decoding happens in this
+        call, on this thread, while the device still works on the other slot's picture; everything else is queued.  `collect_jpeg(slot)`
+        returns the detections."""
+        _check(self.L.mi_fd_submit_jpeg(self.h, slot, im_bytes, len(im_bytes), cap))
+        self._jpeg_cap = getattr(self, "_jpeg_cap", {})
+        self._jpeg_cap[slot] = cap
+
+    def collect_jpeg(self, slot, with_size=False):
+        cap = self._jpeg_cap.pop(slot)
+        buf = (CDetection * cap)()
+        n, w, h = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(self.L.mi_fd_collect_jpeg(self.h, slot, buf, cap, C.byref(n), C.byref(w), C.byref(h)))
+        dets = [Detection(np.frombuffer(buf[i].data, np.float32, 16).reshape(8, 2).copy(), float(buf[i].score)) for i in range(min(n.value, cap))]
+        return (dets, (w.value, h.value)) if with_size else dets
 
     def postprocess(self, raw_boxes, raw_scores, padding=None, cap=64):
         """Post-network stage only (decode + sigmoid + weighted NMS + letterbox removal) on host arrays."""

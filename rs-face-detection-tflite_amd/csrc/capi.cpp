@@ -197,6 +197,28 @@ struct FdSlot {
     }
 };
 
+// One of the two slots of the streamed JPEG form (mi_fd_submit_jpeg / mi_fd_collect_jpeg; utils.rs:8-21 + face_detection.rs:205 for a stream of
+// encoded pictures): the entropy decoder writes the coefficients into the slot's pinned block, their copy runs on the slot's own stream, the
+// sample arithmetic / image_to_tensor / network / post-processing on the handle's stream, the results land in the slot's pinned mapped block.
+struct JpegSlot {
+    hipStream_t copy = nullptr;
+    hipEvent_t copied = nullptr, done = nullptr;
+    void* h_coef = nullptr;        // pinned: coefficients, then the quantisation tables
+    size_t h_coef_cap = 0;
+    DeviceBuf d_coef, d_qt, d_planes, d_rgb;
+    OneShot one;                   // padding in; detections + count out
+    mi::JpegFrame f;               // the picture in flight (its coefficients live in h_coef)
+    int cap = 0;
+    bool pending = false, band = false, suspect = false, claimed = false;
+    ~JpegSlot() {
+        if (pending && done) hipEventSynchronize(done);
+        if (copy) hipStreamDestroy(copy);
+        if (copied) hipEventDestroy(copied);
+        if (done) hipEventDestroy(done);
+        if (h_coef) hipHostFree(h_coef);
+    }
+};
+
 struct mi_fd {
     mi_model model;
     int kind = 0, in_w = 0, in_h = 0, n_anchors = 0;
@@ -206,7 +228,12 @@ struct mi_fd {
     DeviceBuf d_in, d_pad, d_out, d_counts, d_img, d_geom, d_roi;
     OneShot one;
     FdSlot slot[2];
+    JpegSlot jslot[2];
+    std::unique_ptr<BandClaim> jclaim;   // the CUs of the single-launch plan, held while a streamed picture is in flight (both slots run on one stream: one claim)
+    int jclaim_users = 0;
     ~mi_fd() {
+        for (JpegSlot& sl : jslot)
+            if (sl.pending && sl.done) hipEventSynchronize(sl.done);
         //  a batch that was submitted and never collected still reads the anchors and the table: wait for it before
         // anything is freed (hipFree happens to synchronise the device; this does not rely on it)
         for (FdSlot& sl : slot)
@@ -617,9 +644,142 @@ int mi_fd_infer_image(mi_fd* h, const uint8_t* rgb, int width, int height, int s
             mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
         };
         network(claim.ok);
-        if (claim.ok && m.band_failed()) network(false);  // the single launch did not get its CUs (someone else's kernels hold them): the batched plan
+        if (claim.ok && m.band_failed()) {  // the single launch did not get its CUs (someone else's kernels hold them): the batched plan
+            for (JpegSlot& js : h->jslot)       // (the flag is the handle's: a streamed picture in flight may have raised it)
+                if (js.pending && js.band) js.suspect = true;
+            network(false);
+        }
         *count = *o.h<int>(kOneCount);
         std::memcpy(out, o.h<char>(kOneResults), nout);
+        if (*count < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
+    });
+}
+
+// ---- convert_image_to_mat + FaceDetection::infer for a stream of encoded pictures (utils.rs:8-21, lib.rs:20-24), two slots.
+// submit: Huffman decoding on the calling thread, straight into the slot's pinned block — the GPU is still busy with the previous picture's
+// kernels — then, all asynchronous: coefficients to the device (slot's copy stream), dequantise + IDCT, up-sampling + colour conversion
+// (the RGB picture stays in HBM), image_to_tensor, the network (single-launch plan when its CUs are free), post-processing into the slot's
+// pinned mapped block.  collect: waits for the slot, repeats the network on the batched plan if its single launch gave up, hands the results out.
+static void fd_jpeg_network(mi_fd* h, JpegSlot& sl, bool one_shot, hipStream_t s) {
+    mi::Model& m = *h->model.m;
+    OneShot& o = sl.one;
+    float* d_t = static_cast<float*>(h->d_in.get(m.input_elems() * sizeof(float)));
+    mi::image_to_tensor_enqueue_device(static_cast<const uint8_t*>(sl.d_rgb.p), sl.f.width, sl.f.height, 3 * sl.f.width, nullptr, h->in_w, h->in_h, true, -1.0, 1.0, false,
+                                       d_t, o.h<double>(kOnePad), s);
+    std::memset(o.h<char>(kOneResults), 0, sizeof(mi_detection) * static_cast<size_t>(sl.cap));
+    m.run_device(d_t, 1, s, one_shot);
+    fd_post(h, m.output_device(0), m.output_device(1), 1, o.d<double>(kOnePad), o.d<mi_detection>(kOneResults), sl.cap, o.d<int>(kOneCount), MI_MEM_DEVICE, s);
+}
+
+int mi_fd_submit_jpeg(mi_fd* h, int slot, const uint8_t* bytes, size_t nbytes, int cap) {
+    return guarded([&] {
+        require(h && bytes, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        require(cap > 0, "cap must be positive");
+        JpegSlot& sl = h->jslot[slot];
+        if (sl.pending) throw ApiError(MI_EINVAL, "slot holds a picture that has not been collected");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        // (1) the serial part, on this thread, while the device works on the other slot's picture: the coefficients go straight into pinned memory
+        sl.f.coef.ctx = &sl;
+        sl.f.coef.provide = [](size_t count, void* ctx) -> int16_t* {
+            JpegSlot& q = *static_cast<JpegSlot*>(ctx);
+            const size_t need = count * sizeof(int16_t) + sizeof q.f.qt;
+            if (need > q.h_coef_cap) {
+                if (q.h_coef) hipHostFree(q.h_coef);
+                q.h_coef = nullptr;
+                q.h_coef_cap = 0;
+                mi::hip_check(hipHostMalloc(&q.h_coef, need + need / 4, hipHostMallocDefault), "hipHostMalloc coefficients");
+                q.h_coef_cap = need + need / 4;
+            }
+            return static_cast<int16_t*>(q.h_coef);
+        };
+        try {
+            mi::jpeg_entropy_decode(bytes, nbytes, &sl.f);
+        } catch (const std::runtime_error& e) {
+            throw ApiError(MI_EINVAL, e.what());
+        }
+        const mi::JpegFrame& f = sl.f;
+        const size_t coef_bytes = f.coef.size() * sizeof(int16_t);
+        char* h_qt = static_cast<char*>(sl.h_coef) + coef_bytes;
+        std::memcpy(h_qt, f.qt, sizeof f.qt);
+        // (2) everything else is queued
+        if (!sl.copy) {
+            mi::hip_check(hipStreamCreateWithFlags(&sl.copy, hipStreamNonBlocking), "hipStreamCreate");
+            mi::hip_check(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate");
+            mi::hip_check(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate");
+        }
+        auto* d_coef = static_cast<int16_t*>(sl.d_coef.get(coef_bytes + sizeof f.qt));
+        auto* d_qt = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_coef) + coef_bytes);
+        auto* d_planes = static_cast<uint8_t*>(sl.d_planes.get(mi::jpeg_plane_bytes(f)));
+        auto* d_rgb = static_cast<uint8_t*>(sl.d_rgb.get(static_cast<size_t>(3) * f.width * f.height));
+        const size_t nout = sizeof(mi_detection) * static_cast<size_t>(cap);
+        sl.one.reserve(kOneResults + nout);
+        sl.cap = cap;
+        mi::hip_check(hipMemcpyAsync(d_coef, sl.h_coef, coef_bytes + sizeof f.qt, hipMemcpyHostToDevice, sl.copy), "H2D coefficients");
+        mi::hip_check(hipEventRecord(sl.copied, sl.copy), "hipEventRecord");
+        hipStream_t s = m.stream();
+        Use use(h->model, s);
+        mi::hip_check(hipStreamWaitEvent(s, sl.copied, 0), "hipStreamWaitEvent");
+        int rc = mi::launch_jpeg_idct(f, d_coef, d_qt, d_planes, s);
+        if (rc == 0) rc = mi::launch_jpeg_color(f, d_planes, d_rgb, s);
+        if (rc) throw std::runtime_error(std::string("jpeg kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        // the single-launch plan's CUs: one claim for the handle while any of its streamed pictures is in flight
+        if (h->jclaim_users == 0) h->jclaim.reset(new BandClaim(m, 1));
+        h->jclaim_users++;
+        sl.claimed = true;
+        sl.band = h->jclaim && h->jclaim->ok;
+        sl.suspect = false;
+        fd_jpeg_network(h, sl, sl.band, s);
+        mi::hip_check(hipEventRecord(sl.done, s), "hipEventRecord");
+        sl.pending = true;
+    });
+}
+
+int mi_fd_collect_jpeg(mi_fd* h, int slot, mi_detection* out, int cap, int* count, int* width, int* height) {
+    return guarded([&] {
+        require(h && out && count, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        JpegSlot& sl = h->jslot[slot];
+        if (!sl.pending) throw ApiError(MI_EINVAL, "nothing was submitted to this slot");
+        require(cap >= sl.cap, "cap is smaller than the one the picture was submitted with");
+        mi::Model& m = *h->model.m;
+        mi::hip_check(hipSetDevice(m.device()), "hipSetDevice");
+        mi::hip_check(hipEventSynchronize(sl.done), "hipEventSynchronize");
+        {
+            hipStream_t s = m.stream();
+            Use use(h->model, s);
+            auto release = [&] {
+                if (sl.claimed && --h->jclaim_users == 0) h->jclaim.reset();
+                sl.claimed = false;
+                sl.pending = false;
+            };
+            try {
+                if (sl.band) {
+                    // a single launch that gave up leaves void results; the flag is the handle's: with the other slot's picture in flight behind
+                    // this one it may be that launch's — both are repeated on the batched plan (from the RGB pictures, which are still in HBM)
+                    if (m.band_failed()) {
+                        sl.suspect = true;
+                        JpegSlot& other = h->jslot[1 - slot];
+                        if (other.pending && other.band) other.suspect = true;
+                    }
+                    if (sl.suspect) {
+                        fd_jpeg_network(h, sl, false, s);
+                        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+                    }
+                }
+            } catch (...) {
+                release();
+                throw;
+            }
+            release();
+        }
+        const OneShot& o = sl.one;
+        *count = *o.h<int>(kOneCount);
+        std::memcpy(out, o.h<char>(kOneResults), sizeof(mi_detection) * static_cast<size_t>(sl.cap));
+        if (cap > sl.cap) std::memset(out + sl.cap, 0, sizeof(mi_detection) * static_cast<size_t>(cap - sl.cap));
+        if (width) *width = sl.f.width;
+        if (height) *height = sl.f.height;
         if (*count < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
     });
 }

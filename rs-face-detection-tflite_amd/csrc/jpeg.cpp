@@ -351,7 +351,13 @@ void jpeg_parse_size(const uint8_t* data, size_t n, int* width, int* height) {
 
 void jpeg_entropy_decode(const uint8_t* data, size_t n, JpegFrame* out) {
     JpegFrame& f = *out;
-    f = JpegFrame();
+    {
+        const auto provide = f.coef.provide;   // (where the coefficients go survives the reset)
+        void* const ctx = f.coef.ctx;
+        f = JpegFrame();
+        f.coef.provide = provide;
+        f.coef.ctx = ctx;
+    }
     Parser p{data, n, &f};
     ScanHdr sh;
     const size_t ecs = p.headers(false, 2, &sh);

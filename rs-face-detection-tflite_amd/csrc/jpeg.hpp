@@ -20,12 +20,35 @@ struct JpegComponent {
     size_t coef_off = 0;  // first coefficient of this component in JpegFrame::coef
 };
 
+// The coefficient buffer of a frame: the decoder's own vector, or memory the caller provides (`provide`, asked once per picture for `count`
+// int16 values: the streamed entries decode straight into pinned host memory, so that the copy to the device is asynchronous).
+struct JpegCoefBuf {
+    std::vector<int16_t> own;
+    int16_t* ext = nullptr;
+    size_t n = 0;
+    int16_t* (*provide)(size_t count, void* ctx) = nullptr;
+    void* ctx = nullptr;
+    void assign(size_t count, int16_t v) {
+        n = count;
+        if (provide) {
+            ext = provide(count, ctx);
+            for (size_t i = 0; i < count; i++) ext[i] = v;
+        } else {
+            ext = nullptr;
+            own.assign(count, v);
+        }
+    }
+    int16_t* data() { return ext ? ext : own.data(); }
+    const int16_t* data() const { return ext ? ext : own.data(); }
+    size_t size() const { return n; }
+};
+
 struct JpegFrame {             // host-side result of the entropy decoder
     int width = 0, height = 0, ncomp = 0, hmax = 1, vmax = 1;
     bool progressive = false;  // SOF2: the coefficients are the sum of several scans (T.81 Annex G)
     JpegComponent comp[3];
     uint16_t qt[4][64] = {};   // natural order
-    std::vector<int16_t> coef; // per component [bh][bw][64], natural order, quantised
+    JpegCoefBuf coef;          // per component [bh][bw][64], natural order, quantised
 };
 
 // Parses the headers only. Throws std::runtime_error("unsupported ...") for streams outside the subset.

@@ -477,4 +477,19 @@ void image_to_tensor_enqueue(const uint8_t* rgb_host, int width, int height, int
     padding[0] = g.pad_x; padding[1] = g.pad_y; padding[2] = g.pad_x; padding[3] = g.pad_y;
 }
 
+void image_to_tensor_enqueue_device(const uint8_t* d_img, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
+                                    bool keep_aspect, double range_min, double range_max, bool flip, float* d_out, double padding[4], hipStream_t s) {
+    RectD r;
+    if (roi) std::memcpy(&r, roi, sizeof r);
+    const PreGeom g = compute_geom(width, height, roi ? &r : nullptr, out_w, out_h, keep_aspect);
+    if (!g.valid) throw std::runtime_error("ROI is empty or degenerate (singular perspective transform)");
+    PreItems it{};
+    it.frames = d_img; it.frame_bytes = 0; it.width = width; it.height = height; it.stride = stride;
+    it.items_per_frame = 1; it.N = 1; it.out_w = out_w; it.out_h = out_h; it.keep_aspect = keep_aspect;
+    it.range_min = range_min; it.range_max = range_max;
+    hipLaunchKernelGGL(pre_tensor_one_kernel, dim3((out_w * out_h + 255) / 256), dim3(256), 0, s, it, g, flip ? 1 : 0, d_out);
+    hip_check(hipGetLastError(), "pre_tensor kernel launch");
+    padding[0] = g.pad_x; padding[1] = g.pad_y; padding[2] = g.pad_x; padding[3] = g.pad_y;
+}
+
 }  // namespace mi

@@ -53,6 +53,10 @@ void image_to_tensor_device(const uint8_t* rgb_host, int width, int height, int 
 void image_to_tensor_enqueue(const uint8_t* rgb_host, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
                              bool keep_aspect_ratio, double range_min, double range_max, bool flip_horizontal, float* d_out,
                              double padding[4], uint8_t* d_img, hipStream_t stream);
+// ... for a picture that is in device memory already (the streamed JPEG entries: the decoder's RGB output never visits the host)
+void image_to_tensor_enqueue_device(const uint8_t* d_img, int width, int height, int stride, const mi_rect* roi, int out_w, int out_h,
+                                    bool keep_aspect_ratio, double range_min, double range_max, bool flip_horizontal, float* d_out,
+                                    double padding[4], hipStream_t stream);
 size_t image_to_tensor_scratch_bytes(int width, int height, int stride, const mi_rect* roi, int out_w, int out_h, bool keep_aspect_ratio);
 
 // Device-side ROI maths between pipeline stages (face_landmark.rs:180-198, iris_landmark.rs:268-292).

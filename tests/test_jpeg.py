@@ -215,3 +215,63 @@ def test_bytes_to_detections_like_the_reference_test(mi):
     xmin, ymin, xmax, ymax = faces[0].bbox()
     H, W = image.shape[:2]
     assert int(xmin * W) == 195 and int(ymin * H) == 74 and int((xmax - xmin) * W) == 139 and int((ymax - ymin) * H) == 139
+
+
+@pytest.mark.gpu
+def test_streamed_jpeg_entries_equal_decode_then_infer(mi):
+    """mi_fd_submit_jpeg / mi_fd_collect_jpeg (utils.rs:8-21 + face_detection.rs:205 for a stream of encoded pictures, two slots): every picture's
+    detections are bit-equal to convert_image_to_mat + FaceDetection::infer of the same bytes — baseline, progressive, 4:4:4 / 4:2:2 / 4:2:0,
+    greyscale, restart intervals, the reference's three test pictures — whatever is in flight in the other slot; a slot must be collected before
+    it is reused, a bad stream is refused by submit and leaves the slot free; a single launch that gives up (engine test hook: absent workgroups)
+    is repeated on the batched plan at collect."""
+    rels = [r for r in FILES if "unsupported" not in r]
+    for kind in (mi.FaceDetectionModel.BackCamera, mi.FaceDetectionModel.Short):
+        fd = mi.FaceDetection(kind)
+        ref = mi.FaceDetection(kind)
+        want = {}
+        for r in rels:
+            want[r] = ref.infer(mi.convert_image_to_mat(_bytes(r)), None)
+        assert len(want["man.jpg"]) == 1
+
+        def same(got, r):
+            assert len(got) == len(want[r]), r
+            for a, b in zip(got, want[r]):
+                np.testing.assert_array_equal(a.data, b.data, err_msg=r)
+                assert a.score == b.score
+
+        order = rels + rels[::-1] + ["man.jpg"] * 5
+        fd.submit_jpeg(0, _bytes(order[0]))
+        for i in range(1, len(order)):
+            fd.submit_jpeg(i & 1, _bytes(order[i]))
+            dets, size = fd.collect_jpeg((i - 1) & 1, with_size=True)
+            same(dets, order[i - 1])
+            assert size == mi.jpeg_info(_bytes(order[i - 1]))
+        same(fd.collect_jpeg((len(order) - 1) & 1), order[-1])
+        # slot discipline and refusals
+        fd.submit_jpeg(0, _bytes("man.jpg"))
+        with pytest.raises(mi.MiError):
+            fd.submit_jpeg(0, _bytes("man.jpg"))                   # not collected yet
+        with pytest.raises(mi.MiError):
+            fd.submit_jpeg(1, _bytes("man.jpg")[:300])             # truncated headers: refused, slot 1 stays free
+        fd.submit_jpeg(1, _bytes("russ_cox_1.jpg"))
+        same(fd.collect_jpeg(0), "man.jpg")
+        same(fd.collect_jpeg(1), "russ_cox_1.jpg")
+        with pytest.raises(mi.MiError):
+            fd._jpeg_cap[0] = 64
+            fd.collect_jpeg(0)                                     # nothing submitted
+        # the other entries of the handle still work between streamed pictures
+        fd.submit_jpeg(0, _bytes("man.jpg"))
+        got_img = fd.infer(mi.convert_image_to_mat(_bytes("russ_cox_2.jpg")), None)
+        same(got_img, "russ_cox_2.jpg")
+        same(fd.collect_jpeg(0), "man.jpg")
+        # a single launch that gives up: the picture is repeated on the batched plan when it is collected (tolerance between the two plans)
+        fd.model.set_option("band_test_absent", 4)
+        fd.submit_jpeg(0, _bytes("man.jpg"))
+        fd.submit_jpeg(1, _bytes("russ_cox_1.jpg"))
+        for slot, r in ((0, "man.jpg"), (1, "russ_cox_1.jpg")):
+            got = fd.collect_jpeg(slot)
+            assert len(got) == len(want[r])
+            for a, b in zip(got, want[r]):
+                np.testing.assert_allclose(a.data, b.data, atol=1e-4)
+        fd.close()
+        ref.close()

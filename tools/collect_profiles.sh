@@ -16,6 +16,8 @@ for m in "back 256" "front 256" "full 128" "landmark 512" "iris 1024"; do set --
 CONFIGS=${CONFIGS:-"2 1 3 5"}   # (CONFIGS="3" for a quick partial collection)
 for c in $CONFIGS; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -- python3 bench.py --config $c --warmup 10 --steps 100 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --no-event-profile --single-window --in-flight 1 > "$OUT/trace_c$c.log" 2>&1; echo trace $c done
+  # the mode bench.py times by default (VERDICT r5 missing #3): two batches in flight, whole-frame bands for the row pipelines
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace2_c$c" -- python3 bench.py --config $c --warmup 10 --steps 100 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --no-event-profile --single-window --in-flight 2 > "$OUT/trace2_c$c.log" 2>&1; echo trace in-flight-2 $c done
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window --in-flight 1 > "$OUT/fetch_c$c.log" 2>&1; echo fetch $c done
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write_c$c" -- python3 bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-latency --no-host-feed --no-secondary --single-window --in-flight 1 > "$OUT/write_c$c.log" 2>&1; echo write $c done
   i=0

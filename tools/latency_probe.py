@@ -36,6 +36,20 @@ def measure(n=300):
         out["FaceDetection::infer %s (man.jpg 540x360, Mat in host memory)" % kind] = timed(lambda: fd.infer(img, None), n)
         if kind == "BackCamera":
             out["convert_image_to_mat + FaceDetection::infer BackCamera (JPEG bytes -> detections)"] = timed(lambda: fd.infer(mi.convert_image_to_mat(jpg), None), n)
+            # the same for a STREAM of pictures (mi_fd_submit_jpeg / mi_fd_collect_jpeg, two slots): Huffman decoding of picture n + 1 on this thread
+            # while the device runs picture n; one "call" = submit n + 1, collect n — the sustained time per picture
+            fd.submit_jpeg(0, jpg)
+            state = {"k": 0}
+
+            def stream_step():
+                k = state["k"]
+                fd.submit_jpeg(1 - k, jpg)
+                dets = fd.collect_jpeg(k)
+                state["k"] = 1 - k
+                return dets
+            out["streamed JPEG bytes -> detections, BackCamera (mi_fd_submit_jpeg / collect_jpeg, two slots; sustained per picture)"] = timed(stream_step, n)
+            fd.collect_jpeg(state["k"])
+            out["one JPEG at a time through the same entries (submit + collect of one slot)"] = timed(lambda: (fd.submit_jpeg(0, jpg), fd.collect_jpeg(0))[1], n)
         fd.close()
     fl = mi.FaceLandmark()
     roi = mi.Rect(*[float(v) for v in gold["man_face_roi"][:5]], int(gold["man_face_roi"][5]))

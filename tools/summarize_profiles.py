@@ -62,6 +62,9 @@ for c in WORKLOADS:
     ks = one("trace_c%d/**/*_kernel_stats.csv" % c)
     if ks:
         shutil.copy(ks, os.path.join(out, "%s_kernel_stats_config%d.csv" % (tag, c)))
+    ks2 = one("trace2_c%d/**/*_kernel_stats.csv" % c)   # the same run with two batches in flight (the mode bench.py times by default)
+    if ks2:
+        shutil.copy(ks2, os.path.join(out, "%s_kernel_stats_config%d_in_flight2.csv" % (tag, c)))
 
 
 STEADY = {}   # per config: kernel label -> steady-state nanoseconds per launch
@@ -157,11 +160,19 @@ for c, workload in WORKLOADS.items():
             t = tot[label(r["Name"])]
             t[0] += float(r["TotalDurationNs"]); t[1] += int(r["Calls"])
         avg = {k: v[0] / max(v[1], 1) for k, v in tot.items()}
+    ksc2 = os.path.join(out, "%s_kernel_stats_config%d_in_flight2.csv" % (tag, c))
+    avg2 = {}
+    if os.path.exists(ksc2):
+        tot = collections.defaultdict(lambda: [0.0, 0])
+        for r in csv.DictReader(open(ksc2)):
+            t = tot[label(r["Name"])]
+            t[0] += float(r["TotalDurationNs"]); t[1] += int(r["Calls"])
+        avg2 = {k: v[0] / max(v[1], 1) for k, v in tot.items()}
     by_label = collections.defaultdict(list)
     for r in crow:
         by_label[r["label"]].append(r)
     entries += [{"round": tag, "workload": workload, "kernel": lab, "source_hash": bench.kernel_source_hash(), "rocprof_avg_ns": avg.get(lab),
-                 "rocprof_steady_ns": STEADY.get(c, {}).get(lab),
+                 "rocprof_steady_ns": STEADY.get(c, {}).get(lab), "rocprof_in_flight2_avg_ns": avg2.get(lab),
                  "hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["dispatches"] for r in rs) / sum(r["dispatches"] for r in rs)),
                  "note": "reads = %d x FETCH_SIZE (gfx950: FETCH_SIZE counts half of a 16 B/lane stream) + WRITE_SIZE, KiB -> bytes; separate --pmc passes" % rs[0]["fetch_correction"]}
                 for lab, rs in by_label.items()]
