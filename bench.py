@@ -697,6 +697,11 @@ def run_rank(args):
             "metric": metric, "value": round(value, 1), "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the in-flight setting beside the headline, and the one-handle figure (the measurement of rounds 1 - 4, and what `roofline`
+            # and every profile under profiles/ describe) as a first-class field — round-over-round comparisons are like for like
+            "batches_in_flight": NW,
+            "value_one_batch_in_flight": round(world * B / (one_in_flight_ms * 1e-3), 1) if one_in_flight_ms else (round(value, 1) if NW == 1 else None),
+            "ms_per_step_one_batch_in_flight": round(one_in_flight_ms, 4) if one_in_flight_ms else (round(elapsed / args.steps * 1e3, 4) if NW == 1 else None),
             "timing": {"windows": len(windows), "steps_per_window": args.steps, "timed_s": round(sum(windows), 4),
                        "ms_per_step_median": round(sorted(windows)[len(windows) // 2] / args.steps * 1e3, 4),
                        "ms_per_step_min": round(min(windows) / args.steps * 1e3, 4),
@@ -713,7 +718,7 @@ def run_rank(args):
                        "note": "ms_per_step / value = the first window (the driver's K steps, directly behind the W warm-up steps); the others repeat it. "
                                "Before the warm-up steps a per-launch HIP-event pass over the plan runs once (figures discarded; the recorded pass "
                                "for `roofline` runs behind the windows)"},
-            "config": {"workload": workload, "global_batch": world * B, "frames_with_faces": n_found,
+            "config": {"workload": workload, "global_batch": world * B, "batches_in_flight": NW, "frames_with_faces": n_found,
                        "parallelism": "frames sharded %d/GPU, one process per GPU, no data-path collective" % B,
                        "weight_broadcast_ms": round(bcast_ms, 3), "weight_broadcast_bytes": sum(len(b) for b in blobs),
                        "frames_with_faces_per_rank": gathered,
