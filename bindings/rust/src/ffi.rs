@@ -63,6 +63,9 @@ extern "C" {
     pub fn mi_fd_submit_images(h: *mut mi_fd, slot: c_int, frames: *const u8, batch: c_int, width: c_int, height: c_int, stride: c_int,
                                cap_per_frame: c_int) -> c_int;
     pub fn mi_fd_collect(h: *mut mi_fd, slot: c_int, out: *mut mi_detection, counts: *mut c_int) -> c_int;
+    pub fn mi_fd_submit_jpeg(h: *mut mi_fd, slot: c_int, bytes: *const u8, nbytes: usize, cap: c_int) -> c_int;
+    pub fn mi_fd_collect_jpeg(h: *mut mi_fd, slot: c_int, out: *mut mi_detection, cap: c_int, count: *mut c_int, width: *mut c_int,
+                              height: *mut c_int) -> c_int;
     pub fn mi_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn mi_host_free(p: *mut c_void);
 

@@ -136,6 +136,20 @@ class FaceDetection {
             }
         return res;
     }
+    // convert_image_to_mat + infer for a stream of encoded pictures (utils.rs:8-21, face_detection.rs:205): submit_jpeg decodes the entropy-coded
+    // data on this thread while the device still runs the other slot's picture and queues the rest; collect_jpeg returns that slot's detections
+    void submit_jpeg(int slot, const std::uint8_t* bytes, std::size_t nbytes, int cap = 64) const { detail::check(mi_fd_submit_jpeg(h_, slot, bytes, nbytes, cap)); }
+    std::vector<Detection> collect_jpeg(int slot, int cap = 64, int* width = nullptr, int* height = nullptr) const {
+        std::vector<mi_detection> out(static_cast<std::size_t>(cap));
+        int n = 0;
+        detail::check(mi_fd_collect_jpeg(h_, slot, out.data(), cap, &n, width, height));
+        std::vector<Detection> dets(static_cast<std::size_t>(std::min(n, cap)));
+        for (std::size_t i = 0; i < dets.size(); i++) {
+            for (int k = 0; k < 16; k++) dets[i].data[k] = out[i].data[k];
+            dets[i].score = out[i].score;
+        }
+        return dets;
+    }
     mi_fd* handle() const { return h_; }
 
    private:
