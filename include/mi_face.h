@@ -309,6 +309,14 @@ int mi_pipeline_set_option(mi_pipeline *p, const char *key, int value);
  * All pointers follow `mem`. */
 int mi_pipeline_run(mi_pipeline *p, const uint8_t *frames, int batch, int width, int height, int stride, mi_detection *faces,
                     int *face_counts, float *landmarks, int *present, float *eyes, int mem, void *stream);
+/* The same flow from ENCODED pictures, as the reference's own test runs it (lib.rs:18-40: include_bytes!(man.jpg) -> convert_image_to_mat ->
+ * FaceDetection::infer -> FaceLandmark::infer -> 2 x IrisLandmark::infer), for a stream of them, two slots (see mi_fd_submit_jpeg): submit decodes the
+ * entropy-coded data on the calling thread while the device still works through the other slot's picture, and queues the decoder's sample arithmetic
+ * and the three stages; collect waits for that slot.  Outputs as mi_pipeline_run with batch = 1: face = faces[0] (zeros when none), *face_count,
+ * landmarks f32 [468][3], *present, eyes f32 [2][76][3]; width / height (may be NULL) = the picture's size.  Host memory. */
+int mi_pipeline_submit_jpeg(mi_pipeline *p, int slot, const uint8_t *bytes, size_t nbytes);
+int mi_pipeline_collect_jpeg(mi_pipeline *p, int slot, mi_detection *face, int *face_count, float *landmarks, int *present, float *eyes,
+                             int *width, int *height);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Host-side helpers the reference exports next to the three structs

@@ -34,7 +34,7 @@ EXPORTS = [
     "mi_dist_broadcast_bytes", "mi_streams_create_distinct", "mi_streams_destroy", "mi_model_set_option", "mi_model_get_option", "mi_plan_describe", "mi_model_plan_stats", "mi_model_single_launch_workgroups", "mi_model_profile",
     "mi_fd_create", "mi_fd_create_from_bytes", "mi_fd_free", "mi_fd_model", "mi_fd_input_size", "mi_fd_num_anchors",
     "mi_fd_anchors", "mi_fd_infer_tensor", "mi_fd_postprocess", "mi_fd_infer_image", "mi_fd_infer_images", "mi_fd_submit_images",
-    "mi_fd_collect", "mi_fd_submit_jpeg", "mi_fd_collect_jpeg", "mi_host_alloc", "mi_host_free",
+    "mi_fd_collect", "mi_fd_submit_jpeg", "mi_fd_collect_jpeg", "mi_pipeline_submit_jpeg", "mi_pipeline_collect_jpeg", "mi_host_alloc", "mi_host_free",
     "mi_fl_create", "mi_fl_create_from_bytes", "mi_fl_free", "mi_fl_model", "mi_fl_infer_tensor", "mi_fl_infer_images", "mi_fl_submit_images", "mi_fl_collect", "mi_fl_infer_image",
     "mi_iris_create", "mi_iris_create_from_bytes", "mi_iris_free", "mi_iris_model", "mi_iris_infer_tensor", "mi_iris_infer_images",
     "mi_iris_infer_image",
@@ -203,6 +203,8 @@ def lib():
     L.mi_fd_collect.argtypes = [vp, C.c_int, vp, vp]
     L.mi_fd_submit_jpeg.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int]
     L.mi_fd_collect_jpeg.argtypes = [vp, C.c_int, vp, C.c_int, ip, ip, ip]
+    L.mi_pipeline_submit_jpeg.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+    L.mi_pipeline_collect_jpeg.argtypes = [vp, C.c_int, vp, ip, vp, ip, vp, ip, ip]
     L.mi_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.mi_host_free.argtypes = [vp]
     L.mi_host_free.restype = None
@@ -886,6 +888,27 @@ class Pipeline:
         _check(self.L.mi_pipeline_run(self.h, p, B, W, H, stride, _ptr(out["faces"])[0], _ptr(out["face_counts"])[0],
                                       _ptr(out["landmarks"])[0], _ptr(out["present"])[0], _ptr(out["eyes"])[0], mem, C.c_void_p(stream or 0)))
         return out
+
+
+def _pipeline_submit_jpeg(self, slot, im_bytes):
+    """lib.rs:18-40 for a stream of encoded pictures: Huffman decoding of this picture happens in this call (on this thread, beside the device's work
+    on the other slot's picture); the decoder's sample arithmetic and the three stages are queued.  `collect_jpeg(slot)` returns the results."""
+    _check(self.L.mi_pipeline_submit_jpeg(self.h, slot, im_bytes, len(im_bytes)))
+
+
+def _pipeline_collect_jpeg(self, slot):
+    """-> dict(faces [1,17], face_counts [1], landmarks [1,468,3], present [1], eyes [1,2,76,3], size (w, h)) of the picture submitted to `slot`."""
+    out = dict(faces=np.zeros((1, 17), np.float32), face_counts=np.zeros((1,), np.int32), landmarks=np.zeros((1, 468, 3), np.float32),
+               present=np.zeros((1,), np.int32), eyes=np.zeros((1, 2, 76, 3), np.float32))
+    w, h = C.c_int(0), C.c_int(0)
+    _check(self.L.mi_pipeline_collect_jpeg(self.h, slot, _ptr(out["faces"])[0], C.cast(_ptr(out["face_counts"])[0], C.POINTER(C.c_int)), _ptr(out["landmarks"])[0],
+                                           C.cast(_ptr(out["present"])[0], C.POINTER(C.c_int)), _ptr(out["eyes"])[0], C.byref(w), C.byref(h)))
+    out["size"] = (w.value, h.value)
+    return out
+
+
+Pipeline.submit_jpeg = _pipeline_submit_jpeg
+Pipeline.collect_jpeg = _pipeline_collect_jpeg
 
 
 def face_detection_to_roi(face_detection: Detection, image_size, size_mode=None) -> Rect:

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <atomic>
 #include <cstring>
+#include <cstdlib>
 #include <fstream>
 #include <memory>
 #include <mutex>
@@ -123,6 +124,11 @@ struct BandClaim {
         dev = device;
         n = workgroups;
         if (n <= 0 || dev < 0 || dev >= 64) return;
+        // A CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK) takes CUs away that hipDeviceAttributeMultiprocessorCount still counts: the launch's
+        // workgroups would not all be resident, every call would wait out the kernel's bounded spin and then repeat itself.  Under a
+        // mask the single-image entries stay on the batched plan (MI_BAND_WITH_CU_MASK=1: the mask leaves enough CUs, use the plan anyway).
+        static const bool masked = (getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK")) && !getenv("MI_BAND_WITH_CU_MASK");
+        if (masked) return;
         if (g_band_cus[dev].fetch_add(n) + n <= mi::device_cu_count()) ok = true;
         else g_band_cus[dev].fetch_sub(n);
     }
@@ -288,7 +294,23 @@ struct mi_pipeline {
     DeviceBuf geom_det;                              // the detector's letterbox geometry of `geom_B` pictures of geom_w x geom_h (no ROI: uploaded once)
     int geom_B = 0, geom_w = 0, geom_h = 0;
     int sizes_B = 0, sizes_w = 0, sizes_h = 0;  // what `sizes` holds (uploaded once per batch geometry, not per call)
+    // the streamed form from encoded pictures (mi_pipeline_submit_jpeg / mi_pipeline_collect_jpeg): per slot the decoder's state and picture, the
+    // results' device block and its pinned image
+    struct PipeJpegSlot {
+        JpegSlot jpeg;
+        DeviceBuf results;
+        OneShot out;
+        bool pending = false, band = false, suspect = false, claimed = false;
+    };
+    PipeJpegSlot jslot[2];
+    std::unique_ptr<BandClaim> jclaim;
+    int jclaim_users = 0;
+    ~mi_pipeline() {
+        for (PipeJpegSlot& sl : jslot)
+            if (sl.pending && sl.jpeg.done) hipEventSynchronize(sl.jpeg.done);
+    }
 };
+using PipeJpegSlot = mi_pipeline::PipeJpegSlot;
 
 struct mi_iris {
     mi_model model;
@@ -1509,6 +1531,146 @@ int mi_pipeline_set_option(mi_pipeline* p, const char* key, int value) {
     });
 }
 
+namespace {
+struct PipeOut {   // DEVICE pointers the stages of one pipeline pass write their results to
+    mi_detection* faces;   // [B] top-1 detection
+    int* counts;           // [B]
+    float* lm;             // [B][468][3]
+    int* present;          // [B]
+    float* eyes;           // [B][2][76][3]
+};
+constexpr int kPipeCap = 4;
+constexpr long kEyeFs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
+struct PipeLayout {        // one block: faces | counts | landmarks | present | eyes
+    size_t faces, counts, lm, present, eyes, bytes;
+    explicit PipeLayout(int B) {
+        auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+        faces = 0;
+        counts = up16(faces + sizeof(mi_detection) * B);
+        lm = up16(counts + sizeof(int) * B);
+        present = up16(lm + sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B);
+        eyes = up16(present + sizeof(int) * B);
+        bytes = up16(eyes + sizeof(float) * kEyeFs * 2 * B);
+    }
+    PipeOut in(char* base) const {
+        return PipeOut{reinterpret_cast<mi_detection*>(base + faces), reinterpret_cast<int*>(base + counts), reinterpret_cast<float*>(base + lm),
+                       reinterpret_cast<int*>(base + present), reinterpret_cast<float*>(base + eyes)};
+    }
+};
+}  // namespace
+
+// One pass of the flow of lib.rs:24-40 over B frames that are in device memory: everything is queued on `s`, nothing is waited for (but the
+// upload of the per-item image sizes when the batch geometry changes).  The caller holds the three handles (Use) and, for one_shot, the CUs.
+static void pipeline_enqueue(mi_pipeline* p, const uint8_t* d_frames, int B, int width, int height, int stride, const PipeOut& o, bool one_shot, hipStream_t s) {
+    mi::Model& fdm = *p->fd->model.m;
+    mi::Model& flm = *p->fl->model.m;
+    mi::Model& irm = *p->iris->model.m;
+    const int cap = kPipeCap;
+    const long eye_fs = kEyeFs;
+    const size_t frame_bytes = static_cast<size_t>(stride) * height;
+    auto* d_geom = static_cast<mi::PreGeom*>(p->geom.get(sizeof(mi::PreGeom) * 2 * B));
+    // (w, h) of the source image of every ROI, for Rect::scaled in project_landmarks
+    int* d_sizes = static_cast<int*>(p->sizes.get(sizeof(int) * 4 * B));
+    if (p->sizes_B != B || p->sizes_w != width || p->sizes_h != height) {  // a host round trip only when the batch geometry changes
+        std::vector<int> hs(4 * static_cast<size_t>(B));
+        for (int i = 0; i < 2 * B; i++) { hs[2 * i] = width; hs[2 * i + 1] = height; }
+        p->sizes_B = 0;
+        mi::hip_check(hipMemcpyAsync(d_sizes, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D sizes");
+        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
+        p->sizes_B = B; p->sizes_w = width; p->sizes_h = height;
+    }
+    static const bool ptrace = getenv("MI_PIPE_TRACE") != nullptr;
+    auto t_start = std::chrono::steady_clock::now();
+    auto tr = [&](const char* what) { if (ptrace) std::fprintf(stderr, "  %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count()); };
+    // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
+    mi::PreItems it{};
+    it.frames = d_frames; it.frame_bytes = static_cast<long>(frame_bytes); it.width = width; it.height = height; it.stride = stride;
+    it.items_per_frame = 1; it.N = B; it.out_w = p->fd->in_w; it.out_h = p->fd->in_h; it.keep_aspect = 1;
+    it.range_min = -1.0; it.range_max = 1.0;
+    double* d_pad_det = static_cast<double*>(p->pad_det.get(sizeof(double) * 4 * B));
+    float* d_in_det = static_cast<float*>(p->in_det.get(fdm.input_elems() * sizeof(float) * B));
+    // (no ROI: the geometry is the same for every call on pictures of this size — no pre_geom launch, 9 us of a one-picture call)
+    auto* d_geom_det = static_cast<mi::PreGeom*>(p->geom_det.get(sizeof(mi::PreGeom) * B));
+    if (p->geom_B != B || p->geom_w != width || p->geom_h != height) {
+        p->geom_B = 0;
+        mi::upload_whole_image_geom(width, height, it.out_w, it.out_h, true, B, d_geom_det, d_pad_det, s);
+        p->geom_B = B; p->geom_w = width; p->geom_h = height;
+    }
+    mi::launch_pre_tensor(it, d_geom_det, d_in_det, s);
+    tr("pre det");
+    fdm.run_device(d_in_det, B, s, one_shot);
+    tr("det run_device");
+    float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
+    // ---- 2. faces[0] -> face_detection_to_roi -> image_to_tensor(frame, roi, (192,192), false, (0,1)) -> mesh net
+    // (the post-processing launch writes zeros behind a frame's last detection — frames without a face report zeros — and faces[0]'s ROI)
+    auto* d_roi_face = static_cast<mi::RectD*>(p->roi_face.get(sizeof(mi::RectD) * B));
+    int* d_valid_face = static_cast<int*>(p->valid_face.get(sizeof(int) * B));
+    fd_post(p->fd.get(), fdm.output_device(0), fdm.output_device(1), B, d_pad_det, reinterpret_cast<mi_detection*>(d_dets), cap, o.counts,
+            MI_MEM_DEVICE, s, d_roi_face, d_valid_face, width, height);
+    tr("fd_post");
+    it.rois = d_roi_face; it.roi_valid = d_valid_face; it.out_w = p->fl->in_w; it.out_h = p->fl->in_h; it.keep_aspect = 0;
+    it.range_min = 0.0; it.range_max = 1.0;
+    float* d_in_lm = static_cast<float*>(p->in_lm.get(flm.input_elems() * sizeof(float) * B));
+    mi::launch_pre_geom(it, d_geom, nullptr, s);
+    mi::launch_pre_tensor(it, d_geom, d_in_lm, s);
+    tr("pre mesh");
+    flm.run_device(d_in_lm, B, s, one_shot);
+    tr("mesh run_device");
+    {
+        mi::ProjArgs a;
+        a.B = B; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = p->fl->in_w; a.tensor_h = p->fl->in_h;
+        a.roi = d_roi_face; a.image_size = d_sizes; a.gate = d_valid_face;
+        a.raw = flm.output_device(0); a.raw_fs = static_cast<long>(flm.output_elems(0));
+        a.flag = flm.output_device(1) + (flm.output_elems(1) - 1); a.flag_fs = static_cast<long>(flm.output_elems(1));
+        a.out = o.lm; a.present = o.present;
+        int rc = mi::launch_project(a, s);
+        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+    }
+    // ---- 3. iris_roi_from_face_landmarks -> image_to_tensor(frame, eye roi, (64,64), true, (0,1), flip = right eye) -> iris net
+    auto* d_roi_eye = static_cast<mi::RectD*>(p->roi_eye.get(sizeof(mi::RectD) * 2 * B));
+    int* d_valid_eye = static_cast<int*>(p->valid_eye.get(sizeof(int) * 2 * B));
+    int* d_flip_eye = static_cast<int*>(p->flip_eye.get(sizeof(int) * 2 * B));
+    mi::launch_iris_rois(o.lm, o.present, B, width, height, d_roi_eye, d_valid_eye, d_flip_eye, s);
+    it.rois = d_roi_eye; it.roi_valid = d_valid_eye; it.flip = d_flip_eye; it.items_per_frame = 2; it.N = 2 * B;
+    it.out_w = p->iris->in_w; it.out_h = p->iris->in_h; it.keep_aspect = 1;
+    double* d_pad_eye = static_cast<double*>(p->pad_eye.get(sizeof(double) * 8 * B));
+    float* d_in_eye = static_cast<float*>(p->in_eye.get(irm.input_elems() * sizeof(float) * 2 * B));
+    mi::launch_pre_geom(it, d_geom, d_pad_eye, s);
+    mi::launch_pre_tensor(it, d_geom, d_in_eye, s);
+    tr("pre iris");
+    irm.run_device(d_in_eye, 2 * B, s, one_shot);
+    tr("iris run_device");
+    {   // contour and iris landmarks of both eyes in one launch
+        mi::ProjArgs a;
+        a.B = 2 * B; a.n = MI_NUM_EYE_LANDMARKS; a.n2 = MI_NUM_IRIS_LANDMARKS; a.tensor_w = p->iris->in_w; a.tensor_h = p->iris->in_h;
+        a.roi = d_roi_eye; a.image_size = d_sizes; a.padding = d_pad_eye; a.flip = d_flip_eye; a.gate = d_valid_eye;
+        a.raw = irm.output_device(0); a.raw_fs = static_cast<long>(irm.output_elems(0));
+        a.raw2 = irm.output_device(1); a.raw2_fs = static_cast<long>(irm.output_elems(1));
+        a.out = o.eyes; a.out_fs = eye_fs;
+        a.out2 = o.eyes + 3 * MI_NUM_EYE_LANDMARKS; a.out2_fs = eye_fs;
+        int rc = mi::launch_project(a, s);
+        if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+    }
+    // ---- top-1 faces out (strided gather [B][cap][17] -> [B][17])
+    tr("projections");
+    mi::hip_check(hipMemcpy2DAsync(o.faces, sizeof(mi_detection), d_dets, sizeof(mi_detection) * cap, sizeof(mi_detection), B,
+                                   hipMemcpyDeviceToDevice, s), "gather faces");
+    tr("gather");
+}
+
+// the results of one pass, from the pinned image of its block into the caller's arrays
+static void pipeline_hand_out(const OneShot& out, const PipeLayout& L, int B, mi_detection* faces, int* face_counts, float* landmarks, int* present, float* eyes) {
+    std::memcpy(faces, out.h<char>(L.faces), sizeof(mi_detection) * B);
+    std::memcpy(face_counts, out.h<char>(L.counts), sizeof(int) * B);
+    std::memcpy(landmarks, out.h<char>(L.lm), sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B);
+    std::memcpy(present, out.h<char>(L.present), sizeof(int) * B);
+    std::memcpy(eyes, out.h<char>(L.eyes), sizeof(float) * kEyeFs * 2 * B);
+    for (int b = 0; b < B; b++) {
+        if (face_counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
+        if (face_counts[b] == 0) std::memset(&faces[b], 0, sizeof(mi_detection));
+    }
+}
+
 int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width, int height, int stride, mi_detection* faces,
                     int* face_counts, float* landmarks, int* present, float* eyes, int mem, void* stream) {
     return guarded([&] {
@@ -1521,16 +1683,12 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
         mi::hip_check(hipSetDevice(fdm.device()), "hipSetDevice");
         hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fdm.stream();
         Use use_fd(p->fd->model, s), use_fl(p->fl->model, s), use_ir(p->iris->model, s);  // the pipeline's own three handles, fixed order
-        const int B = batch, cap = 4;
-        const long eye_fs = 3L * (MI_NUM_EYE_LANDMARKS + MI_NUM_IRIS_LANDMARKS);
-        auto up16 = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
-        const size_t off_faces = 0, off_counts = up16(off_faces + sizeof(mi_detection) * B), off_lm = up16(off_counts + sizeof(int) * B),
-                     off_present = up16(off_lm + sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B), off_eyes = up16(off_present + sizeof(int) * B),
-                     results_bytes = up16(off_eyes + sizeof(float) * eye_fs * 2 * B);
+        const int B = batch;
+        const PipeLayout L(B);
         char* d_results = nullptr;
         if (mem == MI_MEM_HOST) {
-            d_results = static_cast<char*>(p->results.get(results_bytes));
-            p->out.reserve(results_bytes);
+            d_results = static_cast<char*>(p->results.get(L.bytes));
+            p->out.reserve(L.bytes);
         }
         const size_t frame_bytes = static_cast<size_t>(stride) * height;
         const uint8_t* d_frames = frames;
@@ -1540,123 +1698,140 @@ int mi_pipeline_run(mi_pipeline* p, const uint8_t* frames, int batch, int width,
             const size_t host_bytes = frame_bytes * (B - 1) + static_cast<size_t>(stride) * (height - 1) + static_cast<size_t>(3) * width;
             mi::hip_check(hipMemcpyAsync(const_cast<uint8_t*>(d_frames), frames, host_bytes, hipMemcpyHostToDevice, s), "H2D frames");
         }
-        auto* d_geom = static_cast<mi::PreGeom*>(p->geom.get(sizeof(mi::PreGeom) * 2 * B));
-        // (w, h) of the source image of every ROI, for Rect::scaled in project_landmarks
-        int* d_sizes = static_cast<int*>(p->sizes.get(sizeof(int) * 4 * B));
-        if (p->sizes_B != B || p->sizes_w != width || p->sizes_h != height) {  // a host round trip only when the batch geometry changes
-            std::vector<int> hs(4 * static_cast<size_t>(B));
-            for (int i = 0; i < 2 * B; i++) { hs[2 * i] = width; hs[2 * i + 1] = height; }
-            p->sizes_B = 0;
-            mi::hip_check(hipMemcpyAsync(d_sizes, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, s), "H2D sizes");
-            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");  // hs is a host temporary
-            p->sizes_B = B; p->sizes_w = width; p->sizes_h = height;
-        }
         // A picture or two from host memory (lib.rs:24-40 on one image): the detector and the face mesh may take their single-launch plans —
         // this call holds the CUs until its synchronisation below, and repeats itself on the batched plan should such a launch have given up.
         std::unique_ptr<BandClaim> claim;
         if (mem == MI_MEM_HOST) claim = std::make_unique<BandClaim>(fdm.device(), std::max(std::max(fdm.band_workgroups(B), flm.band_workgroups(B)), irm.band_workgroups(2 * B)));
-        static const bool ptrace = getenv("MI_PIPE_TRACE") != nullptr;
-        auto t_start = std::chrono::steady_clock::now();
-        auto tr = [&](const char* what) { if (ptrace) std::fprintf(stderr, "  %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count()); };
+        const PipeOut o = mem == MI_MEM_DEVICE ? PipeOut{faces, face_counts, landmarks, present, eyes} : L.in(d_results);
         for (int attempt = 0; attempt < 2; attempt++) {
-        const bool one_shot = claim && claim->ok && attempt == 0;
-        // ---- 1. detector: image_to_tensor(frame, None, (w,h), keep_aspect = true, (-1,1)) -> net -> decode + NMS
-        mi::PreItems it{};
-        it.frames = d_frames; it.frame_bytes = static_cast<long>(frame_bytes); it.width = width; it.height = height; it.stride = stride;
-        it.items_per_frame = 1; it.N = B; it.out_w = p->fd->in_w; it.out_h = p->fd->in_h; it.keep_aspect = 1;
-        it.range_min = -1.0; it.range_max = 1.0;
-        double* d_pad_det = static_cast<double*>(p->pad_det.get(sizeof(double) * 4 * B));
-        float* d_in_det = static_cast<float*>(p->in_det.get(fdm.input_elems() * sizeof(float) * B));
-        // (no ROI: the geometry is the same for every call on pictures of this size — no pre_geom launch, 9 us of a one-picture call)
-        auto* d_geom_det = static_cast<mi::PreGeom*>(p->geom_det.get(sizeof(mi::PreGeom) * B));
-        if (p->geom_B != B || p->geom_w != width || p->geom_h != height) {
-            p->geom_B = 0;
-            mi::upload_whole_image_geom(width, height, it.out_w, it.out_h, true, B, d_geom_det, d_pad_det, s);
-            p->geom_B = B; p->geom_w = width; p->geom_h = height;
-        }
-        mi::launch_pre_tensor(it, d_geom_det, d_in_det, s);
-        tr("pre det");
-        fdm.run_device(d_in_det, B, s, one_shot);
-        tr("det run_device");
-        float* d_dets = static_cast<float*>(p->dets.get(sizeof(mi_detection) * cap * B));
-        int* d_counts = mem == MI_MEM_DEVICE ? face_counts : reinterpret_cast<int*>(d_results + off_counts);
-        // ---- 2. faces[0] -> face_detection_to_roi -> image_to_tensor(frame, roi, (192,192), false, (0,1)) -> mesh net
-        // (the post-processing launch writes zeros behind a frame's last detection — frames without a face report zeros — and faces[0]'s ROI)
-        auto* d_roi_face = static_cast<mi::RectD*>(p->roi_face.get(sizeof(mi::RectD) * B));
-        int* d_valid_face = static_cast<int*>(p->valid_face.get(sizeof(int) * B));
-        fd_post(p->fd.get(), fdm.output_device(0), fdm.output_device(1), B, d_pad_det, reinterpret_cast<mi_detection*>(d_dets), cap, d_counts,
-                MI_MEM_DEVICE, s, d_roi_face, d_valid_face, width, height);
-        tr("fd_post");
-        it.rois = d_roi_face; it.roi_valid = d_valid_face; it.out_w = p->fl->in_w; it.out_h = p->fl->in_h; it.keep_aspect = 0;
-        it.range_min = 0.0; it.range_max = 1.0;
-        float* d_in_lm = static_cast<float*>(p->in_lm.get(flm.input_elems() * sizeof(float) * B));
-        mi::launch_pre_geom(it, d_geom, nullptr, s);
-        mi::launch_pre_tensor(it, d_geom, d_in_lm, s);
-        tr("pre mesh");
-        flm.run_device(d_in_lm, B, s, one_shot);
-        tr("mesh run_device");
-        float* d_lm = mem == MI_MEM_DEVICE ? landmarks : reinterpret_cast<float*>(d_results + off_lm);
-        int* d_present = mem == MI_MEM_DEVICE ? present : reinterpret_cast<int*>(d_results + off_present);
-        {
-            mi::ProjArgs a;
-            a.B = B; a.n = MI_NUM_FACE_LANDMARKS; a.tensor_w = p->fl->in_w; a.tensor_h = p->fl->in_h;
-            a.roi = d_roi_face; a.image_size = d_sizes; a.gate = d_valid_face;
-            a.raw = flm.output_device(0); a.raw_fs = static_cast<long>(flm.output_elems(0));
-            a.flag = flm.output_device(1) + (flm.output_elems(1) - 1); a.flag_fs = static_cast<long>(flm.output_elems(1));
-            a.out = d_lm; a.present = d_present;
-            int rc = mi::launch_project(a, s);
-            if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-        }
-        // ---- 3. iris_roi_from_face_landmarks -> image_to_tensor(frame, eye roi, (64,64), true, (0,1), flip = right eye) -> iris net
-        auto* d_roi_eye = static_cast<mi::RectD*>(p->roi_eye.get(sizeof(mi::RectD) * 2 * B));
-        int* d_valid_eye = static_cast<int*>(p->valid_eye.get(sizeof(int) * 2 * B));
-        int* d_flip_eye = static_cast<int*>(p->flip_eye.get(sizeof(int) * 2 * B));
-        mi::launch_iris_rois(d_lm, d_present, B, width, height, d_roi_eye, d_valid_eye, d_flip_eye, s);
-        it.rois = d_roi_eye; it.roi_valid = d_valid_eye; it.flip = d_flip_eye; it.items_per_frame = 2; it.N = 2 * B;
-        it.out_w = p->iris->in_w; it.out_h = p->iris->in_h; it.keep_aspect = 1;
-        double* d_pad_eye = static_cast<double*>(p->pad_eye.get(sizeof(double) * 8 * B));
-        float* d_in_eye = static_cast<float*>(p->in_eye.get(irm.input_elems() * sizeof(float) * 2 * B));
-        mi::launch_pre_geom(it, d_geom, d_pad_eye, s);
-        mi::launch_pre_tensor(it, d_geom, d_in_eye, s);
-        tr("pre iris");
-        irm.run_device(d_in_eye, 2 * B, s, one_shot);
-        tr("iris run_device");
-        float* d_eyes = mem == MI_MEM_DEVICE ? eyes : reinterpret_cast<float*>(d_results + off_eyes);
-        {   // contour and iris landmarks of both eyes in one launch
-            mi::ProjArgs a;
-            a.B = 2 * B; a.n = MI_NUM_EYE_LANDMARKS; a.n2 = MI_NUM_IRIS_LANDMARKS; a.tensor_w = p->iris->in_w; a.tensor_h = p->iris->in_h;
-            a.roi = d_roi_eye; a.image_size = d_sizes; a.padding = d_pad_eye; a.flip = d_flip_eye; a.gate = d_valid_eye;
-            a.raw = irm.output_device(0); a.raw_fs = static_cast<long>(irm.output_elems(0));
-            a.raw2 = irm.output_device(1); a.raw2_fs = static_cast<long>(irm.output_elems(1));
-            a.out = d_eyes; a.out_fs = eye_fs;
-            a.out2 = d_eyes + 3 * MI_NUM_EYE_LANDMARKS; a.out2_fs = eye_fs;
-            int rc = mi::launch_project(a, s);
-            if (rc) throw std::runtime_error(std::string("projection kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
-        }
-        // ---- top-1 faces out (strided gather [B][cap][17] -> [B][17]) and host copies
-        tr("projections");
-        mi_detection* d_faces = mem == MI_MEM_DEVICE ? faces : reinterpret_cast<mi_detection*>(d_results + off_faces);
-        mi::hip_check(hipMemcpy2DAsync(d_faces, sizeof(mi_detection), d_dets, sizeof(mi_detection) * cap, sizeof(mi_detection), B,
-                                       hipMemcpyDeviceToDevice, s), "gather faces");
-        tr("gather");
-        if (mem == MI_MEM_HOST) {
-            mi::hip_check(hipMemcpyAsync(p->out.host, d_results, results_bytes, hipMemcpyDeviceToHost, s), "D2H results");
-            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
-            if (one_shot && (static_cast<int>(fdm.band_failed()) | static_cast<int>(flm.band_failed()) | static_cast<int>(irm.band_failed()))) continue;
-            std::memcpy(faces, p->out.h<char>(off_faces), sizeof(mi_detection) * B);
-            std::memcpy(face_counts, p->out.h<char>(off_counts), sizeof(int) * B);
-            std::memcpy(landmarks, p->out.h<char>(off_lm), sizeof(float) * 3 * MI_NUM_FACE_LANDMARKS * B);
-            std::memcpy(present, p->out.h<char>(off_present), sizeof(int) * B);
-            std::memcpy(eyes, p->out.h<char>(off_eyes), sizeof(float) * eye_fs * 2 * B);
-            for (int b = 0; b < B; b++) {
-                if (face_counts[b] < 0) throw ApiError(MI_ERANGE, "letterbox scale is too small (reference asserts at transform.rs:121-122)");
-                if (face_counts[b] == 0) std::memset(&faces[b], 0, sizeof(mi_detection));
+            const bool one_shot = claim && claim->ok && attempt == 0;
+            pipeline_enqueue(p, d_frames, B, width, height, stride, o, one_shot, s);
+            if (mem == MI_MEM_HOST) {
+                mi::hip_check(hipMemcpyAsync(p->out.host, d_results, L.bytes, hipMemcpyDeviceToHost, s), "D2H results");
+                mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+                if (one_shot && (static_cast<int>(fdm.band_failed()) | static_cast<int>(flm.band_failed()) | static_cast<int>(irm.band_failed()))) continue;
+                pipeline_hand_out(p->out, L, B, faces, face_counts, landmarks, present, eyes);
+            } else if (!stream) {
+                mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
             }
-        } else if (!stream) {
-            mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+            break;
         }
-        break;
+    });
+}
+
+// ---- the flow of lib.rs:18-40 for a STREAM of encoded pictures: convert_image_to_mat + FaceDetection::infer + FaceLandmark::infer + 2 x
+// IrisLandmark::infer per picture, two slots (see mi_fd_submit_jpeg): the entropy decoder of picture n + 1 runs on the calling thread while the
+// device works through picture n's four networks.
+int mi_pipeline_submit_jpeg(mi_pipeline* p, int slot, const uint8_t* bytes, size_t nbytes) {
+    return guarded([&] {
+        require(p && bytes, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        PipeJpegSlot& sl = p->jslot[slot];
+        if (sl.pending) throw ApiError(MI_EINVAL, "slot holds a picture that has not been collected");
+        mi::Model& fdm = *p->fd->model.m;
+        mi::Model& flm = *p->fl->model.m;
+        mi::Model& irm = *p->iris->model.m;
+        mi::hip_check(hipSetDevice(fdm.device()), "hipSetDevice");
+        JpegSlot& js = sl.jpeg;
+        js.f.coef.ctx = &js;
+        js.f.coef.provide = [](size_t count, void* ctx) -> int16_t* {
+            JpegSlot& q = *static_cast<JpegSlot*>(ctx);
+            const size_t need = count * sizeof(int16_t) + sizeof q.f.qt;
+            if (need > q.h_coef_cap) {
+                if (q.h_coef) hipHostFree(q.h_coef);
+                q.h_coef = nullptr;
+                q.h_coef_cap = 0;
+                mi::hip_check(hipHostMalloc(&q.h_coef, need + need / 4, hipHostMallocDefault), "hipHostMalloc coefficients");
+                q.h_coef_cap = need + need / 4;
+            }
+            return static_cast<int16_t*>(q.h_coef);
+        };
+        try {
+            mi::jpeg_entropy_decode(bytes, nbytes, &js.f);
+        } catch (const std::runtime_error& e) {
+            throw ApiError(MI_EINVAL, e.what());
         }
+        const mi::JpegFrame& f = js.f;
+        const size_t coef_bytes = f.coef.size() * sizeof(int16_t);
+        std::memcpy(static_cast<char*>(js.h_coef) + coef_bytes, f.qt, sizeof f.qt);
+        if (!js.copy) {
+            mi::hip_check(hipStreamCreateWithFlags(&js.copy, hipStreamNonBlocking), "hipStreamCreate");
+            mi::hip_check(hipEventCreateWithFlags(&js.copied, hipEventDisableTiming), "hipEventCreate");
+            mi::hip_check(hipEventCreateWithFlags(&js.done, hipEventDisableTiming), "hipEventCreate");
+        }
+        auto* d_coef = static_cast<int16_t*>(js.d_coef.get(coef_bytes + sizeof f.qt));
+        auto* d_qt = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(d_coef) + coef_bytes);
+        auto* d_planes = static_cast<uint8_t*>(js.d_planes.get(mi::jpeg_plane_bytes(f)));
+        auto* d_rgb = static_cast<uint8_t*>(js.d_rgb.get(static_cast<size_t>(3) * f.width * f.height));
+        const PipeLayout L(1);
+        char* d_results = static_cast<char*>(sl.results.get(L.bytes));
+        sl.out.reserve(L.bytes);
+        mi::hip_check(hipMemcpyAsync(d_coef, js.h_coef, coef_bytes + sizeof f.qt, hipMemcpyHostToDevice, js.copy), "H2D coefficients");
+        mi::hip_check(hipEventRecord(js.copied, js.copy), "hipEventRecord");
+        hipStream_t s = fdm.stream();
+        Use use_fd(p->fd->model, s), use_fl(p->fl->model, s), use_ir(p->iris->model, s);
+        mi::hip_check(hipStreamWaitEvent(s, js.copied, 0), "hipStreamWaitEvent");
+        int rc = mi::launch_jpeg_idct(f, d_coef, d_qt, d_planes, s);
+        if (rc == 0) rc = mi::launch_jpeg_color(f, d_planes, d_rgb, s);
+        if (rc) throw std::runtime_error(std::string("jpeg kernel launch failed: ") + hipGetErrorString(static_cast<hipError_t>(rc)));
+        if (p->jclaim_users == 0)
+            p->jclaim.reset(new BandClaim(fdm.device(), std::max(std::max(fdm.band_workgroups(1), flm.band_workgroups(1)), irm.band_workgroups(2))));
+        p->jclaim_users++;
+        sl.claimed = true;
+        sl.band = p->jclaim && p->jclaim->ok;
+        sl.suspect = false;
+        pipeline_enqueue(p, d_rgb, 1, f.width, f.height, 3 * f.width, L.in(d_results), sl.band, s);
+        mi::hip_check(hipMemcpyAsync(sl.out.host, d_results, L.bytes, hipMemcpyDeviceToHost, s), "D2H results");
+        mi::hip_check(hipEventRecord(js.done, s), "hipEventRecord");
+        sl.pending = true;
+    });
+}
+
+int mi_pipeline_collect_jpeg(mi_pipeline* p, int slot, mi_detection* face, int* face_count, float* landmarks, int* present, float* eyes, int* width, int* height) {
+    return guarded([&] {
+        require(p && face && face_count && landmarks && present && eyes, "null argument");
+        require(slot == 0 || slot == 1, "slot must be 0 or 1");
+        PipeJpegSlot& sl = p->jslot[slot];
+        if (!sl.pending) throw ApiError(MI_EINVAL, "nothing was submitted to this slot");
+        mi::Model& fdm = *p->fd->model.m;
+        mi::Model& flm = *p->fl->model.m;
+        mi::Model& irm = *p->iris->model.m;
+        mi::hip_check(hipSetDevice(fdm.device()), "hipSetDevice");
+        JpegSlot& js = sl.jpeg;
+        mi::hip_check(hipEventSynchronize(js.done), "hipEventSynchronize");
+        const PipeLayout L(1);
+        {
+            hipStream_t s = fdm.stream();
+            Use use_fd(p->fd->model, s), use_fl(p->fl->model, s), use_ir(p->iris->model, s);
+            auto release = [&] {
+                if (sl.claimed && --p->jclaim_users == 0) p->jclaim.reset();
+                sl.claimed = false;
+                sl.pending = false;
+            };
+            try {
+                if (sl.band) {
+                    // (the flags are the handles': with the other slot's picture in flight behind this one a raised flag may be that picture's — both are repeated)
+                    if (static_cast<int>(fdm.band_failed()) | static_cast<int>(flm.band_failed()) | static_cast<int>(irm.band_failed())) {
+                        sl.suspect = true;
+                        PipeJpegSlot& other = p->jslot[1 - slot];
+                        if (other.pending && other.band) other.suspect = true;
+                    }
+                    if (sl.suspect) {
+                        char* d_results = static_cast<char*>(sl.results.p);
+                        pipeline_enqueue(p, static_cast<const uint8_t*>(js.d_rgb.p), 1, js.f.width, js.f.height, 3 * js.f.width, L.in(d_results), false, s);
+                        mi::hip_check(hipMemcpyAsync(sl.out.host, d_results, L.bytes, hipMemcpyDeviceToHost, s), "D2H results");
+                        mi::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+                    }
+                }
+            } catch (...) {
+                release();
+                throw;
+            }
+            release();
+        }
+        pipeline_hand_out(sl.out, L, 1, face, face_count, landmarks, present, eyes);
+        if (width) *width = js.f.width;
+        if (height) *height = js.f.height;
     });
 }
 

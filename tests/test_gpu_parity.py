@@ -445,7 +445,7 @@ def test_single_launch_plan_only_where_the_graph_has_one(gpu):
         m.close()
 
 
-def test_single_image_entry_on_the_single_launch_plan(gpu, oracle, man_image):
+def test_single_image_entry_on_the_single_launch_plan(gpu, oracle, gold, man_image):
     """mi_fd_infer_image (one Mat per call, face_detection.rs:205) takes the single-launch plan: the same detections as a handle with the
     plan turned off, a run that reports it gave up is repeated on the batched plan, and handles on several threads share the device's CUs
     (256 CUs, 128 workgroups per BackCamera call: the third concurrent call runs on the batched plan instead of waiting)."""
@@ -458,10 +458,14 @@ def test_single_image_entry_on_the_single_launch_plan(gpu, oracle, man_image):
     want = off.infer(man_image, None)
     assert len(want) >= 1
 
+    ref = gold["man_back_dets"]   # the oracle's detections on man.jpg (tests/test_pins.py asserts golden.npz equal to the oracle's run)
+
     def same(got):
         assert len(got) == len(want)
         for g, w in zip(got, want):
             assert np.abs(g.data - w.data).max() <= 1e-5 and abs(g.score - w.score) <= 1e-5
+        for g, r in zip(got, ref):     # ... and against the oracle itself, at the detector tolerance
+            np.testing.assert_allclose(np.concatenate([g.data.reshape(-1), [g.score]]), r, atol=2e-5)
 
     same(fd.infer(man_image, None))
     fd.model.set_option("band_test_fail", 1)   # the next single launch "gives up": the call must repeat itself on the batched plan
@@ -556,9 +560,15 @@ def test_mesh_and_iris_single_image_entries_on_threads(gpu, gold, man_image):
     assert len(want_lm) == 468
 
     def same(lm, eyes):
-        np.testing.assert_allclose(lm.array, want_lm, atol=2e-3)          # (pixel coordinates of a 540 x 360 picture)
-        np.testing.assert_allclose(eyes.contour.array, want_eye.contour.array, atol=2e-3)
-        np.testing.assert_allclose(eyes.iris.array, want_eye.iris.array, atol=2e-3)
+        # against the ORACLE's values for the same ROIs (golden.npz, asserted equal to the oracle's run by tests/test_pins.py), at the landmark
+        # tolerance of the batched plan's tests — not only against the other plan ...
+        np.testing.assert_allclose(lm.array, gold["man_face_landmarks"], atol=2e-5)
+        np.testing.assert_allclose(eyes.contour.array, gold["man_eye_left_contour"], atol=2e-5)
+        np.testing.assert_allclose(eyes.iris.array, gold["man_eye_left_iris"], atol=2e-5)
+        # ... and against the batched plan of this build (the two plans differ by re-association only)
+        np.testing.assert_allclose(lm.array, want_lm, atol=2e-5)
+        np.testing.assert_allclose(eyes.contour.array, want_eye.contour.array, atol=2e-5)
+        np.testing.assert_allclose(eyes.iris.array, want_eye.iris.array, atol=2e-5)
 
     fl, ir = gpu.FaceLandmark(), gpu.IrisLandmark()
     assert fl.model.single_launch_workgroups(1) == 96 and ir.model.single_launch_workgroups(1) == 32

@@ -275,3 +275,59 @@ def test_streamed_jpeg_entries_equal_decode_then_infer(mi):
                 np.testing.assert_allclose(a.data, b.data, atol=1e-4)
         fd.close()
         ref.close()
+
+
+@pytest.mark.gpu
+def test_streamed_jpeg_pipeline_equals_decode_then_pipeline_run(mi):
+    """mi_pipeline_submit_jpeg / mi_pipeline_collect_jpeg: the whole flow of the reference's own test (lib.rs:18-40: bytes -> convert_image_to_mat ->
+    FaceDetection::infer -> FaceLandmark::infer -> 2 x IrisLandmark::infer) for a stream of encoded pictures, two slots.  Every picture's results are
+    bit-equal to convert_image_to_mat + mi_pipeline_run (batch 1, host memory) on the same bytes, whatever is in flight in the other slot and
+    whatever the picture's size (the reference's three test pictures: 540x360, 200x133, 200x225); a single launch that gives up is repeated."""
+    rels = ["man.jpg", "russ_cox_1.jpg", "russ_cox_2.jpg", "jpeg/prog_420.jpg" if "jpeg/prog_420.jpg" in FILES else "man.jpg"]
+    for kind in (mi.FaceDetectionModel.BackCamera, mi.FaceDetectionModel.Short):
+        pipe = mi.Pipeline(kind)
+        ref = mi.Pipeline(kind)
+        want = {}
+        for r in rels:
+            img = mi.convert_image_to_mat(_bytes(r))
+            want[r] = ref.run(np.ascontiguousarray(img[None]))
+            want[r]["size"] = (img.shape[1], img.shape[0])
+        assert want["man.jpg"]["face_counts"][0] >= 1 and want["man.jpg"]["present"][0] == 1
+
+        def same(got, r, exact=True):
+            assert got["size"] == want[r]["size"], r
+            for k in ("faces", "face_counts", "landmarks", "present", "eyes"):
+                if exact:
+                    np.testing.assert_array_equal(got[k], want[r][k], err_msg="%s %s" % (r, k))
+                else:
+                    np.testing.assert_allclose(got[k], want[r][k], atol=2e-4, err_msg="%s %s" % (r, k))
+
+        order = rels + rels[::-1] + ["man.jpg"] * 4
+        pipe.submit_jpeg(0, _bytes(order[0]))
+        for i in range(1, len(order)):
+            pipe.submit_jpeg(i & 1, _bytes(order[i]))
+            same(pipe.collect_jpeg((i - 1) & 1), order[i - 1])
+        same(pipe.collect_jpeg((len(order) - 1) & 1), order[-1])
+        with pytest.raises(mi.MiError):
+            pipe.collect_jpeg(0)                                       # nothing submitted
+        pipe.submit_jpeg(0, _bytes("man.jpg"))
+        with pytest.raises(mi.MiError):
+            pipe.submit_jpeg(0, _bytes("man.jpg"))                     # not collected yet
+        with pytest.raises(mi.MiError):
+            pipe.submit_jpeg(1, b"\xff\xd8\xff\xe0junk")               # not a picture: refused, slot 1 stays free
+        same(pipe.collect_jpeg(0), "man.jpg")
+        # mi_pipeline_run between two streamed pictures
+        pipe.submit_jpeg(1, _bytes("russ_cox_1.jpg"))
+        img = mi.convert_image_to_mat(_bytes("man.jpg"))
+        got = pipe.run(np.ascontiguousarray(img[None]))
+        for k in ("faces", "face_counts", "landmarks", "present", "eyes"):
+            np.testing.assert_array_equal(got[k], want["man.jpg"][k])
+        same(pipe.collect_jpeg(1), "russ_cox_1.jpg")
+        # single launches that give up (absent workgroups in the detector's program): repeated on the batched plan at collect
+        pipe.set_option("band_test_absent", 4)
+        pipe.submit_jpeg(0, _bytes("man.jpg"))
+        pipe.submit_jpeg(1, _bytes("russ_cox_2.jpg"))
+        same(pipe.collect_jpeg(0), "man.jpg", exact=False)
+        same(pipe.collect_jpeg(1), "russ_cox_2.jpg", exact=False)
+        pipe.close()
+        ref.close()

@@ -61,6 +61,19 @@ def measure(n=300):
     pipe = mi.Pipeline(mi.FaceDetectionModel.BackCamera)
     one = np.ascontiguousarray(img[None])
     out["lib.rs flow on one picture: mi_pipeline_run, batch 1 (detector -> mesh -> 2 x iris)"] = timed(lambda: pipe.run(one), n)
+    # ... and for a stream of ENCODED pictures (lib.rs:18-40 from the bytes; mi_pipeline_submit_jpeg / collect_jpeg, two slots): sustained per picture
+    pipe.submit_jpeg(0, jpg)
+    state = {"k": 0}
+
+    def flow_step():
+        k = state["k"]
+        pipe.submit_jpeg(1 - k, jpg)
+        res = pipe.collect_jpeg(k)
+        state["k"] = 1 - k
+        return res
+    out["lib.rs flow from JPEG bytes, streamed (mi_pipeline_submit_jpeg / collect_jpeg, two slots; sustained per picture)"] = timed(flow_step, n)
+    pipe.collect_jpeg(state["k"])
+    out["lib.rs flow from JPEG bytes, one picture at a time (convert_image_to_mat + mi_pipeline_run)"] = timed(lambda: pipe.run(np.ascontiguousarray(mi.convert_image_to_mat(jpg)[None])), n)
     pipe.close()
     return out
 
