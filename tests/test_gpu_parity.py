@@ -1666,3 +1666,45 @@ def test_streams_on_distinct_hardware_queues(gpu):
     gpu.streams_destroy(three)
     with pytest.raises(gpu.MiError):
         gpu.streams_create_distinct(5)
+
+
+def test_single_image_entries_from_several_processes(gpu, gold):
+    """ADVICE r5 (medium), the real case: the CU budget of the single-launch plan is per PROCESS, so three processes that each call
+    mi_fd_infer_image (128 workgroups per BackCamera call, 256 CUs) can put launches on the device whose workgroups are not all resident.  Every
+    call must still return the oracle's detections (a launch that gave up is repeated on the batched plan; a handle that keeps giving up stops
+    trying), and nobody may stall: round 5's 0.3 s per stage would make this test take minutes."""
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, %r)
+import rs_face_detection_tflite_amd as mi
+from PIL import Image
+img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(%r, "tests", "golden", "man.jpg")).convert("RGB")))
+fd = mi.FaceDetection(mi.FaceDetectionModel.BackCamera)
+fd.infer(img, None)
+t0 = time.perf_counter(); worst = 0.0; rows = None
+for k in range(300):
+    t = time.perf_counter()
+    d = fd.infer(img, None)
+    worst = max(worst, time.perf_counter() - t)
+    r = [np.concatenate([x.data.reshape(-1), [x.score]]).tolist() for x in d]
+    if rows is None: rows = r
+    assert len(r) == len(rows) and all(np.allclose(a, b, atol=2e-5) for a, b in zip(r, rows)), k
+print(json.dumps({"rows": rows, "total_s": time.perf_counter() - t0, "worst_s": worst, "band": fd.model.get_option("band"), "streak": fd.model.get_option("band_fail_streak")}))
+''' % (root, root)
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    wall = time.perf_counter() - t0
+    import json
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+        res = json.loads(so.strip().splitlines()[-1])
+        assert len(res["rows"]) == 1
+        np.testing.assert_allclose(np.asarray(res["rows"][0]), gold["man_back_dets"][0], atol=2e-5)
+        print("process: 300 calls in %.3f s, worst call %.1f ms, band option now %d, give-ups in a row %d" % (res["total_s"], res["worst_s"] * 1e3, res["band"], res["streak"]))
+        assert res["worst_s"] < 0.25, res          # one bounded wait + the batched plan, never seconds
+        assert res["total_s"] < 30, res
+    assert wall < 120
