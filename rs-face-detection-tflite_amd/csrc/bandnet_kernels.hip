@@ -88,24 +88,24 @@ unsigned long long* g_band_stamps = nullptr;
 // global memory at the top of a stage is a dependent round trip in front of everything else — and a descriptor is then ONE LDS read
 // per lane (dword `lane` of it), a v_readlane per dword and scalar bit-field extracts.
 struct StageRegs {
-    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, res_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats, res_co;
+    int kind, S, H, W, C, Ho, Wo, Co, R, wshift, nbands, dep, Rin, src_tile, dst_tile, res_tile, pub_lo, pub_hi, src_base, dst_base, res_mode, act, c_floats, res_c;
     int wpc_shift, per_ct;
     unsigned mC4, mWo, mrowq;
     int src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
 };
-// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3 res_co:1
+// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3
 // word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:12 woff:4 per_ct:16
-// words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)
+// words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)    word 17: res_c:16 (channels of the skip tensor in res_tile)
 __host__ __device__ inline unsigned bf(unsigned v, int lo, int n) { return (v >> lo) & ((1u << n) - 1u); }
 __device__ __forceinline__ int stage_word(const BandPacked* p, int lane) { return reinterpret_cast<const int*>(p)[lane < kBandPackedWords ? lane : 0]; }
 __device__ __forceinline__ StageRegs stage_regs(int word) {
-    unsigned w[17];
+    unsigned w[18];
 #pragma unroll
-    for (int k = 0; k < 17; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
+    for (int k = 0; k < 18; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
     StageRegs r;
     r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
     r.src_tile = bf(w[0], 12, 2); r.dst_tile = (int)bf(w[0], 14, 3) - 1; r.pub_lo = bf(w[0], 17, 1); r.pub_hi = bf(w[0], 18, 1);
-    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1; r.res_co = bf(w[0], 31, 1);
+    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1; r.res_c = bf(w[17], 0, 16);
     r.R = bf(w[1], 0, 8); r.Rin = bf(w[1], 8, 8); r.dep = (int)bf(w[1], 16, 8) - 1; r.nbands = bf(w[1], 24, 8);
     r.H = bf(w[2], 0, 16); r.W = bf(w[2], 16, 16); r.Ho = bf(w[3], 0, 16); r.Wo = bf(w[3], 16, 16); r.C = bf(w[4], 0, 16); r.Co = bf(w[4], 16, 16);
     r.c_floats = bf(w[5], 0, 12); r.per_ct = bf(w[5], 16, 16);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     const unsigned base = (unsigned)uni((int)poll(a.sync)) * 64u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float* const ws = a.base[0] + (long)f * a.ws_frame_floats;
-    float* const dwb = lds + a.ntiles * a.tile_floats;
+    float* const dwb = lds + a.tile_off[a.ntiles];   // (the tiles have sizes of their own: tile t at tile_off[t], round 6)
     float* const lC = dwb + a.dw_floats;
     const BandPacked* const lprog = reinterpret_cast<const BandPacked*>(lC + kConstFloats);
     int* const lfail = reinterpret_cast<int*>(lC + kConstFloats) + a.nstages * (int)(sizeof(BandPacked) / 4);   // this workgroup has given up (16 bytes behind the program)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         const int Rin = st.dep >= 0 ? min(st.Rin, st.H - p0) : 0;
         const int ya = blk && S == 1 ? p0 - 1 : p0;
         const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : (cv2 ? p0 + 2 * nro : p0 + nro);
-        float* const tile = lds + st.src_tile * a.tile_floats;
+        float* const tile = lds + a.tile_off[st.src_tile];
         const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C >> 3) & 1, has4 = (C >> 2) & 1;
         const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
         // wpc = 8 / nct rounded down to a power of two (nct <= 8) waves share an output-channel tile and take its pixel tiles in turn.  The channel
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             const int npt = (npx + 15) >> 4;
             const int n = lane & 15, kq = lane >> 4;
             const int Cso = Co + 4, TWo = Wo + 2;
-            float* const dtile = st.dst_tile >= 0 ? lds + st.dst_tile * a.tile_floats : nullptr;
+            float* const dtile = st.dst_tile >= 0 ? lds + a.tile_off[st.dst_tile] : nullptr;
             float* const gout = st.dst_base >= 0 ? a.base[st.dst_base] + st.dst_off + (long)f * st.dst_fs + (long)r0 * Wo * Co : nullptr;
             float* const llo = st.dst_ll >= 0 ? ws + st.dst_ll : nullptr;
             const float hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
@@ -371,15 +371,15 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     const int c0 = 16 * myct + 4 * kq;
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);
                     f32x4 sk = zero4;
-                    if (st.res_mode == RES_DIRECT && st.res_tile >= 0) {   // a tensor of Co channels on the same rows, in another tile
-                        sk = *reinterpret_cast<const f32x4*>(lds + st.res_tile * a.tile_floats + ((1 + oy) * TW + ox + 1) * Cso + c0);
+                    if (st.res_mode == RES_DIRECT && st.res_tile >= 0) {   // a tensor of res_c <= Co channels (zero-padded to Co) on the same rows, in another tile
+                        if (c0 < st.res_c) sk = *reinterpret_cast<const f32x4*>(lds + a.tile_off[st.res_tile] + ((1 + oy) * TWo + ox + 1) * (st.res_c + 4) + c0);
                     } else if (st.res_mode == RES_DIRECT) {
                         if (c0 < C) sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // channels >= C: the zero pad of a widening block
-                    } else if (st.res_mode == RES_MAXPOOL && c0 < (st.res_co ? Co : C)) {
+                    } else if (st.res_mode == RES_MAXPOOL && c0 < (st.res_tile >= 0 ? st.res_c : C)) {
                         // 2x2 max of a tensor of twice the output's size: the stride-2 block's own input (C channels), or (res_tile) the tensor the
-                        // 2x2 convolution in front of this block read (C, or with res_co Co channels) — its rows 2r, 2r + 1 are still in that tile
-                        const float* rt = st.res_tile >= 0 ? lds + st.res_tile * a.tile_floats : tile;
-                        const int TWr = 2 * Wo + 2, Csr = st.res_co ? Cso : Cs;
+                        // 2x2 convolution / the stride-2 block in front of this block read (res_c channels, zero-padded to Co) — its rows 2r, 2r + 1 are still in that tile
+                        const float* rt = st.res_tile >= 0 ? lds + a.tile_off[st.res_tile] : tile;
+                        const int TWr = 2 * Wo + 2, Csr = st.res_tile >= 0 ? st.res_c + 4 : Cs;
                         const float* t0 = rt + ((1 + 2 * oy) * TWr + 2 * ox + 1) * Csr + c0;
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(t0), s1 = *reinterpret_cast<const f32x4*>(t0 + Csr);
                         const f32x4 s2 = *reinterpret_cast<const f32x4*>(t0 + TWr * Csr), s3 = *reinterpret_cast<const f32x4*>(t0 + TWr * Csr + Csr);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 int bandnet_tile_floats(int R, int W, int C, int halo) { return (R + halo) * (W + 2) * (C + 4); }
 int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
 int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
-int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages) { return (ntiles * tile_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked) + 16; }
+int bandnet_lds_bytes(int tiles_floats, int dw_floats, int nstages) { return (tiles_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked) + 16; }
 
 bool bandnet_pack(const BandStage& st, BandPacked* out) {
     auto fits = [](long v, int bits) { return v >= 0 && v < (1L << bits); };
@@ -458,7 +458,7 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
     for (long v : offs)
         if (v < -1 || v > 0x7fffffffL) return false;
     if (!fits(st.kind, 1) || !fits(st.S, 2) || !fits(st.wshift, 4) || !fits(st.res_mode, 2) || !fits(st.act, 3) || !fits(st.src_tile, 2) || !fits(st.dst_tile + 1, 3) ||
-        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 4) || !fits(st.wpc_shift, 2) || !fits(st.res_tile + 1, 3) || !fits(st.res_co, 1) ||
+        !fits(st.pub_lo, 1) || !fits(st.pub_hi, 1) || !fits(st.src_base, 3) || !fits(st.dst_base + 1, 4) || !fits(st.wpc_shift, 2) || !fits(st.res_tile + 1, 3) || !fits(st.res_c, 16) ||
         st.src_tile >= kBandTiles || st.dst_tile >= kBandTiles || st.res_tile >= kBandTiles || st.dst_base >= kBandBases || !fits(st.R, 8) || !fits(st.Rin, 8) ||
         !fits(st.dep + 1, 8) || !fits(st.nbands, 8) || !fits(st.H, 16) || !fits(st.W, 16) || !fits(st.Ho, 16) || !fits(st.Wo, 16) || !fits(st.C, 16) || !fits(st.Co, 16) ||
         !fits(st.c_floats, 12) || !fits(st.woff, 4) || st.woff >= (1 << st.wshift) || !fits(st.per_ct, 16))
@@ -466,7 +466,7 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
     BandPacked p{};
     p.w[0] = (unsigned)st.kind | (unsigned)st.S << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
              (unsigned)(st.dst_tile + 1) << 14 | (unsigned)st.pub_lo << 17 | (unsigned)st.pub_hi << 18 | (unsigned)st.src_base << 19 | (unsigned)(st.dst_base + 1) << 22 |
-             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28 | (unsigned)st.res_co << 31;
+             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28;
     p.w[1] = (unsigned)st.R | (unsigned)st.Rin << 8 | (unsigned)(st.dep + 1) << 16 | (unsigned)st.nbands << 24;
     p.w[2] = (unsigned)st.H | (unsigned)st.W << 16;
     p.w[3] = (unsigned)st.Ho | (unsigned)st.Wo << 16;
@@ -474,13 +474,16 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
     p.w[5] = (unsigned)st.c_floats | (unsigned)st.woff << 12 | (unsigned)st.per_ct << 16;
     p.w[6] = st.mC4; p.w[7] = st.mWo; p.w[8] = st.mrowq;
     for (int k = 0; k < 8; k++) p.w[9 + k] = (unsigned)(int)offs[k];
+    p.w[17] = (unsigned)st.res_c;
     *out = p;
     return true;
 }
 
 int launch_bandnet(const BandLaunch& a, void* stream) {
     if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles || a.halo < 2 || a.halo > 3) return (int)hipErrorInvalidValue;
-    if (bandnet_lds_bytes(a.ntiles, a.tile_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
+    for (int t = 0; t < a.ntiles; t++)
+        if (a.tile_off[t] < 0 || a.tile_off[t + 1] < a.tile_off[t] || (a.tile_off[t] & 3)) return (int)hipErrorInvalidValue;
+    if (bandnet_lds_bytes(a.tile_off[a.ntiles], a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
     auto kern = a.cv2 ? bandnet_kernel<true, false> : (a.xb ? bandnet_kernel<false, true> : bandnet_kernel<false, false>);
     if (a.cv2 && a.xb) return (int)hipErrorInvalidValue;   // (no such program: the planner does not build one)

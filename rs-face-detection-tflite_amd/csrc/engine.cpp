@@ -733,7 +733,13 @@ void Model::build_bandnet_try(bool conv2_ok) {
         BandStage st;
         st.kind = dw_block ? BAND_BLOCK : BAND_PW;
         st.H = si[1]; st.W = si[2]; st.C = si[3]; st.Ho = so[1]; st.Wo = so[2]; st.Co = so[3];
-        if (st.C % 4 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) BAND_GIVE_UP;
+        if (st.C % 4 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) {
+            // channel counts the kernel does not take (a wave keeps ONE 16-channel output tile and at most eight 16-value chunks of A operands): the
+            // program ends in front of this node when it has stages already (full_range: the trunk down to 12x12x36; round 6), else there is none
+            if (prog.empty()) BAND_GIVE_UP;
+            cut = i;
+            break;
+        }
         st.S = 1;
         if (dw_block) {
             if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) BAND_GIVE_UP;
@@ -756,17 +762,20 @@ void Model::build_bandnet_try(bool conv2_ok) {
                 // owner of output row r needs are in the LDS tile that convolution read them from
                 const auto& sr = g.tensors[n.res].shape;
                 const int d = producer[static_cast<size_t>(n.in[0])];
-                if (st.S != 1 || sr.size() != 4 || sr[1] != 2 * st.Ho || sr[2] != 2 * st.Wo || (sr[3] != st.C && sr[3] != st.Co) || st.Co < st.C || d < 0) BAND_GIVE_UP;
+                // (round 6: ... or the stride-2 BLOCK in front — full_range's down-sampling pairs: DW s2 + PW reduce, then DW + PW expand + 2x2 max of the
+                // pair's input, zero-padded from its res_c channels to Co)
+                if (st.S != 1 || sr.size() != 4 || sr[1] != 2 * st.Ho || sr[2] != 2 * st.Wo || sr[3] > st.Co || (sr[3] & 3) || d < 0) BAND_GIVE_UP;
                 const BandStage& cv = prog[static_cast<size_t>(d)];
-                if (cv.kind != BAND_PW || cv.S != 2 || cv.dep < 0 || cv.dep != producer[static_cast<size_t>(n.res)]) BAND_GIVE_UP;
+                if (cv.S != 2 || cv.dep < 0 || cv.dep != producer[static_cast<size_t>(n.res)]) BAND_GIVE_UP;
                 st.res_dep = cv.dep;
                 st.res_mode = RES_MAXPOOL;
-                st.res_co = sr[3] != st.C ? 1 : 0;
+                st.res_c = sr[3];
             }
             else if (n.res != n.in[0]) {
                 // the skip is another tensor of the program, with the output's shape (its rows then have the output's owners)
                 const auto& sr = g.tensors[n.res].shape;
-                if (n.res_mode != RES_DIRECT || st.S != 1 || sr.size() != 4 || sr[1] != st.Ho || sr[2] != st.Wo || sr[3] != st.Co) BAND_GIVE_UP;
+                if (n.res_mode != RES_DIRECT || st.S != 1 || sr.size() != 4 || sr[1] != st.Ho || sr[2] != st.Wo || sr[3] > st.Co || (sr[3] & 3)) BAND_GIVE_UP;   // (fewer channels than Co: zero-padded)
+                st.res_c = sr[3];
                 if (n.res == band_stem_out_) st.res_dep = -1;
                 else if (producer[static_cast<size_t>(n.res)] >= 0) st.res_dep = producer[static_cast<size_t>(n.res)];
                 else BAND_GIVE_UP;
@@ -1106,7 +1115,8 @@ void Model::build_bandnet_try(bool conv2_ok) {
         if (st.res_dep == -1) input_last_reader = k;
     }
     long ws = 0;
-    int tile_floats = 0, dw_floats = 0, ntiles = 2;
+    int dw_floats = 0, ntiles = 2;
+    int slot_floats[kBandTiles] = {};   // every tile has the size of the largest tensor it ever holds (round 6: full_range's 96x96x32 tensors are 56 KB a band, its 8- to 16-channel ones 19 KB)
     int halo = 2;   // tile rows beside a band's own: one above and one below, two below where a stride-2 block reads the tensor
     for (const BandStage& st : prog)
         if (st.kind == BAND_BLOCK && st.S == 2) halo = 3;
@@ -1125,7 +1135,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
             holder[0] = -1;
             st.src_tile = 0;
             const int rows = st.kind == BAND_BLOCK ? (st.S == 1 ? st.R + 2 : 2 * st.R + 2) : st.R + 1;
-            tile_floats = std::max(tile_floats, rows * (st.W + 2) * (st.C + 4));
+            slot_floats[0] = std::max(slot_floats[0], rows * (st.W + 2) * (st.C + 4));
         } else {
             st.src_tile = tile_of(st.dep);
             if (st.src_tile < 0) BAND_GIVE_UP;   // its input is no longer in LDS
@@ -1144,29 +1154,35 @@ void Model::build_bandnet_try(bool conv2_ok) {
                 if (st.dep < 0 || st.res_dep < 0) BAND_GIVE_UP;
                 const BandStage& cv = prog[static_cast<size_t>(st.dep)];
                 const BandStage& rd = prog[static_cast<size_t>(st.res_dep)];
-                if (cv.kind != BAND_PW || cv.S != 2 || cv.dep != st.res_dep || cv.src_tile != st.res_tile || cv.R != st.R || cv.wshift != st.wshift || cv.nbands != st.nbands)
+                if (cv.S != 2 || cv.dep != st.res_dep || cv.src_tile != st.res_tile || cv.R != st.R || cv.wshift != st.wshift || cv.nbands != st.nbands)
                     BAND_GIVE_UP;
-                if (rd.Ho != 2 * st.Ho || rd.Wo != 2 * st.Wo || rd.Co != (st.res_co ? st.Co : st.C)) BAND_GIVE_UP;
+                if (rd.Ho != 2 * st.Ho || rd.Wo != 2 * st.Wo || rd.Co != st.res_c) BAND_GIVE_UP;
             } else if (st.res_dep >= 0) {
                 const BandStage& rd = prog[static_cast<size_t>(st.res_dep)];
-                if (rd.Ho != st.Ho || rd.Wo != st.Wo || rd.Co != st.Co || rd.R != st.R || rd.wshift != st.wshift) BAND_GIVE_UP;
+                if (rd.Ho != st.Ho || rd.Wo != st.Wo || rd.Co != st.res_c || rd.R != st.R || rd.wshift != st.wshift) BAND_GIVE_UP;
             } else {
                 const BandStage& first = prog[0];   // (the stage that loaded the program's input: own rows at tile rows 1 ..)
-                if (first.dep >= 0 || first.H != st.Ho || first.W != st.Wo || first.C != st.Co || first.R != st.R || first.wshift != st.wshift || first.S != 1) BAND_GIVE_UP;
+                if (first.dep >= 0 || first.H != st.Ho || first.W != st.Wo || first.C != st.res_c || first.R != st.R || first.wshift != st.wshift || first.S != 1) BAND_GIVE_UP;
             }
         }
         if (last_reader[static_cast<size_t>(k)] >= 0) {
+            // a free tile, best fit: the smallest one that holds this tensor as it is, else the one that has to grow least (a narrow middle tensor must
+            // not take the place of a wide one: full_range's 96x96x8 between two 96x96x32)
+            const int need = bandnet_tile_floats(st.R, st.Wo, st.Co, halo);
             int pick = -1;
-            for (int t = 0; t < kBandTiles && pick < 0; t++) {
+            for (int t = 0; t < kBandTiles; t++) {
                 if (t == st.src_tile || t == st.res_tile) continue;
                 const int h = holder[t];
-                if (h == -2 || (h >= 0 && last_reader[static_cast<size_t>(h)] <= k) || (h == -1 && input_last_reader <= k)) pick = t;
+                if (!(h == -2 || (h >= 0 && last_reader[static_cast<size_t>(h)] <= k) || (h == -1 && input_last_reader <= k))) continue;
+                if (pick < 0) { pick = t; continue; }
+                const bool fits_t = slot_floats[t] >= need, fits_p = slot_floats[pick] >= need;
+                if (fits_t && fits_p ? slot_floats[t] < slot_floats[pick] : (fits_t != fits_p ? fits_t : slot_floats[t] > slot_floats[pick])) pick = t;
             }
             if (pick < 0) BAND_GIVE_UP;   // more tensors alive than tiles
             st.dst_tile = pick;
             holder[pick] = k;
             ntiles = std::max(ntiles, pick + 1);
-            tile_floats = std::max(tile_floats, bandnet_tile_floats(st.R, st.Wo, st.Co, halo));
+            slot_floats[pick] = std::max(slot_floats[pick], need);
             if (st.pub_lo || st.pub_hi) {
                 st.dst_ll = ws;
                 ws += align_up(2 * static_cast<long>(st.Ho) * st.Wo * st.Co, 64);
@@ -1174,9 +1190,10 @@ void Model::build_bandnet_try(bool conv2_ok) {
         }
         dw_floats = std::max(dw_floats, bandnet_dw_floats(st));
     }
-    tile_floats = static_cast<int>(align_up(tile_floats, 4));
     dw_floats = static_cast<int>(align_up(dw_floats, 4));
-    band_tile_floats_ = tile_floats;
+    band_tile_off_[0] = 0;
+    for (int t = 0; t < kBandTiles; t++) band_tile_off_[t + 1] = band_tile_off_[t] + (t < ntiles ? static_cast<int>(align_up(std::max(slot_floats[t], 4), 4)) : 0);
+    const int tiles_floats = band_tile_off_[ntiles];
     band_dw_floats_ = dw_floats;
     band_ntiles_ = ntiles;
     band_halo_ = halo;
@@ -1185,7 +1202,17 @@ void Model::build_bandnet_try(bool conv2_ok) {
     band_xb_ = false;
     for (const BandStage& st : prog) band_xb_ = band_xb_ || (st.kind == BAND_BLOCK && st.cross);
     if (band_cv2_ && band_xb_) BAND_GIVE_UP;   // (no kernel instantiation for both: the iris network's second branch starts with a 1x1 stage)
-    band_lds_bytes_ = bandnet_lds_bytes(ntiles, tile_floats, dw_floats, NS);
+    band_lds_bytes_ = bandnet_lds_bytes(tiles_floats, dw_floats, NS);
+    if (std::getenv("MI_BAND_DEBUG")) {
+        std::fprintf(stderr, "bandnet: %d stages, NW %d, halo %d, LDS %d B = tiles", NS, NW, halo, band_lds_bytes_);
+        for (int t = 0; t < ntiles; t++) std::fprintf(stderr, " %d", slot_floats[t] * 4);
+        std::fprintf(stderr, " + depthwise %d + constants\n", dw_floats * 4);
+        for (int k = 0; k < NS; k++) {
+            const BandStage& st = prog[static_cast<size_t>(k)];
+            std::fprintf(stderr, "  stage %2d %s S%d %dx%dx%d -> %dx%dx%d R %d wshift %d src %d dst %d res %d (dep %d, mode %d, c %d) last reader %d\n", k, st.kind == BAND_BLOCK ? "block" : "pw   ", st.S, st.H, st.W, st.C,
+                         st.Ho, st.Wo, st.Co, st.R, st.wshift, st.src_tile, st.dst_tile, st.res_tile, st.res_dep, st.res_mode, st.res_c, last_reader[static_cast<size_t>(k)]);
+        }
+    }
     if (band_lds_bytes_ > 160 * 1024) BAND_GIVE_UP;
     band_ws_frame_floats_ = std::max<long>(ws, 64);
     band_nstages_ = NS;
@@ -1441,7 +1468,8 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             if (labels) labels->push_back("bandnet_kernel");
             BandLaunch a;
             a.prog = d_band_prog_; a.nstages = band_nstages_; a.NW = band_nw_used_; a.F = F; a.lds_bytes = band_lds_bytes_;
-            a.tile_floats = band_tile_floats_; a.dw_floats = band_dw_floats_; a.ws_frame_floats = band_ws_frame_floats_;
+            for (int t = 0; t <= kBandTiles; t++) a.tile_off[t] = band_tile_off_[t];
+            a.dw_floats = band_dw_floats_; a.ws_frame_floats = band_ws_frame_floats_;
             long fs = 0;
             a.base[0] = d_band_ws_;
             a.base[1] = const_cast<float*>(tensor_ptr(band_stem_out_, in, chunk_start, &fs));

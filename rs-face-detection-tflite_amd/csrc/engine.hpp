@@ -142,7 +142,8 @@ class Model {
     size_t band_ws_bytes_ = 0;
     int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it that band_node_runs_ does not name)
     int band_stem_out_ = -1;        // tensor the first convolution writes = the band program's input
-    int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_tile_floats_ = 0, band_dw_floats_ = 0;
+    int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_dw_floats_ = 0;
+    int band_tile_off_[kBandTiles + 1] = {};   // LDS floats in front of each tile of the program (the tiles end at [ntiles])
     long band_ws_frame_floats_ = 0;
     struct BandExt { int out_k = -1, tensor = -1; };   // BandLaunch::base[2 + j]: graph output out_k, or the arena storage of `tensor` (read by a launch behind the band program)
     std::vector<BandExt> band_ext_;

@@ -478,7 +478,7 @@ struct alignas(16) BandStage {
                                  // the iris network's bottlenecks add the tensor in front of their 1x1 reduction), or RES_MAXPOOL of the C-channel
                                  // tensor of twice the size in this tile (the input of the 2x2 convolution in front of this block)
     int cross = 0;               // (host only) the stage reads a tensor of the other branch's workgroups: Rin = 0, every row from the packets
-    int res_co = 0;              // RES_MAXPOOL from res_tile: that tensor has Co channels (no zero pad), not C
+    int res_c = 0;               // channels of the skip tensor in res_tile (<= Co: the rest of the skip is the zero pad of a widening block)
     int act = ACT_NONE;
     long src_off = 0, dst_off = 0;   // floats from the base to frame 0 of the tensor
     long src_fs = 0, dst_fs = 0;     // floats between frames
@@ -506,7 +506,7 @@ struct BandLaunch {
     int cv2 = 0;                    // the program has 2x2 stride-2 convolution stages (the kernel instantiation with their code)
     int xb = 0;                     // ... a BLOCK stage that takes all of its input rows from the packets (Rin = 0: zeroes its tile's border pixels)
     int halo = 3;                   // tile rows beside the band's own: 3 when a stride-2 block reads two rows below its band, else 2
-    int tile_floats = 0;            // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]
+    int tile_off[kBandTiles + 1] = {};   // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]; tile t starts tile_off[t] floats in, the tiles end at tile_off[ntiles]
     int dw_floats = 0;
     long ws_frame_floats = 0;       // base[0]: floats between the frames' workspaces
     float* base[kBandBases] = {};   // 0: the launch's own workspace (packet buffers), 1: the first stage's input, 2..: graph outputs / tensors later launches read
@@ -521,7 +521,7 @@ int launch_bandnet(const BandLaunch& a, void* stream);
 int bandnet_tile_floats(int R, int W, int C, int halo);
 int bandnet_dw_floats(const BandStage& st);
 int bandnet_const_floats(const BandStage& st);
-int bandnet_lds_bytes(int ntiles, int tile_floats, int dw_floats, int nstages);
+int bandnet_lds_bytes(int tiles_floats, int dw_floats, int nstages);
 
 // Pointwise weight packing for the fused block kernel: [Co][C] (TFLite [O,1,1,I]) -> [Cop][Cp] zero padded.
 void block_weight_dims(int C, int Co, int* Cp, int* Cop);
