@@ -122,7 +122,8 @@ __device__ __forceinline__ StageRegs stage_regs(int word) {
 // XB: a BLOCK stage of the program takes ALL of its input rows from the packets (the first block of a branch that runs on the workgroups its
 // sibling leaves idle: the face mesh) and has to zero its tile's border pixels itself — an instantiation of its own for the same reason (the
 // three lines cost every stage of BackCamera 0.04 us).
-template <bool CV2, bool XB>
+// WIDE: the program has stages of more than 128 input or output channels (full_range's 12x12 and 6x6 layers) — again an instantiation of its own.
+template <bool CV2, bool XB, bool WIDE>
 __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     // a stage's A operands for this wave (it keeps one 16-channel output tile for the whole stage) and its small constants
     auto fetch = [&](const StageRegs& st, f32x4 (&A)[kMaxN16], f32x2& A8, float& A4, f32x4& creg) {
         const bool cv2 = CV2 && st.kind != BAND_BLOCK && st.S == 2;   // (its first round of eight 16-value chunks; C % 32 == 0)
-        const int nct = (st.Co + 15) >> 4, n16 = cv2 ? kMaxN16 : st.C >> 4, has8 = cv2 ? 0 : (st.C >> 3) & 1, has4 = cv2 ? 0 : (st.C >> 2) & 1;
+        // (wide stages — more than 128 input channels, C % 16 == 0: the first eight chunks here, the others in rounds like a 2x2 convolution's)
+        const int nct = (st.Co + 15) >> 4, n16 = cv2 ? kMaxN16 : min(st.C >> 4, kMaxN16), has8 = cv2 ? 0 : (st.C >> 3) & 1, has4 = cv2 ? 0 : (st.C >> 2) & 1;
         const int myct = MI_BAND_MYCT(wave, st.wpc_shift);
         const float* ga = a.consts + st.w_a + (myct < nct ? myct : 0) * st.per_ct;
 #pragma unroll
@@ -197,6 +199,11 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         // tile is the wave's LOW bits — waves w and w + 4 sit on one SIMD, and of a tile's waves only the first has work where a band is one pixel tile
         const int wpc = 1 << st.wpc_shift, myct = MI_BAND_MYCT(wave, st.wpc_shift), mypt = MI_BAND_MYPT(wave, st.wpc_shift);
         const bool wave_on = myct < nct;
+        // Wide stages (the WIDE instantiation only; round 6: full_range's 12x12 and 6x6 layers, 144 .. 384 channels): more than eight chunks of input
+        // channels are contracted in rounds of eight (A operands of the later rounds read from L2 like a 2x2 convolution's), more than eight output
+        // tiles are taken by the waves in turn (tile ct, ct + 8, ct + 16: their A operands read when their turn comes), and the depthwise taps
+        // (9 C + C floats: more than the constants' LDS area) are read from L2 by the depthwise phase
+        const bool wide = WIDE && !cv2 && (C > 128 || Co > 128);
 
         // ---- the rows of the input that this workgroup does not own: above [ya, p0) and below [p0 + Rin, yb)
         const int nA = p0 - ya, nH = nA + (yb - (p0 + Rin));
@@ -277,6 +284,31 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         // ---- depthwise 3x3: one thread per (output pixel, channel quad); taps at tile rows trow + S oy + ky
         const int trow = blk && S == 1 ? 0 : 1;
         if (blk) {
+            if (WIDE && st.c_floats < 32 * nct + 10 * C) {
+                // (wide: the taps did not fit the constants' LDS area — c_floats holds bias and slopes only — and come from L2; a code path of its own:
+                // a run-time choice between an LDS and a global pointer would make every tap read a FLAT load)
+                const float* wdw = a.consts + st.w_c + 32 * nct;
+                const float* bdw = wdw + 9 * C;
+                for (int i = tid; i < npx * C4; i += kThreads) {
+                    const int px = mdiv(i, st.mC4), q = i - px * C4, oy = mdiv(px, st.mWo), ox = px - oy * Wo;
+                    const float* t = tile + ((trow + S * oy) * TW + S * ox + (S - 1)) * Cs + 4 * q;
+                    f32x4 k[9];
+#pragma unroll
+                    for (int j = 0; j < 9; j++) k[j] = *reinterpret_cast<const f32x4*>(wdw + j * C + 4 * q);
+                    f32x4 acc = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++) {
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(t + (ky * TW + kx) * Cs);
+                            acc.x = fmaf(d.x, k[ky * 3 + kx].x, acc.x);
+                            acc.y = fmaf(d.y, k[ky * 3 + kx].y, acc.y);
+                            acc.z = fmaf(d.z, k[ky * 3 + kx].z, acc.z);
+                            acc.w = fmaf(d.w, k[ky * 3 + kx].w, acc.w);
+                        }
+                    *reinterpret_cast<f32x4*>(dwb + px * Cs + 4 * q) = acc;
+                }
+            } else {
             const float* wdw = lC + 32 * nct;
             const float* bdw = wdw + 9 * C;
             for (int i = tid; i < npx * C4; i += kThreads) {
@@ -295,6 +327,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                         acc.w = fmaf(d.w, k.w, acc.w);
                     }
                 *reinterpret_cast<f32x4*>(dwb + px * Cs + 4 * q) = acc;
+            }
             }
             __syncthreads();
         }
@@ -315,6 +348,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     *reinterpret_cast<f32x4*>(dtile + (rr * TWo + (side ? Wo + 1 : 0)) * Cso + 4 * q) = zero4;
                 }
             if (wave_on)
+              for (int ct = myct; ct < (WIDE ? nct : myct + 1); ct += kThreads / 64) {   // (one turn unless the stage has more than eight output tiles — wpc == 1 then —: no loop at all outside the WIDE instantiation)
                 for (int pt = mypt; pt < npt; pt += wpc) {
                     const int px = 16 * pt + n, pxc = min(px, npx - 1);
                     const int oy = mdiv(pxc, st.mWo), ox = pxc - oy * Wo;
@@ -349,6 +383,38 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                                 D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].w, bv.w, D3, 0, 0, 0);
                             }
                         }
+                    } else if (wide) {
+                        // rounds of eight 16-channel chunks; the first round of the wave's first tile is in A (it came with the stage's descriptor)
+                        const float* ga = a.consts + st.w_a + ct * st.per_ct;
+                        const int nr = (n16 + kMaxN16 - 1) >> 3;
+                        f32x4 Ar[kMaxN16];
+#pragma unroll
+                        for (int j = 0; j < kMaxN16; j++) Ar[j] = A[j];
+                        for (int r = 0; r < nr; r++) {
+                            if (r > 0 || ct != myct) {
+#pragma unroll
+                                for (int j = 0; j < kMaxN16; j++) Ar[j] = r * kMaxN16 + j < n16 ? *reinterpret_cast<const f32x4*>(ga + ((r * kMaxN16 + j) * 64 + lane) * 4) : zero4;
+                            }
+#pragma unroll
+                            for (int j = 0; j < kMaxN16; j++)
+                                if (r * kMaxN16 + j < n16) {
+                                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 16 * (r * kMaxN16 + j) + 4 * kq);
+                                    D = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].x, bv.x, D, 0, 0, 0);
+                                    D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].y, bv.y, D1, 0, 0, 0);
+                                    D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].z, bv.z, D2, 0, 0, 0);
+                                    D3 = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[j].w, bv.w, D3, 0, 0, 0);
+                                }
+                        }
+                        if (has8) {   // (a stage that is wide by its OUTPUT may have any input width: 12x12x36 -> 144)
+                            const f32x2 a8 = ct == myct ? A8 : *reinterpret_cast<const f32x2*>(ga + n16 * 256 + lane * 2);
+                            const f32x2 bv = *reinterpret_cast<const f32x2*>(bp + 16 * n16 + 2 * kq);
+                            D = __builtin_amdgcn_mfma_f32_16x16x4f32(a8.x, bv.x, D, 0, 0, 0);
+                            D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a8.y, bv.y, D1, 0, 0, 0);
+                        }
+                        if (has4) {
+                            const float a4 = ct == myct ? A4 : ga[n16 * 256 + has8 * 128 + lane];
+                            D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4, bp[16 * n16 + 8 * has8 + kq], D2, 0, 0, 0);
+                        }
                     } else {
 #pragma unroll
                     for (int j = 0; j < kMaxN16; j++)
@@ -368,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     }
                     D = (D + D1) + (D2 + D3);
                     // D[i] = output channel 16 ct + 4 kq + i of pixel px
-                    const int c0 = 16 * myct + 4 * kq;
+                    const int c0 = 16 * ct + 4 * kq;
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);
                     f32x4 sk = zero4;
                     if (st.res_mode == RES_DIRECT && st.res_tile >= 0) {   // a tensor of res_c <= Co channels (zero-padded to Co) on the same rows, in another tile
@@ -415,6 +481,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                         }
                     }
                 }
+              }
         }
         MI_BAND_STAMP(4)
         // ---- the next stage's A operands and constants: requested here, needed behind its halo rows.  (Requested in front of the depthwise phase
@@ -449,7 +516,10 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
 
 int bandnet_tile_floats(int R, int W, int C, int halo) { return (R + halo) * (W + 2) * (C + 4); }
 int bandnet_dw_floats(const BandStage& st) { return st.kind == BAND_BLOCK ? st.R * st.Wo * (st.C + 4) : 0; }
-int bandnet_const_floats(const BandStage& st) { return 32 * ((st.Co + 15) / 16) + (st.kind == BAND_BLOCK ? 10 * st.C : 0); }
+int bandnet_const_floats(const BandStage& st) {   // what a stage stages in the constants' LDS area: bias and slopes, and the depthwise taps + biases where they fit beside them
+    const int head = 32 * ((st.Co + 15) / 16), all = head + (st.kind == BAND_BLOCK ? 10 * st.C : 0);
+    return all <= kConstFloats ? all : head;
+}
 int bandnet_lds_bytes(int tiles_floats, int dw_floats, int nstages) { return (tiles_floats + dw_floats + kConstFloats) * 4 + nstages * (int)sizeof(BandPacked) + 16; }
 
 bool bandnet_pack(const BandStage& st, BandPacked* out) {
@@ -485,8 +555,8 @@ int launch_bandnet(const BandLaunch& a, void* stream) {
         if (a.tile_off[t] < 0 || a.tile_off[t + 1] < a.tile_off[t] || (a.tile_off[t] & 3)) return (int)hipErrorInvalidValue;
     if (bandnet_lds_bytes(a.tile_off[a.ntiles], a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
-    auto kern = a.cv2 ? bandnet_kernel<true, false> : (a.xb ? bandnet_kernel<false, true> : bandnet_kernel<false, false>);
-    if (a.cv2 && a.xb) return (int)hipErrorInvalidValue;   // (no such program: the planner does not build one)
+    auto kern = a.wide ? bandnet_kernel<false, false, true> : (a.cv2 ? bandnet_kernel<true, false, false> : (a.xb ? bandnet_kernel<false, true, false> : bandnet_kernel<false, false, false>));
+    if ((a.cv2 && a.xb) || (a.wide && (a.cv2 || a.xb))) return (int)hipErrorInvalidValue;   // (no such program: the planner does not build one)
     if (hipError_t e = allow_full_lds(reinterpret_cast<const void*>(kern)); e != hipSuccess) return (int)e;
 #ifdef MI_BAND_STAMPS
     BandLaunch b = a;

@@ -85,6 +85,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "band_test_fail") { band_test_fail_ = value != 0; }   // test hook: the next single-launch run reports that it gave up
     else if (key == "band_test_absent") { band_test_absent_ = std::max(0, std::min(value, 256)); }   // test hook: every k-th workgroup of a single-launch run leaves at once without publishing (a workgroup that is not resident; 0: off)
     else if (key == "band_test_gen") { band_gen_ = static_cast<unsigned>(std::max(0, value)); band_gen_force_ = true; }   // test hook: the host's count of band launches (the packet tags wrap at 2^26: see run_device)
+    else if (key == "band_wide") { band_wide_ok_ = value != 0; dirty_ = true; }   // single-launch plan: stages of more than 128 channels (0: the program ends in front of the first one)
     else if (key == "band_fork") { band_fork_ = value != 0; dirty_ = true; }   // single-launch plan: the second branch behind a fork on the idle workgroups
     else if (key == "band_nw") { band_nw_ = std::max(8, std::min(value, 256)); dirty_ = true; }   // its workgroups per frame
     else if (key == "fork") { fork_ = value != 0; }
@@ -112,6 +113,7 @@ int Model::get_option(const std::string& key) const {
     if (key == "tail_g") return tail_g_;
     if (key == "band") return band_;
     if (key == "band_fork") return band_fork_;
+    if (key == "band_wide") return band_wide_ok_;
     if (key == "band_nw") return band_nw_;
     if (key == "band_fail_streak") return band_fail_streak_;
     if (key == "band_wraps") return band_wraps_;
@@ -726,14 +728,19 @@ void Model::build_bandnet_try(bool conv2_ok) {
                            g.tensors[n.in[0]].shape[3] % 32 == 0 && n.in[0] != band_stem_out_;
         if (!pw_block && !dw_block && !conv1 && !conv2) { cut = i; break; }
         if (conv2) band_saw_conv2_ = true;
-        if (n.in.size() != 1 || n.ept >= 0 || n.res_after) BAND_GIVE_UP;
+        if (n.in.size() != 1 || n.ept >= 0 || n.res_after) {   // (full_range's lateral convolutions, whose skip joins behind the activation: the program ends in front of them)
+            if (prog.empty()) BAND_GIVE_UP;
+            cut = i;
+            break;
+        }
         const auto& si = g.tensors[n.in[0]].shape;
         const auto& so = g.tensors[n.out].shape;
         if (si.size() != 4 || so.size() != 4) BAND_GIVE_UP;
         BandStage st;
         st.kind = dw_block ? BAND_BLOCK : BAND_PW;
         st.H = si[1]; st.W = si[2]; st.C = si[3]; st.Ho = so[1]; st.Wo = so[2]; st.Co = so[3];
-        if (st.C % 4 || st.C < 8 || st.C > 128 || st.Co < 1 || st.Co > 128) {
+        const bool wide_ok = band_wide_ok_ && !conv2 && st.C <= 384 && st.Co <= 384 && (st.C <= 128 || st.C % 16 == 0) && (st.Co <= 128 || st.Co % 16 == 0);   // (the WIDE instantiation: round 6)
+        if (st.C % 4 || st.C < 8 || st.Co < 1 || ((st.C > 128 || st.Co > 128) && !wide_ok)) {
             // channel counts the kernel does not take (a wave keeps ONE 16-channel output tile and at most eight 16-value chunks of A operands): the
             // program ends in front of this node when it has stages already (full_range: the trunk down to 12x12x36; round 6), else there is none
             if (prog.empty()) BAND_GIVE_UP;
@@ -844,11 +851,11 @@ void Model::build_bandnet_try(bool conv2_ok) {
                     for (int e = 0; e < 2; e++) A[static_cast<size_t>(ct) * per_ct + n16 * 256 + l * 2 + e] = wsrc[static_cast<size_t>(o) * C + 16 * n16 + 2 * kq + e];
                 if (has4) A[static_cast<size_t>(ct) * per_ct + n16 * 256 + has8 * 128 + l] = wsrc[static_cast<size_t>(o) * C + 16 * n16 + 8 * has8 + kq];
             }
-        st.c_floats = bandnet_const_floats(st);
+        st.c_floats = bandnet_const_floats(st);   // (what the kernel stages in LDS: without the depthwise taps where they do not fit — a wide stage reads them from L2)
         st.per_ct = per_ct;
-        if (nct > 8) BAND_GIVE_UP;
+        if (nct > 24 || (nct > 8 && !wide_ok)) BAND_GIVE_UP;
         st.wpc_shift = nct == 1 ? 3 : (nct == 2 ? 2 : (nct <= 4 ? 1 : 0));
-        std::vector<float> cb(static_cast<size_t>(st.c_floats), 0.f);
+        std::vector<float> cb(static_cast<size_t>(32 * nct + (dw_block ? 10 * C : 0)), 0.f);
         for (int c = 0; c < Co; c++) {
             cb[static_cast<size_t>(c)] = bt >= 0 ? g.tensors[bt].f32[static_cast<size_t>(c)] : 0.f;
             cb[static_cast<size_t>(16 * nct + c)] = n.act == ACT_PRELU ? g.tensors[n.alpha].f32[static_cast<size_t>(c)] : (n.act == ACT_NONE ? 1.f : 0.f);
@@ -1202,6 +1209,9 @@ void Model::build_bandnet_try(bool conv2_ok) {
     band_xb_ = false;
     for (const BandStage& st : prog) band_xb_ = band_xb_ || (st.kind == BAND_BLOCK && st.cross);
     if (band_cv2_ && band_xb_) BAND_GIVE_UP;   // (no kernel instantiation for both: the iris network's second branch starts with a 1x1 stage)
+    band_wide_ = false;
+    for (const BandStage& st : prog) band_wide_ = band_wide_ || st.C > 128 || st.Co > 128;
+    if (band_wide_ && (band_cv2_ || band_xb_)) BAND_GIVE_UP;   // (likewise)
     band_lds_bytes_ = bandnet_lds_bytes(tiles_floats, dw_floats, NS);
     if (std::getenv("MI_BAND_DEBUG")) {
         std::fprintf(stderr, "bandnet: %d stages, NW %d, halo %d, LDS %d B = tiles", NS, NW, halo, band_lds_bytes_);
@@ -1477,6 +1487,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             a.halo = band_halo_;
             a.cv2 = band_cv2_ ? 1 : 0;
             a.xb = band_xb_ ? 1 : 0;
+            a.wide = band_wide_ ? 1 : 0;
             for (size_t k = 0; k < band_ext_.size(); k++) {
                 long efs = 0;
                 a.base[2 + k] = band_ext_[k].out_k >= 0 ? d_out_[static_cast<size_t>(band_ext_[k].out_k)] : tensor_ptr_mut(band_ext_[k].tensor, chunk_start, &efs);

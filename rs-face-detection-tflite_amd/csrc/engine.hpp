@@ -149,7 +149,7 @@ class Model {
     std::vector<BandExt> band_ext_;
     std::vector<char> band_node_runs_;   // per plan_ node from band_first_ on: 1 = it runs as its own launch behind the band launch (the program stops in front of it)
     int band_ntiles_ = 2, band_halo_ = 3;
-    bool band_fork_ = true, band_cv2_ = false, band_xb_ = false, band_saw_conv2_ = false;
+    bool band_fork_ = true, band_cv2_ = false, band_xb_ = false, band_saw_conv2_ = false, band_wide_ = false, band_wide_ok_ = true;
     BandPacked* d_band_prog_ = nullptr;
     float* d_band_consts_ = nullptr;
     float* d_band_ws_ = nullptr;

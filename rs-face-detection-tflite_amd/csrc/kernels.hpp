@@ -504,6 +504,7 @@ struct BandLaunch {
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
     int ntiles = 2;                 // LDS tiles (2 .. kBandTiles)
     int cv2 = 0;                    // the program has 2x2 stride-2 convolution stages (the kernel instantiation with their code)
+    int wide = 0;                   // ... stages of more than 128 input or output channels (the WIDE instantiation)
     int xb = 0;                     // ... a BLOCK stage that takes all of its input rows from the packets (Rin = 0: zeroes its tile's border pixels)
     int halo = 3;                   // tile rows beside the band's own: 3 when a stride-2 block reads two rows below its band, else 2
     int tile_off[kBandTiles + 1] = {};   // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]; tile t starts tile_off[t] floats in, the tiles end at tile_off[ntiles]

@@ -371,7 +371,7 @@ def test_tail_programs_on_other_shapes(gpu, oracle, synth_models, case):
     m.close()
 
 
-@pytest.mark.parametrize("name,frames", [("back", 2), ("front", 4), ("short", 4), ("landmark", 2), ("iris", 8), ("full", 2)])
+@pytest.mark.parametrize("name,frames", [("back", 2), ("front", 4), ("short", 4), ("landmark", 2), ("iris", 8), ("full", 2), ("sparse", 2)])
 def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames):
     """Round 5: the single-image plan (bandnet_kernels.hip) — everything behind the first convolution ONE launch, a row band per workgroup
     kept in LDS, halo rows handed over as tagged packets.  Option "band" = 2 runs it for every call of few enough frames: against the
@@ -411,15 +411,22 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)]
     behind = {"landmark": ["head_dot_kernel"] * 2,     # (the whole-frame convolutions of one to four frames: a wave per output, kernels.hip)
               "iris": ["head_dot_kernel"] * 2}.get(name, [])
-    if name == "full":
-        assert labels[1] == "bandnet_kernel" and "bandnet_kernel" not in labels[2:] and len(labels) == 22, labels
+    if name in ("full", "sparse"):
+        assert "bandnet_kernel" in labels[:4] and labels.count("bandnet_kernel") == 1, labels   # (sparse: its program ends in front of the first explicitly padded stride-2 block)
+        if name == "full":
+            assert labels[1] == "bandnet_kernel" and len(labels) == 15 and "xc_kernel" not in labels, labels
+            m.set_option("band_wide", 0)      # the program ends in front of 12x12x36 -> 144: 17 stages, 20 launches behind it
+            for o, r in zip(m.run(x[:2]), refs):
+                _raw_close(o, r[:2])
+            assert len(m.profile(torch.from_numpy(x[:1]).cuda(), reps=1)) == 22
+            m.set_option("band_wide", 1)
     else:
         assert labels[1:] == ["bandnet_kernel"] + behind, labels
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
     assert "bandnet_kernel" not in labels, labels
     # fewer workgroups per frame: several rows per band (both edge rows of a band travel), more frames per launch
     one = [o.copy() for o in m.run(x[:1])]
-    for nw in {"back": (128,), "landmark": (48,), "iris": (16,), "full": ()}.get(name, (32,)):   # (full: two-row bands of 96x96x32 do not fit the LDS)
+    for nw in {"back": (128,), "landmark": (48,), "iris": (16,), "full": (), "sparse": ()}.get(name, (32,)):   # (full: two-row bands of 96x96x32 do not fit the LDS)
         m.set_option("band_nw", nw)
         assert m.single_launch_workgroups(1) == nw
         for nb in (1, 3):
@@ -444,10 +451,12 @@ def test_single_launch_plan_vs_oracle_and_batched_plan(gpu, oracle, name, frames
     m.close()
 
 
-def test_single_launch_plan_only_where_the_graph_has_one(gpu):
-    for name in ("sparse",):
+def test_every_shipped_graph_has_a_single_launch_program(gpu):
+    """Round 6: full_range and full_range_sparse have one too (the trunk, through the 6x6 run, to the first lateral convolution of the decoder); with
+    option band_wide = 0 their programs end in front of the first tensor of more than 128 channels."""
+    for name in MODEL_FILES:
         m = gpu.Model(model_path(name))
-        assert m.single_launch_workgroups(1) == 0, name
+        assert m.single_launch_workgroups(1) > 0, name
         m.close()
 
 

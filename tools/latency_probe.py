@@ -61,6 +61,9 @@ def measure(n=300):
     pipe = mi.Pipeline(mi.FaceDetectionModel.BackCamera)
     one = np.ascontiguousarray(img[None])
     out["lib.rs flow on one picture: mi_pipeline_run, batch 1 (detector -> mesh -> 2 x iris)"] = timed(lambda: pipe.run(one), n)
+    pipe_full = mi.Pipeline(mi.FaceDetectionModel.Full)   # (the same flow with the full-range detector: its trunk is one launch since round 6)
+    out["lib.rs flow on one picture with FaceDetectionModel::Full (mi_pipeline_run, batch 1)"] = timed(lambda: pipe_full.run(one), n)
+    pipe_full.close()
     # ... and for a stream of ENCODED pictures (lib.rs:18-40 from the bytes; mi_pipeline_submit_jpeg / collect_jpeg, two slots): sustained per picture
     pipe.submit_jpeg(0, jpg)
     state = {"k": 0}
