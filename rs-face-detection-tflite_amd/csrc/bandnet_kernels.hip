@@ -92,26 +92,30 @@ struct StageRegs {
     int wpc_shift, per_ct;
     unsigned mC4, mWo, mrowq;
     int src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
+    int res_ll, res_stage;   // RES_UP2X: the packet buffer and the stage of the coarse tensor
+    int src_lds, dst_lds, res_lds, dst_h3;   // LDS floats in front of the stage's tiles (placed by liveness, sizes of their own); dst_h3: the output tile has R + 3 rows (a stride-2 block reads it), else R + 2
 };
-// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3
+// word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3 dst_h3:1
 // word 1: R:8 Rin:8 dep+1:8 nbands:8    word 2: H:16 W:16    word 3: Ho:16 Wo:16    word 4: C:16 Co:16    word 5: c_floats:12 woff:4 per_ct:16
-// words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)    word 17: res_c:16 (channels of the skip tensor in res_tile)
+// words 6-8: mC4 mWo mrowq    words 9-16: src_off dst_off src_fs dst_fs src_ll dst_ll w_a w_c (floats; -1: none)    word 17: res_c:16 (channels of the skip tensor in res_tile) src_lds:12
+// word 18: res_ll (RES_UP2X: packet buffer of the coarse tensor, floats)    word 19: res_stage:6 (its producer) dst_lds:12 res_lds:12    (the *_lds: units of 16 floats)
 __host__ __device__ inline unsigned bf(unsigned v, int lo, int n) { return (v >> lo) & ((1u << n) - 1u); }
 __device__ __forceinline__ int stage_word(const BandPacked* p, int lane) { return reinterpret_cast<const int*>(p)[lane < kBandPackedWords ? lane : 0]; }
 __device__ __forceinline__ StageRegs stage_regs(int word) {
-    unsigned w[18];
+    unsigned w[20];
 #pragma unroll
-    for (int k = 0; k < 18; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
+    for (int k = 0; k < 20; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
     StageRegs r;
     r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
     r.src_tile = bf(w[0], 12, 2); r.dst_tile = (int)bf(w[0], 14, 3) - 1; r.pub_lo = bf(w[0], 17, 1); r.pub_hi = bf(w[0], 18, 1);
-    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1; r.res_c = bf(w[17], 0, 16);
+    r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1; r.dst_h3 = bf(w[0], 31, 1); r.res_c = bf(w[17], 0, 16); r.src_lds = (int)bf(w[17], 16, 12) << 4;
     r.R = bf(w[1], 0, 8); r.Rin = bf(w[1], 8, 8); r.dep = (int)bf(w[1], 16, 8) - 1; r.nbands = bf(w[1], 24, 8);
     r.H = bf(w[2], 0, 16); r.W = bf(w[2], 16, 16); r.Ho = bf(w[3], 0, 16); r.Wo = bf(w[3], 16, 16); r.C = bf(w[4], 0, 16); r.Co = bf(w[4], 16, 16);
     r.c_floats = bf(w[5], 0, 12); r.per_ct = bf(w[5], 16, 16);
     r.mC4 = w[6]; r.mWo = w[7]; r.mrowq = w[8];
     r.src_off = (int)w[9]; r.dst_off = (int)w[10]; r.src_fs = (int)w[11]; r.dst_fs = (int)w[12];
     r.src_ll = (int)w[13]; r.dst_ll = (int)w[14]; r.w_a = (int)w[15]; r.w_c = (int)w[16];
+    r.res_ll = (int)w[18]; r.res_stage = (int)bf(w[19], 0, 6); r.dst_lds = (int)bf(w[19], 6, 12) << 4; r.res_lds = (int)bf(w[19], 18, 12) << 4;
     return r;
 }
 
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
     const unsigned base = (unsigned)uni((int)poll(a.sync)) * 64u;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float* const ws = a.base[0] + (long)f * a.ws_frame_floats;
-    float* const dwb = lds + a.tile_off[a.ntiles];   // (the tiles have sizes of their own: tile t at tile_off[t], round 6)
+    float* const dwb = lds + a.tiles_floats;   // (behind the tiles, which have places and sizes of their own since round 6)
     float* const lC = dwb + a.dw_floats;
     const BandPacked* const lprog = reinterpret_cast<const BandPacked*>(lC + kConstFloats);
     int* const lfail = reinterpret_cast<int*>(lC + kConstFloats) + a.nstages * (int)(sizeof(BandPacked) / 4);   // this workgroup has given up (16 bytes behind the program)
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         const int Rin = st.dep >= 0 ? min(st.Rin, st.H - p0) : 0;
         const int ya = blk && S == 1 ? p0 - 1 : p0;
         const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : (cv2 ? p0 + 2 * nro : p0 + nro);
-        float* const tile = lds + a.tile_off[st.src_tile];
+        float* const tile = lds + st.src_lds;
         const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C >> 3) & 1, has4 = (C >> 2) & 1;
         const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
         // wpc = 8 / nct rounded down to a power of two (nct <= 8) waves share an output-channel tile and take its pixel tiles in turn.  The channel
@@ -278,6 +282,57 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             }
         }
         if (tid < (st.c_floats >> 2)) reinterpret_cast<f32x4*>(lC)[tid] = creg;
+        // ---- RES_UP2X (the WIDE instantiation: full_range's lateral convolutions, round 6): out = act(W x + b) + the bilinear x2 up-sampling
+        // (TFLite ResizeBilinear, half_pixel_centers) of a tensor of half the size, whose two rows this band's ONE output row reads come from their
+        // owners' packets into the (unused: a 1x1 stage) depthwise area: [2][Wo / 2][Co + 4]
+        int up_y0 = 0, up_y1 = 0;
+        float up_dy = 0.f;
+        if (WIDE && st.res_mode == RES_UP2X) {
+            const int Hc = st.Ho >> 1, Wc = Wo >> 1, Cq = Co >> 2;
+            const float iy = ((float)r0 + 0.5f) * 0.5f - 0.5f;
+            up_y0 = max((int)floorf(iy), 0);
+            up_y1 = min((int)ceilf(iy), Hc - 1);
+            up_dy = iy - (float)up_y0;
+            const int per_row = Wc * Cq;   // <= 512: one element (two packets) per thread and row
+            const unsigned tag_res = base + (unsigned)st.res_stage + 1u;
+            __amdgpu_buffer_rsrc_t rsrc = packet_buffer(ws + st.res_ll, 2L * Hc * Wc * Co);
+            const bool mine = tid < per_row;
+            const int px = mine ? tid / Cq : 0, q = mine ? tid - px * Cq : 0;
+            int off[2];
+            u32x4 ua[2], ub[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                off[e] = (((e ? up_y1 : up_y0) * Wc + px) * Cq + q) * 32;
+                ua[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[e], 0, kPacketAux);
+                ub[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[e] + 16, 0, kPacketAux);
+            }
+            int it = *lfail ? kSpinLimit : 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int e = 0; e < 2; e++) ok = ok && (!mine || (ua[e].y == tag_res && ua[e].w == tag_res && ub[e].y == tag_res && ub[e].w == tag_res));
+                if (ok) break;
+                if (++it > kSpinLimit || (it % kFailCheck == 0 && poll(a.sync + 2) != 0u)) {
+                    *a.fail = 1;
+                    *lfail = 1;
+                    __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    ua[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[e], 0, kPacketAux);
+                    ub[e] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[e] + 16, 0, kPacketAux);
+                }
+            }
+            if (mine) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const f32x4 v = {__uint_as_float(ua[e].x), __uint_as_float(ua[e].z), __uint_as_float(ub[e].x), __uint_as_float(ub[e].z)};
+                    *reinterpret_cast<f32x4*>(dwb + ((e * Wc + px) * (Co + 4)) + 4 * q) = v;
+                }
+            }
+        }
         MI_BAND_STAMP(1)
         __syncthreads();
         MI_BAND_STAMP(2)
@@ -337,13 +392,13 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             const int npt = (npx + 15) >> 4;
             const int n = lane & 15, kq = lane >> 4;
             const int Cso = Co + 4, TWo = Wo + 2;
-            float* const dtile = st.dst_tile >= 0 ? lds + a.tile_off[st.dst_tile] : nullptr;
+            float* const dtile = st.dst_tile >= 0 ? lds + st.dst_lds : nullptr;
             float* const gout = st.dst_base >= 0 ? a.base[st.dst_base] + st.dst_off + (long)f * st.dst_fs + (long)r0 * Wo * Co : nullptr;
             float* const llo = st.dst_ll >= 0 ? ws + st.dst_ll : nullptr;
             const float hi = st.act == ACT_RELU6 ? 6.f : INFINITY;
             __amdgpu_buffer_rsrc_t osrc = packet_buffer(ws + (llo ? st.dst_ll : 0), llo ? 2L * st.Ho * Wo * Co : 0);
             if (dtile)   // the output band's border pixels
-                for (int i = tid; i < (st.R + a.halo) * 2 * (Co >> 2); i += kThreads) {
+                for (int i = tid; i < (st.R + 2 + st.dst_h3) * 2 * (Co >> 2); i += kThreads) {
                     const int rr = i / (2 * (Co >> 2)), e = i - rr * 2 * (Co >> 2), side = e / (Co >> 2), q = e - side * (Co >> 2);
                     *reinterpret_cast<f32x4*>(dtile + (rr * TWo + (side ? Wo + 1 : 0)) * Cso + 4 * q) = zero4;
                 }
@@ -438,13 +493,13 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     const f32x4 bb = *reinterpret_cast<const f32x4*>(lC + c0), sl = *reinterpret_cast<const f32x4*>(lC + 16 * nct + c0);
                     f32x4 sk = zero4;
                     if (st.res_mode == RES_DIRECT && st.res_tile >= 0) {   // a tensor of res_c <= Co channels (zero-padded to Co) on the same rows, in another tile
-                        if (c0 < st.res_c) sk = *reinterpret_cast<const f32x4*>(lds + a.tile_off[st.res_tile] + ((1 + oy) * TWo + ox + 1) * (st.res_c + 4) + c0);
+                        if (c0 < st.res_c) sk = *reinterpret_cast<const f32x4*>(lds + st.res_lds + ((1 + oy) * TWo + ox + 1) * (st.res_c + 4) + c0);
                     } else if (st.res_mode == RES_DIRECT) {
                         if (c0 < C) sk = *reinterpret_cast<const f32x4*>(tile + ((1 + oy) * TW + ox + 1) * Cs + c0);   // channels >= C: the zero pad of a widening block
                     } else if (st.res_mode == RES_MAXPOOL && c0 < (st.res_tile >= 0 ? st.res_c : C)) {
                         // 2x2 max of a tensor of twice the output's size: the stride-2 block's own input (C channels), or (res_tile) the tensor the
                         // 2x2 convolution / the stride-2 block in front of this block read (res_c channels, zero-padded to Co) — its rows 2r, 2r + 1 are still in that tile
-                        const float* rt = st.res_tile >= 0 ? lds + a.tile_off[st.res_tile] : tile;
+                        const float* rt = st.res_tile >= 0 ? lds + st.res_lds : tile;
                         const int TWr = 2 * Wo + 2, Csr = st.res_tile >= 0 ? st.res_c + 4 : Cs;
                         const float* t0 = rt + ((1 + 2 * oy) * TWr + 2 * ox + 1) * Csr + c0;
                         const f32x4 s0 = *reinterpret_cast<const f32x4*>(t0), s1 = *reinterpret_cast<const f32x4*>(t0 + Csr);
@@ -460,6 +515,20 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                     v.y = fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), hi);
                     v.z = fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), hi);
                     v.w = fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), hi);
+                    if (WIDE && st.res_mode == RES_UP2X) {   // the skip joins BEHIND the activation (Epilogue::res_after); the arithmetic of block_kernels.hip's RES_UP2X
+                        const int Wc = Wo >> 1;
+                        const float ix = ((float)ox + 0.5f) * 0.5f - 0.5f;
+                        const int x0 = max((int)floorf(ix), 0), x1 = min((int)ceilf(ix), Wc - 1);
+                        const float dx = ix - (float)x0, dy = up_dy;
+                        const float* c0p = dwb + c0;
+                        const f32x4 p00 = *reinterpret_cast<const f32x4*>(c0p + x0 * Cso), p01 = *reinterpret_cast<const f32x4*>(c0p + x1 * Cso);
+                        const f32x4 p10 = *reinterpret_cast<const f32x4*>(c0p + (Wc + x0) * Cso), p11 = *reinterpret_cast<const f32x4*>(c0p + (Wc + x1) * Cso);
+                        const float w00 = (1 - dy) * (1 - dx), w10 = dy * (1 - dx), w01 = (1 - dy) * dx, w11 = dy * dx;
+                        v.x += p00.x * w00 + p10.x * w10 + p01.x * w01 + p11.x * w11;
+                        v.y += p00.y * w00 + p10.y * w10 + p01.y * w01 + p11.y * w11;
+                        v.z += p00.z * w00 + p10.z * w10 + p01.z * w01 + p11.z * w11;
+                        v.w += p00.w * w00 + p10.w * w10 + p01.w * w01 + p11.w * w11;
+                    }
                     if (px < npx && c0 < Co) {
                         if (llo && (oy < st.pub_lo || oy >= nro - st.pub_hi)) {   // a row some other workgroup reads
                             const int pko = (((r0 + oy) * Wo + ox) * (Co >> 2) + (c0 >> 2)) * 32;
@@ -536,7 +605,7 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
     BandPacked p{};
     p.w[0] = (unsigned)st.kind | (unsigned)st.S << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
              (unsigned)(st.dst_tile + 1) << 14 | (unsigned)st.pub_lo << 17 | (unsigned)st.pub_hi << 18 | (unsigned)st.src_base << 19 | (unsigned)(st.dst_base + 1) << 22 |
-             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28;
+             (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28 | (unsigned)st.dst_h3 << 31;
     p.w[1] = (unsigned)st.R | (unsigned)st.Rin << 8 | (unsigned)(st.dep + 1) << 16 | (unsigned)st.nbands << 24;
     p.w[2] = (unsigned)st.H | (unsigned)st.W << 16;
     p.w[3] = (unsigned)st.Ho | (unsigned)st.Wo << 16;
@@ -544,16 +613,19 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
     p.w[5] = (unsigned)st.c_floats | (unsigned)st.woff << 12 | (unsigned)st.per_ct << 16;
     p.w[6] = st.mC4; p.w[7] = st.mWo; p.w[8] = st.mrowq;
     for (int k = 0; k < 8; k++) p.w[9 + k] = (unsigned)(int)offs[k];
-    p.w[17] = (unsigned)st.res_c;
+    if (st.res_ll < -1 || st.res_ll > 0x7fffffffL || !fits(st.res_stage, 6) || !fits(st.dst_h3, 1)) return false;
+    for (int off : {st.src_lds, st.dst_lds, st.res_lds})
+        if (off < 0 || (off & 15) || !fits(off >> 4, 12)) return false;
+    p.w[17] = (unsigned)st.res_c | (unsigned)(st.src_lds >> 4) << 16;
+    p.w[18] = (unsigned)(int)st.res_ll;
+    p.w[19] = (unsigned)st.res_stage | (unsigned)(st.dst_lds >> 4) << 6 | (unsigned)(st.res_lds >> 4) << 18;
     *out = p;
     return true;
 }
 
 int launch_bandnet(const BandLaunch& a, void* stream) {
-    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.ntiles < 2 || a.ntiles > kBandTiles || a.halo < 2 || a.halo > 3) return (int)hipErrorInvalidValue;
-    for (int t = 0; t < a.ntiles; t++)
-        if (a.tile_off[t] < 0 || a.tile_off[t + 1] < a.tile_off[t] || (a.tile_off[t] & 3)) return (int)hipErrorInvalidValue;
-    if (bandnet_lds_bytes(a.tile_off[a.ntiles], a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
+    if (a.nstages < 1 || a.nstages > 63 || a.NW < 1 || a.F < 1 || a.lds_bytes > 160 * 1024 || a.tiles_floats < 0 || (a.tiles_floats & 3)) return (int)hipErrorInvalidValue;
+    if (bandnet_lds_bytes(a.tiles_floats, a.dw_floats, a.nstages) > a.lds_bytes) return (int)hipErrorInvalidValue;
     if ((long)a.NW * a.F > device_cu_count()) return (int)hipErrorInvalidValue;   // every workgroup must be resident: one per CU
     auto kern = a.wide ? bandnet_kernel<false, false, true> : (a.cv2 ? bandnet_kernel<true, false, false> : (a.xb ? bandnet_kernel<false, true, false> : bandnet_kernel<false, false, false>));
     if ((a.cv2 && a.xb) || (a.wide && (a.cv2 || a.xb))) return (int)hipErrorInvalidValue;   // (no such program: the planner does not build one)

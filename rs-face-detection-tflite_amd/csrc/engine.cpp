@@ -726,9 +726,16 @@ void Model::build_bandnet_try(bool conv2_ok) {
         const bool conv2 = conv2_ok && n.kind == Node::Conv && n.KH == 2 && n.KW == 2 && n.sh == 2 && n.sw == 2 && !n.gemm_head && n.in.size() == 1 &&
                            g.tensors[n.in[0]].shape.size() == 4 && g.tensors[n.in[0]].shape[1] % 2 == 0 && g.tensors[n.in[0]].shape[2] % 2 == 0 &&
                            g.tensors[n.in[0]].shape[3] % 32 == 0 && n.in[0] != band_stem_out_;
+        if (std::getenv("MI_BAND_DEBUG"))
+            std::fprintf(stderr, "bandnet: node %zu kind %d K %dx%d s %d in %zu res %d mode %d after %d ept %d act %d gemm %d\n", i, static_cast<int>(n.kind), n.KH, n.KW, n.sh, n.in.size(), n.res, n.res_mode,
+                         n.res_after ? 1 : 0, n.ept, n.act, n.gemm_head ? 1 : 0);
         if (!pw_block && !dw_block && !conv1 && !conv2) { cut = i; break; }
         if (conv2) band_saw_conv2_ = true;
-        if (n.in.size() != 1 || n.ept >= 0 || n.res_after) {   // (full_range's lateral convolutions, whose skip joins behind the activation: the program ends in front of them)
+        // full_range's lateral convolutions — a 1x1 convolution with a fused activation, then ADD with the bilinearly up-sampled coarser map: the skip
+        // joins BEHIND the activation — are stages of the WIDE instantiation when the coarse tensor is the program's (round 6); any other such node ends the program
+        const bool up2x = (conv1 || pw_block) && n.res_after && n.res >= 0 && n.res_mode == RES_UP2X && band_wide_ok_ && n.in.size() == 1 && n.ept < 0 &&
+                          producer[static_cast<size_t>(n.res)] >= 0 && g.tensors[n.res].shape.size() == 4;
+        if (n.in.size() != 1 || n.ept >= 0 || (n.res_after && !up2x)) {
             if (prog.empty()) BAND_GIVE_UP;
             cut = i;
             break;
@@ -762,7 +769,14 @@ void Model::build_bandnet_try(bool conv2_ok) {
         st.act = n.act;
         if (n.act != ACT_NONE && n.act != ACT_RELU && n.act != ACT_RELU6 && n.act != ACT_PRELU) BAND_GIVE_UP;
         st.res_mode = RES_NONE;
-        if (n.res >= 0) {
+        if (up2x) {
+            const auto& sr = g.tensors[n.res].shape;
+            const BandStage& cd = prog[static_cast<size_t>(producer[static_cast<size_t>(n.res)])];
+            if (sr[1] * 2 != st.Ho || sr[2] * 2 != st.Wo || sr[3] != st.Co || (st.Co & 3) || cd.R != 1 || (st.Wo / 2) * (st.Co / 4) > 512) { if (prog.empty()) BAND_GIVE_UP; cut = i; break; }
+            st.res_mode = RES_UP2X;
+            st.res_dep = producer[static_cast<size_t>(n.res)];   // (its rows come through the packets, not from a tile: pass 2)
+            st.res_c = st.Co;
+        } else if (n.res >= 0) {
             if (!dw_block) BAND_GIVE_UP;
             if (n.res != n.in[0] && n.res_mode == RES_MAXPOOL) {
                 // the skip is the 2x2 max of the tensor the 2x2 convolution in front of this block read: the rows 2r, 2r + 1 of it that the
@@ -1108,6 +1122,15 @@ void Model::build_bandnet_try(bool conv2_ok) {
         const BandStage& st = prog[static_cast<size_t>(k)];
         if (st.dep >= 0) {
             BandStage& pd = prog[static_cast<size_t>(st.dep)];
+            // a lateral convolution reads a trunk tensor that is 10 - 30 stages old: its rows are this workgroup's own, so the producer also writes them to
+            // the launch's workspace and this stage reads them back from there (like the program's input) — the tile does not have to stay alive
+            BandStage& me = prog[static_cast<size_t>(k)];
+            if (st.res_mode == RES_UP2X && st.kind == BAND_PW && st.S == 1 && !st.cross && k - st.dep > 2 && pd.R == st.R && pd.wshift == st.wshift && pd.woff == st.woff &&
+                pd.nbands == st.nbands && (pd.dst_base < 0 || pd.far_copy) && (pd.Co & 3) == 0) {
+                me.far_src = 1;
+                pd.far_copy = 1;
+                pd.dst_base = 0;
+            } else {
             last_reader[static_cast<size_t>(st.dep)] = k;
             const bool cv2_halo = st.kind == BAND_PW && st.S == 2 && pd.R < 2 * st.R;   // its row 2r + 1 is the next workgroup's
             if (st.cross) pd.pub_lo = 1;   // (one-row bands: all of the tensor)
@@ -1115,53 +1138,149 @@ void Model::build_bandnet_try(bool conv2_ok) {
                 pd.pub_lo = 1;
                 if (st.kind == BAND_BLOCK && st.S == 1 && pd.R > 1) pd.pub_hi = 1;
             }
+            }
         } else {
             input_last_reader = k;
         }
         if (st.res_dep >= 0) last_reader[static_cast<size_t>(st.res_dep)] = k;
         if (st.res_dep == -1) input_last_reader = k;
+        if (st.res_mode == RES_UP2X) {
+            if (st.res_dep < 0) BAND_GIVE_UP;
+            prog[static_cast<size_t>(st.res_dep)].pub_lo = 1;   // (one-row bands: all of the coarse tensor travels)
+        }
     }
     long ws = 0;
-    int dw_floats = 0, ntiles = 2;
-    int slot_floats[kBandTiles] = {};   // every tile has the size of the largest tensor it ever holds (round 6: full_range's 96x96x32 tensors are 56 KB a band, its 8- to 16-channel ones 19 KB)
-    int halo = 2;   // tile rows beside a band's own: one above and one below, two below where a stride-2 block reads the tensor
+    int dw_floats = 0;
+    // LDS tiles, placed by liveness (round 6: an interval allocator — before, up to four equal tiles; full_range's tensors go from 56 KB for a band of
+    // 96x96x32 to 14 KB for one of 96x96x8, and its decoder keeps three 31 KB tensors of 48x48x48 alive): a tensor gets the lowest gap that holds it
+    // when it is produced and keeps it until its last reader has run.  Rows of a tile: the band's own + one above + one below, + one more below where a
+    // stride-2 BLOCK reads the tensor.
+    std::vector<char> read_s2(static_cast<size_t>(NS), 0);
     for (const BandStage& st : prog)
-        if (st.kind == BAND_BLOCK && st.S == 2) halo = 3;
-    int holder[kBandTiles];   // stage whose output a tile holds (-1: the program's input, -2: nothing)
-    for (int& h : holder) h = -2;
-    auto tile_of = [&](int stage) {
-        for (int t = 0; t < kBandTiles; t++)
-            if (holder[t] == stage) return t;
+        if (st.kind == BAND_BLOCK && st.S == 2 && st.dep >= 0) read_s2[static_cast<size_t>(st.dep)] = 1;
+    struct Alloc { int off, size, stage; };   // stage: producer (-1: the program's input, -3: a far input held for one stage)
+    auto dead_at = [&](const Alloc& al, int k) { return al.stage == -3 || (al.stage == -1 ? input_last_reader <= k : last_reader[static_cast<size_t>(al.stage)] <= k); };
+    // The places are found first, for the smallest arena that takes them: a tensor goes to the lowest or to the highest gap that holds it, whichever leaves
+    // the larger free block (first fit from the bottom alone puts full_range's second 96x96x32 tensor in the middle of the arena, and the third, 56 KB,
+    // behind it: 155 KB for 113 KB of live tensors)
+    std::vector<int> in_off(static_cast<size_t>(NS), -1), out_off(static_cast<size_t>(NS), -1);
+    auto layout = [&](int S, int policy) {
+        std::vector<Alloc> lv;
+        auto put = [&](int need, int stage) {
+            need = static_cast<int>(align_up(std::max(need, 16), 16));
+            std::sort(lv.begin(), lv.end(), [](const Alloc& x, const Alloc& y) { return x.off < y.off; });
+            std::vector<std::pair<int, int>> gaps;   // [begin, end)
+            int at = 0;
+            for (const Alloc& al : lv) { if (al.off > at) gaps.push_back({at, al.off}); at = std::max(at, al.off + al.size); }
+            if (S > at) gaps.push_back({at, S});
+            int best = -1, best_left = -1;
+            for (const auto& gp : gaps) {
+                if (gp.second - gp.first < need) continue;
+                for (int end = 0; end < 2; end++) {
+                    const int off = end ? gp.second - need : gp.first;
+                    int left = 0;   // the largest free block that remains
+                    for (const auto& g2 : gaps) {
+                        if (&g2 != &gp) left = std::max(left, g2.second - g2.first);
+                        else left = std::max(left, std::max(off - g2.first, g2.second - (off + need)));
+                    }
+                    // policy 0: whichever end leaves the larger free block; 1 / 2: wide tensors (>= 32 KB) at the bottom and narrow ones at the top, or the
+                    // other way round (then the first / last gap that fits)
+                    const bool wide_t = need >= 8192;
+                    const int score = policy == 0 ? left : ((policy == 1) == wide_t ? (end ? -1 : S - off) : (end ? off : -1));
+                    if (score > best_left) { best_left = score; best = off; }
+                }
+            }
+            if (best >= 0) lv.push_back(Alloc{best, need, stage});
+            return best;
+        };
+        for (int k = 0; k < NS; k++) {
+            const BandStage& st = prog[static_cast<size_t>(k)];
+            const int keep_src = st.dep >= 0 && !st.far_src ? st.dep : (st.dep < 0 ? -1 : -4);
+            const int keep_res = st.res_mode != RES_UP2X && st.res_dep >= -1 ? st.res_dep : -4;
+            std::vector<Alloc> kept;
+            for (const Alloc& al : lv)
+                if (!dead_at(al, k) || al.stage == keep_src || al.stage == keep_res) kept.push_back(al);
+            lv.swap(kept);
+            in_off[static_cast<size_t>(k)] = out_off[static_cast<size_t>(k)] = -1;
+            if (st.dep < 0) {
+                const int rows = st.kind == BAND_BLOCK ? (st.S == 1 ? st.R + 2 : 2 * st.R + 2) : st.R + 1;
+                if ((in_off[static_cast<size_t>(k)] = put(rows * (st.W + 2) * (st.C + 4), -1)) < 0) return false;
+            } else if (st.far_src) {
+                if ((in_off[static_cast<size_t>(k)] = put((st.R + 1) * (st.W + 2) * (st.C + 4), -3)) < 0) return false;
+            }
+            if (last_reader[static_cast<size_t>(k)] >= 0)
+                if ((out_off[static_cast<size_t>(k)] = put(bandnet_tile_floats(st.R, st.Wo, st.Co, 2 + (read_s2[static_cast<size_t>(k)] ? 1 : 0)), k)) < 0) return false;
+        }
+        return true;
+    };
+    {
+        int S = 4096;
+        bool ok = false;
+        for (; S <= 40960 && !ok; S += ok ? 0 : 64)   // (floats: 16 .. 160 KB in steps of 256 bytes; three placement policies each)
+            for (int policy = 0; policy < 3 && !ok; policy++) ok = layout(S, policy);
+        if (!ok) BAND_GIVE_UP;
+    }
+    std::vector<Alloc> live;
+    int tiles_floats = 0;
+    auto place = [&](int off, int need, int stage) {   // (the place found above)
+        need = static_cast<int>(align_up(std::max(need, 16), 16));
+        live.push_back(Alloc{off, need, stage});
+        tiles_floats = std::max(tiles_floats, off + need);
+        return off;
+    };
+    auto where = [&](int stage) {
+        for (const Alloc& al : live)
+            if (al.stage == stage) return al.off;
         return -1;
     };
     for (int k = 0; k < NS; k++) {
         BandStage& st = prog[static_cast<size_t>(k)];
+        // what nobody reads any more is free — but for what THIS stage reads (its last reader may be this very stage)
+        {
+            const int keep_src = st.dep >= 0 && !st.far_src ? st.dep : (st.dep < 0 ? -1 : -4);
+            const int keep_res = st.res_mode != RES_UP2X && st.res_dep >= -1 ? st.res_dep : -4;
+            std::vector<Alloc> kept;
+            for (const Alloc& al : live)
+                if (!dead_at(al, k) || al.stage == keep_src || al.stage == keep_res) kept.push_back(al);
+            live.swap(kept);
+        }
         if (st.dep < 0) {
-            // the program's input comes from global memory into tile 0: only its first reader may be such a stage (a skip may read it there later)
-            if (holder[0] != -2) BAND_GIVE_UP;
-            holder[0] = -1;
-            st.src_tile = 0;
+            // the program's input comes from global memory into a tile of its own: only its first reader may be such a stage (a skip may read it there later)
+            if (where(-1) >= 0) BAND_GIVE_UP;
             const int rows = st.kind == BAND_BLOCK ? (st.S == 1 ? st.R + 2 : 2 * st.R + 2) : st.R + 1;
-            slot_floats[0] = std::max(slot_floats[0], rows * (st.W + 2) * (st.C + 4));
+            st.src_lds = place(in_off[static_cast<size_t>(k)], rows * (st.W + 2) * (st.C + 4), -1);
+            st.src_tile = 0;
+        } else if (st.far_src) {
+            // its own rows come back from the workspace into a free place (held for this stage only)
+            st.src_lds = place(in_off[static_cast<size_t>(k)], (st.R + 1) * (st.W + 2) * (st.C + 4), -3);
+            st.src_tile = 0;
         } else {
-            st.src_tile = tile_of(st.dep);
-            if (st.src_tile < 0) BAND_GIVE_UP;   // its input is no longer in LDS
+            st.src_lds = where(st.dep);
+            if (st.src_lds < 0) BAND_GIVE_UP;   // its input is no longer in LDS
+            st.src_tile = 0;
             st.src_ll = prog[static_cast<size_t>(st.dep)].dst_ll;
             const BandStage& pd = prog[static_cast<size_t>(st.dep)];
             const bool cv2_halo = st.kind == BAND_PW && st.S == 2 && pd.R < 2 * st.R;
             if (((st.kind == BAND_BLOCK || cv2_halo) && st.nbands > 1 && st.src_ll < 0) || (st.cross && st.src_ll < 0)) BAND_GIVE_UP;
         }
-        if (st.res_dep >= -1) {
-            st.res_tile = tile_of(st.res_dep);
-            if (st.res_tile < 0) BAND_GIVE_UP;
+        if (st.res_mode == RES_UP2X) {
+            const BandStage& cd = prog[static_cast<size_t>(st.res_dep)];
+            if (cd.dst_ll < 0 || cd.R != 1 || cd.Ho * 2 != st.Ho || cd.Wo * 2 != st.Wo || cd.Co != st.Co || st.R != 1) BAND_GIVE_UP;
+            st.res_ll = cd.dst_ll;
+            st.res_stage = st.res_dep;
+            dw_floats = std::max(dw_floats, 2 * cd.Wo * (st.Co + 4));   // its two rows land in the depthwise area (a 1x1 stage does not use it)
+        } else if (st.res_dep >= -1) {
+            st.res_lds = where(st.res_dep);
+            if (st.res_lds < 0) BAND_GIVE_UP;
+            st.res_tile = 1;   // (a flag now: the skip comes from another tile, at res_lds)
             // the skip is read at the output's pixel positions: its band must have the output's rows (same shape, same owners)
             if (st.res_mode == RES_MAXPOOL) {
-                // ... or, the 2x2 max of the input of the 2x2 convolution in front: that stage, run by the same workgroups on the same bands,
-                // left rows 2 r0 .. 2 r0 + 2 R - 1 of the tensor in the tile it read them from
+                // ... or, the 2x2 max of the input of the 2x2 convolution / stride-2 block in front: that stage, run by the same workgroups on the same
+                // bands, left rows 2 r0 .. 2 r0 + 2 R - 1 of the tensor in the tile it read them from
                 if (st.dep < 0 || st.res_dep < 0) BAND_GIVE_UP;
                 const BandStage& cv = prog[static_cast<size_t>(st.dep)];
                 const BandStage& rd = prog[static_cast<size_t>(st.res_dep)];
-                if (cv.S != 2 || cv.dep != st.res_dep || cv.src_tile != st.res_tile || cv.R != st.R || cv.wshift != st.wshift || cv.nbands != st.nbands)
+                if (cv.S != 2 || cv.dep != st.res_dep || cv.src_lds != st.res_lds || cv.far_src || cv.R != st.R || cv.wshift != st.wshift || cv.nbands != st.nbands)
                     BAND_GIVE_UP;
                 if (rd.Ho != 2 * st.Ho || rd.Wo != 2 * st.Wo || rd.Co != st.res_c) BAND_GIVE_UP;
             } else if (st.res_dep >= 0) {
@@ -1173,54 +1292,45 @@ void Model::build_bandnet_try(bool conv2_ok) {
             }
         }
         if (last_reader[static_cast<size_t>(k)] >= 0) {
-            // a free tile, best fit: the smallest one that holds this tensor as it is, else the one that has to grow least (a narrow middle tensor must
-            // not take the place of a wide one: full_range's 96x96x8 between two 96x96x32)
-            const int need = bandnet_tile_floats(st.R, st.Wo, st.Co, halo);
-            int pick = -1;
-            for (int t = 0; t < kBandTiles; t++) {
-                if (t == st.src_tile || t == st.res_tile) continue;
-                const int h = holder[t];
-                if (!(h == -2 || (h >= 0 && last_reader[static_cast<size_t>(h)] <= k) || (h == -1 && input_last_reader <= k))) continue;
-                if (pick < 0) { pick = t; continue; }
-                const bool fits_t = slot_floats[t] >= need, fits_p = slot_floats[pick] >= need;
-                if (fits_t && fits_p ? slot_floats[t] < slot_floats[pick] : (fits_t != fits_p ? fits_t : slot_floats[t] > slot_floats[pick])) pick = t;
-            }
-            if (pick < 0) BAND_GIVE_UP;   // more tensors alive than tiles
-            st.dst_tile = pick;
-            holder[pick] = k;
-            ntiles = std::max(ntiles, pick + 1);
-            slot_floats[pick] = std::max(slot_floats[pick], need);
+            st.dst_h3 = read_s2[static_cast<size_t>(k)] ? 1 : 0;
+            st.dst_lds = place(out_off[static_cast<size_t>(k)], bandnet_tile_floats(st.R, st.Wo, st.Co, 2 + st.dst_h3), k);
+            st.dst_tile = 0;   // (a flag now: the output stays in LDS, at dst_lds)
             if (st.pub_lo || st.pub_hi) {
                 st.dst_ll = ws;
                 ws += align_up(2 * static_cast<long>(st.Ho) * st.Wo * st.Co, 64);
             }
         }
+        if (st.far_copy) {   // the plain copy a lateral convolution reads back (frame stride = the workspace's: patched below)
+            st.dst_off = ws;
+            ws += align_up(static_cast<long>(st.Ho) * st.Wo * st.Co, 64);
+        }
+        if (st.far_src) {
+            const BandStage& pd = prog[static_cast<size_t>(st.dep)];
+            if (!pd.far_copy || pd.dst_base != 0) BAND_GIVE_UP;
+            st.src_base = 0;
+            st.src_off = pd.dst_off;
+        }
         dw_floats = std::max(dw_floats, bandnet_dw_floats(st));
     }
     dw_floats = static_cast<int>(align_up(dw_floats, 4));
-    band_tile_off_[0] = 0;
-    for (int t = 0; t < kBandTiles; t++) band_tile_off_[t + 1] = band_tile_off_[t] + (t < ntiles ? static_cast<int>(align_up(std::max(slot_floats[t], 4), 4)) : 0);
-    const int tiles_floats = band_tile_off_[ntiles];
+    tiles_floats = static_cast<int>(align_up(tiles_floats, 16));
+    band_tiles_floats_ = tiles_floats;
     band_dw_floats_ = dw_floats;
-    band_ntiles_ = ntiles;
-    band_halo_ = halo;
     band_cv2_ = false;
     for (const BandStage& st : prog) band_cv2_ = band_cv2_ || (st.kind == BAND_PW && st.S == 2);
     band_xb_ = false;
     for (const BandStage& st : prog) band_xb_ = band_xb_ || (st.kind == BAND_BLOCK && st.cross);
     if (band_cv2_ && band_xb_) BAND_GIVE_UP;   // (no kernel instantiation for both: the iris network's second branch starts with a 1x1 stage)
     band_wide_ = false;
-    for (const BandStage& st : prog) band_wide_ = band_wide_ || st.C > 128 || st.Co > 128;
+    for (const BandStage& st : prog) band_wide_ = band_wide_ || st.C > 128 || st.Co > 128 || st.res_mode == RES_UP2X;
     if (band_wide_ && (band_cv2_ || band_xb_)) BAND_GIVE_UP;   // (likewise)
     band_lds_bytes_ = bandnet_lds_bytes(tiles_floats, dw_floats, NS);
     if (std::getenv("MI_BAND_DEBUG")) {
-        std::fprintf(stderr, "bandnet: %d stages, NW %d, halo %d, LDS %d B = tiles", NS, NW, halo, band_lds_bytes_);
-        for (int t = 0; t < ntiles; t++) std::fprintf(stderr, " %d", slot_floats[t] * 4);
-        std::fprintf(stderr, " + depthwise %d + constants\n", dw_floats * 4);
+        std::fprintf(stderr, "bandnet: %d stages, NW %d, LDS %d B = tiles %d + depthwise %d + constants + program\n", NS, NW, band_lds_bytes_, tiles_floats * 4, dw_floats * 4);
         for (int k = 0; k < NS; k++) {
             const BandStage& st = prog[static_cast<size_t>(k)];
             std::fprintf(stderr, "  stage %2d %s S%d %dx%dx%d -> %dx%dx%d R %d wshift %d src %d dst %d res %d (dep %d, mode %d, c %d) last reader %d\n", k, st.kind == BAND_BLOCK ? "block" : "pw   ", st.S, st.H, st.W, st.C,
-                         st.Ho, st.Wo, st.Co, st.R, st.wshift, st.src_tile, st.dst_tile, st.res_tile, st.res_dep, st.res_mode, st.res_c, last_reader[static_cast<size_t>(k)]);
+                         st.Ho, st.Wo, st.Co, st.R, st.wshift, st.src_lds * 4, st.dst_tile >= 0 ? st.dst_lds * 4 : -1, st.res_tile >= 0 ? st.res_lds * 4 : -1, st.res_dep, st.res_mode, st.res_c, last_reader[static_cast<size_t>(k)]);
         }
     }
     if (band_lds_bytes_ > 160 * 1024) BAND_GIVE_UP;
@@ -1228,8 +1338,12 @@ void Model::build_bandnet_try(bool conv2_ok) {
     band_nstages_ = NS;
     consts.resize(consts.size() + 64, 0.f);
     std::vector<BandPacked> packed(prog.size());
-    for (size_t k = 0; k < prog.size(); k++)
-        if (!bandnet_pack(prog[k], &packed[k])) BAND_GIVE_UP;
+    for (size_t k = 0; k < prog.size(); k++) {
+        BandStage q = prog[k];
+        if (q.far_copy) q.dst_fs = band_ws_frame_floats_;
+        if (q.far_src) { q.src_fs = band_ws_frame_floats_; q.dep = -1; q.Rin = 0; }   // (the kernel's "input in plain memory" path; the stage order keeps the host's dep)
+        if (!bandnet_pack(q, &packed[k])) BAND_GIVE_UP;
+    }
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_prog_), packed.size() * sizeof(BandPacked)), "hipMalloc band program");
     hip_check(hipMemcpy(d_band_prog_, packed.data(), packed.size() * sizeof(BandPacked), hipMemcpyHostToDevice), "upload band program");
     hip_check(hipMalloc(reinterpret_cast<void**>(&d_band_consts_), consts.size() * sizeof(float)), "hipMalloc band constants");
@@ -1478,13 +1592,11 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
             if (labels) labels->push_back("bandnet_kernel");
             BandLaunch a;
             a.prog = d_band_prog_; a.nstages = band_nstages_; a.NW = band_nw_used_; a.F = F; a.lds_bytes = band_lds_bytes_;
-            for (int t = 0; t <= kBandTiles; t++) a.tile_off[t] = band_tile_off_[t];
+            a.tiles_floats = band_tiles_floats_;
             a.dw_floats = band_dw_floats_; a.ws_frame_floats = band_ws_frame_floats_;
             long fs = 0;
             a.base[0] = d_band_ws_;
             a.base[1] = const_cast<float*>(tensor_ptr(band_stem_out_, in, chunk_start, &fs));
-            a.ntiles = band_ntiles_;
-            a.halo = band_halo_;
             a.cv2 = band_cv2_ ? 1 : 0;
             a.xb = band_xb_ ? 1 : 0;
             a.wide = band_wide_ ? 1 : 0;

@@ -143,12 +143,11 @@ class Model {
     int band_first_ = 0;            // plan_ node the band launch stands for (with every node behind it that band_node_runs_ does not name)
     int band_stem_out_ = -1;        // tensor the first convolution writes = the band program's input
     int band_nstages_ = 0, band_lds_bytes_ = 0, band_max_frames_ = 0, band_dw_floats_ = 0;
-    int band_tile_off_[kBandTiles + 1] = {};   // LDS floats in front of each tile of the program (the tiles end at [ntiles])
+    int band_tiles_floats_ = 0;     // LDS floats of the program's tiles
     long band_ws_frame_floats_ = 0;
     struct BandExt { int out_k = -1, tensor = -1; };   // BandLaunch::base[2 + j]: graph output out_k, or the arena storage of `tensor` (read by a launch behind the band program)
     std::vector<BandExt> band_ext_;
     std::vector<char> band_node_runs_;   // per plan_ node from band_first_ on: 1 = it runs as its own launch behind the band launch (the program stops in front of it)
-    int band_ntiles_ = 2, band_halo_ = 3;
     bool band_fork_ = true, band_cv2_ = false, band_xb_ = false, band_saw_conv2_ = false, band_wide_ = false, band_wide_ok_ = true;
     BandPacked* d_band_prog_ = nullptr;
     float* d_band_consts_ = nullptr;

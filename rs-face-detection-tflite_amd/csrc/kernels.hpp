@@ -478,6 +478,13 @@ struct alignas(16) BandStage {
                                  // the iris network's bottlenecks add the tensor in front of their 1x1 reduction), or RES_MAXPOOL of the C-channel
                                  // tensor of twice the size in this tile (the input of the 2x2 convolution in front of this block)
     int cross = 0;               // (host only) the stage reads a tensor of the other branch's workgroups: Rin = 0, every row from the packets
+    int src_lds = 0, dst_lds = 0, res_lds = 0;   // LDS floats in front of the input / output / skip tile (multiples of 16; placed by liveness in build_bandnet)
+    int dst_h3 = 0;              // the output tile has R + 3 rows (a stride-2 block reads the tensor: two rows below the band), else R + 2
+    int far_src = 0;             // (host only) the stage reads its input — rows this workgroup wrote itself, many stages ago — back from the launch's workspace instead
+                                 // of keeping the tile alive (full_range's lateral convolutions read trunk tensors 10 - 30 stages old); packed with dep = -1
+    int far_copy = 0;            // (host only) ... and the producer writes that copy (dst_base = 0: the workspace)
+    long res_ll = -1;            // RES_UP2X (a 1x1 stage whose skip, added behind the activation, is the bilinear x2 up-sampling of the output of stage
+    int res_stage = 0;           // res_stage, half its size): that tensor's packet buffer
     int res_c = 0;               // channels of the skip tensor in res_tile (<= Co: the rest of the skip is the zero pad of a widening block)
     int act = ACT_NONE;
     long src_off = 0, dst_off = 0;   // floats from the base to frame 0 of the tensor
@@ -502,13 +509,11 @@ bool bandnet_pack(const BandStage& st, BandPacked* out);
 struct BandLaunch {
     const BandPacked* prog = nullptr;
     int nstages = 0, NW = 0, F = 0, lds_bytes = 0;
-    int ntiles = 2;                 // LDS tiles (2 .. kBandTiles)
+    int tiles_floats = 0;           // LDS floats of the tiles (each stage names its own: BandStage::src_lds ...)
     int cv2 = 0;                    // the program has 2x2 stride-2 convolution stages (the kernel instantiation with their code)
     int wide = 0;                   // ... stages of more than 128 input or output channels (the WIDE instantiation)
     int xb = 0;                     // ... a BLOCK stage that takes all of its input rows from the packets (Rin = 0: zeroes its tile's border pixels)
-    int halo = 3;                   // tile rows beside the band's own: 3 when a stride-2 block reads two rows below its band, else 2
-    int tile_off[kBandTiles + 1] = {};   // LDS: [tile 0] .. [tile ntiles - 1][depthwise result][small constants]; tile t starts tile_off[t] floats in, the tiles end at tile_off[ntiles]
-    int dw_floats = 0;
+    int dw_floats = 0;              // LDS: [tiles][depthwise result][small constants][program]
     long ws_frame_floats = 0;       // base[0]: floats between the frames' workspaces
     float* base[kBandBases] = {};   // 0: the launch's own workspace (packet buffers), 1: the first stage's input, 2..: graph outputs / tensors later launches read
     const float* consts = nullptr;
