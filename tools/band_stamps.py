@@ -10,7 +10,7 @@ import rs_face_detection_tflite_amd.api as api
 api.LIB_PATH = os.path.join(ROOT, "rs-face-detection-tflite_amd", "libmiface-stamps.so")
 import rs_face_detection_tflite_amd as mi
 name = sys.argv[1]
-files = {"landmark": "face_landmark.tflite", "iris": "iris_landmark.tflite", "back": "face_detection_back.tflite", "front": "face_detection_front.tflite"}
+files = {"landmark": "face_landmark.tflite", "iris": "iris_landmark.tflite", "back": "face_detection_back.tflite", "front": "face_detection_front.tflite", "full": "face_detection_full_range.tflite"}
 m = mi.Model(os.path.join(ROOT, "models", files[name]))
 m.set_option("graph", 0)
 m.set_option("band", 2)
