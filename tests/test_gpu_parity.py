@@ -96,6 +96,31 @@ def test_synthetic_graphs_vs_oracle(gpu, oracle, synth_models, case, fuse):
     m.close()
 
 
+@pytest.mark.parametrize("case", sorted(__import__("synth_tflite").CASES))
+def test_synthetic_graphs_on_the_single_launch_plan(gpu, oracle, synth_models, case):
+    """Round 6: the single-launch plan's lowering grew (tiles of their own sizes placed by an interval allocator, skips with fewer channels than the
+    output, stages of more than 128 channels, lateral convolutions with an up-sampled skip, inputs read back from the workspace).  Every synthetic graph
+    — the reference's operator chains on OTHER shapes — runs with option band = 2 at one and two frames: where the graph has a program (wholly or as a
+    prefix) its results must be the oracle's, run to run bit-identical; where it has none the batched plan answers.  band_wide = 0 likewise."""
+    path, h, w = synth_models[case]
+    om = oracle.Model(path)
+    rs = np.random.RandomState(321)
+    x = rs.uniform(-1, 1, (2, h, w, 3)).astype(np.float32)
+    x[1, : h // 2] = 0.0
+    refs = om.run(x, nthreads=2)
+    for wide in (1, 0):
+        m = gpu.Model(path)
+        m.set_option("band", 2)
+        m.set_option("band_wide", wide)
+        for nb in (1, 2):
+            outs = [o.copy() for o in m.run(x[:nb])]
+            for o, r in zip(outs, refs):
+                _raw_close(o, r[:nb])
+            for o, o2 in zip(outs, m.run(x[:nb])):
+                np.testing.assert_array_equal(o, o2)
+        m.close()
+
+
 @pytest.mark.parametrize("batch", [1, 97, 300])
 def test_walking_band_kernel_many_items(gpu, oracle, synth_models, batch):
     """Row-band bottleneck launches put one workgroup on every CU and let it walk over its share of the bands with the next band's
