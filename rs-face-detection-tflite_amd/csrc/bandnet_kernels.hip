@@ -93,6 +93,7 @@ struct StageRegs {
     unsigned mC4, mWo, mrowq;
     int src_off, dst_off, src_fs, dst_fs, src_ll, dst_ll, w_a, w_c;
     int res_ll, res_stage;   // RES_UP2X: the packet buffer and the stage of the coarse tensor
+    int pre;   // a stride-2 BLOCK whose window starts one row / column BEFORE pixel 2r (explicit zero pad in front, VALID behind it: full_range_sparse): S is packed as 3
     int src_lds, dst_lds, res_lds, dst_h3;   // LDS floats in front of the stage's tiles (placed by liveness, sizes of their own); dst_h3: the output tile has R + 3 rows (a stride-2 block reads it), else R + 2
 };
 // word 0: kind:1 S:2 wshift:4 res_mode:2 act:3 src_tile:2 dst_tile+1:3 pub_lo:1 pub_hi:1 src_base:3 dst_base+1:4 wpc_shift:2 res_tile+1:3 dst_h3:1
@@ -106,7 +107,7 @@ __device__ __forceinline__ StageRegs stage_regs(int word) {
 #pragma unroll
     for (int k = 0; k < 20; k++) w[k] = (unsigned)__builtin_amdgcn_readlane(word, k);
     StageRegs r;
-    r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
+    r.kind = bf(w[0], 0, 1); r.S = bf(w[0], 1, 2); r.pre = r.S == 3; r.S = r.pre ? 2 : r.S; r.wshift = bf(w[0], 3, 4); r.res_mode = bf(w[0], 7, 2); r.act = bf(w[0], 9, 3);
     r.src_tile = bf(w[0], 12, 2); r.dst_tile = (int)bf(w[0], 14, 3) - 1; r.pub_lo = bf(w[0], 17, 1); r.pub_hi = bf(w[0], 18, 1);
     r.src_base = bf(w[0], 19, 3); r.dst_base = (int)bf(w[0], 22, 4) - 1; r.wpc_shift = bf(w[0], 26, 2); r.res_tile = (int)bf(w[0], 28, 3) - 1; r.dst_h3 = bf(w[0], 31, 1); r.res_c = bf(w[17], 0, 16); r.src_lds = (int)bf(w[17], 16, 12) << 4;
     r.R = bf(w[1], 0, 8); r.Rin = bf(w[1], 8, 8); r.dep = (int)bf(w[1], 16, 8) - 1; r.nbands = bf(w[1], 24, 8);
@@ -194,8 +195,10 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         const int r0 = bi * st.R, nro = min(st.Ho, r0 + st.R) - r0, npx = nro * Wo;
         const int p0 = S * r0;                     // first input row of the band; tile row of input row y: y - p0 + 1
         const int Rin = st.dep >= 0 ? min(st.Rin, st.H - p0) : 0;
-        const int ya = blk && S == 1 ? p0 - 1 : p0;
-        const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : (cv2 ? p0 + 2 * nro : p0 + nro);
+        // (the WIDE instantiation only: a stride-2 block with its pad in front reads rows 2r - 1 .. 2r + 1 — one row above the band, none below)
+        const int pre = WIDE && blk ? st.pre : 0;
+        const int ya = blk && (S == 1 || pre) ? p0 - 1 : p0;
+        const int yb = blk ? (S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1 - pre) : (cv2 ? p0 + 2 * nro : p0 + nro);
         float* const tile = lds + st.src_lds;
         const int nct = (Co + 15) >> 4, n16 = C >> 4, has8 = (C >> 3) & 1, has4 = (C >> 2) & 1;
         const unsigned tag_in = base + (unsigned)st.dep + 1u, tag_out = base + (unsigned)s + 1u;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
         __syncthreads();
         MI_BAND_STAMP(2)
         // ---- depthwise 3x3: one thread per (output pixel, channel quad); taps at tile rows trow + S oy + ky
-        const int trow = blk && S == 1 ? 0 : 1;
+        const int trow = blk && (S == 1 || pre) ? 0 : 1;
         if (blk) {
             if (WIDE && st.c_floats < 32 * nct + 10 * C) {
                 // (wide: the taps did not fit the constants' LDS area — c_floats holds bias and slopes only — and come from L2; a code path of its own:
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
                 const float* bdw = wdw + 9 * C;
                 for (int i = tid; i < npx * C4; i += kThreads) {
                     const int px = mdiv(i, st.mC4), q = i - px * C4, oy = mdiv(px, st.mWo), ox = px - oy * Wo;
-                    const float* t = tile + ((trow + S * oy) * TW + S * ox + (S - 1)) * Cs + 4 * q;
+                    const float* t = tile + ((trow + S * oy) * TW + S * ox + (S - 1 - pre)) * Cs + 4 * q;
                     f32x4 k[9];
 #pragma unroll
                     for (int j = 0; j < 9; j++) k[j] = *reinterpret_cast<const f32x4*>(wdw + j * C + 4 * q);
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void bandnet_kernel(BandLaunch a) {
             const float* bdw = wdw + 9 * C;
             for (int i = tid; i < npx * C4; i += kThreads) {
                 const int px = mdiv(i, st.mC4), q = i - px * C4, oy = mdiv(px, st.mWo), ox = px - oy * Wo;
-                const float* t = tile + ((trow + S * oy) * TW + S * ox + (S - 1)) * Cs + 4 * q;
+                const float* t = tile + ((trow + S * oy) * TW + S * ox + (S - 1 - pre)) * Cs + 4 * q;
                 f32x4 acc = *reinterpret_cast<const f32x4*>(bdw + 4 * q);
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
@@ -603,7 +606,8 @@ bool bandnet_pack(const BandStage& st, BandPacked* out) {
         !fits(st.c_floats, 12) || !fits(st.woff, 4) || st.woff >= (1 << st.wshift) || !fits(st.per_ct, 16))
         return false;
     BandPacked p{};
-    p.w[0] = (unsigned)st.kind | (unsigned)st.S << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
+    if (st.pre && (st.S != 2 || st.kind != BAND_BLOCK)) return false;
+    p.w[0] = (unsigned)st.kind | (unsigned)(st.pre ? 3 : st.S) << 1 | (unsigned)st.wshift << 3 | (unsigned)st.res_mode << 7 | (unsigned)st.act << 9 | (unsigned)st.src_tile << 12 |
              (unsigned)(st.dst_tile + 1) << 14 | (unsigned)st.pub_lo << 17 | (unsigned)st.pub_hi << 18 | (unsigned)st.src_base << 19 | (unsigned)(st.dst_base + 1) << 22 |
              (unsigned)st.wpc_shift << 26 | (unsigned)(st.res_tile + 1) << 28 | (unsigned)st.dst_h3 << 31;
     p.w[1] = (unsigned)st.R | (unsigned)st.Rin << 8 | (unsigned)(st.dep + 1) << 16 | (unsigned)st.nbands << 24;

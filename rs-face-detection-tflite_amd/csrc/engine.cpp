@@ -735,7 +735,9 @@ void Model::build_bandnet_try(bool conv2_ok) {
         // joins BEHIND the activation — are stages of the WIDE instantiation when the coarse tensor is the program's (round 6); any other such node ends the program
         const bool up2x = (conv1 || pw_block) && n.res_after && n.res >= 0 && n.res_mode == RES_UP2X && band_wide_ok_ && n.in.size() == 1 && n.ept < 0 &&
                           producer[static_cast<size_t>(n.res)] >= 0 && g.tensors[n.res].shape.size() == 4;
-        if (n.in.size() != 1 || n.ept >= 0 || (n.res_after && !up2x)) {
+        // (full_range_sparse pads its stride-2 blocks explicitly, one pixel in front: the same stage with its window one row / column earlier — round 6)
+        const bool pre = dw_block && n.ept == 1 && n.epl == 1 && n.sh == 2 && n.sw == 2 && n.padding == Padding::Valid && n.res < 0 && band_wide_ok_;
+        if (n.in.size() != 1 || (n.ept >= 0 && !pre) || (n.res_after && !up2x)) {
             if (prog.empty()) BAND_GIVE_UP;
             cut = i;
             break;
@@ -756,8 +758,9 @@ void Model::build_bandnet_try(bool conv2_ok) {
         }
         st.S = 1;
         if (dw_block) {
-            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || n.padding != Padding::Same) BAND_GIVE_UP;
+            if (n.KH != 3 || n.KW != 3 || n.sh != n.sw || (n.sh != 1 && n.sh != 2) || (n.padding != Padding::Same && !pre)) BAND_GIVE_UP;
             st.S = n.sh;
+            st.pre = pre ? 1 : 0;
             if (st.S == 2 && ((st.H & 1) || (st.W & 1))) BAND_GIVE_UP;
             if (st.Ho != st.H / st.S || st.Wo != st.W / st.S) BAND_GIVE_UP;
         } else if (conv2) {
@@ -787,7 +790,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
                 // pair's input, zero-padded from its res_c channels to Co)
                 if (st.S != 1 || sr.size() != 4 || sr[1] != 2 * st.Ho || sr[2] != 2 * st.Wo || sr[3] > st.Co || (sr[3] & 3) || d < 0) BAND_GIVE_UP;
                 const BandStage& cv = prog[static_cast<size_t>(d)];
-                if (cv.S != 2 || cv.dep < 0 || cv.dep != producer[static_cast<size_t>(n.res)]) BAND_GIVE_UP;
+                if (cv.S != 2 || cv.pre || cv.dep < 0 || cv.dep != producer[static_cast<size_t>(n.res)]) BAND_GIVE_UP;
                 st.res_dep = cv.dep;
                 st.res_mode = RES_MAXPOOL;
                 st.res_c = sr[3];
@@ -830,10 +833,10 @@ void Model::build_bandnet_try(bool conv2_ok) {
                 const int r0 = b * st.R, nro = std::min(st.Ho, r0 + st.R) - r0, p0 = st.S * r0;
                 if (((p0 / pd.R) << pd.wshift) != (b << st.wshift) || p0 % pd.R) BAND_GIVE_UP;
                 const int rin = std::min(pd.R, st.H - p0);
-                const int yb = dw_block ? (st.S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1) : (conv2 ? p0 + 2 * nro : p0 + nro);
+                const int yb = dw_block ? (st.S == 1 ? p0 + nro + 1 : p0 + 2 * nro + 1 - st.pre) : (conv2 ? p0 + 2 * nro : p0 + nro);
                 const int below = yb - (p0 + rin);
                 if (below < 0 || below > 2) BAND_GIVE_UP;
-                if (((dw_block && st.S == 1 ? 1 : 0) + below) * st.W * (st.C / 4) > 4 * 512) BAND_GIVE_UP;   // the halo rows: four 16-byte elements per lane
+                if (((dw_block && (st.S == 1 || st.pre) ? 1 : 0) + below) * st.W * (st.C / 4) > 4 * 512) BAND_GIVE_UP;   // the halo rows: four 16-byte elements per lane
             }
         }
         // a plain copy of the output where it is a graph output (through the reshape / concatenation views behind it)
@@ -1136,7 +1139,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
             if (st.cross) pd.pub_lo = 1;   // (one-row bands: all of the tensor)
             if ((st.kind == BAND_BLOCK || cv2_halo) && pd.nbands > 1) {
                 pd.pub_lo = 1;
-                if (st.kind == BAND_BLOCK && st.S == 1 && pd.R > 1) pd.pub_hi = 1;
+                if (st.kind == BAND_BLOCK && (st.S == 1 || st.pre) && pd.R > 1) pd.pub_hi = 1;
             }
             }
         } else {
@@ -1157,7 +1160,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
     // stride-2 BLOCK reads the tensor.
     std::vector<char> read_s2(static_cast<size_t>(NS), 0);
     for (const BandStage& st : prog)
-        if (st.kind == BAND_BLOCK && st.S == 2 && st.dep >= 0) read_s2[static_cast<size_t>(st.dep)] = 1;
+        if (st.kind == BAND_BLOCK && st.S == 2 && !st.pre && st.dep >= 0) read_s2[static_cast<size_t>(st.dep)] = 1;
     struct Alloc { int off, size, stage; };   // stage: producer (-1: the program's input, -3: a far input held for one stage)
     auto dead_at = [&](const Alloc& al, int k) { return al.stage == -3 || (al.stage == -1 ? input_last_reader <= k : last_reader[static_cast<size_t>(al.stage)] <= k); };
     // The places are found first, for the smallest arena that takes them: a tensor goes to the lowest or to the highest gap that holds it, whichever leaves
@@ -1322,7 +1325,7 @@ void Model::build_bandnet_try(bool conv2_ok) {
     for (const BandStage& st : prog) band_xb_ = band_xb_ || (st.kind == BAND_BLOCK && st.cross);
     if (band_cv2_ && band_xb_) BAND_GIVE_UP;   // (no kernel instantiation for both: the iris network's second branch starts with a 1x1 stage)
     band_wide_ = false;
-    for (const BandStage& st : prog) band_wide_ = band_wide_ || st.C > 128 || st.Co > 128 || st.res_mode == RES_UP2X;
+    for (const BandStage& st : prog) band_wide_ = band_wide_ || st.C > 128 || st.Co > 128 || st.res_mode == RES_UP2X || st.pre;
     if (band_wide_ && (band_cv2_ || band_xb_)) BAND_GIVE_UP;   // (likewise)
     band_lds_bytes_ = bandnet_lds_bytes(tiles_floats, dw_floats, NS);
     if (std::getenv("MI_BAND_DEBUG")) {

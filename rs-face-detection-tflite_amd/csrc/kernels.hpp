@@ -479,6 +479,8 @@ struct alignas(16) BandStage {
                                  // tensor of twice the size in this tile (the input of the 2x2 convolution in front of this block)
     int cross = 0;               // (host only) the stage reads a tensor of the other branch's workgroups: Rin = 0, every row from the packets
     int src_lds = 0, dst_lds = 0, res_lds = 0;   // LDS floats in front of the input / output / skip tile (multiples of 16; placed by liveness in build_bandnet)
+    int pre = 0;                 // a stride-2 BLOCK whose 3x3 window starts at row / column 2r - 1 (an explicit zero pad of one pixel in front, VALID behind it:
+                                 // full_range_sparse); the WIDE instantiation only
     int dst_h3 = 0;              // the output tile has R + 3 rows (a stride-2 block reads the tensor: two rows below the band), else R + 2
     int far_src = 0;             // (host only) the stage reads its input — rows this workgroup wrote itself, many stages ago — back from the launch's workspace instead
                                  // of keeping the tile alive (full_range's lateral convolutions read trunk tensors 10 - 30 stages old); packed with dep = -1

@@ -181,6 +181,13 @@ class GraphBuilder:
         self.ops.append((PAD, [x, p], [y], OPT_PAD, []))
         return y
 
+    def pad_spatial(self, x, top, bottom, left, right):
+        n, h, w, c = self.shape(x)
+        p = self.const(np.array([[0, 0], [top, bottom], [left, right], [0, 0]]), "pads", dtype=2)
+        y = self._act([n, h + top + bottom, w + left + right, c], "pad")
+        self.ops.append((PAD, [x, p], [y], OPT_PAD, []))
+        return y
+
     def reshape(self, x, shape):
         s = self.const(np.array(shape), "shape", dtype=2)
         y = self._act(list(shape), "reshape")
@@ -333,6 +340,21 @@ def full_like(seed, size, c=32, cm=12):
     return g.finish()
 
 
+def sparse_like(seed, h, w, c=32, cm=12):
+    """full_range_sparse's down-sampling: the stride-2 depthwise stage reads an explicitly padded input (PAD of one pixel all round, VALID behind it:
+    its window starts at row / column 2r - 1, not 2r as SAME's does), no skip around the pair."""
+    g = GraphBuilder(seed, [1, h, w, 3])
+    x = g.relu(g.conv(g.input, c, 3, 2))
+    x = g.double_block(x, cm)
+    a = g.relu(g.conv(g.dw(g.pad_spatial(x, 1, 1, 1, 1), 3, 2, VALID), cm + 4))
+    x = g.relu(g.conv(g.dw(a), 2 * c))
+    x = g.double_block(x, cm * 2)
+    a = g.relu(g.conv(g.dw(g.pad_spatial(x, 1, 1, 1, 1), 3, 2, VALID), 2 * cm))
+    x = g.relu(g.conv(g.dw(a), 3 * c))
+    g.outputs = [g.conv(x, 6)]
+    return g.finish()
+
+
 def full_tail(seed, h, w, cn=32, cw=128, cp=64, pairs=2, pointwise_last=True):
     """full_range's coarsest resolution: a narrow tensor from a stride-2 block, an expand block whose skip is the max-pooled, channel-padded
     previous resolution, `pairs` double blocks (wide -> narrow -> wide, skip around both), a contract block (pointwise only, as in the
@@ -398,4 +420,7 @@ CASES = {
     "full_tail_5x7": (lambda: full_tail(36, 20, 28, 48, 328, 24, 1), 20, 28),                  # 35 pixels (partial second group), 328 wide channels = 10.25 tiles, 6 k-chunks per stage-1 wave
     "full_64": (lambda: full_like(31, 64), 64, 64),                                        # double blocks, odd middle widths
     "full_80_c48": (lambda: full_like(32, 80, 48, 20), 80, 80),
+    # round 6: explicitly padded stride-2 blocks (full_range_sparse), one-row bands and — 256 rows on 128 workgroups — two-row bands whose LAST row travels
+    "sparse_64": (lambda: sparse_like(37, 64, 64), 64, 64),
+    "sparse_512x48_two_row_bands": (lambda: sparse_like(38, 512, 48, 24, 8), 512, 48),
 }

@@ -35,8 +35,8 @@ python3 tools/summarize_profiles.py "$TAG" "$OUT/summary" > "$OUT/summarize.log"
 {
   echo "# per-launch HIP-event times at a batch of ONE frame (tools/profile_model.py <model> 1): the batched plan, and for the graphs that have one"
   echo "# the single-launch plan the single-image entries take (option band=2 makes every small run take it)"
-  for m in back front short full landmark iris; do echo "== $m 1 (batched plan)"; python3 tools/profile_model.py $m 1 band=0 2>/dev/null | grep -v amdgpu; done
-  for m in back front short landmark iris; do echo "== $m 1 (single-launch plan)"; python3 tools/profile_model.py $m 1 band=2 2>/dev/null | grep -v amdgpu; done
+  for m in back front short full sparse landmark iris; do echo "== $m 1 (batched plan)"; python3 tools/profile_model.py $m 1 band=0 2>/dev/null | grep -v amdgpu; done
+  for m in back front short full sparse landmark iris; do echo "== $m 1 (single-launch plan)"; python3 tools/profile_model.py $m 1 band=2 2>/dev/null | grep -v amdgpu; done
   echo; echo "# tools/latency_probe.py: per call, host Mat in, results out (us); then the same calls timed at the C ABI"
   python3 tools/latency_probe.py 2>/dev/null | grep -v amdgpu
 } > "$OUT/summary/${TAG}_launches_batch1.txt"; echo batch-1 lists done

@@ -31,7 +31,7 @@ def measure(n=300):
     jpg = open(os.path.join(ROOT, "tests", "golden", "man.jpg"), "rb").read()
     img = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "man.jpg")).convert("RGB"))
     out = {}
-    for kind in ("BackCamera", "Short", "Full"):
+    for kind in ("BackCamera", "Short", "Full", "FullSparse"):
         fd = mi.FaceDetection(getattr(mi.FaceDetectionModel, kind))
         out["FaceDetection::infer %s (man.jpg 540x360, Mat in host memory)" % kind] = timed(lambda: fd.infer(img, None), n)
         if kind == "BackCamera":
@@ -92,7 +92,7 @@ def measure_c_abi(n=300):
     h, w = img.shape[:2]
     p = C.c_void_p(img.ctypes.data)
     out = {}
-    for kind in ("BackCamera", "Short", "Full"):
+    for kind in ("BackCamera", "Short", "Full", "FullSparse"):
         fd = mi.FaceDetection(getattr(mi.FaceDetectionModel, kind))
         dets, cnt = (api.CDetection * 256)(), C.c_int()
         def call():
