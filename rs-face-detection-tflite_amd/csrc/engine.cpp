@@ -77,6 +77,8 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "pipe_rows") { pipe_rows_ = (value == 1 || value == 2 || value == 4) ? value : 0; }     // 1: one row per pipeline step (strip_pipe_kernel), 2: two rows, packed-FMA pointwise convs (strip_pipe2_kernel), 4: one row, MFMA pointwise convs (strip_pipe1m_kernel)
     else if (key == "pipe_band") { pipe_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the row pipelines (0: automatic)
     else if (key == "strip") { strip_ = value != 0; }
+    else if (key == "stem_fuse") { stem_fuse_ = value != 0; }   // 0: the first convolution keeps its own launch in front of the face mesh's block pair (mdblock_kernel<stem+pair>, round 6)
+    else if (key == "mdb_band") { mdb_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the mdblock_kernel launches (0: chosen per launch)
     else if (key == "mchain") { mchain_ = value != 0; }   // 0: the 32x32x48 blocks run one launch each (mstrip_kernel) instead of one launch per run
     else if (key == "tail") { tail_ = value != 0; dirty_ = true; }   // 0: no stage program runs on tail_kernels.hip (the round-4 plan)
     else if (key == "tail_pre") { tail_pre_ = std::max(0, std::min(value, 2)); }   // tail programs: 0 = chosen per launch, 1 = constants a stage ahead (one workgroup per CU), 2 = 128 registers (two per CU)
@@ -107,6 +109,8 @@ int Model::get_option(const std::string& key) const {
     if (key == "pipe_rows") return pipe_rows_;
     if (key == "pipe_band") return pipe_band_;
     if (key == "strip") return strip_;
+    if (key == "stem_fuse") return stem_fuse_;
+    if (key == "mdb_band") return mdb_band_;
     if (key == "mchain") return mchain_;
     if (key == "tail") return tail_;
     if (key == "tail_pre") return tail_pre_;
@@ -150,6 +154,7 @@ void Model::rebuild() {
     chain_head_off_.assign(NN, {});
     node_strip_.assign(NN, -1);
     node_mwalk_.assign(NN, -1);
+    node_stem_.assign(NN, -1);
     res_cblob_.assign(NN, {});
     res_wblk_.assign(NN, {});
     tail_wa_.assign(NN, {});
@@ -451,6 +456,16 @@ void Model::rebuild() {
                         for (int c = 0; c < I; c++)
                             r[((static_cast<size_t>(ky) * KW + kx) * I + c) * Cop + o] = src[((static_cast<size_t>(o) * KH + ky) * KW + kx) * I + c];
             node_w_[i] = put(r);
+            // the face mesh's first convolution can run inside the launch of the block pair behind it (mdblock_kernels.hip, MD::STEM)
+            const auto& sxi = g.tensors[n.in[0]].shape;
+            const auto& sxo = g.tensors[n.out].shape;
+            if (sxi.size() == 4 && sxo.size() == 4 && n.padding == Padding::Same && n.ept < 0 && n.res < 0 && n.in[0] == g.inputs[0] &&
+                (n.act == ACT_NONE || n.act == ACT_RELU || n.act == ACT_RELU6 || n.act == ACT_PRELU) &&
+                mdblock_stem_shape_ok(sxi[1], sxi[2], sxi[3], n.KH, n.KW, n.sh, n.sw, sxo[1], sxo[2], sxo[3])) {
+                std::vector<float> sc(static_cast<size_t>(mdblock_stem_consts_floats()));
+                mdblock_pack_stem(src.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, n.act == ACT_PRELU && n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
+                node_stem_[i] = put(sc);
+            }
         } else if (n.kind == Node::Dw) {
             node_w_[i] = put(g.tensors[n.w].f32);
         } else if (n.kind == Node::Block) {
@@ -1681,6 +1696,41 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     if (labels) labels->back() = F <= 4 ? "head_dot_kernel" : "head_gemm_kernel";   // (launch_head_gemm: a handful of frames take the dot-product form)
                     break;
                 }
+                // the first convolution inside the launch of the pair of BlazeBlocks behind it (f32 pictures, from 32 frames on: mdblock_kernels.hip, MD::STEM)
+                if (strip_ && stem_fuse_ && node_stem_[i] >= 0 && !u8_.frames && !(n.act == ACT_PRELU && n.alpha < 0)) {
+                    size_t j = i + 1;
+                    while (j < plan_.nodes.size() && (plan_.nodes[j].kind == Node::Reshape || plan_.nodes[j].kind == Node::Concat)) j++;
+                    int readers = 0;
+                    for (const Node& m : plan_.nodes) {
+                        for (int t : m.in) readers += t == n.out ? 1 : 0;
+                        if (m.res == n.out) readers++;
+                    }
+                    bool is_out = false;
+                    for (int t : g.outputs) is_out = is_out || plan_.storage[t].root == plan_.storage[n.out].root;
+                    if (j == i + 1 && j < plan_.nodes.size() && plan_.nodes[j].kind == Node::Chain && node_mwalk_[j] >= 0 && plan_.nodes[j].members.size() == 2 &&
+                        plan_.nodes[j].in[0] == n.out && readers == 1 && !is_out && !event_after_[i] && head_slot_[j] < 0) {
+                        const Node& c = plan_.nodes[j];
+                        const auto& co = g.tensors[c.out].shape;
+                        DblockArgs d;
+                        long ofs = 0;
+                        d.out = tensor_ptr_mut(c.out, chunk_start, &ofs); d.out_fs = ofs;
+                        d.B = F; d.H = so[1]; d.W = so[2]; d.C = so[3]; d.Cm = g.tensors[c.members[0].out].shape[3]; d.Co = co[3];
+                        d.hi1 = c.members[0].act == ACT_RELU6 ? 6.f : INFINITY;
+                        d.hi2 = c.members[1].act == ACT_RELU6 ? 6.f : INFINITY;
+                        d.skip1 = 1; d.skip2_from_a = 1;
+                        d.act1 = c.members[0].act; d.act2 = c.members[1].act;
+                        d.mconsts = d_weights_ + node_mwalk_[j];
+                        d.stem_in = ip; d.stem_in_fs = in_fs; d.stem_consts = d_weights_ + node_stem_[i];
+                        d.stem_hi = n.act == ACT_RELU6 ? 6.f : INFINITY;
+                        d.band_rows = mdb_band_;
+                        if (mdblock_kernel_supports(d)) {
+                            if (labels) labels->back() = "mdblock_kernel<stem+pair>";
+                            rc = launch_mdblock(d, s);
+                            fused_behind = 1;
+                            break;
+                        }
+                    }
+                }
                 ConvArgs a;
                 a.in = ip; a.out = op; a.in_fs = in_fs; a.out_fs = out_fs;
                 a.w = d_weights_ + node_w_[i];
@@ -1885,6 +1935,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     d.skip1 = 1; d.skip2_from_a = 1;
                     d.act1 = n.members[0].act; d.act2 = n.members[1].act;
                     d.mconsts = d_weights_ + node_mwalk_[i];
+                    d.band_rows = mdb_band_;
                     if (mdblock_kernel_supports(d)) {
                         if (labels) labels->back() = "mdblock_kernel<pair>";
                         rc = launch_mdblock(d, s);

@@ -407,6 +407,12 @@ struct DblockArgs {
     float hi1 = 0.f, hi2 = 0.f;
     const float* mconsts = nullptr; // mdblock_pack_consts() blob when the layer has an mdblock_kernels.hip form (else null)
     int act1 = ACT_RELU, act2 = ACT_RELU;
+    // mdblock_kernels.hip, pair form behind the network's first convolution (MD::STEM, round 6): that convolution runs inside the launch — `in` is never read
+    const float* stem_in = nullptr;      // [B][2 H][2 W][3] f32
+    long stem_in_fs = 0;
+    const float* stem_consts = nullptr;  // mdblock_pack_stem()
+    float stem_hi = 0.f;                 // upper clamp of its activation
+    int band_rows = 0;                   // mdblock_kernels.hip: rows per band (0: chosen by the launcher)
 };
 bool dblock_kernel_supports(const DblockArgs& a);
 // mdblock_kernels.hip: the double blocks of the 96- and 48-pixel-wide layers with both pointwise convs as 16x16x4 MFMAs in the
@@ -417,6 +423,9 @@ int mdblock_consts_floats(int W, int C, int Cm, int Co, bool pair = false);
 void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1,
                          const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst, bool pair = false);
 bool mdblock_kernel_supports(const DblockArgs& a);
+bool mdblock_stem_shape_ok(int H, int W, int C, int KH, int KW, int sh, int sw, int Ho, int Wo, int Co);
+int mdblock_stem_consts_floats();
+void mdblock_pack_stem(const float* w, const float* bias, const float* alpha, int act, float* dst);
 int launch_mdblock(const DblockArgs& a, void* stream);
 int dblock_const_floats(int C, int Cm, int Co);
 int launch_dblock(const DblockArgs& a, void* stream);

@@ -48,15 +48,25 @@ struct MdbArgs {
     int B, H;
     int bands, band_rows;
     float hi1, hi2;        // upper clamps of the two activations (6 for ReLU6, +inf otherwise)
+    // STEM (round 6): `in` does not exist — x = act0(conv3x3 stride 2 (img) + b0) is computed row by row from the picture itself
+    const float* sin;      // [B][2 H][2 W][3] f32
+    const float* sconsts;  // mdblock_pack_stem(): A0 [7][64] | bias0 [16] | slope0 [16]
+    long sin_fs;
+    float hi0;
 };
 
 // CK1 = C / 4 k-steps of stage 1, CK2 = Cm / 4 of stage 2, MT2 = Co / 16 output tiles, WT pixel tiles per wave, NWV waves per workgroup
 // DPX: pixels per LDS-DMA instruction; NF: frames per workgroup (NF x NWV waves share the constants); PW1: stage 1 is pointwise only
 // (the bottleneck pair of the iris network: a = act1(W1 . x + b1), mbneck_kernel below)
 // PAIR: two plain BlazeBlocks in a row instead of the double block — a = act1(.. + x), y = act2(.. + a): each stage adds its own input
-template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false, int DPX_ = 4, int NF_ = 1, bool PW1_ = false, bool PAIR_ = false>
+// STEM: the network's first convolution (3 x 3, stride 2, RGB -> C = 16, SAME: one zero column / row behind the picture) runs inside this launch: a wave
+// computes ITS 16 WT pixels of x row r + 1 while it works on row r — the 27 values of a pixel's window are the contraction (7 k-steps of
+// v_mfma_f32_16x16x4_f32, B operands straight from global memory: lane (kq, p) reads value 4 ks + kq of pixel p's window), the result tile (4 consecutive
+// channels of a pixel per lane) goes to the x row image the DMA would have filled.  The 96 x 96 x 16 tensor is never written nor read.
+template <int CK1_, int CK2_, int MT2_, int WT_, int NWV_, bool TAPL2_ = false, int DPX_ = 4, int NF_ = 1, bool PW1_ = false, bool PAIR_ = false, bool STEM_ = false>
 struct MD {
-    static constexpr bool PAIR = PAIR_;
+    static constexpr bool PAIR = PAIR_, STEM = STEM_;
+    static constexpr int SK = 7, STEM_F = STEM_ ? SK * 64 + 32 : 0;   // stem constants behind the row images
     static constexpr int CK1 = CK1_, CK2 = CK2_, MT2 = MT2_, WT = WT_, NWV = NWV_, NF = NF_;
     static constexpr bool TAPL2 = TAPL2_;   // stage 2's taps stay in LDS (the registers do not hold 9 x (CK1 + CK2) taps beside the accumulators)
     static constexpr bool PW1 = PW1_;
@@ -72,7 +82,8 @@ struct MD {
     // constants blob (floats): A1 [CK1][MT1][64] | A2 [CK2][MT2][64] | taps1 [CK1][4][12] | taps2 [CK2][4][12] | bias1 [16 MT1] | slope1 [16 MT1] | bias2 [Co] | slope2 [Co]
     static constexpr int OFF_A1 = 0, A1_F = CK1 * MT1 * 64, OFF_A2 = A1_F, A2_F = CK2 * MT2 * 64, OFF_T1 = OFF_A2 + A2_F, T1_F = PW1 ? 0 : CK1 * 48, OFF_T2 = OFF_T1 + T1_F, T2_F = CK2 * 48;
     static constexpr int OFF_B1 = OFF_T2 + T2_F, OFF_S1 = OFF_B1 + 16 * MT1, OFF_B2 = OFF_S1 + 16 * MT1, OFF_S2 = OFF_B2 + Co, TOTAL = OFF_S2 + Co;
-    static constexpr int LDS_F = TOTAL + NF * (2 * XIMG_F + 2 * AIMG_F);
+    static constexpr int LDS_F = TOTAL + NF * (2 * XIMG_F + 2 * AIMG_F) + STEM_F;
+    static_assert(!STEM_ || (CK1_ == 4 && NF_ == 1), "stem: 16 output channels");
 };
 
 template <class K, bool RELU>
@@ -90,7 +101,63 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     const int band = blockIdx.x / a.B, b = blockIdx.x - band * a.B;
     const int y0 = band * a.band_rows, y1 = min(y0 + a.band_rows, a.H);
     const int x0 = wave * K::SW;            // this wave's pixels [x0, x0 + SW)
-    const float* in = a.in + (long)b * a.in_fs;
+    const float* in = K::STEM ? nullptr : a.in + (long)b * a.in_fs;
+    // ---- STEM: this wave's 16 WT pixels of an x row from the picture
+    float* wst = aimg + 2 * AIMG_F;         // [A0 SK x 64][bias0 16][slope0 16]
+    const float* sin = K::STEM ? a.sin + (long)b * a.sin_fs : nullptr;
+    constexpr int SKN = K::STEM ? K::SK : 1, SWT = K::STEM ? WT : 1;
+    float sb[SWT][SKN];                     // B operands of the row in flight: issued at the top of a step, consumed at its end
+    // Per lane and k-step, fixed for the whole launch: the byte offset of value 4 ks + kq of pixel x0 + p's window from the start of picture row 2 r.  The loads
+    // are buffer loads — resource = this frame's picture, scalar offset = the row, vector offset = that register [+ 384 for the second tile]: no address
+    // arithmetic per row, and the zero ROW behind the picture (ky = 2 of x row H - 1) is what a buffer load returns behind the end of its resource.  The zero
+    // COLUMN (kx = 2 of the picture's last pixel: the last lane of the last wave's last tile) is the next row's first pixel in memory: a bit mask over the
+    // k-steps replaces those values at the MFMA.  (The first version computed (ky, kx, channel) and both conditions per row: 250 VALU operations a row,
+    // 0.284 ms against 0.277 for the two launches.)
+    int voff[SKN];
+    unsigned zcm = 0;
+    if constexpr (K::STEM) {
+#pragma unroll
+        for (int ks = 0; ks < SKN; ks++) {
+            const int k = min(4 * ks + kq, 26);           // (value 27 does not exist: its A operand is zero)
+            const int ky = k >= 18 ? 2 : (k >= 9 ? 1 : 0), kr = k - 9 * ky;
+            voff[ks] = (ky * (2 * W * 3) + kr + 6 * (x0 + p)) * 4;
+            zcm |= (kr >= 6 && x0 + 16 * (WT - 1) + p == W - 1 ? 1u : 0u) << ks;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(K::STEM ? sin : a.consts), 0, K::STEM ? 2 * a.H * 2 * W * 3 * 4 : 0, 0x00020000);
+    auto stem_load = [&](int rr) {
+        const int rc = min(max(rr, 0), a.H - 1);   // (rows outside the image: any row — the result is replaced by zeros)
+        const int soff = 2 * rc * (2 * W * 3) * 4;
+#pragma unroll
+        for (int ks = 0; ks < SKN; ks++)
+#pragma unroll
+            for (int nt = 0; nt < SWT; nt++) sb[nt][ks] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(srsrc, voff[ks] + 384 * nt, soff, 0));
+    };
+    auto stem_emit = [&](int rr, int slot) {
+        float* dstp = ximg + slot * XIMG_F + (1 + x0 + p) * PS + 4 * kq;
+        const bool inside = rr >= 0 && rr < a.H;   // rows outside the image are the depthwise convolution's zero padding
+        const float4 bs = *reinterpret_cast<const float4*>(wst + K::SK * 64 + 4 * kq), sl = *reinterpret_cast<const float4*>(wst + K::SK * 64 + 16 + 4 * kq);
+        df32x4 D0[SWT];
+#pragma unroll
+        for (int nt = 0; nt < SWT; nt++) D0[nt] = df32x4{bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int ks = 0; ks < SKN; ks++) {
+            const float a0 = wst[ks * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < SWT; nt++) {
+                const bool z = nt == SWT - 1 && ((zcm >> ks) & 1u) != 0u;
+                D0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, z ? 0.f : sb[nt][ks], D0[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < SWT; nt++) {
+            const df32x4 v = D0[nt];
+            float4 o = make_float4(fminf(fmaxf(v.x, 0.f) + sl.x * fminf(v.x, 0.f), a.hi0), fminf(fmaxf(v.y, 0.f) + sl.y * fminf(v.y, 0.f), a.hi0),
+                                   fminf(fmaxf(v.z, 0.f) + sl.z * fminf(v.z, 0.f), a.hi0), fminf(fmaxf(v.w, 0.f) + sl.w * fminf(v.w, 0.f), a.hi0));
+            if (!inside) o = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(dstp + 16 * nt * PS) = o;
+        }
+    };
 
     // ---- LDS-DMA of this wave's part of one input row: instruction k brings in pixels [x0 + 4 k, x0 + 4 k + 4): lane -> (pixel
     // lane / QP, quad min(lane % QP, CK1 - 1)), lanes >= 4 QP idle; the immediate offset moves source and destination alike, M0 makes
@@ -98,6 +165,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     const int goff = ((lane / QP) * C + 4 * min(lane % QP, CK1 - 1)) * 4;
     const unsigned lds_x = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ximg);
     auto issue_row = [&](int r, int slot) {
+        if constexpr (K::STEM) return;
         const char* src = reinterpret_cast<const char*>(in + ((long)min(max(r, 0), a.H - 1) * W + x0) * C);
         const unsigned dstb = lds_x + (unsigned)((slot * XIMG_F + (1 + x0) * PS) * 4);
         unsigned long long saved;
@@ -123,7 +191,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     };
     // rows outside the image are zero padding: the landed (clamped) row is cleared before anybody reads it
     auto fix_row = [&](int r, int slot) {
-        if (r >= 0 && r < a.H) return;  // wave-uniform
+        if (K::STEM || (r >= 0 && r < a.H)) return;  // wave-uniform
         float zz = 0.f;
         asm volatile("" : "+v"(zz));
         const float4 z = make_float4(zz, zz, zz, zz);
@@ -151,11 +219,15 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     // flight when the row loop starts (vector-memory operations retire in issue order; the loop's counted waits assume that nothing
     // else is outstanding)
     issue_row(y0 - 2, 0);
+    if constexpr (K::STEM) stem_load(y0 - 2);
     for (int i = threadIdx.x; i < K::TOTAL / 4; i += NWV * 64) reinterpret_cast<float4*>(wgc)[i] = reinterpret_cast<const float4*>(a.consts)[i];
+    if constexpr (K::STEM)
+        for (int i = threadIdx.x; i < K::STEM_F / 4; i += NWV * 64) reinterpret_cast<float4*>(wst)[i] = reinterpret_cast<const float4*>(a.sconsts)[i];
     issue_row(y0 - 1, 1);
-    dwait_vm<NLD>();
-    dwg_barrier();
+    if constexpr (K::STEM) __syncthreads();   // (the constants: also drains the loads above)
+    else { dwait_vm<NLD>(); dwg_barrier(); }
     asm volatile("" ::: "memory");
+    if constexpr (K::STEM) stem_emit(y0 - 2, 0);   // x row y0 - 2: complete for everybody at step 0's barrier
     // depthwise taps of this lane's channels: tap[ks][t] = w_dw[t][4 ks + kq], resident in registers for the whole kernel
     dv2f tap1[CK1][5], tap2[K::TAPL2 ? 1 : CK2][5];
     dload_taps<CK1>(reinterpret_cast<const float4*>(wgc + K::OFF_T1) + kq * 3, tap1);
@@ -253,6 +325,7 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     constexpr int NST = MT2 * WT;
     const int TL = (y1 - y0) + 3;   // last step; step t handles x row y0 - 2 + t, a row y0 - 3 + t (from t = 2), y row y0 - 4 + t (from t = 4)
     auto wait_row = [&](int t) {
+        if constexpr (K::STEM) return;   // (no DMA: the compiler counts the loads and stores it sees)
         const bool st = t - 1 >= 4, dm = t == 0 || t + 1 <= TL;  // step 0: the prologue's second row is behind it
         if (st && dm) dwait_vm<NST + NLD>();
         else if (dm) dwait_vm<NLD>();
@@ -263,9 +336,10 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
     auto step = [&](auto e1c, auto e2c, int t, RowAcc<WT> (&q1PN)[CK1], RowAcc<WT> (&q1C)[CK1], RowAcc<WT> (&q2PN)[CK2], RowAcc<WT> (&q2C)[CK2], df32x4 (&P)[MT2][WT]) {
         constexpr bool E1 = decltype(e1c)::value, E2 = decltype(e2c)::value;
         const int r = y0 - 2 + t, slot = t & 1;
+        if constexpr (K::STEM) stem_load(r + 1);   // the picture's values for x row r + 1: on their way during this step
         wait_row(t);
         fix_row(r, slot);
-        dwg_barrier();   // x row r is complete (every wave's part has landed and is fixed)
+        dwg_barrier();   // x row r is complete (every wave's part has landed and is fixed / with STEM: was written in the previous step)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (E1 && !K::PAIR) init_D1(slot);
         mdb_row<CK1, MT1, WT, PS, E1>(x_lds + (unsigned)(slot * XIMG_F * 4), a1_lds, tap1, q1PN, q1C, D1);
@@ -297,7 +371,10 @@ __global__ __launch_bounds__(K::NWV * 64, 2) void mdblock_kernel(MdbArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         dwave_sync();      // every read of x image `slot` by this wave is issued before the DMA below overwrites this wave's part of it
         __builtin_amdgcn_s_waitcnt(0xC07F);  // ... and has returned (the other waves read row r's halo pixels before the a-row barrier)
-        if (t + 2 <= TL) issue_row(r + 2, slot);
+        if constexpr (K::STEM) {
+            // x row r + 1 -> the other image: its last readers (row r - 1: stage 1 and the skips) passed the previous step's a-row barrier
+            stem_emit(r + 1, slot ^ 1);   // (also in the last step: a row nobody reads)
+        } else if (t + 2 <= TL) issue_row(r + 2, slot);
     };
     const std::false_type F{};
     const std::true_type T{};
@@ -561,6 +638,7 @@ using MD48a = MD<12, 3, 3, 1, 3>;  // 48 x 48: 48 -> 12 -> 48
 using MD48b = MD<12, 4, 4, 1, 3>;  // 48 x 48: 48 -> 16 -> 64
 using MD48c = MD<12, 6, 3, 1, 3, true>;  // 48 x 48: 48 -> 24 -> 48
 using MP96 = MD<4, 4, 1, 2, 3, false, 8, 1, false, true>;  // 96 x 96: two BlazeBlocks 16 -> 16 -> 16 (face mesh)
+using MP96S = MD<4, 4, 1, 2, 3, true, 8, 1, false, true, true>;  // ... with the network's first convolution (192 x 192 x 3 -> 96 x 96 x 16) in front, in the same launch
 
 template <class K>
 void mdb_pack(const float* w_dw1, const float* b_dw1, const float* w_pw1, const float* b1, const float* alpha1, int act1, const float* w_dw2, const float* b_dw2,
@@ -607,6 +685,7 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
     ma.in = a.in; ma.out = a.out; ma.consts = a.mconsts; ma.in_fs = a.in_fs; ma.out_fs = a.out_fs;
     ma.B = a.B; ma.H = a.H;
     ma.hi1 = a.hi1; ma.hi2 = a.hi2;
+    ma.sin = a.stem_in; ma.sconsts = a.stem_consts; ma.sin_fs = a.stem_in_fs; ma.hi0 = a.stem_hi;
     // bands: enough workgroups for every CU to hold as many as its LDS takes; a band costs four priming steps
     static const int forced = getenv("MI_MDB_BAND") ? atoi(getenv("MI_MDB_BAND")) : 0;  // tuning aid
     // (the pair form on 16 channels needs ~160 registers: three waves per SIMD)
@@ -615,6 +694,7 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
     int rows = (int)((a.H + bands - 1) / bands);
     rows = std::max(rows, std::min(a.H, 8));
     if (forced > 0) rows = std::min(forced, a.H);
+    if (a.band_rows > 0) rows = std::min(a.band_rows, a.H);
     ma.band_rows = rows;
     ma.bands = (a.H + rows - 1) / rows;
     const bool relu = a.act1 == ACT_RELU && a.act2 == ACT_RELU;
@@ -635,7 +715,7 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
 int mdb_shape(int W, int C, int Cm, int Co, bool pair = false) {
     static const bool off = getenv("MI_NO_MDBLOCK") != nullptr;  // tuning aid: the LDS-tensor double-block kernel instead
     if (off) return 0;
-    if (pair) return (W == 96 && C == 16 && Cm == 16 && Co == 16) ? 5 : 0;
+    if (pair) return (W == 96 && C == 16 && Cm == 16 && Co == 16) ? 5 : 0;   // (6: the same behind the first convolution, launch_mdblock)
     if (W == 96 && C == 32 && Cm == 8 && Co == 32) return 1;
     if (W == 48 && C == 48 && Cm == 12 && Co == 48) return 2;
     if (W == 48 && C == 48 && Cm == 16 && Co == 64) return 3;
@@ -679,12 +759,36 @@ bool mdblock_kernel_supports(const DblockArgs& a) {
     static const int min_b = getenv("MI_MDB_MIN_B") ? atoi(getenv("MI_MDB_MIN_B")) : 32;
     if (a.B < min_b) return false;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (a.stem_in)   // the pair behind the first convolution, which runs inside the launch: `in` is not read
+        return mdb_shape(a.W, a.C, a.Cm, a.Co, true) == 5 && a.H == 96 && a.stem_consts && aligned16(a.stem_in) && aligned16(a.stem_consts) && !(a.stem_in_fs & 3) &&
+               aligned16(a.out) && aligned16(a.mconsts) && !(a.out_fs & 3);
     return aligned16(a.in) && aligned16(a.out) && aligned16(a.mconsts) && !(a.in_fs & 3) && !(a.out_fs & 3);
+}
+
+// the face mesh's first convolution as the pair kernel's stage 0 (MD::STEM): 3 x 3, stride 2, SAME, 192 x 192 x 3 -> 96 x 96 x 16
+bool mdblock_stem_shape_ok(int H, int W, int C, int KH, int KW, int sh, int sw, int Ho, int Wo, int Co) {
+    return H == 192 && W == 192 && C == 3 && KH == 3 && KW == 3 && sh == 2 && sw == 2 && Ho == 96 && Wo == 96 && Co == 16;
+}
+int mdblock_stem_consts_floats() { return MP96S::STEM_F; }
+// w [16][3][3][3] (TFLite OHWI), bias [16] or null, alpha [16] or null
+void mdblock_pack_stem(const float* w, const float* bias, const float* alpha, int act, float* dst) {
+    std::fill(dst, dst + MP96S::STEM_F, 0.f);
+    // A operand of k-step ks: lane l holds w[l % 16][4 ks + l / 16] — the window's 27 values in (ky, kx, channel) order, value 27 = 0
+    for (int ks = 0; ks < MP96S::SK; ks++)
+        for (int l = 0; l < 64; l++) {
+            const int k = 4 * ks + (l >> 4);
+            if (k < 27) dst[ks * 64 + l] = w[(size_t)(l & 15) * 27 + k];
+        }
+    for (int c = 0; c < 16; c++) {
+        dst[MP96S::SK * 64 + c] = bias ? bias[c] : 0.f;
+        dst[MP96S::SK * 64 + 16 + c] = act == ACT_PRELU ? alpha[c] : (act == ACT_NONE ? 1.f : 0.f);
+    }
 }
 
 int launch_mdblock(const DblockArgs& a, void* stream) {
     if (!mdblock_kernel_supports(a)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
+    if (a.stem_in) return mdb_launch<MP96S>(a, s);
     switch (mdb_shape(a.W, a.C, a.Cm, a.Co, a.skip1 != 0)) {
         case 5: return mdb_launch<MP96>(a, s);
         case 1: return mdb_launch<MD96>(a, s);

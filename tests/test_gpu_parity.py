@@ -271,7 +271,7 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<pair>", "ms2_kernel<8,4,2>", "ms2_kernel<4,2,3>"]), ("iris", ["mbneck_kernel"])])
+@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<stem+pair>", "ms2_kernel<8,4,2>", "ms2_kernel<4,2,3>"]), ("iris", ["mbneck_kernel"])])
 def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, kernels):
     """The row-walking MFMA kernels of round 3 (mdblock / mwalk / ms2 / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand
     layout) take the wide double blocks and stride-2 blocks of full_range, the 48x48x32 / 24x24x64 blocks, the 96x96x16 block pair and the
@@ -299,6 +299,43 @@ def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, ker
     assert not any(l.startswith(("mdblock", "mwalk", "mbneck", "ms2")) for l in labels0), labels0
     for o, r in zip(m.run(x), outs):
         _raw_close(o, r)
+    m.close()
+
+
+@pytest.mark.parametrize("nb", [32, 61, 200])
+def test_first_convolution_inside_the_block_pair_launch(gpu, oracle, nb):
+    """Round 6: the face mesh's first convolution (3x3 stride 2, 192x192x3 -> 96x96x16, PReLU; face_landmark.rs:265 behind
+    `interpreter.invoke()`) runs inside the launch of the two BlazeBlocks behind it (mdblock_kernel<stem+pair>: a wave computes its pixels of x row
+    r + 1 from the picture — 7 k-steps of v_mfma_f32_16x16x4_f32 over the window's 27 values, B operands straight from global memory — while it works on
+    row r; the 96x96x16 tensor is neither written nor read).  Against the oracle frame by frame, against the plan with the convolution as a launch of its own
+    (option stem_fuse = 0), with pictures whose last row / column (the SAME padding's zero row / column lies behind them) and first row carry large values, band
+    sizes that end ragged, and through the u8 entry (which keeps the separate launch)."""
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path("landmark"))
+    x = seeded_input("landmark", nb, 99 + nb, m.input_dims[1:3])
+    x[1, -1, :, :] = 7.0          # the last row and column: the window of output row / column 95 ends one pixel behind them
+    x[1, :, -1, :] = -5.0
+    x[2, 0, :, :] = 9.0
+    x[3] = 0.0
+    om = oracle.Model(model_path("landmark"))
+    refs = om.run(x, nthreads=8)
+    outs = [o.copy() for o in m.run(x)]
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert labels[0] == "mdblock_kernel<stem+pair>" and labels[1] == "ms2_kernel<4,2,3>", labels
+    for o, r in zip(outs, refs):
+        _raw_close(o, r)
+    for o, o2 in zip(outs, m.run(x)):
+        np.testing.assert_array_equal(o, o2)
+    m.set_option("stem_fuse", 0)
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert labels[0].startswith("stem_conv_kernel") and labels[1] == "mdblock_kernel<pair>", labels
+    for o, r in zip(m.run(x), outs):
+        _raw_close(o, r)
+    m.set_option("stem_fuse", 1)
+    for band in (5, 13, 96):      # rows per band (option "mdb_band"; 0 = chosen by the launcher): ragged last bands, one band per frame
+        m.set_option("mdb_band", band)
+        for o, r in zip(m.run(x), refs):
+            _raw_close(o, r)
     m.close()
 
 
