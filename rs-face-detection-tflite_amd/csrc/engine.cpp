@@ -78,6 +78,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "pipe_band") { pipe_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the row pipelines (0: automatic)
     else if (key == "strip") { strip_ = value != 0; }
     else if (key == "stem_fuse") { stem_fuse_ = value != 0; }   // 0: the first convolution keeps its own launch in front of the face mesh's block pair (mdblock_kernel<stem+pair>, round 6)
+    else if (key == "pair_fuse") { pair_fuse_ = value != 0; }   // 0: two plain blocks in a row keep a launch each (the face mesh's 48x48x32 blocks: mwalk_kernel) instead of one mdblock_kernel<pair>
     else if (key == "mdb_band") { mdb_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the mdblock_kernel launches (0: chosen per launch)
     else if (key == "mchain") { mchain_ = value != 0; }   // 0: the 32x32x48 blocks run one launch each (mstrip_kernel) instead of one launch per run
     else if (key == "tail") { tail_ = value != 0; dirty_ = true; }   // 0: no stage program runs on tail_kernels.hip (the round-4 plan)
@@ -110,6 +111,7 @@ int Model::get_option(const std::string& key) const {
     if (key == "pipe_band") return pipe_band_;
     if (key == "strip") return strip_;
     if (key == "stem_fuse") return stem_fuse_;
+    if (key == "pair_fuse") return pair_fuse_;
     if (key == "mdb_band") return mdb_band_;
     if (key == "mchain") return mchain_;
     if (key == "tail") return tail_;
@@ -155,6 +157,7 @@ void Model::rebuild() {
     node_strip_.assign(NN, -1);
     node_mwalk_.assign(NN, -1);
     node_stem_.assign(NN, -1);
+    node_pair_.assign(NN, -1);
     res_cblob_.assign(NN, {});
     res_wblk_.assign(NN, {});
     tail_wa_.assign(NN, {});
@@ -501,6 +504,23 @@ void Model::rebuild() {
                 node_mwalk_[i] = put(sc);
             }
         }
+    }
+    // two plain BlazeBlocks in a row on a layer mdblock_kernels.hip has a pair form for (the face mesh's 48x48x32 blocks, round 6): the constants of the pair
+    // launch, kept at the first node; which form runs is decided per launch
+    for (size_t i = 0; i + 1 < NN; i++) {
+        const Node &pa = plan_.nodes[i], &pb = plan_.nodes[i + 1];
+        auto plain = [&](const Node& m) {
+            return m.kind == Node::Block && m.w >= 0 && m.in.size() == 1 && m.sh == 1 && m.sw == 1 && m.res == m.in[0] && m.res_mode == RES_DIRECT && !m.res_after &&
+                   m.padding == Padding::Same && m.ept < 0 && (m.act != ACT_PRELU || m.alpha >= 0);
+        };
+        if (!plain(pa) || !plain(pb) || pb.in[0] != pa.out) continue;
+        const auto& sx = g.tensors[pa.in[0]].shape;
+        if (sx.size() != 4 || g.tensors[pa.out].shape != sx || g.tensors[pb.out].shape != sx || !mdblock_shape_ok(sx[2], sx[3], sx[3], sx[3], true)) continue;
+        std::vector<float> mc(static_cast<size_t>(mdblock_consts_floats(sx[2], sx[3], sx[3], sx[3], true)));
+        auto ptr = [&](int t) { return t >= 0 ? g.tensors[t].f32.data() : nullptr; };
+        mdblock_pack_consts(sx[2], sx[3], sx[3], sx[3], ptr(pa.w), ptr(pa.b), ptr(pa.w2), ptr(pa.b2), pa.act == ACT_PRELU ? ptr(pa.alpha) : nullptr, pa.act,
+                            ptr(pb.w), ptr(pb.b), ptr(pb.w2), ptr(pb.b2), pb.act == ACT_PRELU ? ptr(pb.alpha) : nullptr, pb.act, mc.data(), true);
+        node_pair_[i] = put(mc);
     }
     host.resize(host.size() + 4096, 0.f);  // slack: the stage programs' A-fragment prefetch walks up to 8 KiB past a tile's last chunk
     if (d_weights_) hip_check(hipFree(d_weights_), "hipFree");
@@ -2017,6 +2037,39 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 a.ep = ep;
                 a.w_strip = node_strip_[i] >= 0 ? d_weights_ + node_strip_[i] : nullptr;
                 a.w_mwalk = node_mwalk_[i] >= 0 ? d_weights_ + node_mwalk_[i] : nullptr;
+                // this block and the next one as ONE launch (mdblock_kernel, pair form): the tensor between them is neither written nor read
+                if (strip_ && pair_fuse_ && node_pair_[i] >= 0 && i + 1 < plan_.nodes.size() && !event_after_[i] && head_slot_[i + 1] < 0 && head_slot_[i] < 0) {
+                    const Node& nb = plan_.nodes[i + 1];
+                    bool only_reader = true;
+                    for (size_t j = 0; j < plan_.nodes.size() && only_reader; j++) {
+                        if (j == i + 1) continue;
+                        const Node& m = plan_.nodes[j];
+                        for (int t : m.in) only_reader = only_reader && t != n.out;
+                        only_reader = only_reader && m.res != n.out;
+                    }
+                    for (int t : g.outputs) only_reader = only_reader && plan_.storage[t].root != plan_.storage[n.out].root;
+                    if (only_reader) {
+                        DblockArgs d;
+                        long ofs = 0;
+                        d.in = ip; d.in_fs = in_fs;
+                        d.out = tensor_ptr_mut(nb.out, chunk_start, &ofs); d.out_fs = ofs;
+                        d.B = F; d.H = si[1]; d.W = si[2]; d.C = si[3]; d.Cm = si[3]; d.Co = si[3];
+                        d.hi1 = n.act == ACT_RELU6 ? 6.f : INFINITY;
+                        d.hi2 = nb.act == ACT_RELU6 ? 6.f : INFINITY;
+                        d.skip1 = 1; d.skip2_from_a = 1;
+                        d.act1 = n.act; d.act2 = nb.act;
+                        d.mconsts = d_weights_ + node_pair_[i];
+                        d.band_rows = mdb_band_;
+                        // (the launch reads its input while it writes its output: the arena keeps the two apart — plan.cpp, liveness — and this checks it)
+                        const bool apart = d.out + d.out_fs * F <= d.in || d.in + d.in_fs * F <= d.out;
+                        if (apart && mdblock_kernel_supports(d)) {
+                            if (labels) labels->back() = "mdblock_kernel<pair>";
+                            rc = launch_mdblock(d, s);
+                            fused_behind = 1;
+                            break;
+                        }
+                    }
+                }
                 if (strip_ && ms2_kernel_supports(a)) {
                     if (labels) { char buf[96]; labels->back() = ms2_kernel_label(a, buf, sizeof buf); }
                     rc = launch_ms2(a, s);

@@ -85,7 +85,7 @@ class Model {
     int device_ = 0;
     std::vector<uint8_t> blob_;
     Plan plan_;
-    int fuse_level_ = 5, res_budget_ = 156 * 1024, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, pipe_band_ = 0, fork_ = 1, head_streams_opt_ = 1, stem_fuse_ = 1, mdb_band_ = 0;
+    int fuse_level_ = 5, res_budget_ = 156 * 1024, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, pipe_band_ = 0, fork_ = 1, head_streams_opt_ = 1, stem_fuse_ = 1, pair_fuse_ = 1, mdb_band_ = 0;
     int arena_lane_ = 0;                    // arena region the chunk being enqueued writes to
     std::vector<hipStream_t> side_streams_;  // lanes 1.. run on their own streams (forked/joined with events)
     std::vector<hipEvent_t> lane_events_;
@@ -99,6 +99,7 @@ class Model {
 
     float* d_weights_ = nullptr;
     std::vector<long> node_w_, node_b_, node_w2_, node_b2_, node_alpha_;  // float offsets into d_weights_ (-1 none)
+    std::vector<long> node_pair_;   // constants of the pair launch this Block node and the next one share (mdblock_pack_consts, pair form), -1: no such form
     std::vector<long> node_stem_;   // the first convolution's constants for the launch it shares with the block pair behind it (mdblock_pack_stem), -1: no such form
     std::vector<long> node_mwalk_;  // mwalk-kernel constants of a Block node (mwalk_pack_consts), -1 when the shape does not qualify
     std::vector<long> node_strip_;  // strip-kernel constants of a Block node (strip_pack_consts), -1 when the shape does not qualify

@@ -638,6 +638,7 @@ using MD48a = MD<12, 3, 3, 1, 3>;  // 48 x 48: 48 -> 12 -> 48
 using MD48b = MD<12, 4, 4, 1, 3>;  // 48 x 48: 48 -> 16 -> 64
 using MD48c = MD<12, 6, 3, 1, 3, true>;  // 48 x 48: 48 -> 24 -> 48
 using MP96 = MD<4, 4, 1, 2, 3, false, 8, 1, false, true>;  // 96 x 96: two BlazeBlocks 16 -> 16 -> 16 (face mesh)
+using MP48 = MD<8, 8, 2, 1, 3, true, 4, 1, false, true>;   // 48 x 48: two BlazeBlocks 32 -> 32 -> 32 (face mesh; round 6: the tensor between them is neither written nor read)
 using MP96S = MD<4, 4, 1, 2, 3, true, 8, 1, false, true, true>;  // ... with the network's first convolution (192 x 192 x 3 -> 96 x 96 x 16) in front, in the same launch
 
 template <class K>
@@ -715,7 +716,7 @@ int mdb_launch(const DblockArgs& a, hipStream_t s) {
 int mdb_shape(int W, int C, int Cm, int Co, bool pair = false) {
     static const bool off = getenv("MI_NO_MDBLOCK") != nullptr;  // tuning aid: the LDS-tensor double-block kernel instead
     if (off) return 0;
-    if (pair) return (W == 96 && C == 16 && Cm == 16 && Co == 16) ? 5 : 0;   // (6: the same behind the first convolution, launch_mdblock)
+    if (pair) return (W == 96 && C == 16 && Cm == 16 && Co == 16) ? 5 : ((W == 48 && C == 32 && Cm == 32 && Co == 32) ? 7 : 0);   // (6: shape 5 behind the first convolution, launch_mdblock)
     if (W == 96 && C == 32 && Cm == 8 && Co == 32) return 1;
     if (W == 48 && C == 48 && Cm == 12 && Co == 48) return 2;
     if (W == 48 && C == 48 && Cm == 16 && Co == 64) return 3;
@@ -730,6 +731,7 @@ bool mdblock_shape_ok(int W, int C, int Cm, int Co, bool pair) { return mdb_shap
 int mdblock_consts_floats(int W, int C, int Cm, int Co, bool pair) {
     switch (mdb_shape(W, C, Cm, Co, pair)) {
         case 5: return MP96::TOTAL;
+        case 7: return MP48::TOTAL;
         case 1: return MD96::TOTAL;
         case 2: return MD48a::TOTAL;
         case 3: return MD48b::TOTAL;
@@ -743,6 +745,7 @@ void mdblock_pack_consts(int W, int C, int Cm, int Co, const float* w_dw1, const
                          const float* w_dw2, const float* b_dw2, const float* w_pw2, const float* b2, const float* alpha2, int act2, float* dst, bool pair) {
     switch (mdb_shape(W, C, Cm, Co, pair)) {
         case 5: mdb_pack<MP96>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
+        case 7: mdb_pack<MP48>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 1: mdb_pack<MD96>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 2: mdb_pack<MD48a>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
         case 3: mdb_pack<MD48b>(w_dw1, b_dw1, w_pw1, b1, alpha1, act1, w_dw2, b_dw2, w_pw2, b2, alpha2, act2, dst); break;
@@ -791,6 +794,7 @@ int launch_mdblock(const DblockArgs& a, void* stream) {
     if (a.stem_in) return mdb_launch<MP96S>(a, s);
     switch (mdb_shape(a.W, a.C, a.Cm, a.Co, a.skip1 != 0)) {
         case 5: return mdb_launch<MP96>(a, s);
+        case 7: return mdb_launch<MP48>(a, s);
         case 1: return mdb_launch<MD96>(a, s);
         case 2: return mdb_launch<MD48a>(a, s);
         case 3: return mdb_launch<MD48b>(a, s);

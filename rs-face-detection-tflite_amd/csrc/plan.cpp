@@ -1841,6 +1841,14 @@ Plan build_plan_impl(Graph graph, int fuse_level, int pipe_max_opt, int res_budg
         for (int t : plan.nodes[i].extra_out) touch(t, i);
     }
     for (int t : g.outputs) touch(t, NN);
+    // two plain BlazeBlocks of one shape in a row may run as ONE launch (engine.cpp: mdblock_kernel, pair form) that reads the first one's input while it
+    // writes the second one's output: that input stays allocated one node longer
+    for (int i = 0; i + 1 < NN; i++) {
+        const Node &pa = plan.nodes[i], &pb = plan.nodes[i + 1];
+        if (pa.kind != Node::Block || pb.kind != Node::Block || pa.w < 0 || pb.w < 0 || pa.in.size() != 1 || pb.in.size() != 1 || pb.in[0] != pa.out) continue;
+        if (pa.sh != 1 || pb.sh != 1 || g.tensors[pa.in[0]].shape != g.tensors[pb.out].shape) continue;
+        touch(pa.in[0], i + 1);
+    }
     // tail branches may run side by side in any interleaving: everything they read or write stays allocated to the end of the plan
     for (int i = 0; i < NN; i++) {
         if (plan.branch[static_cast<size_t>(i)] < 0) continue;

@@ -271,7 +271,7 @@ def test_mstrip_blocks_vs_oracle_and_block_kernel(gpu, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mwalk_kernel<8,2,3>", "mwalk_kernel<16,4,2>", "mdblock_kernel<stem+pair>", "ms2_kernel<8,4,2>", "ms2_kernel<4,2,3>"]), ("iris", ["mbneck_kernel"])])
+@pytest.mark.parametrize("name,kernels", [("full", ["mdblock_kernel", "ms2_kernel<8,1,3>", "ms2_kernel<16,2,2>", "xc_kernel"]), ("landmark", ["mdblock_kernel<pair>", "mwalk_kernel<16,4,2>", "mdblock_kernel<stem+pair>", "ms2_kernel<8,4,2>", "ms2_kernel<4,2,3>"]), ("iris", ["mbneck_kernel"])])
 def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, kernels):
     """The row-walking MFMA kernels of round 3 (mdblock / mwalk / ms2 / mbneck: depthwise stages in the v_mfma_f32_16x16x4_f32 operand
     layout) take the wide double blocks and stride-2 blocks of full_range, the 48x48x32 / 24x24x64 blocks, the 96x96x16 block pair and the
@@ -322,6 +322,7 @@ def test_first_convolution_inside_the_block_pair_launch(gpu, oracle, nb):
     outs = [o.copy() for o in m.run(x)]
     labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
     assert labels[0] == "mdblock_kernel<stem+pair>" and labels[1] == "ms2_kernel<4,2,3>", labels
+    assert labels[2] == "mdblock_kernel<pair>" and labels[3] == "ms2_kernel<8,4,2>", labels   # the two 48x48x32 blocks: one launch, the tensor between them stays in LDS
     for o, r in zip(outs, refs):
         _raw_close(o, r)
     for o, o2 in zip(outs, m.run(x)):
@@ -331,7 +332,13 @@ def test_first_convolution_inside_the_block_pair_launch(gpu, oracle, nb):
     assert labels[0].startswith("stem_conv_kernel") and labels[1] == "mdblock_kernel<pair>", labels
     for o, r in zip(m.run(x), outs):
         _raw_close(o, r)
+    m.set_option("pair_fuse", 0)
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert labels[3] == labels[4] == "mwalk_kernel<8,2,3>", labels
+    for o, r in zip(m.run(x), outs):
+        _raw_close(o, r)
     m.set_option("stem_fuse", 1)
+    m.set_option("pair_fuse", 1)
     for band in (5, 13, 96):      # rows per band (option "mdb_band"; 0 = chosen by the launcher): ragged last bands, one band per frame
         m.set_option("mdb_band", band)
         for o, r in zip(m.run(x), refs):
