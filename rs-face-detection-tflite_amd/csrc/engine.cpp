@@ -78,6 +78,7 @@ void Model::set_option(const std::string& key, int value) {
     else if (key == "pipe_band") { pipe_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the row pipelines (0: automatic)
     else if (key == "strip") { strip_ = value != 0; }
     else if (key == "stem_fuse") { stem_fuse_ = value != 0; }   // 0: the first convolution keeps its own launch in front of the face mesh's block pair (mdblock_kernel<stem+pair>, round 6)
+    else if (key == "stem_mfma") { stem_mfma_ = value != 0; }   // 0: the detectors' 5x5 first convolution stays on stem_conv_kernel (packed VALU FMAs) at every batch size; the results are bit-identical
     else if (key == "pair_fuse") { pair_fuse_ = value != 0; }   // 0: two plain blocks in a row keep a launch each (the face mesh's 48x48x32 blocks: mwalk_kernel) instead of one mdblock_kernel<pair>
     else if (key == "mdb_band") { mdb_band_ = std::max(0, std::min(value, 4096)); }   // rows per band of the mdblock_kernel launches (0: chosen per launch)
     else if (key == "mchain") { mchain_ = value != 0; }   // 0: the 32x32x48 blocks run one launch each (mstrip_kernel) instead of one launch per run
@@ -111,6 +112,7 @@ int Model::get_option(const std::string& key) const {
     if (key == "pipe_band") return pipe_band_;
     if (key == "strip") return strip_;
     if (key == "stem_fuse") return stem_fuse_;
+    if (key == "stem_mfma") return stem_mfma_;
     if (key == "pair_fuse") return pair_fuse_;
     if (key == "mdb_band") return mdb_band_;
     if (key == "mchain") return mchain_;
@@ -1759,6 +1761,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 if (n.padding == Padding::Same) { same_pad(a.H, a.KH, a.sh, a.Ho, &a.pt); same_pad(a.W, a.KW, a.sw, a.Wo, &a.pl); }
                 if (n.ept >= 0) { a.pt = n.ept; a.pl = n.epl; }
                 a.ep = ep;
+                a.no_mfma = stem_mfma_ ? 0 : 1;
                 if (u8_.frames && plan_.storage[n.in[0]].root == plan_.storage[g.inputs[0]].root) {
                     if (!conv_takes_u8(a)) throw std::runtime_error("plan: this graph's first convolution has no u8 input form");
                     a.in_u8 = u8_.frames + static_cast<long>(chunk_start) * u8_.frame_bytes;

@@ -85,7 +85,7 @@ class Model {
     int device_ = 0;
     std::vector<uint8_t> blob_;
     Plan plan_;
-    int fuse_level_ = 5, res_budget_ = 156 * 1024, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, pipe_band_ = 0, fork_ = 1, head_streams_opt_ = 1, stem_fuse_ = 1, pair_fuse_ = 1, mdb_band_ = 0;
+    int fuse_level_ = 5, res_budget_ = 156 * 1024, chunk_ = 0, use_graph_ = 1, reuse_ = 1, lanes_ = 1, pipe_max_ = 4, strip_ = 1, pipe_rows_ = 0, pipe_band_ = 0, fork_ = 1, head_streams_opt_ = 1, stem_fuse_ = 1, pair_fuse_ = 1, mdb_band_ = 0, stem_mfma_ = 1;
     int arena_lane_ = 0;                    // arena region the chunk being enqueued writes to
     std::vector<hipStream_t> side_streams_;  // lanes 1.. run on their own streams (forked/joined with events)
     std::vector<hipEvent_t> lane_events_;

@@ -12,6 +12,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #include "kernels.hpp"
 #include "launch.hpp"
@@ -290,6 +294,186 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
     }
 }
 
+// ---- the 5 x 5 stem (BackCamera 256x256 -> 128x128x24, Short / Front 128x128 -> 64x64x24) on the matrix cores, round 6.
+// stem_conv_kernel does its 1 800 FMAs per output pixel as packed VALU FMAs with the weights as scalar operands: 83 TFLOP/s at 256 frames, of the 104 - 116 the
+// packed FMAs reach on this part (0.18 ms of BASELINE config 2's 1.30).  v_mfma_f32_4x4x1_16b_f32 is 16 independent (4 x 1)(1 x 4) outer products with
+// D[i][lane] = A[block, i] * B[lane] + C[i][lane] (strip_kernels.hip uses it the same way): with lane = OUTPUT PIXEL, B = one value of the pixel's 5 x 5 x 3
+// window and A = four output-channel weights W[4 t .. 4 t + 3][k], broadcast from one block of a weight register (cbsz = 4, abid = block), D = four output
+// channels of 64 pixels.  The whole filter — 75 x 24 weights — is 29 registers of 64 lanes, loaded once per wave; a tile of 64 pixels is 75 x 6 = 450 MFMAs
+// and nothing else but its loads: five rows of 15 consecutive floats per lane (the window's row: 3 x dwordx4 + dwordx3 buffer loads, the next row's
+// in flight while this row's 90 MFMAs issue).  Rows above / below the picture are whole loads outside the buffer resource (zeros); the pixel left of
+// column 0 and the two right of column W - 1 are handled in the two edge lanes, which load a window shifted into the picture and move the values
+// over (every load is wholly inside or wholly outside the resource).  Each output is the same k-sequential f32 FMA chain from 0, bias added behind it,
+// as in stem_conv_kernel: the results are bit-identical (tests/test_gpu_parity.py::test_mfma_stem_bit_equal_to_the_valu_stem).
+// Measured (BackCamera, 256 frames; profiles/r06_stem_mfma.txt): 0.182 -> 0.165 ms.  What bounds it now is memory, not the matrix cores: without its MFMAs the
+// kernel takes 0.140 ms (201 MB in + 403 MB out = 4.3 TB/s), without its stores 0.147, its 29.5 M MFMAs alone are 0.105 ms at the 8.2 cycles
+// tools/probes/mfma4_probe.hip measures for this stream; the tensor it writes is read once more by the first row pipeline.
+typedef float sv4f __attribute__((ext_vector_type(4)));
+typedef unsigned su4 __attribute__((ext_vector_type(4)));
+typedef unsigned su3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ sv4f stem_mfma4(float a, float b, sv4f c, int blk) {   // (the builtin wants the block as a literal: the switch folds away once the loops are unrolled)
+    switch (blk) {
+#define MI_SM4(N) case N: return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, N, 0);
+        MI_SM4(0) MI_SM4(1) MI_SM4(2) MI_SM4(3) MI_SM4(4) MI_SM4(5) MI_SM4(6) MI_SM4(7) MI_SM4(8) MI_SM4(9) MI_SM4(10) MI_SM4(11) MI_SM4(12) MI_SM4(13) MI_SM4(14)
+#undef MI_SM4
+        default: return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, 15, 0);
+    }
+}
+
+template <int N, class F, int... KS>
+__device__ __forceinline__ void dfor_tiles_impl(F&& f, std::integer_sequence<int, KS...>) { (f(std::integral_constant<int, KS>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void dfor_tiles(F&& f) { dfor_tiles_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(ConvArgs a, int tiles, int tpr) {
+    constexpr int KW3 = 15, NK = 75, CQ = 6, NA = (NK * CQ + 15) / 16;   // 29 weight registers
+    const int lane = threadIdx.x & 63;
+    // Workgroup i runs on XCD i % 8, each with an L2 of its own: the workgroups of one XCD take CONSECUTIVE tiles (the rows of one stretch of a frame: a picture
+    // row is read by two or three output rows), not every eighth group of four — interleaved, an XCD fetched 7 picture rows per 2 output rows
+    const int G = (int)gridDim.x, wg = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+    const int wv = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6)), nwv = G * 4;
+    // weight register r, lanes 4 (n % 16) + i = W[4 t + i][k] for n = 16 r + ... = k CQ + t  (a.w: [k][24])
+    float wa[NA];
+#pragma unroll
+    for (int r = 0; r < NA; r++) {
+        const int n = 16 * r + (lane >> 2), k = n / CQ, t = n - CQ * k;
+        wa[r] = n < NK * CQ ? a.w[k * 24 + 4 * t + (lane & 3)] : 0.f;
+    }
+    const float hi = a.ep.act == ACT_RELU6 ? 6.f : INFINITY, base_slope = a.ep.act == ACT_NONE ? 1.f : 0.f;
+    const bool prelu = a.ep.act == ACT_PRELU;
+    // bias and slopes: wave-uniform, read ONCE into scalar registers (read behind the row loop's stores they become vector loads the compiler orders behind
+    // each store: six store round trips per tile)
+    float bs[24], sl[RELU ? 1 : 24];
+    {
+        const float* __restrict__ bias = a.ep.bias;
+        const float* __restrict__ al = prelu ? a.ep.alpha : a.ep.bias;   // always a readable array
+#pragma unroll
+        for (int i = 0; i < 24; i++) bs[i] = bias[i];
+        if constexpr (!RELU) {
+#pragma unroll
+            for (int i = 0; i < 24; i++) sl[i] = prelu ? al[i] : base_slope;
+        }
+    }
+    const int rowb = a.W * 12;                                       // bytes of a picture row
+    __shared__ __attribute__((aligned(16))) float otile[4 * 64 * 24];
+    // A wave's row loads form one stream over its tiles — five rows per tile, the next row's loads issued before this row's 90 MFMAs, the NEXT TILE's first row
+    // before this tile's last 90: without that every tile began with an exposed memory round trip that the other waves of the SIMD, in step with this
+    // one, did not cover (0.220 ms with, 0.147 ms without the MFMAs, 0.105 ms of MFMAs).  NB buffers in turn, a row's loads issued NB - 1 rows ahead; five
+    // rows per tile, so the buffers' roles rotate from tile to tile (P).
+    struct Tile { int b, y, half, px, lane_off; bool left, right; };
+    auto setup = [&](int t) {
+        Tile c;
+        c.b = t / (a.Ho * tpr);
+        const int rem = t - c.b * (a.Ho * tpr);
+        c.y = rem / tpr; c.half = rem - c.y * tpr;                   // wave-uniform
+        c.px = 64 * c.half + lane;
+        c.left = c.px == 0; c.right = c.px == a.Wo - 1;
+        // the window of pixel px starts at column 2 px - 1: the edge lanes read columns 0 .. 4 / W - 5 .. W - 1 instead
+        c.lane_off = (2 * c.px - 1 + (c.left ? 1 : 0) - (c.right ? 2 : 0)) * 12;
+        return c;
+    };
+    auto load_row = [&](const Tile& c, int ky, float (&x)[KW3]) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in + (long)c.b * a.in_fs), 0, a.H * rowb, 0x00020000);
+        const int vo = (2 * c.y - 1 + ky) * rowb + c.lane_off;   // row -1: negative = far outside; rows >= H: outside
+        const su4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0), q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 16, 0, 0),
+                  q2 = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 32, 0, 0);
+        const su3 q3 = __builtin_amdgcn_raw_buffer_load_b96(rs, vo + 48, 0, 0);
+        x[0] = __uint_as_float(q0.x); x[1] = __uint_as_float(q0.y); x[2] = __uint_as_float(q0.z); x[3] = __uint_as_float(q0.w);
+        x[4] = __uint_as_float(q1.x); x[5] = __uint_as_float(q1.y); x[6] = __uint_as_float(q1.z); x[7] = __uint_as_float(q1.w);
+        x[8] = __uint_as_float(q2.x); x[9] = __uint_as_float(q2.y); x[10] = __uint_as_float(q2.z); x[11] = __uint_as_float(q2.w);
+        x[12] = __uint_as_float(q3.x); x[13] = __uint_as_float(q3.y); x[14] = __uint_as_float(q3.z);
+    };
+    constexpr int NB = 2;   // (three buffers, loads two rows ahead: the same 0.165 ms)
+    float xb[NB][KW3];
+    auto tile = [&](auto pc, const Tile& c, const Tile& nx) {
+        constexpr int P = decltype(pc)::value;
+        sv4f D[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; q++) D[q] = sv4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 5; ky++) {
+            if (ky + NB - 1 < 5) load_row(c, ky + NB - 1, xb[(ky + NB - 1 + P) % NB]);
+            else load_row(nx, ky + NB - 1 - 5, xb[(ky + NB - 1 + P) % NB]);   // (the last tile loads its own first rows again: no branch around a load)
+            float (&x)[KW3] = xb[(ky + P) % NB];
+            if (c.half == 0) {          // wave-uniform: lane 0 holds columns 0 .. 4, its window is (zero), 0 .. 3
+#pragma unroll
+                for (int e = KW3 - 1; e >= 0; e--) x[e] = c.left ? (e >= 3 ? x[e - 3] : 0.f) : x[e];
+            }
+            if (c.half == tpr - 1) {    // lane 63 holds columns W - 5 .. W - 1, its window is W - 3 .. W - 1, (zero), (zero)
+#pragma unroll
+                for (int e = 0; e < KW3; e++) x[e] = c.right ? (e < 9 ? x[e + 6] : 0.f) : x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < KW3; e++)
+#pragma unroll
+                for (int q = 0; q < CQ; q++) {
+                    const int n = (ky * KW3 + e) * CQ + q;
+                    D[q] = stem_mfma4(wa[n >> 4], x[e], D[q], n & 15);
+                }
+        }
+        // The tile's 64 x 24 results are 6 KB of consecutive addresses, but a lane holds ONE pixel's 96 bytes: stored from the registers, each of the six
+        // 16-byte store instructions touches every line of the tile (partial sectors at the memory side: loads + stores alone took 0.22 ms).  Through LDS
+        // instead: every store instruction writes 1 KB of consecutive addresses.
+        float* ot = otile + (threadIdx.x >> 6) * (64 * 24);
+#pragma unroll
+        for (int q = 0; q < CQ; q++) {
+            float r[4] = {D[q].x, D[q].y, D[q].z, D[q].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = r[i] + bs[4 * q + i];
+                if constexpr (RELU) r[i] = fmaxf(v, 0.f);
+                else r[i] = fminf(fmaxf(v, 0.f) + sl[4 * q + i] * fminf(v, 0.f), hi);
+            }
+            *reinterpret_cast<float4*>(ot + lane * 24 + 4 * q) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+        __builtin_amdgcn_wave_barrier();   // (the tile is this wave's own: LDS operations of a wave execute in order)
+        float* op = a.out + (long)c.b * a.out_fs + ((long)c.y * a.Wo + 64 * c.half) * 24;
+#pragma unroll
+        for (int q = 0; q < CQ; q++)
+            *reinterpret_cast<float4*>(op + (q * 64 + lane) * 4) = *reinterpret_cast<const float4*>(ot + (q * 64 + lane) * 4);
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (wv >= tiles) return;
+    Tile tl[2];
+    tl[0] = setup(wv);
+#pragma unroll
+    for (int r = 0; r < NB - 1; r++) load_row(tl[0], r, xb[r]);
+    // tile k of this wave starts at row 5 k of the stream: P = 5 k mod NB
+    for (int t = wv;;) {
+        bool done = false;
+        dfor_tiles<NB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (done) return;
+            const int tn = t + nwv;
+            tl[(k + 1) & 1] = setup(min(tn, tiles - 1));
+            tile(std::integral_constant<int, (5 * k) % NB>{}, tl[k & 1], tl[(k + 1) & 1]);
+            if (tn >= tiles) done = true;
+            t = tn;
+        });
+        if (done) break;
+        if constexpr (NB & 1) { const Tile sw = tl[0]; tl[0] = tl[1]; tl[1] = sw; }   // (an odd number of tiles per round: the roles of tl[] swap)
+    }
+}
+
+static bool stem_mfma_applicable(const ConvArgs& a) {
+    static const bool off = getenv("MI_NO_STEM_MFMA") != nullptr;   // tuning aid
+    if (off || a.no_mfma || a.in_u8 || a.KH != 5 || a.KW != 5 || a.C != 3 || a.Co != 24 || a.Cop != 24 || a.sh != 2 || a.sw != 2 || a.pt != 1 || a.pl != 1) return false;
+    if (a.W != 2 * a.Wo || a.H != 2 * a.Ho || a.Wo % 64 || a.W < 8 || !a.ep.bias || a.ep.res_mode != RES_NONE) return false;
+    if ((reinterpret_cast<uintptr_t>(a.in) & 15) || (a.in_fs & 3) || (reinterpret_cast<uintptr_t>(a.out) & 15) || (a.out_fs & 3)) return false;
+    if ((long)a.H * a.W * 12 > 0x7fffffffL) return false;
+    return (long)a.B * a.Ho * (a.Wo / 64) >= 2048;   // tiles of 64 pixels: from about a tile per wave slot of the chip on (a handful of frames keep the split forms)
+}
+
+static int launch_stem_mfma(const ConvArgs& a, hipStream_t s) {
+    const int tpr = a.Wo / 64, tiles = a.B * a.Ho * tpr;
+    const int per_cu = 4;   // workgroups of four waves (2 .. 6 per CU measured alike: 0.165 - 0.168 ms)
+    unsigned grid = (unsigned)std::min<long>((tiles + 3) / 4, (long)per_cu * device_cu_count());
+    if (grid >= 64) grid &= ~7u;   // (a multiple of the XCD count: the kernel's tile order assumes it)
+    if (a.ep.act == ACT_RELU) return (int)launch_kernel(stem_mfma_kernel<true>, dim3(grid), dim3(256), 0, s, a, tiles, tpr);
+    return (int)launch_kernel(stem_mfma_kernel<false>, dim3(grid), dim3(256), 0, s, a, tiles, tpr);
+}
+
 template <int K, int CO>
 static int launch_stem(const ConvArgs& a, hipStream_t s) {
     constexpr int TH = 16;  // rows of a tile (two output pixels per thread)
@@ -315,11 +499,12 @@ static bool pw_few_applicable(const ConvArgs& a) {
            (reinterpret_cast<uintptr_t>(a.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
 }
 bool conv_takes_u8(const ConvArgs& a) { return stem_applicable(a); }
-const char* conv_kernel_label(const ConvArgs& a) { return stem_applicable(a) ? "stem_conv_kernel" : (pw_few_applicable(a) ? "pw_few_kernel" : "conv_generic_kernel"); }
+const char* conv_kernel_label(const ConvArgs& a) { return stem_applicable(a) ? (stem_mfma_applicable(a) ? "stem_mfma_kernel" : "stem_conv_kernel") : (pw_few_applicable(a) ? "pw_few_kernel" : "conv_generic_kernel"); }
 
 int launch_conv(const ConvArgs& a, void* stream) {
     if (stem_applicable(a)) {
         hipStream_t st = (hipStream_t)stream;
+        if (stem_mfma_applicable(a)) return launch_stem_mfma(a, st);
         if (a.KH == 5) return launch_stem<5, 24>(a, st);
         if (a.Co == 16) return launch_stem<3, 16>(a, st);
         if (a.Co == 32) return launch_stem<3, 32>(a, st);

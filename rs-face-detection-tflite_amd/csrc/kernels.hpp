@@ -42,6 +42,7 @@ struct ConvArgs {
     int B = 0, H = 0, W = 0, C = 0, Ho = 0, Wo = 0, Co = 0, Cop = 0;
     int KH = 1, KW = 1, sh = 1, sw = 1, pt = 0, pl = 0;
     Epilogue ep;
+    int no_mfma = 0;            // 1: the 5 x 5 stem stays on stem_conv_kernel (engine option "stem_mfma" = 0)
 };
 
 // Convolution whose window is the whole frame (VALID, H == KH, W == KW: the 3x3-stride-3 mesh head 32 -> 1404, the 2x2 iris

@@ -302,6 +302,37 @@ def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, ker
     m.close()
 
 
+@pytest.mark.parametrize("name,nb", [("back", 256), ("back", 17), ("short", 256), ("front", 70)])
+def test_mfma_stem_bit_equal_to_the_valu_stem(gpu, oracle, name, nb):
+    """Round 6: the detectors' 5x5 first convolution (face_detection.rs:235, first operator behind `interpreter.invoke()`) on the matrix cores from about
+    2 000 64-pixel tiles per launch on (stem_mfma_kernel: lane = output pixel, v_mfma_f32_4x4x1_16b_f32 with the weights broadcast from one block of a weight
+    register, the window's rows by buffer loads).  Every output is the same k-sequential chain of f32 FMAs as in stem_conv_kernel, so the two agree BIT FOR
+    BIT: raw outputs of the whole network with option stem_mfma = 1 / 0, on frames whose first / last rows and columns carry large values (the zero padding
+    sits beside them: one pixel left / above, two right / below), an all-zero frame, batches with a ragged last round of tiles; originals against the oracle."""
+    torch = pytest.importorskip("torch")
+    m = gpu.Model(model_path(name))
+    x = seeded_input(name, nb, 4000 + nb, m.input_dims[1:3])
+    x[1, 0, :, :] = 11.0
+    x[1, -1, :, :] = -7.0
+    x[2, :, 0, :] = 5.0
+    x[2, :, -1, :] = -9.0
+    x[2, :, -2, :] = 3.0
+    x[3] = 0.0
+    outs = [o.copy() for o in m.run(x)]
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert labels[0] == "stem_mfma_kernel", labels
+    m.set_option("stem_mfma", 0)
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert labels[0] == "stem_conv_kernel", labels
+    for o, o2 in zip(outs, m.run(x)):
+        np.testing.assert_array_equal(o, o2)
+    om = oracle.Model(model_path(name))
+    sel = [0, 1, 2, 3, nb - 1]
+    for o, r in zip(outs, om.run(x[sel], nthreads=5)):
+        _raw_close(o[sel], r)
+    m.close()
+
+
 @pytest.mark.parametrize("nb", [32, 61, 200])
 def test_first_convolution_inside_the_block_pair_launch(gpu, oracle, nb):
     """Round 6: the face mesh's first convolution (3x3 stride 2, 192x192x3 -> 96x96x16, PReLU; face_landmark.rs:265 behind

@@ -35,6 +35,8 @@ def label(name):
         a = [x.strip() for x in m0.group(2).split(",")]
         if m0.group(1) == "mwalk_kernel":
             return "mwalk_kernel<%s>" % ",".join(a[:3])
+        if m0.group(1) == "mdblock_kernel" and len(a) >= 11 and a[9] == "true" and a[10] == "true":
+            return "mdblock_kernel<stem+pair>"   # (round 6: the face mesh's first convolution inside the pair's launch)
         if m0.group(1) == "mdblock_kernel" and len(a) >= 10 and a[9] == "true":
             return "mdblock_kernel<pair>"
         return m0.group(1)
@@ -49,8 +51,8 @@ def label(name):
         args = args[:1]   # the label carries the tile count only (not the unit-split flag)
     if m.group(1) in ("bneck_kernel", "dblock_kernel", "tail_kernel"):
         return m.group(1)
-    if m.group(1) == "stem_conv_kernel":
-        return "stem_conv_kernel"
+    if m.group(1) in ("stem_conv_kernel", "stem_mfma_kernel"):
+        return m.group(1)
     return "%s<%s>" % (m.group(1), ",".join(args))
 
 
