@@ -1259,6 +1259,14 @@ def test_full_pipeline_on_man_jpg(gpu, oracle, gold, man_image):
     np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in r.iris]), gold["man_eye_right_iris"], atol=1e-4)
     np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in l.contour]), gold["man_eye_left_contour"], atol=1e-4)
     np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in l.iris]), gold["man_eye_left_iris"], atol=1e-4)
+    # ... and at the other stages' tolerance once the oracle's eye stage is given the SAME ROIs (the GPU's): what is left is the stage itself
+    oir = oracle.Model(model_path("iris"))
+    for res, rect, is_right in ((l, left, False), (r, right, True)):
+        orect = oracle.Rect(rect.x_center, rect.y_center, rect.width, rect.height, rect.rotation, rect.normalized)
+        t3, pad3 = oracle.image_to_tensor(man_image, orect, (64, 64), True, (0., 1.), is_right)
+        c71, i5 = oir.run(t3[None])
+        np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in res.contour]), oracle.project_landmarks(c71[0], (64, 64), (W, H), pad3, orect, is_right), atol=2e-5)
+        np.testing.assert_allclose(np.array([[p.x, p.y, p.z] for p in res.iris]), oracle.project_landmarks(i5[0], (64, 64), (W, H), pad3, orect, is_right), atol=2e-5)
     # the GPU results, drawn by the restated renderer, reproduce the reference's own PNGs pixel for pixel (lib.rs:43-83)
     from oracle import render
     from PIL import Image
