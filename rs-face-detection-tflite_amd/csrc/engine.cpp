@@ -466,7 +466,18 @@ void Model::rebuild() {
             const auto& sxo = g.tensors[n.out].shape;
             if (sxi.size() == 4 && sxo.size() == 4 && n.padding == Padding::Same && n.ept < 0 && n.res < 0 && n.in[0] == g.inputs[0] &&
                 (n.act == ACT_NONE || n.act == ACT_RELU || n.act == ACT_RELU6 || n.act == ACT_PRELU) &&
-                mdblock_stem_shape_ok(sxi[1], sxi[2], sxi[3], n.KH, n.KW, n.sh, n.sw, sxo[1], sxo[2], sxo[3])) {
+                mdblock_stem_shape_ok(sxi[1], sxi[2], sxi[3], n.KH, n.KW, n.sh, n.sw, sxo[1], sxo[2], sxo[3]) && !(n.act == ACT_PRELU && n.alpha < 0) &&
+                [&] {   // its output is read by the next node alone (the pair: as input and as the first block's skip) and is no graph output
+                    int readers = 0;
+                    for (const Node& m : plan_.nodes) {
+                        for (int t : m.in) readers += t == n.out ? 1 : 0;
+                        if (m.res == n.out) readers++;
+                    }
+                    bool is_out = false;
+                    for (int t : g.outputs) is_out = is_out || plan_.storage[t].root == plan_.storage[n.out].root;
+                    return readers == 1 && !is_out && i + 1 < NN && plan_.nodes[i + 1].kind == Node::Chain && plan_.nodes[i + 1].members.size() == 2 &&
+                           plan_.nodes[i + 1].in.size() >= 1 && plan_.nodes[i + 1].in[0] == n.out;
+                }()) {
                 std::vector<float> sc(static_cast<size_t>(mdblock_stem_consts_floats()));
                 mdblock_pack_stem(src.data(), n.b >= 0 ? g.tensors[n.b].f32.data() : nullptr, n.act == ACT_PRELU && n.alpha >= 0 ? g.tensors[n.alpha].f32.data() : nullptr, n.act, sc.data());
                 node_stem_[i] = put(sc);
@@ -518,6 +529,15 @@ void Model::rebuild() {
         if (!plain(pa) || !plain(pb) || pb.in[0] != pa.out) continue;
         const auto& sx = g.tensors[pa.in[0]].shape;
         if (sx.size() != 4 || g.tensors[pa.out].shape != sx || g.tensors[pb.out].shape != sx || !mdblock_shape_ok(sx[2], sx[3], sx[3], sx[3], true)) continue;
+        // the tensor between the two is never written by that launch: nobody else may read it
+        bool only_reader = true;
+        for (size_t j = 0; j < NN && only_reader; j++) {
+            if (j == i + 1) continue;
+            for (int t : plan_.nodes[j].in) only_reader = only_reader && t != pa.out;
+            only_reader = only_reader && plan_.nodes[j].res != pa.out;
+        }
+        for (int t : g.outputs) only_reader = only_reader && plan_.storage[t].root != plan_.storage[pa.out].root;
+        if (!only_reader) continue;
         std::vector<float> mc(static_cast<size_t>(mdblock_consts_floats(sx[2], sx[3], sx[3], sx[3], true)));
         auto ptr = [&](int t) { return t >= 0 ? g.tensors[t].f32.data() : nullptr; };
         mdblock_pack_consts(sx[2], sx[3], sx[3], sx[3], ptr(pa.w), ptr(pa.b), ptr(pa.w2), ptr(pa.b2), pa.act == ACT_PRELU ? ptr(pa.alpha) : nullptr, pa.act,
@@ -1719,18 +1739,9 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                     break;
                 }
                 // the first convolution inside the launch of the pair of BlazeBlocks behind it (f32 pictures, from 32 frames on: mdblock_kernels.hip, MD::STEM)
-                if (strip_ && stem_fuse_ && node_stem_[i] >= 0 && !u8_.frames && !(n.act == ACT_PRELU && n.alpha < 0)) {
-                    size_t j = i + 1;
-                    while (j < plan_.nodes.size() && (plan_.nodes[j].kind == Node::Reshape || plan_.nodes[j].kind == Node::Concat)) j++;
-                    int readers = 0;
-                    for (const Node& m : plan_.nodes) {
-                        for (int t : m.in) readers += t == n.out ? 1 : 0;
-                        if (m.res == n.out) readers++;
-                    }
-                    bool is_out = false;
-                    for (int t : g.outputs) is_out = is_out || plan_.storage[t].root == plan_.storage[n.out].root;
-                    if (j == i + 1 && j < plan_.nodes.size() && plan_.nodes[j].kind == Node::Chain && node_mwalk_[j] >= 0 && plan_.nodes[j].members.size() == 2 &&
-                        plan_.nodes[j].in[0] == n.out && readers == 1 && !is_out && !event_after_[i] && head_slot_[j] < 0) {
+                if (strip_ && stem_fuse_ && node_stem_[i] >= 0 && !u8_.frames) {   // (node_stem_: the graph's side of the conditions, checked when the constants were packed)
+                    const size_t j = i + 1;
+                    if (node_mwalk_[j] >= 0 && !event_after_[i] && head_slot_[j] < 0) {
                         const Node& c = plan_.nodes[j];
                         const auto& co = g.tensors[c.out].shape;
                         DblockArgs d;
@@ -2043,15 +2054,7 @@ void Model::enqueue_chunk(const float* in, int chunk_start, int F, hipStream_t s
                 // this block and the next one as ONE launch (mdblock_kernel, pair form): the tensor between them is neither written nor read
                 if (strip_ && pair_fuse_ && node_pair_[i] >= 0 && i + 1 < plan_.nodes.size() && !event_after_[i] && head_slot_[i + 1] < 0 && head_slot_[i] < 0) {
                     const Node& nb = plan_.nodes[i + 1];
-                    bool only_reader = true;
-                    for (size_t j = 0; j < plan_.nodes.size() && only_reader; j++) {
-                        if (j == i + 1) continue;
-                        const Node& m = plan_.nodes[j];
-                        for (int t : m.in) only_reader = only_reader && t != n.out;
-                        only_reader = only_reader && m.res != n.out;
-                    }
-                    for (int t : g.outputs) only_reader = only_reader && plan_.storage[t].root != plan_.storage[n.out].root;
-                    if (only_reader) {
+                    {
                         DblockArgs d;
                         long ofs = 0;
                         d.in = ip; d.in_fs = in_fs;
