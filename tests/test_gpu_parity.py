@@ -377,6 +377,36 @@ def test_first_convolution_inside_the_block_pair_launch(gpu, oracle, nb):
     m.close()
 
 
+@pytest.mark.parametrize("name", ["landmark", "back"])
+def test_round6_launches_in_chunks_and_lanes(gpu, oracle, name):
+    """The launches of round 6 that replace two nodes' launches (the face mesh's first convolution inside the block pair's launch, its two 48x48x32 blocks as one
+    launch) and the detectors' first convolution on the matrix cores, in the plans a host can ask for besides the default: the batch in chunks (a chunk's
+    tensors start at an offset of the arena: 300 frames in chunks of 96 — the last one is 12 frames, below every threshold), two lanes, eager launches
+    instead of graph replay.  Each against the default plan's results on the same frames (bit for bit where the kernels are the same: chunks of >= 96 frames),
+    and a sample against the oracle."""
+    m = gpu.Model(model_path(name))
+    nb = 300
+    x = seeded_input(name, nb, 606, m.input_dims[1:3])
+    ref = [o.copy() for o in m.run(x)]
+    om = oracle.Model(model_path(name))
+    sel = [0, 95, 96, 191, 288, 299]
+    for o, r in zip(ref, om.run(x[sel], nthreads=6)):
+        _raw_close(o[sel], r)
+    m.set_option("chunk", 96)
+    for o, r in zip(m.run(x), ref):
+        _raw_close(o, r)
+        np.testing.assert_array_equal(o[:288], r[:288]) if name == "back" else None   # (BackCamera: the same kernels from 96 frames on; the mesh's tail picks frames per workgroup by the batch)
+    m.set_option("chunk", 0)
+    m.set_option("lanes", 2)
+    for o, r in zip(m.run(x), ref):
+        _raw_close(o, r)
+    m.set_option("lanes", 1)
+    m.set_option("graph", 0)
+    for o, r in zip(m.run(x), ref):
+        np.testing.assert_array_equal(o, r)
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["back", "front", "full", "landmark", "iris"])
 def test_batch_size_sweep_across_kernel_thresholds(gpu, oracle, name):
     """Which kernel runs a layer depends on the batch (the row-walking kernels start at 32 or 96 frames per launch, small grids spread
