@@ -4,12 +4,12 @@ set -o pipefail
 cd /tmp 2>/dev/null; cd - >/dev/null
 export TMPDIR=/tmp
 O=gpurun_out/r06_s25; rm -rf $O; mkdir -p $O
-for v in "0 1" "0 0" "1 1"; do set -- $v
-  MI_STEM_ABL=$1 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/gui_$1_$2 -- python3 tools/profile_model.py back 256 stem_mfma=$2 > $O/gui_$1_$2.log 2>&1; echo "pmc abl $1 mfma $2 rc $?"
+for v in "0 1" "0 0"; do set -- $v   # (the third variant of the session, the MFMA form without its loads, was a development build)
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/gui_$1_$2 -- python3 tools/profile_model.py back 256 stem_mfma=$2 > $O/gui_$1_$2.log 2>&1; echo "pmc abl $1 mfma $2 rc $?"
 done
 python3 - <<'PY'
 import csv, glob, collections
-for tag in ("0_1", "0_0", "1_1"):
+for tag in ("0_1", "0_0"):
     fs = glob.glob('gpurun_out/r06_s25/gui_%s/**/*counter_collection.csv' % tag, recursive=True)
     if not fs: print('no csv for', tag); continue
     by = collections.defaultdict(list)
