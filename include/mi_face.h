@@ -125,7 +125,7 @@ size_t mi_model_describe(const mi_model *m, char *buf, size_t cap);
  * more than 128 channels); "stem_fuse" (0 = the face mesh's first convolution keeps a launch of its own instead of running inside the launch of the
  * block pair behind it, from 32 f32 pictures on), "pair_fuse" (0 = two plain BlazeBlocks in a row keep a launch each where one launch has a form for
  * both: the face mesh's 48x48x32 blocks), "mdb_band" (rows per band of those launches, 0 = chosen per launch), "stem_mfma" (0 = the detectors' 5x5 first
- * convolution stays on the packed-FMA kernel at every batch size instead of moving to the matrix cores from about eight frames on; bit-identical results).
+ * convolution (f32 tensors) stays on the packed-FMA kernel instead of the matrix cores; bit-identical results).
  * Takes effect on the next run. */
 int mi_model_set_option(mi_model *m, const char *key, int value);
 /* Reads an option back (same keys), plus the state the engine keeps about the single-launch plan: "band" reads 0 once three single launches in a

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(ConvArgs a) {
 // column 0 and the two right of column W - 1 are handled in the two edge lanes, which load a window shifted into the picture and move the values
 // over (every load is wholly inside or wholly outside the resource).  Each output is the same k-sequential f32 FMA chain from 0, bias added behind it,
 // as in stem_conv_kernel: the results are bit-identical (tests/test_gpu_parity.py::test_mfma_stem_bit_equal_to_the_valu_stem).
-// Measured (BackCamera, 256 frames; profiles/r06_stem_mfma.txt): 0.182 -> 0.165 ms.  What bounds it now is memory, not the matrix cores: without its MFMAs the
+// Measured (BackCamera, 256 frames; profiles/r06_stem_mfma.txt): 0.182 -> 0.165 ms (one frame: 8.9 -> 7.0 us).  What bounds it now is memory, not the matrix cores: without its MFMAs the
 // kernel takes 0.140 ms (201 MB in + 403 MB out = 4.3 TB/s), without its stores 0.147, its 29.5 M MFMAs alone are 0.105 ms at the 8.2 cycles
 // tools/probes/mfma4_probe.hip measures for this stream; the tensor it writes is read once more by the first row pipeline.
 typedef float sv4f __attribute__((ext_vector_type(4)));
@@ -462,7 +462,7 @@ static bool stem_mfma_applicable(const ConvArgs& a) {
     if (a.W != 2 * a.Wo || a.H != 2 * a.Ho || a.Wo % 64 || a.W < 8 || !a.ep.bias || a.ep.res_mode != RES_NONE) return false;
     if ((reinterpret_cast<uintptr_t>(a.in) & 15) || (a.in_fs & 3) || (reinterpret_cast<uintptr_t>(a.out) & 15) || (a.out_fs & 3)) return false;
     if ((long)a.H * a.W * 12 > 0x7fffffffL) return false;
-    return (long)a.B * a.Ho * (a.Wo / 64) >= 2048;   // tiles of 64 pixels: from about a tile per wave slot of the chip on (a handful of frames keep the split forms)
+    return (long)a.B * a.Ho * (a.Wo / 64) >= 64;   // tiles of 64 pixels.  (One BackCamera frame = 256 tiles on 64 workgroups: 7.0 us against the split packed-FMA form's 8.9, 8.4 against 15.7 at four frames)
 }
 
 static int launch_stem_mfma(const ConvArgs& a, hipStream_t s) {

@@ -302,10 +302,10 @@ def test_operand_layout_kernels_vs_oracle_and_lds_kernels(gpu, oracle, name, ker
     m.close()
 
 
-@pytest.mark.parametrize("name,nb", [("back", 256), ("back", 17), ("short", 256), ("front", 70)])
+@pytest.mark.parametrize("name,nb", [("back", 256), ("back", 17), ("short", 256), ("front", 70), ("short", 5)])
 def test_mfma_stem_bit_equal_to_the_valu_stem(gpu, oracle, name, nb):
-    """Round 6: the detectors' 5x5 first convolution (face_detection.rs:235, first operator behind `interpreter.invoke()`) on the matrix cores from about
-    2 000 64-pixel tiles per launch on (stem_mfma_kernel: lane = output pixel, v_mfma_f32_4x4x1_16b_f32 with the weights broadcast from one block of a weight
+    """Round 6: the detectors' 5x5 first convolution (face_detection.rs:235, first operator behind `interpreter.invoke()`) on the matrix cores
+    (stem_mfma_kernel: lane = output pixel, v_mfma_f32_4x4x1_16b_f32 with the weights broadcast from one block of a weight
     register, the window's rows by buffer loads).  Every output is the same k-sequential chain of f32 FMAs as in stem_conv_kernel, so the two agree BIT FOR
     BIT: raw outputs of the whole network with option stem_mfma = 1 / 0, on frames whose first / last rows and columns carry large values (the zero padding
     sits beside them: one pixel left / above, two right / below), an all-zero frame, batches with a ragged last round of tiles; originals against the oracle."""
