@@ -299,12 +299,13 @@ def back_like(seed, size, c0=24, n1=3, n2=3, coarse_first=False):
     return g.finish()
 
 
-def front_like(seed, size, act="relu"):
+def front_like(seed, size, act="relu", stem_act="relu"):
     """The front / short-range detector's habit of growing by channel PADs on the skip, with widths that are not multiples of 4:
     24 -> 30 -> 42 at size/2, stride 2 to 54 (max-pool + PAD skip), 54 -> 58 -> 58, 1x1 head.  The lowering widens the 30 / 42 /
     54 / 58-channel tensors to 32 / 44 / 56 / 60 with zero channels (plan.cpp pad_odd_channels) so the fused kernels take them."""
     g = GraphBuilder(seed, [1, size, size, 3])
-    x = g.relu(g.conv(g.input, 24, 5, 2))
+    x = g.conv(g.input, 24, 5, 2)
+    x = g.relu(x) if stem_act == "relu" else (g.prelu(x) if stem_act == "prelu" else x)
     x = g.blaze_block(x, 30, act=act)
     x = g.blaze_block(x, 42, act=act)
     x = g.blaze_block(x, 54, 2, act=act)
@@ -410,6 +411,9 @@ CASES = {
     "back_48_odd_head_slices": (lambda: back_like(24, 48, coarse_first=True), 48, 48),     # 3x3 heads first: the 6x6 classifier's slice of the concatenation starts at float 54 (not 16-byte aligned: stored float by float by the chain's fused heads)
     "front_64_odd_widths": (lambda: front_like(25, 64), 64, 64),                            # 30 / 42 / 54 / 58 channels: zero-padded to multiples of 4 at lowering
     "front_48_odd_widths_prelu": (lambda: front_like(26, 48, "prelu"), 48, 48),            # the same with PReLU slopes to pad
+    # round 6: a 5x5 first convolution of 64 output pixels per row (stem_mfma_kernel takes it) with a PReLU / with no activation behind it — the shipped detectors' is ReLU
+    "front_128_prelu_stem": (lambda: front_like(27, 128, "prelu", "prelu"), 128, 128),
+    "front_128_linear_stem": (lambda: front_like(28, 128, "relu", "none"), 128, 128),
     "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads
     "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
     "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames
