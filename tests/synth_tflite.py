@@ -372,25 +372,28 @@ def full_tail(seed, h, w, cn=32, cw=128, cp=64, pairs=2, pointwise_last=True):
     return g.finish()
 
 
-def mesh_like(seed, size, c0=16):
+def mesh_like(seed, size, c0=16, act="prelu"):
     """face-mesh style: stem 3x3 s2 + PReLU -> 2 blocks(c0) -> s2 to 2c0 -> 2 blocks -> s2 to 4c0 -> 2 blocks -> s2 to 8c0 -> 3 blocks -> s2 -> 2 blocks;
     two branches of small-spatial work ending in whole-frame convolutions (the GEMM heads)."""
     g = GraphBuilder(seed, [1, size, size, 3])
-    x = g.prelu(g.conv(g.input, c0, 3, 2))
+    x = g.conv(g.input, c0, 3, 2)
+    x = g.prelu(x) if act == "prelu" else g.relu(x)
     for mult, nb in ((1, 2), (2, 2), (4, 2), (8, 3)):
         if mult > 1:
-            x = g.blaze_block(x, mult * c0, 2, act="prelu")
+            x = g.blaze_block(x, mult * c0, 2, act=act)
         for _ in range(nb):
-            x = g.blaze_block(x, act="prelu")
-    x = g.blaze_block(x, 8 * c0, 2, act="prelu")
+            x = g.blaze_block(x, act=act)
+    x = g.blaze_block(x, 8 * c0, 2, act=act)
     for _ in range(2):
-        x = g.blaze_block(x, act="prelu")
+        x = g.blaze_block(x, act=act)
     n, h, w, c = g.shape(x)
-    a = g.prelu(g.conv(x, 32))
-    a = g.blaze_block(a, act="prelu")
+    a = g.conv(x, 32)
+    a = g.prelu(a) if act == "prelu" else g.relu(a)
+    a = g.blaze_block(a, act=act)
     out_a = g.conv(a, 47, h, 1, VALID)          # window = frame: [1,1,1,47]
-    b = g.blaze_block(x, act="prelu")
-    b = g.prelu(g.conv(b, 32))
+    b = g.blaze_block(x, act=act)
+    b = g.conv(b, 32)
+    b = g.prelu(b) if act == "prelu" else g.relu(b)
     out_b = g.conv(b, 1, h, 1, VALID)
     g.outputs = [out_a, out_b]
     return g.finish()
@@ -416,7 +419,8 @@ CASES = {
     "front_128_linear_stem": (lambda: front_like(28, 128, "relu", "none"), 128, 128),
     "back_128_c32": (lambda: back_like(23, 128, 32, 2, 2), 128, 128),                      # 32 / 64 / 128 channels: strip kernel, 4-tile chains with heads
     "mesh_160": (lambda: mesh_like(41, 160), 160, 160),                                    # 80x80x16 pipelines ... 5x5x128 chains, stage programs, GEMM heads
-    "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),                                # 24-channel PReLU pipelines, 3x3 frames
+    "mesh_96_c24": (lambda: mesh_like(42, 96, 24), 96, 96),
+    "mesh_192_relu": (lambda: mesh_like(43, 192, 16, "relu"), 192, 192),                   # round 6: the face mesh's shapes with ReLU everywhere (mdblock_kernel<stem+pair>'s ReLU instantiation, from 32 frames on)                                # 24-channel PReLU pipelines, 3x3 frames
     "full_widen_70x44": (lambda: full_widen(33, 70, 44), 70, 44),                           # 35 x 22 frames: ragged bands, widening double block
     # (wide tensors too large for the stage programs' depthwise scratch: these runs go to xc_kernel)
     "full_tail_6x6": (lambda: full_tail(34, 24, 24, 96, 384, 256, 2), 24, 24),                  # 6 x 6: expand (max-pool skip) + 2 double blocks + pointwise contract, full_range's widths

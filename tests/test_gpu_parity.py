@@ -377,6 +377,27 @@ def test_first_convolution_inside_the_block_pair_launch(gpu, oracle, nb):
     m.close()
 
 
+def test_first_convolution_inside_the_block_pair_launch_relu_graph(gpu, oracle, synth_models):
+    """The same launches on a synthetic graph of the face mesh's shapes with ReLU behind every operator (the shipped graph has PReLU everywhere: the
+    kernels' ReLU instantiations would otherwise never run): 40 frames against the oracle, the fused launches against the separate ones."""
+    torch = pytest.importorskip("torch")
+    path, h, w = synth_models["mesh_192_relu"]
+    m = gpu.Model(path)
+    x = np.random.RandomState(5).uniform(-1, 1, (40, h, w, 3)).astype(np.float32)
+    x[1, -1] = 6.0
+    x[1, :, -1] = -4.0
+    outs = [o.copy() for o in m.run(x)]
+    labels = [r["kernel"] for r in m.profile(torch.from_numpy(x).cuda(), reps=1)]
+    assert labels[0] == "mdblock_kernel<stem+pair>", labels
+    for o, r in zip(outs, oracle.Model(path).run(x, nthreads=8)):
+        _raw_close(o, r)
+    m.set_option("stem_fuse", 0)
+    m.set_option("pair_fuse", 0)
+    for o, r in zip(m.run(x), outs):
+        _raw_close(o, r)
+    m.close()
+
+
 @pytest.mark.parametrize("name", ["landmark", "back"])
 def test_round6_launches_in_chunks_and_lanes(gpu, oracle, name):
     """The launches of round 6 that replace two nodes' launches (the face mesh's first convolution inside the block pair's launch, its two 48x48x32 blocks as one
